@@ -1,0 +1,74 @@
+/* brotli/batch.h -- batch extension of the C ABI: many independent .br streams per call.
+ *
+ * Not in the reference: its API decodes one stream per BrotliState (src/state.rs:156-278).  A GPU only
+ * pays off when many streams decode at once, so the same decode path is also exposed in batch form.  The
+ * per-stream outcome has exactly the meaning of the reference's one-shot return info (src/lib.rs:336-370):
+ * result, error code and the number of bytes the reference would have delivered.
+ *
+ * Threading: a batch object may be used by one thread at a time; different batch objects are independent.
+ * One batch object is bound to the HIP device that was current when it was created.
+ */
+#ifndef BROTLI_AMD_BATCH_H_
+#define BROTLI_AMD_BATCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#ifndef BROTLI_DEC_API
+#define BROTLI_DEC_API __attribute__((visibility("default")))
+#endif
+
+typedef struct BrotliAmdBatch BrotliAmdBatch;
+
+/* per-stream outcome (same fields as BrotliAmdStreamStatus without the resume block) */
+typedef struct BrotliAmdResult {
+  int32_t result;        /* BrotliDecoderResult */
+  int32_t error_code;    /* BrotliDecoderErrorCode */
+  uint64_t decoded_size; /* bytes delivered (reference: BrotliDecoderReturnInfo.decoded_size) */
+  uint64_t consumed;     /* input bytes consumed */
+  uint64_t produced;     /* bytes written to the output buffer (>= decoded_size after an error) */
+  uint32_t num_metablocks;
+  uint32_t reserved;
+  uint64_t num_commands;
+} BrotliAmdResult;
+
+#define BROTLI_AMD_BATCH_LARGE_WINDOW 1u /* accept large-window streams (reference one-shot default, lib.rs:457) */
+#define BROTLI_AMD_BATCH_NO_CANNY 2u     /* BROTLI_DECODER_PARAM_DISABLE_RING_BUFFER_REALLOCATION */
+
+/* Creates a batch context on the current HIP device for up to max_streams streams per call.
+ * lds_arena_bytes = 0 and grid_blocks = 0 select the defaults.  NULL when no device is usable. */
+BROTLI_DEC_API BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t lds_arena_bytes, uint32_t grid_blocks);
+BROTLI_DEC_API void BrotliAmdBatchDestroy(BrotliAmdBatch* batch);
+
+/* Decodes n streams whose compressed bytes and output buffers already live in DEVICE memory.
+ * d_in[i]/d_out[i] are device pointers (any alignment).  The launch is asynchronous on hip_stream
+ * (a hipStream_t, NULL = default stream); call BrotliAmdBatchWait before reading results.
+ * Returns 0 on success, a negative value if the arguments or the device are unusable. */
+BROTLI_DEC_API int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* batch, uint32_t n, const void* const* d_in, const size_t* in_sizes,
+                                             void* const* d_out, const size_t* out_caps, uint32_t flags, void* hip_stream);
+
+/* Re-launches the decode of the streams described by the previous BrotliAmdBatchDecodeDevice call
+ * (descriptors stay resident in device memory); used to time the kernel with inputs already in HBM. */
+BROTLI_DEC_API int BrotliAmdBatchRelaunch(BrotliAmdBatch* batch, void* hip_stream);
+
+/* Waits for the last launch and copies the per-stream results to the host. */
+BROTLI_DEC_API int BrotliAmdBatchWait(BrotliAmdBatch* batch, BrotliAmdResult* results /* n entries, may be NULL */);
+
+/* Convenience for host buffers: upload, decode, download.  Same per-stream semantics. */
+BROTLI_DEC_API int BrotliAmdBatchDecodeHost(BrotliAmdBatch* batch, uint32_t n, const uint8_t* const* in, const size_t* in_sizes,
+                                           uint8_t* const* out, const size_t* out_caps, uint32_t flags, BrotliAmdResult* results);
+
+/* Milliseconds the last launch spent in the decode kernel (HIP events on the launch stream). */
+BROTLI_DEC_API float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* batch);
+
+/* Text of the last HIP/runtime failure on this thread ("" if none). */
+BROTLI_DEC_API const char* BrotliAmdLastError(void);
+
+#if defined(__cplusplus)
+} /* extern "C" */
+#endif
+#endif /* BROTLI_AMD_BATCH_H_ */

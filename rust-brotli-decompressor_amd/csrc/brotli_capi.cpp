@@ -1,0 +1,675 @@
+// brotli_capi.cpp -- host side of libbrotli_decompressor.so: the reference's C ABI (include/brotli/decode.h)
+// and the batch extension (include/brotli/batch.h) on top of the HIP decode kernel.
+//
+// Mirrors, by behaviour, reference src/ffi/mod.rs (entry points, argument validation, error latching),
+// src/lib.rs:336-468 (one-shot helpers, BrotliDecoderReturnInfo) and the caller-visible contract of
+// src/decode.rs:2779-3403 (BrotliDecompressStream: what is consumed, what is delivered, when each result is
+// returned).  It owns no decoder: all decoding happens in brotli_kernels.hip.  The streaming entry point keeps
+// the stream's compressed bytes and its output in device memory and re-launches the kernel from the last
+// completed metablock boundary each time more input arrives (BrotliAmdResume), which is the device analogue
+// of the reference's resumable state machine.  When no HIP device is usable every entry point fails with
+// BROTLI_DECODER_ERROR_UNREACHABLE and a message -- there is no CPU path to fall back to.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "brotli/batch.h"
+#include "brotli/decode.h"
+#include "brotli_device_abi.h"
+
+extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
+                                               uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
+                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream);
+extern "C" uint32_t brotli_amd_lds_fixed_bytes(void);
+extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictionary.bin, 122784 bytes
+
+namespace {
+
+constexpr size_t kDictSize = 122784;
+constexpr uint64_t kScratchPerBlock = 2u << 20;  // worst-case table arena of one metablock
+constexpr uint32_t kDefaultLdsPerBlock = 32 * 1024;
+
+thread_local std::string g_last_error;
+
+bool hip_ok(hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+
+// ---- per-device constant data (the static dictionary) ----
+std::mutex g_dict_mutex;
+std::vector<uint8_t*> g_dict_by_device;
+
+const uint8_t* device_dictionary(int dev) {
+  std::lock_guard<std::mutex> lock(g_dict_mutex);
+  if ((int)g_dict_by_device.size() <= dev) g_dict_by_device.resize(dev + 1, nullptr);
+  if (!g_dict_by_device[dev]) {
+    uint8_t* p = nullptr;
+    if (!hip_ok(hipMalloc(&p, kDictSize + 64), "hipMalloc(dictionary)")) return nullptr;
+    if (!hip_ok(hipMemcpy(p, brotli_amd_dictionary, kDictSize, hipMemcpyHostToDevice), "hipMemcpy(dictionary)")) { (void)hipFree(p); return nullptr; }
+    g_dict_by_device[dev] = p;
+  }
+  return g_dict_by_device[dev];
+}
+
+bool current_device(int* dev) {
+  int count = 0;
+  if (!hip_ok(hipGetDeviceCount(&count), "hipGetDeviceCount")) return false;
+  if (count <= 0) { g_last_error = "no HIP device present"; return false; }
+  return hip_ok(hipGetDevice(dev), "hipGetDevice");
+}
+
+}  // namespace
+
+// ================================================ batch ================================================
+struct BrotliAmdBatch {
+  int device = 0;
+  uint32_t max_streams = 0, lds_arena = 0, grid_max = 0;
+  uint32_t n = 0, grid = 0;
+  BrotliAmdStreamDesc* d_descs = nullptr;
+  BrotliAmdStreamStatus* d_status = nullptr;
+  uint32_t* d_queue = nullptr;
+  uint8_t* d_scratch = nullptr;
+  uint64_t scratch_blocks = 0;
+  BrotliAmdStreamDesc* h_descs = nullptr;    // pinned
+  BrotliAmdStreamStatus* h_status = nullptr;  // pinned
+  const uint8_t* d_dict = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool launched = false;
+  // staging for BrotliAmdBatchDecodeHost
+  uint8_t* d_stage_in = nullptr; size_t stage_in_cap = 0;
+  uint8_t* d_stage_out = nullptr; size_t stage_out_cap = 0;
+};
+
+namespace {
+
+bool ensure_scratch(BrotliAmdBatch* b, uint32_t grid) {
+  if (b->scratch_blocks >= grid) return true;
+  if (b->d_scratch) (void)hipFree(b->d_scratch);
+  b->d_scratch = nullptr; b->scratch_blocks = 0;
+  if (!hip_ok(hipMalloc(&b->d_scratch, (size_t)grid * kScratchPerBlock), "hipMalloc(table scratch)")) return false;
+  b->scratch_blocks = grid;
+  return true;
+}
+
+int launch(BrotliAmdBatch* b, hipStream_t stream) {
+  if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
+  if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
+  if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->lds_arena,
+                                       b->d_dict, stream), "brotli_amd_decode_kernel launch")) return -1;
+  if (!hip_ok(hipEventRecord(b->ev1, stream), "hipEventRecord")) return -1;
+  b->last_stream = stream;
+  b->launched = true;
+  return 0;
+}
+
+int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n) filled
+  if (n == 0) { b->n = 0; b->launched = false; return 0; }
+  if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+  b->n = n;
+  b->grid = std::min(n, b->grid_max);
+  if (!ensure_scratch(b, b->grid)) return -1;
+  if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
+  return launch(b, stream);
+}
+
+}  // namespace
+
+extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t lds_arena_bytes, uint32_t grid_blocks) {
+  int dev = 0;
+  if (!current_device(&dev)) return nullptr;
+  if (max_streams == 0) max_streams = 1;
+  BrotliAmdBatch* b = new (std::nothrow) BrotliAmdBatch();
+  if (!b) return nullptr;
+  b->device = dev;
+  b->max_streams = max_streams;
+  hipDeviceProp_t prop;
+  if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) { delete b; return nullptr; }
+  uint32_t fixed = brotli_amd_lds_fixed_bytes();
+  uint32_t per_block = lds_arena_bytes ? lds_arena_bytes + fixed : kDefaultLdsPerBlock;
+  size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+  if (per_block > prop.sharedMemPerBlock && prop.sharedMemPerBlock) per_block = (uint32_t)prop.sharedMemPerBlock;
+  b->lds_arena = (per_block - fixed) & ~15u;
+  uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cu / per_block));
+  b->grid_max = grid_blocks ? grid_blocks : (uint32_t)prop.multiProcessorCount * blocks_per_cu;
+  b->d_dict = device_dictionary(dev);
+  bool ok = b->d_dict != nullptr;
+  ok = ok && hip_ok(hipMalloc(&b->d_descs, sizeof(BrotliAmdStreamDesc) * max_streams), "hipMalloc(descs)");
+  ok = ok && hip_ok(hipMalloc(&b->d_status, sizeof(BrotliAmdStreamStatus) * max_streams), "hipMalloc(status)");
+  ok = ok && hip_ok(hipMalloc(&b->d_queue, 64), "hipMalloc(queue)");
+  ok = ok && hip_ok(hipHostMalloc(&b->h_descs, sizeof(BrotliAmdStreamDesc) * max_streams), "hipHostMalloc(descs)");
+  ok = ok && hip_ok(hipHostMalloc(&b->h_status, sizeof(BrotliAmdStreamStatus) * max_streams), "hipHostMalloc(status)");
+  ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
+  if (!ok) { BrotliAmdBatchDestroy(b); return nullptr; }
+  return b;
+}
+
+extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  if (b->launched && b->last_stream != nullptr) (void)hipStreamSynchronize(b->last_stream);
+  else (void)hipDeviceSynchronize();
+  if (b->d_descs) (void)hipFree(b->d_descs);
+  if (b->d_status) (void)hipFree(b->d_status);
+  if (b->d_queue) (void)hipFree(b->d_queue);
+  if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->d_stage_in) (void)hipFree(b->d_stage_in);
+  if (b->d_stage_out) (void)hipFree(b->d_stage_out);
+  if (b->h_descs) (void)hipHostFree(b->h_descs);
+  if (b->h_status) (void)hipHostFree(b->h_status);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+extern "C" int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* b, uint32_t n, const void* const* d_in, const size_t* in_sizes, void* const* d_out,
+                                          const size_t* out_caps, uint32_t flags, void* hip_stream) {
+  if (!b || n > b->max_streams || (n && (!d_in || !in_sizes || !d_out || !out_caps))) { g_last_error = "invalid batch arguments"; return -1; }
+  for (uint32_t i = 0; i < n; i++) {
+    BrotliAmdStreamDesc& d = b->h_descs[i];
+    std::memset(&d, 0, sizeof d);
+    d.in = static_cast<const uint8_t*>(d_in[i]); d.in_size = in_sizes[i];
+    d.out = static_cast<uint8_t*>(d_out[i]); d.out_cap = out_caps[i];
+    d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY);
+  }
+  return submit(b, n, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int BrotliAmdBatchRelaunch(BrotliAmdBatch* b, void* hip_stream) {
+  if (!b || b->n == 0) { g_last_error = "nothing to relaunch"; return -1; }
+  if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+  return launch(b, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
+  if (!b) return -1;
+  if (b->n == 0 || !b->launched) return 0;
+  if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+  if (!hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * b->n, hipMemcpyDeviceToHost, b->last_stream), "hipMemcpyAsync(status)")) return -1;
+  if (!hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize")) return -1;
+  if (results) {
+    for (uint32_t i = 0; i < b->n; i++) {
+      const BrotliAmdStreamStatus& s = b->h_status[i];
+      BrotliAmdResult& r = results[i];
+      r.result = s.result; r.error_code = s.error_code; r.decoded_size = s.decoded_size; r.consumed = s.consumed;
+      r.produced = s.produced; r.num_metablocks = s.num_metablocks; r.reserved = 0; r.num_commands = s.num_commands;
+    }
+  }
+  return 0;
+}
+
+extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
+  if (!b || !b->launched) return 0.0f;
+  float ms = 0.0f;
+  if (!hip_ok(hipEventSynchronize(b->ev1), "hipEventSynchronize")) return -1.0f;
+  if (!hip_ok(hipEventElapsedTime(&ms, b->ev0, b->ev1), "hipEventElapsedTime")) return -1.0f;
+  return ms;
+}
+
+extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uint8_t* const* in, const size_t* in_sizes, uint8_t* const* out,
+                                        const size_t* out_caps, uint32_t flags, BrotliAmdResult* results) {
+  if (!b || n > b->max_streams || (n && (!in || !in_sizes || !out || !out_caps))) { g_last_error = "invalid batch arguments"; return -1; }
+  if (n == 0) return 0;
+  if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+  // one input arena and one output arena, 64-byte aligned slots
+  std::vector<size_t> in_off(n), out_off(n);
+  size_t in_total = 0, out_total = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    in_off[i] = in_total; in_total += (in_sizes[i] + 63) & ~(size_t)63; in_total += 64;
+    out_off[i] = out_total; out_total += (out_caps[i] + 63) & ~(size_t)63; out_total += 64;
+  }
+  if (in_total > b->stage_in_cap) {
+    if (b->d_stage_in) (void)hipFree(b->d_stage_in);
+    b->d_stage_in = nullptr; b->stage_in_cap = 0;
+    if (!hip_ok(hipMalloc(&b->d_stage_in, in_total), "hipMalloc(input arena)")) return -1;
+    b->stage_in_cap = in_total;
+  }
+  if (out_total > b->stage_out_cap) {
+    if (b->d_stage_out) (void)hipFree(b->d_stage_out);
+    b->d_stage_out = nullptr; b->stage_out_cap = 0;
+    if (!hip_ok(hipMalloc(&b->d_stage_out, out_total), "hipMalloc(output arena)")) return -1;
+    b->stage_out_cap = out_total;
+  }
+  for (uint32_t i = 0; i < n; i++) {
+    if (in_sizes[i] && !hip_ok(hipMemcpyAsync(b->d_stage_in + in_off[i], in[i], in_sizes[i], hipMemcpyHostToDevice, nullptr), "hipMemcpyAsync(input)")) return -1;
+    BrotliAmdStreamDesc& d = b->h_descs[i];
+    std::memset(&d, 0, sizeof d);
+    d.in = b->d_stage_in + in_off[i]; d.in_size = in_sizes[i];
+    d.out = b->d_stage_out + out_off[i]; d.out_cap = out_caps[i];
+    d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY);
+  }
+  if (submit(b, n, nullptr) != 0) return -1;
+  std::vector<BrotliAmdResult> local;
+  if (!results) { local.resize(n); results = local.data(); }
+  if (BrotliAmdBatchWait(b, results) != 0) return -1;
+  for (uint32_t i = 0; i < n; i++) {
+    size_t got = (size_t)std::min<uint64_t>(results[i].decoded_size, out_caps[i]);
+    if (got && !hip_ok(hipMemcpyAsync(out[i], b->d_stage_out + out_off[i], got, hipMemcpyDeviceToHost, nullptr), "hipMemcpyAsync(output)")) return -1;
+  }
+  if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return -1;
+  return 0;
+}
+
+extern "C" const char* BrotliAmdLastError(void) { return g_last_error.c_str(); }
+
+// ============================================ error strings ============================================
+// reference src/state.rs:533-578 (including the historical "FL_SPACE" spelling of CL_SPACE)
+extern "C" const char* BrotliDecoderErrorString(BrotliDecoderErrorCode c) {
+  switch ((int)c) {
+    case 0: return "NO_ERROR";
+    case 1: return "SUCCESS";
+    case 2: return "NEEDS_MORE_INPUT";
+    case 3: return "NEEDS_MORE_OUTPUT";
+    case -1: return "ERROR_FORMAT_EXUBERANT_NIBBLE";
+    case -2: return "ERROR_FORMAT_RESERVED";
+    case -3: return "ERROR_FORMAT_EXUBERANT_META_NIBBLE";
+    case -4: return "ERROR_FORMAT_SIMPLE_HUFFMAN_ALPHABET";
+    case -5: return "ERROR_FORMAT_SIMPLE_HUFFMAN_SAME";
+    case -6: return "ERROR_FORMAT_FL_SPACE";
+    case -7: return "ERROR_FORMAT_HUFFMAN_SPACE";
+    case -8: return "ERROR_FORMAT_CONTEXT_MAP_REPEAT";
+    case -9: return "ERROR_FORMAT_BLOCK_LENGTH_1";
+    case -10: return "ERROR_FORMAT_BLOCK_LENGTH_2";
+    case -11: return "ERROR_FORMAT_TRANSFORM";
+    case -12: return "ERROR_FORMAT_DICTIONARY";
+    case -13: return "ERROR_FORMAT_WINDOW_BITS";
+    case -14: return "ERROR_FORMAT_PADDING_1";
+    case -15: return "ERROR_FORMAT_PADDING_2";
+    case -16: return "ERROR_FORMAT_DISTANCE";
+    case -19: return "ERROR_DICTIONARY_NOT_SET";
+    case -20: return "ERROR_INVALID_ARGUMENTS";
+    case -21: return "ERROR_ALLOC_CONTEXT_MODES";
+    case -22: return "ERROR_ALLOC_TREE_GROUPS";
+    case -25: return "ERROR_ALLOC_CONTEXT_MAP";
+    case -26: return "ERROR_ALLOC_RING_BUFFER_1";
+    case -27: return "ERROR_ALLOC_RING_BUFFER_2";
+    case -30: return "ERROR_ALLOC_BLOCK_TYPE_TREES";
+    case -31: return "ERROR_UNREACHABLE";
+    default: return "ERROR_UNREACHABLE";
+  }
+}
+
+extern "C" uint32_t BrotliDecoderVersion(void) { return 0x1000f00; }  // ffi/mod.rs:588-590
+
+// ============================================== one-shot ==============================================
+namespace {
+
+// window bits announced by the first bytes of a stream (RFC 7932 section 9.1; same answer as the reference's
+// lg_window_size, src/decode.rs:1221-1253).  0 when not decidable.
+uint32_t peek_window_bits(const uint8_t* in, size_t n) {
+  if (n == 0) return 0;
+  uint8_t b = in[0];
+  if ((b & 1) == 0) return 16;
+  if ((b & 0xE) != 0) return 17 + ((b >> 1) & 7);
+  uint32_t n3 = (b >> 4) & 7;
+  if (n3 == 1) {  // large window: 6 bits of WBITS follow the reserved bit
+    if (n < 2 || (b & 0x80)) return 0;
+    uint32_t w = in[1] & 0x3F;
+    return (w >= 10 && w <= 30) ? w : 0;
+  }
+  return n3 ? 8 + n3 : 17;
+}
+
+struct OneShot {
+  std::mutex mu;
+  BrotliAmdBatch* batch = nullptr;
+  uint8_t* d_in = nullptr; size_t in_cap = 0;
+  uint8_t* d_out = nullptr; size_t out_cap = 0;
+  int device = -1;
+};
+OneShot g_oneshot;
+
+void fill_error(BrotliDecoderReturnInfo* r, BrotliDecoderErrorCode code, const char* msg) {
+  std::memset(r, 0, sizeof *r);
+  r->result = BROTLI_DECODER_RESULT_ERROR;
+  r->code = code;
+  std::snprintf(r->error, sizeof r->error, "%s", msg ? msg : BrotliDecoderErrorString(code));
+}
+
+bool grow(uint8_t** p, size_t* cap, size_t need) {
+  if (need <= *cap && *p) return true;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  size_t want = std::max<size_t>(need, 4096);
+  if (!hip_ok(hipMalloc(p, want + 256), "hipMalloc(one-shot staging)")) return false;
+  *cap = want;
+  return true;
+}
+
+// Decode with output capacity `cap` on the device; returns false on a runtime (HIP) failure.
+bool run_once(OneShot& o, size_t n_in, size_t cap, uint32_t flags, BrotliAmdStreamStatus* st) {
+  BrotliAmdStreamDesc& d = o.batch->h_descs[0];
+  std::memset(&d, 0, sizeof d);
+  d.in = o.d_in; d.in_size = n_in; d.out = o.d_out; d.out_cap = cap; d.flags = flags;
+  if (submit(o.batch, 1, nullptr) != 0) return false;
+  if (BrotliAmdBatchWait(o.batch, nullptr) != 0) return false;
+  *st = o.batch->h_status[0];
+  return true;
+}
+
+// reference src/lib.rs:447-468 (brotli_decode) + BrotliDecoderReturnInfo::new (lib.rs:343-370)
+BrotliDecoderReturnInfo oneshot_decode(const uint8_t* in, size_t n_in, uint8_t* out, size_t cap) {
+  BrotliDecoderReturnInfo r;
+  std::lock_guard<std::mutex> lock(g_oneshot.mu);
+  OneShot& o = g_oneshot;
+  int dev = 0;
+  if (!current_device(&dev)) { fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP device unavailable: " + g_last_error).c_str()); return r; }
+  if (o.batch && o.device != dev) { BrotliAmdBatchDestroy(o.batch); o.batch = nullptr; if (o.d_in) (void)hipFree(o.d_in); if (o.d_out) (void)hipFree(o.d_out); o.d_in = o.d_out = nullptr; o.in_cap = o.out_cap = 0; }
+  if (!o.batch) { o.batch = BrotliAmdBatchCreate(1, 0, 0); o.device = dev; }
+  if (!o.batch) { fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP device unavailable: " + g_last_error).c_str()); return r; }
+  const uint32_t flags = BROTLI_AMD_FLAG_LARGE_WINDOW;  // lib.rs:457 -> BrotliState::new -> large_window = true
+  BrotliAmdStreamStatus st;
+  bool ok = grow(&o.d_in, &o.in_cap, n_in) && grow(&o.d_out, &o.out_cap, cap);
+  ok = ok && (n_in == 0 || hip_ok(hipMemcpy(o.d_in, in, n_in, hipMemcpyHostToDevice), "hipMemcpy(input)"));
+  ok = ok && run_once(o, n_in, cap, flags, &st);
+  if (ok && st.result == BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT) {
+    // The reference only notices a full output buffer at its next ring-buffer flush (decode.rs:1693-1738),
+    // so what it reports depends on what the stream does up to the next multiple of the window size.  Decode
+    // again with room up to that point and map the outcome.
+    uint32_t wbits = peek_window_bits(in, n_in);
+    if (wbits) {
+      size_t rb = (size_t)1 << wbits;
+      size_t cap2 = (cap / rb + 1) * rb;
+      BrotliAmdStreamStatus st2;
+      if (grow(&o.d_out, &o.out_cap, cap2) && run_once(o, n_in, cap2, flags, &st2)) {
+        if (st2.result == BROTLI_DECODER_RESULT_ERROR) {
+          st = st2;
+          if (st.decoded_size > cap) st.decoded_size = cap;
+        } else if (st2.result == BROTLI_DECODER_RESULT_NEEDS_MORE_INPUT && st2.produced <= cap2) {
+          st = st2; st.decoded_size = std::min<uint64_t>(st2.decoded_size, cap);
+        } else {
+          st.result = BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT; st.error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT; st.decoded_size = cap;
+        }
+      } else ok = false;
+    }
+  }
+  if (!ok) { fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP runtime failure: " + g_last_error).c_str()); return r; }
+  size_t got = (size_t)std::min<uint64_t>(st.decoded_size, cap);
+  if (got && !hip_ok(hipMemcpy(out, o.d_out, got, hipMemcpyDeviceToHost), "hipMemcpy(output)")) {
+    fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP runtime failure: " + g_last_error).c_str());
+    return r;
+  }
+  std::memset(&r, 0, sizeof r);
+  r.decoded_size = got;
+  r.result = (BrotliDecoderResult)st.result;
+  r.code = (BrotliDecoderErrorCode)st.error_code;
+  std::snprintf(r.error, sizeof r.error, "%s", BrotliDecoderErrorString(r.code));
+  return r;
+}
+
+// reference src/ffi/mod.rs:45-61: pointer/length pairs that a slice could not be made of
+template <typename T>
+bool valid_slice(const T* p, size_t len) {
+  if (len == 0) return true;
+  if (!p) return false;
+  if (((uintptr_t)p) % alignof(T) != 0) return false;
+  if (len > (size_t)(PTRDIFF_MAX) / sizeof(T)) return false;
+  return (uintptr_t)p + len * sizeof(T) >= (uintptr_t)p;
+}
+
+BrotliDecoderReturnInfo invalid_arguments() {
+  BrotliDecoderReturnInfo r;
+  fill_error(&r, BROTLI_DECODER_ERROR_INVALID_ARGUMENTS, nullptr);
+  return r;
+}
+
+}  // namespace
+
+extern "C" BrotliDecoderReturnInfo BrotliDecoderDecompressWithReturnInfo(size_t encoded_size, const uint8_t* encoded_buffer, size_t decoded_size,
+                                                                         uint8_t* decoded_buffer) {
+  if (!valid_slice(encoded_buffer, encoded_size) || !valid_slice(decoded_buffer, decoded_size)) return invalid_arguments();
+  return oneshot_decode(encoded_buffer, encoded_size, decoded_buffer, decoded_size);
+}
+
+extern "C" BrotliDecoderResult BrotliDecoderDecompress(size_t encoded_size, const uint8_t* encoded_buffer, size_t* decoded_size,
+                                                       uint8_t* decoded_buffer) {
+  if (!valid_slice(decoded_size, 1)) return BROTLI_DECODER_RESULT_ERROR;  // ffi/mod.rs:269-271
+  BrotliDecoderReturnInfo r = BrotliDecoderDecompressWithReturnInfo(encoded_size, encoded_buffer, *decoded_size, decoded_buffer);
+  *decoded_size = r.decoded_size;
+  return r.result == BROTLI_DECODER_RESULT_SUCCESS ? BROTLI_DECODER_RESULT_SUCCESS : BROTLI_DECODER_RESULT_ERROR;
+}
+
+extern "C" BrotliDecoderReturnInfo BrotliDecoderDecompressPrealloc(size_t encoded_size, const uint8_t* encoded_buffer, size_t decoded_size,
+                                                                   uint8_t* decoded_buffer, size_t scratch_u8_size, uint8_t* scratch_u8_buffer,
+                                                                   size_t scratch_u32_size, uint32_t* scratch_u32_buffer, size_t scratch_hc_size,
+                                                                   HuffmanCode* scratch_hc_buffer) {
+  if (!valid_slice(encoded_buffer, encoded_size) || !valid_slice(decoded_buffer, decoded_size) ||
+      !valid_slice(scratch_u8_buffer, scratch_u8_size) || !valid_slice(scratch_u32_buffer, scratch_u32_size) ||
+      !valid_slice(scratch_hc_buffer, scratch_hc_size))
+    return invalid_arguments();
+  return oneshot_decode(encoded_buffer, encoded_size, decoded_buffer, decoded_size);
+}
+
+// ============================================== streaming ==============================================
+struct BrotliDecoderStateStruct {
+  brotli_alloc_func alloc_func; brotli_free_func free_func; void* opaque;
+  bool large_window, canny, used, finished, have_resume;
+  int error_code;          // BrotliDecoderErrorCode, latched when fatal (decode.rs:2796-2798)
+  int pending_error;       // fatal code found by the device, reported once everything before it is delivered
+  char error_text[256]; bool has_error_text;
+  BrotliAmdBatch* batch;
+  int device;
+  uint8_t* d_in; size_t d_in_len, d_in_cap;
+  uint8_t* d_out; size_t d_out_cap;
+  BrotliAmdResume resume;
+  uint64_t fetched;        // output bytes already copied off the device
+  uint64_t total_out;      // output bytes handed to the caller (partial_pos_out)
+  uint8_t* outq; size_t outq_len, outq_off, outq_cap;  // fetched but not yet handed over
+};
+
+namespace {
+
+void* st_alloc(BrotliDecoderState* s, size_t n) { return s->alloc_func ? s->alloc_func(s->opaque, n) : std::malloc(n); }
+void st_free(BrotliDecoderState* s, void* p) { if (!p) return; if (s->free_func) s->free_func(s->opaque, p); else std::free(p); }
+
+bool fatal(int code) { return code < 0; }
+
+void set_runtime_error(BrotliDecoderState* s, const char* what) {
+  s->error_code = BROTLI_DECODER_ERROR_UNREACHABLE;
+  std::snprintf(s->error_text, sizeof s->error_text, "%s: %s", what, g_last_error.c_str());
+  s->has_error_text = true;
+}
+
+bool dev_grow(uint8_t** p, size_t* cap, size_t keep, size_t need) {  // keeps the first `keep` bytes
+  if (need <= *cap && *p) return true;
+  size_t want = std::max<size_t>(std::max<size_t>(need, *cap * 2), 1 << 16);
+  uint8_t* np = nullptr;
+  if (!hip_ok(hipMalloc(&np, want + 256), "hipMalloc(stream buffer)")) return false;
+  if (*p && keep && !hip_ok(hipMemcpy(np, *p, keep, hipMemcpyDeviceToDevice), "hipMemcpy(grow)")) { (void)hipFree(np); return false; }
+  if (*p) (void)hipFree(*p);
+  *p = np; *cap = want;
+  return true;
+}
+
+size_t hand_over(BrotliDecoderState* s, uint8_t* dst, size_t room) {
+  size_t n = std::min(room, s->outq_len - s->outq_off);
+  if (n) { std::memcpy(dst, s->outq + s->outq_off, n); s->outq_off += n; s->total_out += n; }
+  if (s->outq_off == s->outq_len) s->outq_off = s->outq_len = 0;
+  return n;
+}
+
+// One decode pass over everything received so far, from the last completed metablock boundary.
+bool decode_pass(BrotliDecoderState* s, BrotliAmdStreamStatus* st) {
+  for (;;) {
+    if (!dev_grow(&s->d_out, &s->d_out_cap, (size_t)s->fetched, std::max<size_t>(s->d_out_cap, std::max<size_t>(1 << 16, 6 * s->d_in_len)))) return false;
+    BrotliAmdStreamDesc& d = s->batch->h_descs[0];
+    std::memset(&d, 0, sizeof d);
+    d.in = s->d_in; d.in_size = s->d_in_len; d.out = s->d_out; d.out_cap = s->d_out_cap;
+    d.flags = (s->large_window ? BROTLI_AMD_FLAG_LARGE_WINDOW : 0u) | (s->canny ? 0u : BROTLI_AMD_FLAG_NO_CANNY);
+    if (s->have_resume) { d.flags |= BROTLI_AMD_FLAG_RESUME; d.resume = s->resume; }
+    if (submit(s->batch, 1, nullptr) != 0) return false;
+    if (BrotliAmdBatchWait(s->batch, nullptr) != 0) return false;
+    *st = s->batch->h_status[0];
+    if (st->resume.window_bits != 0) { s->resume = st->resume; s->have_resume = true; }
+    if (st->result != BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT) return true;
+    // device output buffer exhausted: everything below the resume point is final, enlarge and continue
+    if (!dev_grow(&s->d_out, &s->d_out_cap, (size_t)std::max<uint64_t>(s->fetched, s->have_resume ? s->resume.out_pos : 0), s->d_out_cap * 2)) return false;
+  }
+}
+
+}  // namespace
+
+extern "C" BrotliDecoderState* BrotliDecoderCreateInstance(brotli_alloc_func alloc_func, brotli_free_func free_func, void* opaque) {
+  if ((alloc_func == nullptr) != (free_func == nullptr)) return nullptr;  // ffi/mod.rs:132-135
+  void* mem = alloc_func ? alloc_func(opaque, sizeof(BrotliDecoderStateStruct)) : std::malloc(sizeof(BrotliDecoderStateStruct));
+  if (!mem) return nullptr;
+  BrotliDecoderState* s = static_cast<BrotliDecoderState*>(mem);
+  std::memset(s, 0, sizeof *s);
+  s->alloc_func = alloc_func; s->free_func = free_func; s->opaque = opaque;
+  s->large_window = false;  // ffi/mod.rs:127
+  s->canny = true;          // state.rs: canny_ringbuffer_allocation = true
+  s->error_code = BROTLI_DECODER_SUCCESS;
+  s->device = -1;
+  return s;
+}
+
+extern "C" void BrotliDecoderDestroyInstance(BrotliDecoderState* s) {
+  if (!s) return;
+  if (s->batch) BrotliAmdBatchDestroy(s->batch);
+  if (s->d_in) (void)hipFree(s->d_in);
+  if (s->d_out) (void)hipFree(s->d_out);
+  st_free(s, s->outq);
+  brotli_free_func f = s->free_func; void* opaque = s->opaque;
+  if (f) f(opaque, s); else std::free(s);
+}
+
+extern "C" BROTLI_BOOL BrotliDecoderSetParameter(BrotliDecoderState* s, BrotliDecoderParameter param, uint32_t value) {
+  if (!s) return BROTLI_FALSE;
+  if (s->used) return BROTLI_FALSE;  // only in the UNINITED state (ffi/mod.rs:163-166)
+  switch (param) {
+    case BROTLI_DECODER_PARAM_DISABLE_RING_BUFFER_REALLOCATION: s->canny = (value == 0); return BROTLI_TRUE;
+    case BROTLI_DECODER_PARAM_LARGE_WINDOW: s->large_window = (value != 0); return BROTLI_TRUE;
+  }
+  return BROTLI_TRUE;
+}
+
+extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState* s, size_t* available_in, const uint8_t** next_in,
+                                                             size_t* available_out, uint8_t** next_out, size_t* total_out) {
+  if (!s || !available_in || !next_in || !available_out || !next_out) {  // ffi/mod.rs:397-407
+    if (s) s->error_code = BROTLI_DECODER_ERROR_INVALID_ARGUMENTS;
+    return BROTLI_DECODER_RESULT_ERROR;
+  }
+  if (!valid_slice(*next_in, *available_in) || !valid_slice(*next_out, *available_out)) {
+    s->error_code = BROTLI_DECODER_ERROR_INVALID_ARGUMENTS;
+    return BROTLI_DECODER_RESULT_ERROR;
+  }
+  if (fatal(s->error_code)) return BROTLI_DECODER_RESULT_ERROR;  // decode.rs:2796-2798
+  if ((uint64_t)*available_in >= (1ull << 32)) {                 // decode.rs:2799-2801
+    s->error_code = BROTLI_DECODER_ERROR_INVALID_ARGUMENTS;
+    return BROTLI_DECODER_RESULT_ERROR;
+  }
+  // lazily bind to the current device
+  if (!s->batch) {
+    int dev = 0;
+    if (!current_device(&dev)) { set_runtime_error(s, "HIP device unavailable"); return BROTLI_DECODER_RESULT_ERROR; }
+    s->batch = BrotliAmdBatchCreate(1, 0, 0);
+    if (!s->batch) { set_runtime_error(s, "HIP device unavailable"); return BROTLI_DECODER_RESULT_ERROR; }
+    s->device = dev;
+  }
+  if (!hip_ok(hipSetDevice(s->device), "hipSetDevice")) { set_runtime_error(s, "HIP runtime failure"); return BROTLI_DECODER_RESULT_ERROR; }
+
+  const size_t given = *available_in;
+  bool new_input = false;
+  if (!s->finished && !s->pending_error && given) {
+    if (!dev_grow(&s->d_in, &s->d_in_cap, s->d_in_len, s->d_in_len + given) ||
+        !hip_ok(hipMemcpy(s->d_in + s->d_in_len, *next_in, given, hipMemcpyHostToDevice), "hipMemcpy(input)")) {
+      set_runtime_error(s, "HIP runtime failure");
+      return BROTLI_DECODER_RESULT_ERROR;
+    }
+    s->d_in_len += given;
+    *next_in += given; *available_in = 0;
+    s->used = true;
+    new_input = true;
+  }
+  if (new_input) {
+    BrotliAmdStreamStatus st;
+    if (!decode_pass(s, &st)) { set_runtime_error(s, "HIP runtime failure"); return BROTLI_DECODER_RESULT_ERROR; }
+    // bytes the reference would have flushed by now: all of them on success / needs-more-input, the part
+    // below the last ring-buffer boundary on a fatal error (decode.rs:2835-2846, 2899-2913)
+    uint64_t deliverable = st.decoded_size;
+    if (deliverable > s->fetched) {
+      size_t n = (size_t)(deliverable - s->fetched);
+      if (s->outq_len + n > s->outq_cap) {
+        size_t ncap = std::max(s->outq_cap * 2, s->outq_len + n);
+        uint8_t* nq = static_cast<uint8_t*>(st_alloc(s, ncap));
+        if (!nq) { s->error_code = BROTLI_DECODER_ERROR_ALLOC_RING_BUFFER_2; return BROTLI_DECODER_RESULT_ERROR; }
+        if (s->outq_len) std::memcpy(nq, s->outq, s->outq_len);
+        st_free(s, s->outq);
+        s->outq = nq; s->outq_cap = ncap;
+      }
+      if (!hip_ok(hipMemcpy(s->outq + s->outq_len, s->d_out + s->fetched, n, hipMemcpyDeviceToHost), "hipMemcpy(output)")) {
+        set_runtime_error(s, "HIP runtime failure");
+        return BROTLI_DECODER_RESULT_ERROR;
+      }
+      s->outq_len += n;
+      s->fetched = deliverable;
+    }
+    if (st.result == BROTLI_DECODER_RESULT_SUCCESS) {
+      s->finished = true;
+      // give back what lies beyond the end of the stream (decode.rs:3374-3378); it is part of this call's input
+      size_t unused = (size_t)(s->d_in_len - st.consumed);
+      if (unused > given) unused = given;
+      *next_in -= unused; *available_in += unused;
+    } else if (st.result == BROTLI_DECODER_RESULT_ERROR) {
+      s->pending_error = st.error_code;
+    }
+  }
+  size_t n = hand_over(s, *next_out, *available_out);
+  *next_out += n; *available_out -= n;
+  if (total_out) *total_out = (size_t)s->total_out;
+  if (s->outq_len != s->outq_off) { s->error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT; return BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT; }
+  if (s->pending_error) { s->error_code = s->pending_error; return BROTLI_DECODER_RESULT_ERROR; }
+  if (s->finished) { s->error_code = BROTLI_DECODER_SUCCESS; return BROTLI_DECODER_RESULT_SUCCESS; }
+  s->error_code = BROTLI_DECODER_NEEDS_MORE_INPUT;
+  return BROTLI_DECODER_RESULT_NEEDS_MORE_INPUT;
+}
+
+extern "C" BrotliDecoderResult BrotliDecoderDecompressStreaming(BrotliDecoderState* s, size_t* available_in, const uint8_t* next_in,
+                                                                size_t* available_out, uint8_t* next_out) {
+  return BrotliDecoderDecompressStream(s, available_in, &next_in, available_out, &next_out, nullptr);
+}
+
+extern "C" BROTLI_BOOL BrotliDecoderHasMoreOutput(const BrotliDecoderState* s) {
+  if (!s || fatal(s->error_code)) return BROTLI_FALSE;  // decode.rs:2259-2263
+  return s->outq_len != s->outq_off ? BROTLI_TRUE : BROTLI_FALSE;
+}
+
+extern "C" const uint8_t* BrotliDecoderTakeOutput(BrotliDecoderState* s, size_t* size) {
+  if (!s || !size) return nullptr;
+  size_t want = *size ? *size : ((size_t)1 << 24);  // decode.rs:2273
+  if (fatal(s->error_code) || s->outq_len == s->outq_off) { *size = 0; return nullptr; }
+  size_t n = std::min(want, s->outq_len - s->outq_off);
+  const uint8_t* p = s->outq + s->outq_off;
+  s->outq_off += n; s->total_out += n;
+  *size = n;
+  return p;  // valid until the next call on this instance
+}
+
+extern "C" BROTLI_BOOL BrotliDecoderIsUsed(const BrotliDecoderState* s) { return (s && s->used) ? BROTLI_TRUE : BROTLI_FALSE; }
+extern "C" BROTLI_BOOL BrotliDecoderIsFinished(const BrotliDecoderState* s) {
+  return (s && s->finished && !s->pending_error && s->outq_len == s->outq_off) ? BROTLI_TRUE : BROTLI_FALSE;
+}
+extern "C" BrotliDecoderErrorCode BrotliDecoderGetErrorCode(const BrotliDecoderState* s) {
+  return s ? (BrotliDecoderErrorCode)s->error_code : BROTLI_DECODER_ERROR_INVALID_ARGUMENTS;
+}
+extern "C" const char* BrotliDecoderGetErrorString(const BrotliDecoderState* s) {
+  if (s && s->has_error_text) return s->error_text;  // ffi/mod.rs:571-580
+  return BrotliDecoderErrorString(BrotliDecoderGetErrorCode(s));
+}
+
+extern "C" uint8_t* BrotliDecoderMallocU8(BrotliDecoderState* s, size_t size) { return s ? static_cast<uint8_t*>(st_alloc(s, size)) : nullptr; }
+extern "C" void BrotliDecoderFreeU8(BrotliDecoderState* s, uint8_t* data, size_t) { if (s) st_free(s, data); }
+extern "C" size_t* BrotliDecoderMallocUsize(BrotliDecoderState* s, size_t size) {
+  if (!s || size > SIZE_MAX / sizeof(size_t)) return nullptr;  // ffi/mod.rs:507-510
+  return static_cast<size_t*>(st_alloc(s, size * sizeof(size_t)));
+}
+extern "C" void BrotliDecoderFreeUsize(BrotliDecoderState* s, size_t* data, size_t) { if (s) st_free(s, data); }

@@ -1,0 +1,58 @@
+// Host <-> kernel contract of the batch decoder (plain C structs, no HIP types).
+//
+// One StreamDesc per .br stream, one StreamStatus written back per stream.  A stream is the unit of
+// work the reference calls "one BrotliState" (src/state.rs:156-278): its own window, distance ring and
+// output.  Streams never share anything, so a batch partitions freely over wavefronts and over GPUs.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// flags
+#define BROTLI_AMD_FLAG_LARGE_WINDOW 1u  // accept the 14-bit large-window header (state.rs:394, ffi/mod.rs:127)
+#define BROTLI_AMD_FLAG_NO_CANNY 2u      // BROTLI_DECODER_PARAM_DISABLE_RING_BUFFER_REALLOCATION (ffi/mod.rs:167-169)
+#define BROTLI_AMD_FLAG_RESUME 4u        // start from the metablock boundary stored in `resume`
+
+// State at a metablock boundary: everything that survives from one metablock to the next in the
+// reference (state.rs:422-450 resets the rest).  The kernel stores it after every completed metablock;
+// the streaming ABI feeds it back so that a stream delivered in pieces is decoded metablock by metablock
+// instead of from byte 0 (the device analogue of the reference's resumable state machine).
+typedef struct BrotliAmdResume {
+  uint64_t bit_pos;       // absolute bit position in the compressed stream
+  uint64_t out_pos;       // bytes produced so far
+  int32_t dist_rb[4];     // state.rs:296
+  int32_t dist_rb_idx;
+  uint32_t window_bits;   // 0 = stream header not parsed yet
+  uint32_t large_window;  // stream carries the large-window header
+  uint32_t rb_size_log2;  // emulated ring size (0 = not allocated yet), decode.rs:1808-1871
+  uint32_t is_last_done;  // last metablock completed (stream finished up to the final padding)
+  uint32_t reserved;
+} BrotliAmdResume;
+
+typedef struct BrotliAmdStreamDesc {
+  const uint8_t* in;      // device pointer, any alignment
+  uint64_t in_size;
+  uint8_t* out;           // device pointer
+  uint64_t out_cap;
+  uint32_t flags;
+  uint32_t reserved;
+  BrotliAmdResume resume; // only read when BROTLI_AMD_FLAG_RESUME is set
+} BrotliAmdStreamDesc;
+
+typedef struct BrotliAmdStreamStatus {
+  int32_t result;         // BrotliResult: 0 error, 1 success, 2 needs more input, 3 needs more output
+  int32_t error_code;     // BrotliDecoderErrorCode (state.rs:22-65)
+  uint64_t decoded_size;  // bytes the reference would have delivered to the caller (lib.rs:466)
+  uint64_t consumed;      // input bytes consumed
+  uint64_t produced;      // bytes written to `out` (>= decoded_size on errors)
+  uint32_t num_metablocks;
+  uint32_t reserved;
+  uint64_t num_commands;
+  BrotliAmdResume resume; // last completed metablock boundary
+} BrotliAmdStreamStatus;
+
+#ifdef __cplusplus
+}
+#endif

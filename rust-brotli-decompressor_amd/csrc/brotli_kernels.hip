@@ -1,0 +1,1245 @@
+// brotli_kernels.hip -- the Brotli decode hot path as hand-written HIP for gfx950 (MI355X / CDNA4).
+//
+// What this replaces in the reference (paths relative to /root/reference):
+//   src/decode.rs:2330-2744   ProcessCommandsInternal (command loop)          -> process_commands()
+//   src/decode.rs:378-500     DecodeSymbol / ReadSymbol                       -> read_symbol()
+//   src/decode.rs:2017-2189   distance / command readers                      -> inline in process_commands()
+//   src/decode.rs:1469-1524   block switches                                  -> block_switch()
+//   src/decode.rs:1754-1806   CopyUncompressedBlockToOutput                   -> copy_uncompressed()
+//   src/bit_reader/mod.rs     64-bit window + BrotliFillBitWindow             -> struct BitReader (coalesced 256-B chunks)
+//   src/huffman/mod.rs        table builders                                  -> build_tree() (lane-parallel)
+//   src/transform.rs:720-795  TransformDictionaryWord                          -> emit_dictionary_word()
+//   src/decode.rs:152-372, 516-1465, 2921-3288  stream/metablock headers       -> decode_stream() (must run on device:
+//                             a metablock's compressed extent is only known after decoding it)
+//
+// Execution model (v1): ONE WAVEFRONT PER STREAM, fully fused.  The entropy decode of a Brotli stream is a
+// serial dependent chain, so all 64 lanes of the wave execute it uniformly (values live in SGPRs; table
+// entries come back from LDS through v_readfirstlane) and the lanes are used for everything that is data
+// parallel inside one stream:
+//   * input: each lane keeps one dword of a 256-byte window of the compressed stream in a VGPR (two windows,
+//     double buffered, loaded with one coalesced global_load per 256 B); the 64-bit bit buffer is refilled with
+//     v_readlane -- no memory latency on the serial chain;
+//   * small LUTs (insert/copy code ranges, block-length code, the 32-entry code-length code) live one entry
+//     per lane in VGPRs and are indexed with v_readlane;
+//   * Huffman tables are built lane-parallel (ballot counting sort + parallel replicate) into an LDS arena;
+//     objects that do not fit the LDS arena spill to a per-block global scratch area (never straddling);
+//   * LZ77 copies, dictionary words and stored metablocks are moved by all 64 lanes, 64 bytes per step,
+//     overlapping copies as pattern fills (out[pos+k] = out[pos-dist + k mod dist]).
+// Blocks are persistent: each pulls stream indices from an atomic queue until the batch is empty.
+//
+// Roofline that bounds it: HBM traffic is (compressed bytes read + decompressed bytes written); there is no
+// dense contraction, MFMA is not used.  See DESIGN.md.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "brotli_device_abi.h"
+#define BROTLI_TABLE_QUAL __constant__ const
+#include "brotli_tables_gen.h"
+
+namespace {
+
+// ---- result / error codes (src/state.rs:22-65) ----
+constexpr int E_SUCCESS = 1, E_NEEDS_MORE_INPUT = 2, E_NEEDS_MORE_OUTPUT = 3;
+constexpr int E_EXUBERANT_NIBBLE = -1, E_RESERVED = -2, E_EXUBERANT_META_NIBBLE = -3, E_SIMPLE_HUFFMAN_ALPHABET = -4,
+              E_SIMPLE_HUFFMAN_SAME = -5, E_CL_SPACE = -6, E_HUFFMAN_SPACE = -7, E_CONTEXT_MAP_REPEAT = -8,
+              E_BLOCK_LENGTH_1 = -9, E_BLOCK_LENGTH_2 = -10, E_TRANSFORM = -11, E_DICTIONARY = -12, E_WINDOW_BITS = -13,
+              E_PADDING_2 = -15, E_DISTANCE = -16, E_UNREACHABLE = -31;
+
+// ---- small constant tables (RFC 7932 sections 3.5, 4, 5, 6) ----
+__constant__ const uint8_t kCodeLengthCodeOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+__constant__ const uint8_t kCodeLengthPrefixLength[16] = {2, 2, 2, 3, 2, 2, 2, 4, 2, 2, 2, 3, 2, 2, 2, 4};
+__constant__ const uint8_t kCodeLengthPrefixValue[16] = {0, 4, 3, 2, 0, 4, 3, 1, 0, 4, 3, 2, 0, 4, 3, 5};
+// per-lane LUT image: lanes 0..23 insert code (base | extra<<16), lanes 32..55 copy code, see lane_lut_init()
+__constant__ const uint16_t kInsBase[24] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 14, 18, 26, 34, 50, 66, 98, 130, 194, 322, 578, 1090, 2114, 6210, 22594};
+__constant__ const uint8_t kInsExtra[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
+__constant__ const uint16_t kCopyBase[24] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 18, 22, 30, 38, 54, 70, 102, 134, 198, 326, 582, 1094, 2118};
+__constant__ const uint8_t kCopyExtra[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
+__constant__ const uint16_t kBlockLenBase[26] = {1, 5, 9, 13, 17, 25, 33, 41, 49, 65, 81, 97, 113, 145, 177, 209, 241, 305, 369, 497, 753, 1265, 2289, 4337, 8433, 16625};
+__constant__ const uint8_t kBlockLenExtra[26] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 7, 8, 9, 10, 11, 12, 13, 24};
+// upper bound of a 2-level table (8-bit root, max code length 15) for an alphabet of 32*i symbols
+__constant__ const uint16_t kMaxTableSize[37] = {256, 402, 436, 468, 500, 534, 566, 598, 630, 662, 694, 726, 758, 790, 822, 854, 886, 920, 952,
+                                                  984, 1016, 1048, 1080, 1112, 1144, 1176, 1208, 1240, 1272, 1304, 1336, 1368, 1400, 1432,
+                                                  1464, 1496, 1528};
+
+constexpr int ROOT_BITS = 8;
+constexpr uint32_t MAX_ALPHABET = 1152;  // 16 + 120 + (62 << 4) = 1128 for large-window distance codes
+
+// ---- fixed LDS carve (bytes); the arena follows ----
+constexpr uint32_t LDS_CTX_LUT = 0;                         // 2048: literal context lookup (all 4 modes)
+constexpr uint32_t LDS_LENGTHS = LDS_CTX_LUT + 2048;        // 1152: code length per symbol while a tree is read
+constexpr uint32_t LDS_SUBDEPTH = LDS_LENGTHS + MAX_ALPHABET;  // 256: depth of the 2nd-level table under each 8-bit prefix
+constexpr uint32_t LDS_SUBBASE = LDS_SUBDEPTH + 256;        // 512: its base offset (u16)
+constexpr uint32_t LDS_LENINFO = LDS_SUBBASE + 512;         // 128: spare
+constexpr uint32_t LDS_WORD = LDS_LENINFO + 128;            // 128: dictionary word staging
+constexpr uint32_t LDS_MTF = LDS_WORD + 128;                // 256: inverse move-to-front list
+constexpr uint32_t LDS_FIXED = LDS_MTF + 256;               // = 4480, 16-byte aligned
+static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
+
+// All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
+// and every global access through address-space-1 pointers (global_load/global_store).  Generic pointers would
+// become FLAT instructions, and the hardware does not order a FLAT access to LDS against a DS access.
+extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
+typedef __attribute__((address_space(1))) uint8_t gu8;
+typedef __attribute__((address_space(1))) uint16_t gu16;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef __attribute__((address_space(1))) const uint8_t gcu8;
+typedef __attribute__((address_space(1))) const uint32_t gcu32;
+template <typename T, typename U>
+__device__ __forceinline__ T* as_global(U* p) { return (T*)(uintptr_t)p; }
+
+__device__ __forceinline__ uint32_t lds_ld8(uint32_t off) { return g_smem[off]; }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t off) { return *reinterpret_cast<const uint16_t*>(&g_smem[off]); }
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t off) { return *reinterpret_cast<const uint32_t*>(&g_smem[off]); }
+__device__ __forceinline__ void lds_st8(uint32_t off, uint32_t v) { g_smem[off] = (uint8_t)v; }
+__device__ __forceinline__ void lds_st16(uint32_t off, uint32_t v) { *reinterpret_cast<uint16_t*>(&g_smem[off]) = (uint16_t)v; }
+__device__ __forceinline__ void lds_st32(uint32_t off, uint32_t v) { *reinterpret_cast<uint32_t*>(&g_smem[off]) = v; }
+// LDS operations of one wave execute in order; this only stops the compiler from moving accesses across it
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mask_bits(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+__device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return n ? (__brev(v) >> (32 - n)) : 0; }
+
+// =========================================== bit reader ===========================================
+// Replaces src/bit_reader/mod.rs: same values, different mechanics.  The compressed stream is fetched in
+// 256-byte windows, one dword per lane, one coalesced load per window, the next window always in flight.
+struct BitReader {
+  gcu32* base;           // stream start rounded down to 4 bytes
+  uint32_t n_dw;         // dwords that contain stream bytes
+  uint32_t tail_mask;    // valid bytes of the last dword
+  uint32_t skip_bits;    // 8 * (stream start & 3)
+  uint64_t total_bits;   // 8 * in_size
+  uint32_t cur, nxt;     // per-lane dword of window [chunk_base, +64) and [chunk_base+64, +128)
+  uint32_t chunk_base;   // uniform
+  uint32_t next_dw;      // uniform: next dword to shift into buf
+  uint64_t buf;          // uniform
+  uint32_t cnt;          // uniform: valid bits in buf
+
+  __device__ __forceinline__ uint32_t load_window(uint32_t first) const {
+    uint32_t i = first + lane_id();
+    uint32_t v = 0;
+    if (i < n_dw) {
+      v = base[i];
+      if (i == n_dw - 1) v &= tail_mask;
+    }
+    return v;
+  }
+  __device__ void seek(uint64_t bit_pos) {
+    uint64_t abs = bit_pos + skip_bits;
+    uint32_t dw = (uint32_t)(abs >> 5);
+    chunk_base = dw;
+    cur = load_window(dw);
+    nxt = load_window(dw + 64);
+    next_dw = dw;
+    buf = 0; cnt = 0;
+    pull();
+    uint32_t r = (uint32_t)(abs & 31);
+    buf >>= r; cnt -= r;
+  }
+  __device__ __forceinline__ void pull() {  // shift one more dword in (cnt <= 32 on entry)
+    uint32_t idx = next_dw - chunk_base;
+    if (idx >= 64) {
+      cur = nxt;
+      chunk_base += 64;
+      nxt = load_window(chunk_base + 64);
+      idx -= 64;
+    }
+    uint32_t dw = rdlane(cur, idx);
+    buf |= (uint64_t)dw << cnt;
+    cnt += 32;
+    next_dw++;
+  }
+  __device__ __forceinline__ void need32() { if (cnt < 32) pull(); }
+  __device__ __forceinline__ uint32_t peek32() { need32(); return (uint32_t)buf; }
+  __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
+  __device__ __forceinline__ uint32_t read(uint32_t n) {  // n in 0..32
+    need32();
+    uint32_t v = (uint32_t)buf & mask_bits(n);
+    if (n == 32) { buf >>= 16; buf >>= 16; } else buf >>= n;
+    cnt -= n;
+    return v;
+  }
+  __device__ __forceinline__ uint64_t pos() const { return (uint64_t)next_dw * 32 - cnt - skip_bits; }
+  __device__ __forceinline__ bool over() const { return pos() > total_bits; }
+};
+
+// ============================================= arena =============================================
+// Per-metablock tables.  Offsets below lds_limit are LDS, the rest is this block's global scratch.
+struct Arena {
+  gu8* glb;            // this block's global scratch, addressed with the same offsets as the LDS part
+  uint32_t lds_limit;  // arena bytes that live in LDS (at g_smem + LDS_FIXED)
+  uint32_t top;
+
+  __device__ __forceinline__ uint32_t alloc(uint32_t max_bytes) {  // object never straddles the LDS/global split
+    uint32_t off = (top + 3u) & ~3u;
+    if (off < lds_limit && off + max_bytes > lds_limit) off = lds_limit;
+    top = off + max_bytes;
+    return off;
+  }
+  __device__ __forceinline__ void shrink_to(uint32_t off_end) { top = off_end; }
+  // uniform loads
+  __device__ __forceinline__ uint32_t ld16(uint32_t off) const {
+    uint32_t v;
+    if (off < lds_limit) v = lds_ld16(LDS_FIXED + off); else v = *reinterpret_cast<gu16*>(glb + off);
+    return rfl(v);
+  }
+  __device__ __forceinline__ uint32_t ld8(uint32_t off) const {
+    uint32_t v;
+    if (off < lds_limit) v = lds_ld8(LDS_FIXED + off); else v = glb[off];
+    return rfl(v);
+  }
+  __device__ __forceinline__ uint32_t ld32(uint32_t off) const {
+    uint32_t v;
+    if (off < lds_limit) v = lds_ld32(LDS_FIXED + off); else v = *reinterpret_cast<gu32*>(glb + off);
+    return rfl(v);
+  }
+  // per-lane accesses (every active lane uses its own offset)
+  __device__ __forceinline__ uint32_t ld8_lane(uint32_t off) const { return off < lds_limit ? lds_ld8(LDS_FIXED + off) : (uint32_t)glb[off]; }
+  __device__ __forceinline__ void st16_lane(uint32_t off, uint32_t v) const {
+    if (off < lds_limit) lds_st16(LDS_FIXED + off, v); else *reinterpret_cast<gu16*>(glb + off) = (uint16_t)v;
+  }
+  __device__ __forceinline__ void st8_lane(uint32_t off, uint32_t v) const {
+    if (off < lds_limit) lds_st8(LDS_FIXED + off, v); else glb[off] = (uint8_t)v;
+  }
+  // uniform stores (one lane)
+  __device__ __forceinline__ void st16(uint32_t off, uint32_t v) const { if (lane_id() == 0) st16_lane(off, v); }
+  __device__ __forceinline__ void st8(uint32_t off, uint32_t v) const { if (lane_id() == 0) st8_lane(off, v); }
+  __device__ __forceinline__ void st32(uint32_t off, uint32_t v) const {
+    if (lane_id() == 0) { if (off < lds_limit) lds_st32(LDS_FIXED + off, v); else *reinterpret_cast<gu32*>(glb + off) = v; }
+  }
+};
+
+// table entry: (value << 4) | len.  Root entry with len > 8: value = offset of the 2nd-level table from the
+// tree base (entries), len - 8 = its depth.  2nd-level entry: len = code length - 8.
+__device__ __forceinline__ uint32_t read_symbol(BitReader& br, const Arena& a, uint32_t tree) {
+  uint32_t bits = br.peek32();
+  uint32_t e = a.ld16(tree + ((bits & 0xFFu) << 1));
+  uint32_t len = e & 15u;
+  if (len > ROOT_BITS) {
+    uint32_t idx = (e >> 4) + ((bits >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
+    e = a.ld16(tree + (idx << 1));
+    len = ROOT_BITS + (e & 15u);
+  }
+  br.drop(len);
+  return e >> 4;
+}
+
+// ========================================== decoder state ==========================================
+// Everything one stream carries (reference: BrotliState, src/state.rs:156-278).  The object itself may live
+// in private memory (its address is handed to the one non-inlined helper); every function works on register
+// copies of the parts it touches and stores them back on exit.
+struct Stream {
+  BitReader br;
+  Arena ar;
+  gu8* out;
+  uint64_t out_cap;
+  uint64_t P;              // bytes produced
+  uint64_t next_boundary;  // next ring-buffer flush point (multiple of rb_size); 0 = ring not allocated
+  uint64_t rb_size;
+  gcu8* dict;
+  gcu8* in_bytes;
+  uint32_t flags;
+  uint32_t window_bits, large_window;
+  int32_t max_backward;
+  int32_t dist_rb0, dist_rb1, dist_rb2, dist_rb3;
+  int32_t dist_rb_idx;
+  // metablock
+  uint32_t is_last, is_uncompressed, is_metadata;
+  int32_t mlen;
+  uint32_t nbt0, nbt1, nbt2;           // number of block types per category
+  uint32_t bl0, bl1, bl2;              // remaining block length per category
+  uint32_t bt_tree0, bt_tree1, bt_tree2, bl_tree0, bl_tree1, bl_tree2;  // arena offsets of block-type / block-length trees
+  uint32_t postfix_bits, num_direct;
+  uint32_t ctx_modes, ctx_map, dist_ctx_map;          // arena offsets
+  uint32_t lit_trees, cmd_trees, dist_trees;          // arena offsets of u32 arrays of tree offsets
+  uint32_t num_lit_trees, num_dist_trees;
+  uint32_t lut_vgpr;       // per-lane: insert/copy code LUT image
+  uint32_t bl_vgpr;        // per-lane: block length code LUT image
+  uint32_t num_metablocks;
+  uint64_t num_commands;
+};
+
+#ifdef BROTLI_AMD_TRACE
+#define TRACE_STOP(br, e) do { if (lane_id() == 0) printf("stop line %d e=%d pos=%llu total=%llu\n", __LINE__, (int)(e), (unsigned long long)(br).pos(), (unsigned long long)(br).total_bits); } while (0)
+#else
+#define TRACE_STOP(br, e) do { } while (0)
+#endif
+#define TRY(x) do { int _e = (x); if (_e != E_SUCCESS) return _e; } while (0)
+#define NEED_INPUT(br) do { if ((br).over()) { TRACE_STOP(br, E_NEEDS_MORE_INPUT); return E_NEEDS_MORE_INPUT; } } while (0)
+#define FAIL(br, e) do { TRACE_STOP(br, e); return (e); } while (0)
+
+// ======================================= Huffman table build =======================================
+// Lane-parallel construction of the 2-level table from LDS_LENGTHS[sym] (code length per symbol, 0 = unused).
+// Canonical code = first_code[len] + rank of the symbol among the symbols of that length (rank from ballots
+// over 64 symbols at a time).  Returns the table size in entries; the table is written at arena offset `tree`.
+// Same codes as src/huffman/mod.rs:273-386, different (documented) entry layout.
+struct CodeOfLane { uint32_t len, code; };
+template <int LMIN>
+__device__ __forceinline__ CodeOfLane lane_code(uint32_t L, const uint32_t (&first_code)[16], uint32_t (&run)[16]) {
+  const uint64_t lt = (1ull << lane_id()) - 1ull;
+  CodeOfLane r; r.len = L; r.code = 0;
+#pragma unroll
+  for (int l = LMIN; l < 16; l++) {
+    uint64_t m = __ballot(L == (uint32_t)l);
+    if (L == (uint32_t)l) r.code = first_code[l] + run[l] + (uint32_t)__popcll(m & lt);
+    run[l] += (uint32_t)__popcll(m);
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint32_t build_tree(const Arena& a, uint32_t tree, uint32_t n_sym) {
+  const uint32_t lane = lane_id();
+  // 1. histogram of code lengths (uniform, via ballots) and first code per length
+  uint32_t cnt[16], first_code[16], run[16];
+#pragma unroll
+  for (int l = 0; l < 16; l++) { cnt[l] = 0; run[l] = 0; first_code[l] = 0; }
+  for (uint32_t b = 0; b < n_sym; b += 64) {
+    uint32_t sym = b + lane;
+    uint32_t L = sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0;
+#pragma unroll
+    for (int l = 1; l < 16; l++) cnt[l] += (uint32_t)__popcll(__ballot(L == (uint32_t)l));
+  }
+  uint32_t max_len = 0;
+  {
+    uint32_t code = 0;
+#pragma unroll
+    for (int l = 1; l < 16; l++) {
+      first_code[l] = code;
+      code = (code + cnt[l]) << 1;
+      if (cnt[l]) max_len = l;
+    }
+  }
+  const bool two_level = max_len > ROOT_BITS;
+  if (two_level) {
+    for (uint32_t i = lane; i < 256; i += 64) lds_st8(LDS_SUBDEPTH + i, 0);
+    lds_sync();
+  }
+  // 2. pass A: codes of <= 8 bits fill the root (replicated); longer codes record the depth their
+  //    8-bit prefix needs (byte-wise max through compare-and-swap on the containing LDS dword)
+  for (uint32_t b = 0; b < n_sym; b += 64) {
+    uint32_t sym = b + lane;
+    CodeOfLane c = lane_code<1>(sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0, first_code, run);
+    if (c.len != 0) {
+      if (c.len <= ROOT_BITS) {
+        uint32_t e = (sym << 4) | c.len;
+        for (uint32_t j = rev_bits(c.code, c.len); j < 256; j += (1u << c.len)) a.st16_lane(tree + (j << 1), e);
+      } else {
+        uint32_t d = c.len - ROOT_BITS;
+        uint32_t p = c.code >> d;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&g_smem[LDS_SUBDEPTH + (p & ~3u)]);
+        uint32_t sh = (p & 3u) * 8;
+        uint32_t old = *w;
+        while (((old >> sh) & 0xFFu) < d) {
+          uint32_t prev = atomicCAS(w, old, (old & ~(0xFFu << sh)) | (d << sh));
+          if (prev == old) break;
+          old = prev;
+        }
+      }
+    }
+  }
+  uint32_t total = 256;
+  if (two_level) {
+    lds_sync();
+    // 3. 2nd-level bases: exclusive prefix sum of 2^depth over the 256 prefixes (4 per lane, in code order)
+    uint32_t dd = lds_ld32(LDS_SUBDEPTH + lane * 4);
+    uint32_t d0 = dd & 0xFF, d1 = (dd >> 8) & 0xFF, d2 = (dd >> 16) & 0xFF, d3 = dd >> 24;
+    uint32_t s0 = d0 ? (1u << d0) : 0, s1 = d1 ? (1u << d1) : 0, s2 = d2 ? (1u << d2) : 0, s3 = d3 ? (1u << d3) : 0;
+    uint32_t mine = s0 + s1 + s2 + s3;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= (uint32_t)off) incl += t;
+    }
+    total = 256 + rdlane(incl, 63);
+    uint32_t b0 = 256 + incl - mine, b1 = b0 + s0, b2 = b1 + s1, b3 = b2 + s2;
+    lds_st16(LDS_SUBBASE + lane * 8 + 0, b0); lds_st16(LDS_SUBBASE + lane * 8 + 2, b1);
+    lds_st16(LDS_SUBBASE + lane * 8 + 4, b2); lds_st16(LDS_SUBBASE + lane * 8 + 6, b3);
+    // root entries that point down
+    if (d0) a.st16_lane(tree + (rev_bits(lane * 4 + 0, 8) << 1), (b0 << 4) | (ROOT_BITS + d0));
+    if (d1) a.st16_lane(tree + (rev_bits(lane * 4 + 1, 8) << 1), (b1 << 4) | (ROOT_BITS + d1));
+    if (d2) a.st16_lane(tree + (rev_bits(lane * 4 + 2, 8) << 1), (b2 << 4) | (ROOT_BITS + d2));
+    if (d3) a.st16_lane(tree + (rev_bits(lane * 4 + 3, 8) << 1), (b3 << 4) | (ROOT_BITS + d3));
+    lds_sync();
+    // 4. pass B: fill the 2nd-level tables
+#pragma unroll
+    for (int l = 0; l < 16; l++) run[l] = 0;
+    for (uint32_t b = 0; b < n_sym; b += 64) {
+      uint32_t sym = b + lane;
+      CodeOfLane c = lane_code<ROOT_BITS + 1>(sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0, first_code, run);
+      if (c.len > ROOT_BITS) {
+        uint32_t sl = c.len - ROOT_BITS;
+        uint32_t p = c.code >> sl;
+        uint32_t base = lds_ld16(LDS_SUBBASE + p * 2), depth = lds_ld8(LDS_SUBDEPTH + p);
+        uint32_t e = (sym << 4) | sl;
+        for (uint32_t j = rev_bits(c.code & mask_bits(sl), sl); j < (1u << depth); j += (1u << sl))
+          a.st16_lane(tree + ((base + j) << 1), e);
+      }
+    }
+  }
+  lds_sync();
+  return total;
+}
+
+__device__ __forceinline__ uint32_t max_table_entries(uint32_t alphabet) {
+  uint32_t i = (alphabet + 31) >> 5;
+  return kMaxTableSize[i > 36 ? 36 : i];
+}
+
+__device__ __forceinline__ uint32_t log2floor_plus1(uint32_t x) { return x ? 32u - (uint32_t)__clz(x) : 0u; }
+
+// src/decode.rs:868-1013.  Reads one prefix code, builds its table at a fresh arena allocation, returns the
+// arena offset in *tree_off.  The one helper that is a real function call (7 call sites, cold).
+__device__ __noinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off) {
+  struct Scope {  // register copies of the reader and the arena, stored back on every exit
+    Stream& s; BitReader br; Arena ar;
+    __device__ __forceinline__ Scope(Stream& s_) : s(s_), br(s_.br), ar(s_.ar) {}
+    __device__ __forceinline__ ~Scope() { s.br = br; s.ar = ar; }
+  } sc(s);
+  BitReader& br = sc.br;
+  Arena& ar = sc.ar;
+  const uint32_t lane = lane_id();
+  alphabet_size &= 0x7ffu;
+  uint32_t max_entries = max_table_entries(alphabet_size);
+  uint32_t tree = ar.alloc(max_entries * 2);
+  *tree_off = tree;
+  uint32_t hskip = br.read(2); NEED_INPUT(br);
+  for (uint32_t i = lane; i < MAX_ALPHABET; i += 64) lds_st8(LDS_LENGTHS + i, 0);
+  lds_sync();
+  uint32_t size;
+  if (hskip == 1) {
+    uint32_t nsym = br.read(2); NEED_INPUT(br);
+    uint32_t max_bits = log2floor_plus1(alphabet_size - 1);
+    uint32_t sy0 = 0, sy1 = 0, sy2 = 0, sy3 = 0;
+    for (uint32_t i = 0; i <= nsym; i++) {
+      uint32_t v = br.read(max_bits); NEED_INPUT(br);
+      if (v >= max_symbol) FAIL(br, E_SIMPLE_HUFFMAN_ALPHABET);
+      if (i == 0) sy0 = v; else if (i == 1) sy1 = v; else if (i == 2) sy2 = v; else sy3 = v;
+    }
+    if (nsym >= 1 && sy0 == sy1) FAIL(br, E_SIMPLE_HUFFMAN_SAME);
+    if (nsym >= 2 && (sy0 == sy2 || sy1 == sy2)) FAIL(br, E_SIMPLE_HUFFMAN_SAME);
+    if (nsym >= 3 && (sy0 == sy3 || sy1 == sy3 || sy2 == sy3)) FAIL(br, E_SIMPLE_HUFFMAN_SAME);
+    if (nsym == 3) { nsym += br.read(1); NEED_INPUT(br); }
+    if (nsym == 0) {  // single symbol, zero-length code
+      for (uint32_t j = lane; j < 256; j += 64) ar.st16_lane(tree + (j << 1), sy0 << 4);
+      lds_sync();
+      size = 256;
+    } else {
+      if (lane == 0) {
+        if (nsym == 1) { lds_st8(LDS_LENGTHS + sy0, 1); lds_st8(LDS_LENGTHS + sy1, 1); }
+        else if (nsym == 2) { lds_st8(LDS_LENGTHS + sy0, 1); lds_st8(LDS_LENGTHS + sy1, 2); lds_st8(LDS_LENGTHS + sy2, 2); }
+        else if (nsym == 3) { lds_st8(LDS_LENGTHS + sy0, 2); lds_st8(LDS_LENGTHS + sy1, 2); lds_st8(LDS_LENGTHS + sy2, 2); lds_st8(LDS_LENGTHS + sy3, 2); }
+        else { lds_st8(LDS_LENGTHS + sy0, 1); lds_st8(LDS_LENGTHS + sy1, 2); lds_st8(LDS_LENGTHS + sy2, 3); lds_st8(LDS_LENGTHS + sy3, 3); }
+      }
+      lds_sync();
+      size = build_tree(ar, tree, alphabet_size);
+    }
+  } else {
+    // code-length code (decode.rs:801-853): 18 lengths of 0..5 bits, kept one per lane (lane = symbol)
+    uint32_t cl_vgpr = 0;  // lane i: length of code-length symbol i
+    uint32_t space = 32, num_codes = 0;
+    for (uint32_t i = hskip; i < 18; i++) {
+      uint32_t ix = br.peek32() & 0xFu;
+      br.drop(kCodeLengthPrefixLength[ix]); NEED_INPUT(br);
+      uint32_t v = kCodeLengthPrefixValue[ix];
+      if (lane == kCodeLengthCodeOrder[i]) cl_vgpr = v;
+      if (v != 0) {
+        space -= (32u >> v); num_codes++;
+        if (space - 1u >= 32u) break;
+      }
+    }
+    if (!(num_codes == 1 || space == 0)) FAIL(br, E_CL_SPACE);
+    // 32-entry lookup for the code-length code, one entry per lane: (symbol << 4) | bits  (huffman/mod.rs:196-271)
+    uint32_t cl_table;
+    {
+      uint32_t L = lane < 18 ? cl_vgpr : 0;
+      if (num_codes == 1) {
+        uint64_t m = __ballot(L != 0);
+        cl_table = ((uint32_t)__ffsll((long long)m) - 1u) << 4;  // zero-length code
+      } else {
+        uint32_t code = 0, my_code = 0;
+#pragma unroll
+        for (int l = 1; l <= 5; l++) {
+          uint64_t m = __ballot(L == (uint32_t)l);
+          if (L == (uint32_t)l) my_code = code + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          code = (code + (uint32_t)__popcll(m)) << 1;
+        }
+        cl_table = 0;
+        for (uint32_t sy = 0; sy < 18; sy++) {
+          uint32_t sl = rdlane(L, sy);
+          if (sl == 0) continue;
+          uint32_t rc = rev_bits(rdlane(my_code, sy), sl);
+          if ((lane & mask_bits(sl)) == rc) cl_table = (sy << 4) | sl;
+        }
+      }
+    }
+    // symbol code lengths (decode.rs:661-797, 558-658)
+    uint32_t symbol = 0, prev_code_len = 8, repeat = 0, repeat_code_len = 0;
+    space = 32768;
+    while (symbol < max_symbol && space > 0) {
+      uint32_t p = rdlane(cl_table, br.peek32() & 31u);
+      uint32_t code_len = p >> 4;
+      br.drop(p & 15u);
+      if (code_len < 16) {
+        NEED_INPUT(br);
+        repeat = 0;
+        if (code_len != 0) {
+          if (lane == 0) lds_st8(LDS_LENGTHS + symbol, code_len);
+          prev_code_len = code_len;
+          space -= (32768u >> code_len);
+        }
+        symbol++;
+      } else {
+        uint32_t extra = code_len - 14;
+        uint32_t repeat_delta = br.read(extra); NEED_INPUT(br);
+        uint32_t new_len = (code_len == 16) ? prev_code_len : 0;
+        if (repeat_code_len != new_len) { repeat = 0; repeat_code_len = new_len; }
+        uint32_t old_repeat = repeat;
+        if (repeat > 0) { repeat -= 2; repeat <<= extra; }
+        repeat += repeat_delta + 3;
+        repeat_delta = repeat - old_repeat;
+        if (symbol + repeat_delta > max_symbol) { symbol = max_symbol; space = 0xFFFFF; continue; }
+        if (repeat_code_len != 0) {
+          for (uint32_t k = lane; k < repeat_delta; k += 64) lds_st8(LDS_LENGTHS + symbol + k, repeat_code_len);
+          space -= (repeat_delta << (15 - repeat_code_len));
+        }
+        symbol += repeat_delta;
+      }
+    }
+    if (space != 0) FAIL(br, E_HUFFMAN_SPACE);
+    lds_sync();
+    size = build_tree(ar, tree, max_symbol);
+  }
+  ar.shrink_to(tree + size * 2);
+  return E_SUCCESS;
+}
+
+// Working copy of the bit reader for inlined cold code: lives in registers between the helper calls that
+// go through the Stream object in memory.
+struct ColdScope {
+  Stream& s; BitReader br;
+  __device__ __forceinline__ ColdScope(Stream& s_) : s(s_), br(s_.br) {}
+  __device__ __forceinline__ ~ColdScope() { s.br = br; }
+  __device__ __forceinline__ int huffman(uint32_t alphabet, uint32_t max_symbol, uint32_t* tree) {
+    s.br = br;
+    int e = read_huffman_code(s, alphabet, max_symbol, tree);
+    br = s.br;
+    return e;
+  }
+};
+
+// decode.rs:193-241
+__device__ __forceinline__ int decode_varlen_uint8(BitReader& br, uint32_t* value) {
+  uint32_t b = br.read(1); NEED_INPUT(br);
+  if (!b) { *value = 0; return E_SUCCESS; }
+  uint32_t n = br.read(3); NEED_INPUT(br);
+  if (!n) { *value = 1; return E_SUCCESS; }
+  uint32_t v = br.read(n); NEED_INPUT(br);
+  *value = (1u << n) + v;
+  return E_SUCCESS;
+}
+
+// decode.rs:243-372
+__device__ __forceinline__ int decode_metablock_length(BitReader& br, Stream& s) {
+  uint32_t is_last = br.read(1); NEED_INPUT(br);
+  int32_t mlen = 0;
+  s.is_last = is_last; s.mlen = 0; s.is_uncompressed = 0; s.is_metadata = 0;
+  if (is_last) {
+    uint32_t empty = br.read(1); NEED_INPUT(br);
+    if (empty) return E_SUCCESS;
+  }
+  uint32_t nib = br.read(2); NEED_INPUT(br);
+  bool is_metadata = false;
+  if (nib == 3) {
+    is_metadata = true;
+    s.is_metadata = 1;
+    uint32_t reserved = br.read(1); NEED_INPUT(br);
+    if (reserved) return E_RESERVED;
+    uint32_t nbytes = br.read(2); NEED_INPUT(br);
+    if (nbytes == 0) return E_SUCCESS;
+    for (uint32_t i = 0; i < nbytes; i++) {
+      uint32_t b = br.read(8); NEED_INPUT(br);
+      if (i + 1 == nbytes && nbytes > 1 && b == 0) return E_EXUBERANT_META_NIBBLE;
+      mlen |= (int32_t)(b << (i * 8));
+    }
+  } else {
+    uint32_t size_nibbles = nib + 4;
+    for (uint32_t i = 0; i < size_nibbles; i++) {
+      uint32_t b = br.read(4); NEED_INPUT(br);
+      if (i + 1 == size_nibbles && size_nibbles > 4 && b == 0) return E_EXUBERANT_NIBBLE;
+      mlen |= (int32_t)(b << (i * 4));
+    }
+  }
+  if (!is_last && !is_metadata) { s.is_uncompressed = br.read(1); NEED_INPUT(br); }
+  s.mlen = mlen + 1;
+  return E_SUCCESS;
+}
+
+__device__ __forceinline__ bool jump_to_byte_boundary(BitReader& br) {  // bit_reader/mod.rs:378-385
+  uint32_t pad = (uint32_t)((8u - (uint32_t)(br.pos() & 7u)) & 7u);
+  return br.read(pad) == 0;
+}
+
+// decode.rs:1016-1026: block length = base[code] + extra bits
+__device__ __forceinline__ uint32_t read_block_length(BitReader& br, const Arena& ar, uint32_t bl_vgpr, uint32_t tree) {
+  uint32_t code = read_symbol(br, ar, tree);
+  uint32_t e = rdlane(bl_vgpr, code);
+  return (e & 0xFFFFu) + br.read(e >> 16);
+}
+
+// decode.rs:1469-1524.  0 = single block type, 1 = switched, 2 = needs more input
+enum { BS_SINGLE_TYPE = 0, BS_SWITCHED = 1, BS_NEEDS_INPUT = 2 };
+__device__ __forceinline__ int block_switch(BitReader& br, const Arena& ar, uint32_t bl_vgpr, uint32_t bt_tree, uint32_t bl_tree, uint32_t nbt,
+                                            uint32_t& block_len, uint32_t& t0, uint32_t& t1) {
+  if (nbt <= 1) return BS_SINGLE_TYPE;
+  uint32_t block_type = read_symbol(br, ar, bt_tree);
+  uint32_t len = read_block_length(br, ar, bl_vgpr, bl_tree);
+  if (br.over()) return BS_NEEDS_INPUT;
+  block_len = len;
+  if (block_type == 1) block_type = t1 + 1;
+  else if (block_type == 0) block_type = t0;
+  else block_type -= 2;
+  if (block_type >= nbt) block_type -= nbt;
+  t0 = t1; t1 = block_type;
+  return BS_SWITCHED;
+}
+
+// decode.rs:1272-1428.  The map is written to the arena; *num_trees gets NTREES.
+__device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint32_t* num_trees, uint32_t* map_off) {
+  ColdScope c(s);
+  BitReader& br = c.br;
+  const uint32_t lane = lane_id();
+  uint32_t n;
+  TRY(decode_varlen_uint8(br, &n));
+  n += 1; *num_trees = n;
+  uint32_t map = s.ar.alloc(size);
+  *map_off = map;
+  { const Arena ar = s.ar; for (uint32_t i = lane; i < size; i += 64) ar.st8_lane(map + i, 0); }
+  lds_sync();
+  if (n <= 1) return E_SUCCESS;
+  if (br.pos() + 5 > br.total_bits) return E_NEEDS_MORE_INPUT;  // SafeGetBits(5), decode.rs:1311
+  uint32_t bits = br.peek32() & 31u;
+  uint32_t max_rle;
+  if (bits & 1u) { max_rle = (bits >> 1) + 1; br.drop(5); } else { max_rle = 0; br.drop(1); }
+  uint32_t saved_top = s.ar.top, tree;
+  TRY(c.huffman(n + max_rle, n + max_rle, &tree));
+  const Arena ar = s.ar;
+  uint32_t i = 0;
+  while (i < size) {
+    uint32_t code = read_symbol(br, ar, tree); NEED_INPUT(br);
+    if (code == 0) { i++; continue; }
+    if (code > max_rle) { ar.st8(map + i, code - max_rle); i++; continue; }
+    uint32_t reps = br.read(code); NEED_INPUT(br);
+    reps += 1u << code;
+    if (i + reps > size) return E_CONTEXT_MAP_REPEAT;
+    i += reps;
+  }
+  uint32_t imtf = br.read(1); NEED_INPUT(br);
+  lds_sync();
+  if (imtf) {  // decode.rs:1096-1128; serial over the map, the move itself uses the lanes
+    for (uint32_t k = lane; k < 256; k += 64) lds_st8(LDS_MTF + k, k);
+    lds_sync();
+    for (uint32_t k = 0; k < size; k++) {
+      uint32_t idx = ar.ld8(map + k);
+      if (idx == 0) { ar.st8(map + k, rfl(lds_ld8(LDS_MTF))); lds_sync(); continue; }
+      uint32_t val = rfl(lds_ld8(LDS_MTF + idx));
+      // mtf[1..idx] = mtf[0..idx-1]: 64 entries per step, top chunk first, reads of a step before its writes
+      for (int b = (int)((idx - 1) & ~63u); b >= 0; b -= 64) {
+        uint32_t j = (uint32_t)b + lane;
+        uint32_t t = j < idx ? lds_ld8(LDS_MTF + j) : 0;
+        lds_sync();
+        if (j < idx) lds_st8(LDS_MTF + j + 1, t);
+        lds_sync();
+      }
+      if (lane == 0) lds_st8(LDS_MTF, val);
+      ar.st8(map + k, val);
+      lds_sync();
+    }
+  }
+  // the context-map prefix code is dead now; give its arena space back
+  if (tree >= saved_top) s.ar.top = saved_top;
+  return E_SUCCESS;
+}
+
+// decode.rs:1130-1219: `ntrees` prefix codes; their arena offsets go to a u32 array
+__device__ __forceinline__ int decode_tree_group(Stream& s, uint32_t alphabet, uint32_t max_symbol, uint32_t ntrees, uint32_t* group_off) {
+  uint32_t g = s.ar.alloc(ntrees * 4);
+  *group_off = g;
+  for (uint32_t t = 0; t < ntrees; t++) {
+    uint32_t tree;
+    TRY(read_huffman_code(s, alphabet, max_symbol, &tree));
+    s.ar.st32(g + t * 4, tree);
+  }
+  lds_sync();
+  return E_SUCCESS;
+}
+
+// decode.rs:2766-2777
+__device__ __forceinline__ uint32_t max_distance_symbol(uint32_t ndirect, uint32_t npostfix) {
+  uint32_t postfix = 1u << npostfix;
+  uint32_t b = npostfix == 0 ? 0u : npostfix == 1 ? 4u : npostfix == 2 ? 12u : 28u;
+  uint32_t d = npostfix == 0 ? 73u : npostfix == 1 ? 126u : npostfix == 2 ? 228u : 424u;
+  if (ndirect < b) return ndirect + d + postfix;
+  if (ndirect > b + postfix) return ndirect + d;
+  return b + d + postfix;
+}
+
+// ============================== output: literals, copies, dictionary words ==============================
+// out[P .. P+len) = out[P-dist .. ) with LZ77 semantics (decode.rs:2641-2720).  All 64 lanes move bytes.
+// Leaves the last two bytes in p1/p2 (read back from the lanes with v_readlane, no memory round trip).
+__device__ __forceinline__ void lz77_copy(gu8* dst, uint32_t dist, uint32_t len, uint32_t& p1, uint32_t& p2) {
+  const uint32_t lane = lane_id();
+  uint32_t last = 0, prev = 0;  // bytes of the last two 64-byte steps, per lane
+  if (dist >= 64 || dist >= len) {
+    // a 64-byte step never reads what it writes itself; a later step may read an earlier step's bytes
+    // (dist < len), which the in-order vector memory pipeline of one wave allows
+    gu8* src = dst - dist;
+    for (uint32_t k = 0; k < len; k += 64) {
+      uint32_t i = k + lane;
+      uint32_t b = 0;
+      if (i < len) { b = src[i]; dst[i] = (uint8_t)b; }
+      prev = last; last = b;
+    }
+  } else {
+    // overlapping copy with a short period: pattern fill from the `dist` bytes before P
+    gu8* pat = dst - dist;
+    uint32_t m = lane % dist;
+    uint32_t step = 64 % dist;
+    for (uint32_t k = 0; k < len; k += 64) {
+      uint32_t i = k + lane;
+      uint32_t b = 0;
+      if (i < len) { b = pat[m]; dst[i] = (uint8_t)b; }
+      m += step; if (m >= dist) m -= dist;
+      prev = last; last = b;
+    }
+  }
+  uint32_t k1 = len - 1, k2 = len - 2;  // len >= 2
+  p1 = rdlane(last, k1 & 63u);
+  p2 = ((k2 >> 6) == (k1 >> 6)) ? rdlane(last, k2 & 63u) : rdlane(prev, k2 & 63u);
+}
+
+// decode.rs:2593-2640 + transform.rs:737-795.  Writes the (transformed) word at dst (at most `room` bytes),
+// returns its length; p1/p2 = its last two bytes when it has that many.
+__device__ __forceinline__ uint32_t emit_dictionary_word(gcu8* dict, gu8* dst, uint32_t offset, uint32_t len, uint32_t transform_idx,
+                                                         uint64_t room, uint32_t& p1, uint32_t& p2) {
+  const uint32_t lane = lane_id();
+  uint32_t pre = kTransforms[transform_idx * 3], t = kTransforms[transform_idx * 3 + 1], suf = kTransforms[transform_idx * 3 + 2];
+  uint32_t plen = 0; while (kAffixPool[pre + plen]) plen++;
+  uint32_t slen = 0; while (kAffixPool[suf + slen]) slen++;
+  uint32_t skip = t < 12 ? 0 : t - 11;
+  if (skip > len) skip = len;
+  int32_t wl = (int32_t)(len - skip);
+  if (t <= 9) wl -= (int32_t)t;
+  uint32_t wlen = wl > 0 ? (uint32_t)wl : 0;
+  // stage prefix + word in LDS (bytes after the word are zero so that a stray uppercase write is harmless)
+  uint32_t b = 0;
+  if (lane < plen) b = kAffixPool[pre + lane];
+  else if (lane < plen + wlen) b = dict[offset + skip + (lane - plen)];
+  lds_st8(LDS_WORD + lane, b);
+  lds_st8(LDS_WORD + 64 + lane, 0);
+  lds_sync();
+  if (t == 10 || t == 11) {  // transform.rs:720-735 -- serial over UTF-8 sequences
+    if (lane == 0) {
+      uint32_t p = LDS_WORD + plen;
+      int32_t remaining = (t == 10) ? 1 : (int32_t)wlen;
+      while (remaining > 0) {
+        int step;
+        uint32_t c0 = lds_ld8(p);
+        if (c0 < 0xc0) { if (c0 >= 'a' && c0 <= 'z') lds_st8(p, c0 ^ 32); step = 1; }
+        else if (c0 < 0xe0) { lds_st8(p + 1, lds_ld8(p + 1) ^ 32); step = 2; }
+        else { lds_st8(p + 2, lds_ld8(p + 2) ^ 5); step = 3; }
+        p += step; remaining -= step;
+        if (t == 10) break;
+      }
+    }
+    lds_sync();
+  }
+  uint32_t total = plen + wlen + slen;
+  uint32_t ob;
+  if (lane >= plen + wlen && lane < total) ob = kAffixPool[suf + (lane - plen - wlen)];
+  else ob = lds_ld8(LDS_WORD + lane);
+  uint32_t n = total;
+  if ((uint64_t)n > room) n = (uint32_t)room;
+  if (lane < n) dst[lane] = (uint8_t)ob;
+  if (total >= 1) p1 = rdlane(ob, total - 1);
+  if (total >= 2) p2 = rdlane(ob, total - 2);
+  lds_sync();
+  return total;
+}
+
+// ===================================== the command loop (hot path) =====================================
+// src/decode.rs:2330-2744 with a flat output buffer.  Works entirely on register copies of the stream state
+// (SGPRs for everything uniform); the Stream object is read on entry and written on exit.
+__device__ __forceinline__ int process_commands(Stream& s) {
+  BitReader br = s.br;
+  const Arena a = s.ar;
+  const uint32_t lane = lane_id();
+  gu8* const out = s.out;
+  gcu8* const dict = s.dict;
+  const uint64_t out_cap = s.out_cap;
+  uint64_t P = s.P, next_boundary = s.next_boundary;
+  const uint64_t rb_size = s.rb_size;
+  const bool full_ring = rb_size == (1ull << s.window_bits);
+  int32_t mlen = s.mlen;
+  const int32_t max_backward = s.max_backward;
+  int32_t d0 = s.dist_rb0, d1 = s.dist_rb1, d2 = s.dist_rb2, d3 = s.dist_rb3, didx = s.dist_rb_idx;
+  uint32_t bl0 = s.bl0, bl1 = s.bl1, bl2 = s.bl2;
+  const uint32_t nbt0 = s.nbt0, nbt1 = s.nbt1, nbt2 = s.nbt2;
+  uint32_t rb_l0 = 1, rb_l1 = 0, rb_c0 = 1, rb_c1 = 0, rb_d0 = 1, rb_d1 = 0;  // block type rings (state.rs:429-435)
+  const uint32_t bt_tree0 = s.bt_tree0, bt_tree1 = s.bt_tree1, bt_tree2 = s.bt_tree2;
+  const uint32_t bl_tree0 = s.bl_tree0, bl_tree1 = s.bl_tree1, bl_tree2 = s.bl_tree2;
+  const uint32_t postfix_bits = s.postfix_bits, num_direct = s.num_direct;
+  const uint32_t ctx_modes = s.ctx_modes, ctx_map = s.ctx_map, dist_ctx_map = s.dist_ctx_map;
+  const uint32_t lit_trees = s.lit_trees, cmd_trees = s.cmd_trees, dist_trees = s.dist_trees;
+  const uint32_t lut_vgpr = s.lut_vgpr, bl_vgpr = s.bl_vgpr;
+  uint64_t num_commands = s.num_commands;
+  int result = E_SUCCESS;
+
+  auto dist_get = [&](int32_t i) -> int32_t { i &= 3; return i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3; };
+  auto dist_set = [&](int32_t i, int32_t v) { i &= 3; if (i == 0) d0 = v; else if (i == 1) d1 = v; else if (i == 2) d2 = v; else d3 = v; };
+
+  uint32_t cmd_tree = a.ld32(cmd_trees);
+  uint32_t dist_ctx_slice = 0, ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT;
+  // PrepareLiteralDecoding, decode.rs:1554-1570
+  auto prepare_literal = [&]() {
+    uint32_t bt = rb_l1;
+    ctx_slice = bt << 6;
+    // trivial <=> all 64 map entries of the block type are equal (DetectTrivialLiteralBlockTypes, 1525-1553)
+    uint32_t mine = a.ld8_lane(ctx_map + ctx_slice + lane);
+    uint32_t first = rdlane(mine, 0);
+    trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
+    lit_tree = a.ld32(lit_trees + first * 4);
+    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8(ctx_modes + bt) & 3u);
+  };
+  prepare_literal();
+  // last two output bytes (context of the next literal); stream start counts as two zero bytes (decode.rs:1859-1860)
+  uint32_t p1 = 0, p2 = 0;
+  if (P >= 1) p1 = rfl(out[P - 1]);
+  if (P >= 2) p2 = rfl(out[P - 2]);
+
+#define STOP(e) do { result = (e); goto done; } while (0)
+  // ring-buffer flush points (decode.rs:1693-1738, 3299-3344): crossing one with a negative remaining length is
+  // BLOCK_LENGTH_1; the last crossed one is what the caller has received when an error is reported
+#define RING_CROSS() do { while (P >= next_boundary) { if (mlen < 0) STOP(E_BLOCK_LENGTH_1); if (!full_ring) STOP(E_UNREACHABLE); next_boundary += rb_size; } } while (0)
+
+  for (;;) {
+    // ---- COMMAND_BEGIN ----
+    if (bl1 == 0) {
+      int r = block_switch(br, a, bl_vgpr, bt_tree1, bl_tree1, nbt1, bl1, rb_c0, rb_c1);
+      if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
+      if (r == BS_SWITCHED) { cmd_tree = a.ld32(cmd_trees + rb_c1 * 4); continue; }
+    }
+    uint32_t cmd = read_symbol(br, a, cmd_tree);
+    // kCmdLut regenerated arithmetically (RFC 7932 section 5; replaces src/prefix.rs:115-5755)
+    uint32_t cell = cmd >> 6;
+    uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
+    uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);         // {0,1,0,1,0,1,2,0,2,1,2}
+    uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
+    int32_t distance_code = cmd < 128 ? 0 : -1;
+    uint32_t distance_context = copy_code > 2 ? 3u : copy_code;
+    int32_t insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
+    int32_t copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
+    if (br.over()) STOP(E_NEEDS_MORE_INPUT);
+    bl1--;
+    num_commands++;
+
+    if (insert_len != 0) {
+      mlen -= insert_len;
+      // ---- COMMAND_INNER: literals ----
+      int32_t i = insert_len;
+      while (i > 0) {
+        if (bl0 == 0) {
+          int r = block_switch(br, a, bl_vgpr, bt_tree0, bl_tree0, nbt0, bl0, rb_l0, rb_l1);
+          if (r == BS_NEEDS_INPUT) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);
+          if (r == BS_SWITCHED) prepare_literal();
+        }
+        uint32_t tree = lit_tree;
+        if (!trivial) {
+          uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
+          tree = a.ld32(lit_trees + a.ld8(ctx_map + ctx_slice + context) * 4);
+        }
+        uint32_t lit = read_symbol(br, a, tree);
+        if (br.over()) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);  // decode.rs:2835-2846 + 1709-1711
+        if (P >= out_cap) STOP(E_NEEDS_MORE_OUTPUT);
+        p2 = p1; p1 = lit;
+        if (lane == 0) out[P] = (uint8_t)lit;
+        P++;
+        if (bl0 == 0) STOP(E_WINDOW_BITS);  // decode.rs:2434-2439
+        bl0--;
+        i--;
+        if (P >= next_boundary) RING_CROSS();
+      }
+      if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
+    }
+    // ---- COMMAND_POST_DECODE_LITERALS ----
+    if (distance_code >= 0) {
+      distance_context = 1;  // distance_code == 0 here
+      didx--;
+      distance_code = dist_get(didx);
+    } else {
+      if (bl2 == 0) {
+        int r = block_switch(br, a, bl_vgpr, bt_tree2, bl_tree2, nbt2, bl2, rb_d0, rb_d1);
+        if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
+        if (r == BS_SWITCHED) dist_ctx_slice = rb_d1 << 2;
+      }
+      uint32_t dist_tree_idx = a.ld8(dist_ctx_map + dist_ctx_slice + distance_context);
+      uint32_t dtree = a.ld32(dist_trees + dist_tree_idx * 4);
+      // ReadDistanceInternal, decode.rs:2066-2131
+      uint32_t code = read_symbol(br, a, dtree);
+      distance_context = 0;
+      if (code < 16) {
+        if (br.over()) STOP(E_NEEDS_MORE_INPUT);
+        // TakeDistanceFromRingBuffer, decode.rs:2017-2049
+        if (code == 0) {
+          didx--;
+          distance_code = dist_get(didx);
+          distance_context = 1;
+        } else {
+          uint32_t sh = code << 1;
+          int32_t v = dist_get(didx + (int32_t)((0xaaafff1bu >> sh) & 3u));
+          int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+          if (code & 1u) v += mag;
+          else { v -= mag; if (v <= 0) v = 0x7fffffff; }
+          distance_code = v;
+        }
+      } else {
+        int32_t distval = (int32_t)code - (int32_t)num_direct;
+        int32_t dc = (int32_t)code;
+        if (distval >= 0) {
+          int32_t postfix = distval & (int32_t)mask_bits(postfix_bits);
+          distval >>= postfix_bits;
+          uint32_t nbits = ((uint32_t)distval >> 1) + 1;
+          uint32_t bits = br.read(nbits);
+          int64_t offset = (int64_t)(int32_t)((((uint32_t)(distval & 1) + 2u) << nbits) - 4u);
+          dc = (int32_t)(((offset + (int64_t)bits) << postfix_bits) + postfix + (int64_t)num_direct);
+        }
+        if (br.over()) STOP(E_NEEDS_MORE_INPUT);
+        distance_code = (int32_t)((uint32_t)dc - 16u + 1u);
+      }
+      bl2--;
+    }
+    // postReadDistance, decode.rs:2583-2589
+    int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
+    if (distance_code > max_distance) {
+      if (distance_code > 0x7FFFFFFC) STOP(E_DISTANCE);
+      if (copy_len < 4 || copy_len > 24) STOP(E_DICTIONARY);
+      uint32_t shift = kDictSizeBitsByLength[copy_len];
+      int32_t word_id = distance_code - max_distance - 1;
+      uint32_t word_idx = (uint32_t)word_id & mask_bits(shift);
+      uint32_t transform_idx = (uint32_t)word_id >> shift;
+      didx += (int32_t)distance_context;
+      if (transform_idx >= BROTLI_NUM_TRANSFORMS) STOP(E_TRANSFORM);
+      uint32_t offset = kDictOffsetsByLength[copy_len] + word_idx * (uint32_t)copy_len;
+      uint64_t room = out_cap - P;
+      uint32_t q1 = p1, q2 = p2;
+      uint32_t out_len = emit_dictionary_word(dict, out + P, offset, (uint32_t)copy_len, transform_idx, room, q1, q2);
+      if ((uint64_t)out_len > room) { P = out_cap; STOP(E_NEEDS_MORE_OUTPUT); }
+      if (out_len >= 2) { p1 = q1; p2 = q2; } else if (out_len == 1) { p2 = p1; p1 = q1; }
+      P += out_len;
+      mlen -= (int32_t)out_len;
+    } else {
+      dist_set(didx, distance_code);
+      didx++;
+      mlen -= copy_len;
+      if (distance_code <= 0) STOP(E_UNREACHABLE);  // wrapped large-window arithmetic, never on valid streams
+      uint64_t room = out_cap - P;
+      uint32_t n = (uint32_t)copy_len;
+      bool clipped = (uint64_t)n > room;
+      if (clipped) n = (uint32_t)room;
+      if (n >= 2) lz77_copy(out + P, (uint32_t)distance_code, n, p1, p2);
+      else if (n == 1) { uint32_t b = rfl(out[P - (uint32_t)distance_code]); if (lane == 0) out[P] = (uint8_t)b; p2 = p1; p1 = b; }
+      P += n;
+      if (clipped) STOP(E_NEEDS_MORE_OUTPUT);
+    }
+    if (P >= next_boundary) RING_CROSS();
+    if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE
+  }
+#undef STOP
+#undef RING_CROSS
+done:
+  s.br = br;
+  s.P = P; s.next_boundary = next_boundary; s.mlen = mlen;
+  s.dist_rb0 = d0; s.dist_rb1 = d1; s.dist_rb2 = d2; s.dist_rb3 = d3; s.dist_rb_idx = didx;
+  s.num_commands = num_commands;
+  return result;
+}
+
+// decode.rs:1754-1806: stored metablock = byte-aligned memcpy of MLEN bytes, all lanes
+__device__ __forceinline__ int copy_uncompressed(Stream& s) {
+  BitReader br = s.br;
+  const uint32_t lane = lane_id();
+  uint64_t byte = br.pos() >> 3;
+  uint64_t in_size = br.total_bits >> 3;
+  uint64_t avail = in_size > byte ? in_size - byte : 0;
+  uint64_t n = (uint64_t)(uint32_t)s.mlen < avail ? (uint64_t)(uint32_t)s.mlen : avail;
+  uint64_t room = s.out_cap - s.P;
+  bool clipped = n > room;
+  if (clipped) n = room;
+  gcu8* src = s.in_bytes + byte;
+  gu8* dst = s.out + s.P;
+  for (uint64_t k = lane; k < n; k += 64) dst[k] = src[k];
+  s.P += n;
+  s.mlen -= (int32_t)n;
+  if (clipped) return E_NEEDS_MORE_OUTPUT;
+  // flush points inside the copy (ring wraps; a canny ring holds the whole block)
+  if (s.rb_size == (1ull << s.window_bits)) while (s.P >= s.next_boundary) s.next_boundary += s.rb_size;
+  br.seek((byte + n) * 8);
+  s.br = br;
+  if (s.mlen != 0) return E_NEEDS_MORE_INPUT;
+  return E_SUCCESS;
+}
+
+// ring buffer size chosen at the first non-empty data metablock (decode.rs:1808-1871)
+__device__ __forceinline__ void allocate_ring(Stream& s, const BitReader& br) {
+  uint32_t is_last = s.is_last;
+  uint64_t rb = 1ull << s.window_bits;
+  if (s.is_uncompressed) {
+    uint64_t byte = (br.pos() >> 3) + (uint64_t)(uint32_t)s.mlen;
+    if (byte < (br.total_bits >> 3)) {
+      uint32_t b = rfl(s.in_bytes[byte]);
+      if ((b & 3u) == 3u) is_last = 1;
+    }
+  }
+  if (is_last && !(s.flags & BROTLI_AMD_FLAG_NO_CANNY)) {
+    while ((int64_t)rb >= ((int64_t)s.mlen + 16) * 2 && rb > 32) rb >>= 1;
+  }
+  s.rb_size = rb;
+  s.next_boundary = (s.P / rb + 1) * rb;
+}
+
+__device__ __forceinline__ void store_resume(const Stream& s, const BitReader& br, BrotliAmdResume* r) {
+  if (lane_id() == 0) {
+    r->bit_pos = br.pos();
+    r->out_pos = s.P;
+    r->dist_rb[0] = s.dist_rb0; r->dist_rb[1] = s.dist_rb1; r->dist_rb[2] = s.dist_rb2; r->dist_rb[3] = s.dist_rb3;
+    r->dist_rb_idx = s.dist_rb_idx;
+    r->window_bits = s.window_bits;
+    r->large_window = s.large_window;
+    r->rb_size_log2 = s.rb_size ? (uint32_t)(63 - __clzll((long long)s.rb_size)) : 0;
+    r->is_last_done = 0;
+    r->reserved = 0;
+  }
+}
+
+// src/decode.rs:2779-3403 restated for one whole-input call
+__device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64_t in_size, BrotliAmdStreamStatus* st) {
+  if (!have_header) {
+    ColdScope c(s);
+    BitReader& br = c.br;
+    // UNINITED: DecodeWindowBits needs one whole byte (decode.rs:2921-2939, 152-187)
+    if (in_size == 0) return E_NEEDS_MORE_INPUT;
+    s.large_window = 0;
+    if (br.read(1) == 0) s.window_bits = 16;
+    else {
+      uint32_t n = br.read(3);
+      if (n != 0) s.window_bits = 17 + n;
+      else {
+        n = br.read(3);
+        if (n == 1) {
+          if (!(s.flags & BROTLI_AMD_FLAG_LARGE_WINDOW)) return E_WINDOW_BITS;
+          if (br.read(1) == 1) return E_WINDOW_BITS;
+          s.large_window = 1;
+        } else if (n != 0) s.window_bits = 8 + n;
+        else s.window_bits = 17;
+      }
+    }
+    if (s.large_window) {
+      s.window_bits = br.read(6); NEED_INPUT(br);
+      if (s.window_bits < 10 || s.window_bits > 30) return E_WINDOW_BITS;
+    }
+    store_resume(s, br, &st->resume);
+  }
+  s.max_backward = (int32_t)((1u << s.window_bits) - 16u);
+
+  for (;;) {
+    // METABLOCK_BEGIN (state.rs:422-450)
+    s.bl0 = s.bl1 = s.bl2 = 1u << 24;
+    s.nbt0 = s.nbt1 = s.nbt2 = 1;
+    s.ar.top = 0;
+    {
+      ColdScope c(s);
+      BitReader& br = c.br;
+      TRY(decode_metablock_length(br, s));
+      s.num_metablocks++;
+      if ((s.is_metadata || s.is_uncompressed) && !jump_to_byte_boundary(br)) return E_PADDING_2;  // decode.rs:2990-2994
+      if (s.is_metadata) {
+        // skip MLEN bytes (decode.rs:3031-3045)
+        uint64_t byte = br.pos() >> 3, isz = br.total_bits >> 3;
+        uint64_t avail = isz > byte ? isz - byte : 0;
+        if ((uint64_t)(uint32_t)s.mlen > avail) { br.seek(isz * 8 + 8); return E_NEEDS_MORE_INPUT; }
+        br.seek((byte + (uint32_t)s.mlen) * 8);
+        s.mlen = 0;
+      } else if (s.mlen != 0 && s.rb_size == 0) {
+        allocate_ring(s, br);
+      }
+    }
+    if (!s.is_metadata && s.mlen != 0) {
+      if (s.is_uncompressed) {
+        TRY(copy_uncompressed(s));
+      } else {
+        {
+          ColdScope c(s);
+          BitReader& br = c.br;
+          // HUFFMAN_CODE_0..3 (decode.rs:3046-3140)
+          for (int k = 0; k < 3; k++) {
+            uint32_t nbt;
+            TRY(decode_varlen_uint8(br, &nbt));
+            nbt += 1;
+            if (k == 0) s.nbt0 = nbt; else if (k == 1) s.nbt1 = nbt; else s.nbt2 = nbt;
+            if (nbt < 2) continue;
+            uint32_t tt, tl;
+            TRY(c.huffman(nbt + 2, nbt + 2, &tt));
+            TRY(c.huffman(26, 26, &tl));
+            uint32_t len = read_block_length(br, s.ar, s.bl_vgpr, tl); NEED_INPUT(br);
+            if (k == 0) { s.bl0 = len; s.bt_tree0 = tt; s.bl_tree0 = tl; }
+            else if (k == 1) { s.bl1 = len; s.bt_tree1 = tt; s.bl_tree1 = tl; }
+            else { s.bl2 = len; s.bt_tree2 = tt; s.bl_tree2 = tl; }
+          }
+          // METABLOCK_HEADER_2 + CONTEXT_MODES (decode.rs:3141-3172)
+          uint32_t bits = br.read(6); NEED_INPUT(br);
+          s.postfix_bits = bits & 3u;
+          s.num_direct = 16 + ((bits >> 2) << s.postfix_bits);
+          s.ctx_modes = s.ar.alloc(s.nbt0);
+          for (uint32_t k = 0; k < s.nbt0; k++) { uint32_t m = br.read(2); NEED_INPUT(br); s.ar.st8(s.ctx_modes + k, m); }
+        }
+        TRY(decode_context_map(s, s.nbt0 << 6, &s.num_lit_trees, &s.ctx_map));
+        uint32_t ndirect = s.num_direct - 16;
+        uint32_t num_dist_codes = 16 + ndirect + ((s.large_window ? 62u : 24u) << (s.postfix_bits + 1));
+        uint32_t max_dist_symbol = s.large_window ? max_distance_symbol(ndirect, s.postfix_bits) : num_dist_codes;
+        TRY(decode_context_map(s, s.nbt2 << 2, &s.num_dist_trees, &s.dist_ctx_map));
+        TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
+        TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
+        TRY(decode_tree_group(s, num_dist_codes, max_dist_symbol, s.num_dist_trees, &s.dist_trees));
+        TRY(process_commands(s));
+      }
+    }
+    // METABLOCK_DONE (decode.rs:3345-3381)
+    if (s.mlen < 0) return E_BLOCK_LENGTH_2;
+    {
+      ColdScope c(s);
+      BitReader& br = c.br;
+      if (!s.is_last) { store_resume(s, br, &st->resume); continue; }
+      if (!jump_to_byte_boundary(br)) return E_PADDING_2;
+      NEED_INPUT(br);
+      store_resume(s, br, &st->resume);
+    }
+    return E_SUCCESS;
+  }
+}
+
+}  // namespace
+
+// One wave per stream; persistent blocks pull stream indices from `queue`.
+extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
+                                                                           BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
+                                                                           uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
+                                                                           uint64_t scratch_per_block, uint32_t lds_arena_bytes,
+                                                                           const uint8_t* __restrict__ dict) {
+  const uint32_t lane = lane_id();
+  // literal context LUT -> LDS once per block
+  for (uint32_t i = lane; i < 2048; i += 64) lds_st8(LDS_CTX_LUT + i, kContextLookup[i]);
+  // per-lane LUT images
+  uint32_t lut = 0, bl = 0;
+  if (lane < 24) lut = (uint32_t)kInsBase[lane] | ((uint32_t)kInsExtra[lane] << 16);
+  else if (lane >= 32 && lane < 56) lut = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
+  if (lane < 26) bl = (uint32_t)kBlockLenBase[lane] | ((uint32_t)kBlockLenExtra[lane] << 16);
+  lds_sync();
+
+  for (;;) {
+    uint32_t idx = 0;
+    if (lane == 0) idx = atomicAdd(queue, 1u);
+    idx = rfl(idx);
+    if (idx >= n_streams) break;
+    const BrotliAmdStreamDesc d = descs[idx];
+    BrotliAmdStreamStatus* st = status + idx;
+
+    Stream s;
+    s.ar.glb = as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block);
+    s.ar.lds_limit = lds_arena_bytes;
+    s.ar.top = 0;
+    s.out = as_global<gu8>(d.out); s.out_cap = d.out_cap;
+    s.dict = as_global<gcu8>(dict);
+    s.in_bytes = as_global<gcu8>(d.in);
+    s.flags = d.flags;
+    s.lut_vgpr = lut; s.bl_vgpr = bl;
+    s.num_metablocks = 0; s.num_commands = 0;
+    s.mlen = 0;
+    s.is_last = 0; s.is_uncompressed = 0; s.is_metadata = 0;
+    // bit reader over [in, in + in_size)
+    {
+      uint64_t addr = (uint64_t)d.in;
+      uint32_t mis = (uint32_t)(addr & 3u);
+      s.br.base = (gcu32*)(uintptr_t)(addr - mis);
+      uint64_t span = (uint64_t)mis + d.in_size;
+      s.br.n_dw = (uint32_t)((span + 3) >> 2);
+      uint32_t tail = (uint32_t)(span & 3u);
+      s.br.tail_mask = tail ? ((1u << (tail * 8)) - 1u) : 0xFFFFFFFFu;
+      s.br.skip_bits = mis * 8;
+      s.br.total_bits = d.in_size * 8;
+    }
+    const bool resume = (d.flags & BROTLI_AMD_FLAG_RESUME) && d.resume.window_bits != 0;
+    if (resume) {
+      s.P = d.resume.out_pos;
+      s.dist_rb0 = d.resume.dist_rb[0]; s.dist_rb1 = d.resume.dist_rb[1]; s.dist_rb2 = d.resume.dist_rb[2]; s.dist_rb3 = d.resume.dist_rb[3];
+      s.dist_rb_idx = d.resume.dist_rb_idx;
+      s.window_bits = d.resume.window_bits; s.large_window = d.resume.large_window;
+      s.rb_size = d.resume.rb_size_log2 ? (1ull << d.resume.rb_size_log2) : 0;
+      s.next_boundary = s.rb_size ? (s.P / s.rb_size + 1) * s.rb_size : 0;
+      s.br.seek(d.resume.bit_pos);
+      if (lane == 0) st->resume = d.resume;
+    } else {
+      s.P = 0;
+      s.dist_rb0 = 16; s.dist_rb1 = 15; s.dist_rb2 = 11; s.dist_rb3 = 4;  // state.rs:296
+      s.dist_rb_idx = 0;
+      s.window_bits = 0; s.large_window = 0;
+      s.rb_size = 0; s.next_boundary = 0;
+      s.br.seek(0);
+    }
+
+    int e = decode_stream(s, resume, d.in_size, st);
+
+    // result mapping of the one-shot driver (decode.rs:2829-2916, 3382-3397; lib.rs:447-468)
+    const bool over = s.br.over();
+    if (e != E_NEEDS_MORE_INPUT && e != E_BLOCK_LENGTH_1 && e != E_NEEDS_MORE_OUTPUT && over) e = E_NEEDS_MORE_INPUT;
+    uint64_t decoded;
+    if (e == E_SUCCESS || e == E_NEEDS_MORE_INPUT) decoded = s.P;          // everything produced is flushed
+    else if (e == E_NEEDS_MORE_OUTPUT) decoded = s.out_cap;
+    else {
+      // fatal: the caller has what was flushed at the last ring-buffer boundary
+      decoded = s.rb_size ? s.next_boundary - s.rb_size : 0;
+      if (decoded > s.P) decoded = 0;
+    }
+    if (lane == 0) {
+      st->result = e == E_SUCCESS ? 1 : e == E_NEEDS_MORE_INPUT ? 2 : e == E_NEEDS_MORE_OUTPUT ? 3 : 0;
+      st->error_code = e;
+      st->decoded_size = decoded;
+      uint64_t c = (s.br.pos() + 7) >> 3;
+      if (e == E_NEEDS_MORE_INPUT || c > d.in_size) c = d.in_size;
+      st->consumed = c;
+      st->produced = s.P;
+      st->num_metablocks = s.num_metablocks;
+      st->num_commands = s.num_commands;
+      st->reserved = 0;
+    }
+  }
+}
+
+extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
+                                               uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
+                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream) {
+  if (n_streams == 0) return hipSuccess;
+  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(64), smem, stream, descs, status, n_streams, queue, scratch,
+                     scratch_per_block, lds_arena_bytes, dict);
+  return hipGetLastError();
+}
+
+extern "C" uint32_t brotli_amd_lds_fixed_bytes(void) { return LDS_FIXED; }

@@ -1,0 +1,166 @@
+"""Parity of the HIP decode path against the CPU oracle, through the C ABI (needs a real MI355X)."""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import oracle_lib as oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _manifest():
+    return json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+def _data(name):
+    return open(os.path.join(GOLD, "testdata", name), "rb").read()
+
+
+def _check_against_oracle(pkg, datas, caps, flags=1, what=""):
+    batch = pkg.Batch(len(datas))
+    results, outs = batch.decode_host(datas, caps, flags)
+    batch.close()
+    bad = []
+    for i, (d, cap) in enumerate(zip(datas, caps)):
+        info, exp = oracle.decode(d, cap, flags)
+        r = results[i]
+        got = (r.result, r.error_code, r.decoded_size, outs[i])
+        want = (info.result, info.error_code, info.decoded_size, exp)
+        ok = got == want
+        if ok and info.result == 1:
+            ok = r.consumed == info.consumed
+        if not ok:
+            bad.append((i, what, got[:3], want[:3], r.consumed, info.consumed, len(d), cap))
+    assert not bad, (len(bad), bad[:10])
+
+
+def test_reference_fixtures_bit_exact(pkg):
+    """every testdata/*.compressed* of the reference decodes to its original (SHA-256), borked fails"""
+    m = [e for e in _manifest() if e["name"] != "rnd_chunk.br"]
+    datas = [_data(e["name"]) for e in m]
+    caps = [e.get("size", 1 << 16) + 16 for e in m]
+    batch = pkg.Batch(len(m))
+    results, outs = batch.decode_host(datas, caps, pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    for e, r, out in zip(m, results, outs):
+        if e.get("must_fail"):
+            assert r.result != 1, e["name"]
+            continue
+        assert (r.result, r.error_code) == (1, 1), (e["name"], r.result, r.error_code)
+        assert len(out) == e["size"], e["name"]
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e["name"]
+        assert r.consumed == e["csize"], e["name"]
+
+
+def test_fixtures_match_oracle_status(pkg):
+    m = [e for e in _manifest() if e["name"] != "rnd_chunk.br"]
+    _check_against_oracle(pkg, [_data(e["name"]) for e in m], [e.get("size", 1 << 16) + 16 for e in m], 1, "fixtures")
+
+
+def test_large_window_fixture(pkg):
+    """rnd_chunk.br: 100 011 280 bytes, prefix / 1e8 zeros / postfix (src/bin/integration_tests.rs:997-1006)"""
+    edges = json.load(open(os.path.join(GOLD, "rnd_chunk_edges.json")))
+    batch = pkg.Batch(1)
+    results, outs = batch.decode_host([_data("rnd_chunk.br")], [edges["size"] + 64], pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    r, out = results[0], outs[0]
+    assert (r.result, r.decoded_size) == (1, edges["size"])
+    pre, post = bytes.fromhex(edges["prefix_hex"]), bytes.fromhex(edges["postfix_hex"])
+    assert out[:len(pre)] == pre and out[-len(post):] == post
+    assert out[len(pre):len(pre) + edges["zero_count"]].count(0) == edges["zero_count"]
+    # without the large-window flag the same stream is rejected (ffi instances, ffi/mod.rs:127)
+    batch = pkg.Batch(1)
+    results, _ = batch.decode_host([_data("rnd_chunk.br")], [1 << 16], 0)
+    batch.close()
+    assert (results[0].result, results[0].error_code) == (0, -13)
+
+
+def test_inline_vectors(pkg):
+    vec = json.load(open(os.path.join(GOLD, "inline_vectors.json")))
+    datas = [bytes.fromhex(v["input_hex"]) for v in vec]
+    caps = [1 << 18] * len(vec)
+    batch = pkg.Batch(len(vec))
+    results, outs = batch.decode_host(datas, caps, pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    for v, r, out, d in zip(vec, results, outs, datas):
+        if "result" in v:
+            if v["result"] == 1:
+                assert r.result == 1, v["name"]
+            else:
+                assert r.result != 1, v["name"]
+        if "error_code" in v:
+            assert r.error_code == v["error_code"], v["name"]
+        if "output_hex" in v:
+            assert out.hex() == v["output_hex"], v["name"]
+        if "output_sha256" in v:
+            assert hashlib.sha256(out).hexdigest() == v["output_sha256"], v["name"]
+        if "result_is_success" in v:
+            assert (r.result == 1) == v["result_is_success"], v["name"]
+        if v.get("consumed_all"):
+            assert r.consumed == len(d), v["name"]
+    _check_against_oracle(pkg, datas, caps, 1, "inline")
+
+
+def _mutations(seed, count):
+    rnd = random.Random(seed)
+    names = [e["name"] for e in _manifest() if e["csize"] < 200000 and e["name"] != "rnd_chunk.br"]
+    base = {n: _data(n) for n in names}
+    datas = []
+    for _ in range(count):
+        d = bytearray(base[rnd.choice(names)])
+        k = rnd.random()
+        if k < 0.3 and len(d) > 1:
+            d = d[:rnd.randrange(0, len(d))]
+        elif k < 0.8:
+            for _ in range(rnd.choice([1, 1, 1, 2, 3])):
+                if not d:
+                    break
+                pos = rnd.randrange(0, min(len(d), rnd.choice([8, 64, 512, 1 << 20])))
+                d[pos] ^= 1 << rnd.randrange(8)
+        else:
+            pos = rnd.randrange(0, len(d) + 1)
+            d[pos:pos] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 4)))
+        datas.append(bytes(d))
+    return datas
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_mutated_streams_match_oracle(pkg, seed):
+    """truncations, bit flips and insertions: result, error code, delivered size and bytes equal the oracle's"""
+    datas = _mutations(seed, 1500)
+    flags = 1 if seed != 3 else 0
+    _check_against_oracle(pkg, datas, [1 << 20] * len(datas), flags, "mutated seed %d" % seed)
+
+
+def test_unaligned_device_inputs(pkg):
+    """every input alignment mod 4 (the bit reader rounds the base pointer down) and odd output addresses"""
+    torch = pytest.importorskip("torch")
+    alice = _data("alice29.txt.compressed")
+    exp = oracle.decode(alice, 200000, 1)[1]
+    out = torch.zeros(4 * 160000, dtype=torch.uint8, device="cuda")
+    src = torch.frombuffer(bytearray(alice), dtype=torch.uint8).cuda()
+    batch = pkg.Batch(4)
+    in_ptrs, out_ptrs, bufs = [], [], []
+    for a in range(4):
+        b = torch.zeros(len(alice) + 64, dtype=torch.uint8, device="cuda")
+        b[a:a + len(alice)] = src
+        bufs.append(b)
+        in_ptrs.append(b.data_ptr() + a)
+        out_ptrs.append(out.data_ptr() + a * 160000 + a)
+    torch.cuda.synchronize()
+    batch.decode_device(in_ptrs, [len(alice)] * 4, out_ptrs, [152089] * 4, pkg.FLAG_LARGE_WINDOW)
+    res = batch.wait()
+    batch.close()
+    host = out.cpu().numpy().tobytes()
+    for a in range(4):
+        assert (res[a].result, res[a].decoded_size) == (1, 152089)
+        assert host[a * 160000 + a: a * 160000 + a + 152089] == exp
+
+
+def test_tiny_inputs(pkg):
+    _check_against_oracle(pkg, [b"", b"\x06", b"\x00", b"\x01"], [16, 16, 16, 0], 1, "tiny")
