@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- decompressed MB/s of the HIP Brotli decode path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the decode kernel over one batch of compressed streams that already sit in HBM
+(outputs stay in HBM).  Default workload = the configuration the metric is quoted on: a 1 GiB batch of
+wbits-22 (4 MiB window) streams, 256 x 4 MiB, synthetic long-back-reference data (SURVEY.md section 8d, C3 as
+256 independent streams).  N > 1: one process per GPU (torchrun), every rank decodes its own 1 GiB batch --
+streams are independent, so the path shards with no data-path collective ("weak" scaling); RCCL carries only
+the workload descriptor (broadcast) and the per-rank status words (all_gather).
+
+Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
+  roofline     -- HBM roofline of the decode kernel: algorithmic bytes (compressed read + decompressed written)
+                  per launch / mean kernel time from HIP events on the launch stream, against 8 TB/s
+  cpu_baseline -- the CPU oracle ("port": the reference itself is Rust and cannot be built here) on a bounded
+                  sample of the same workload, all host cores
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def load_pkg():
+    import importlib.util
+    name = "rust_brotli_decompressor_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build_workload(name, rank):
+    """-> (label, unique streams [(compressed, raw_size, sha256)], copies per unique stream)"""
+    import workloads as w
+    if name == "alice29x1024" or not w.encoder_available():
+        return "1024 x alice29.txt.compressed (reference fixture, wbits 22)", w.fixture_streams("alice29.txt.compressed"), 1024
+    n_unique = int(os.environ.get("BROTLI_BENCH_UNIQUE", "32"))
+    if name == "longbackref_256x4MiB":
+        u = w.make_streams("long_backref", n_unique, 4 << 20, 1000 + 4096 * rank)
+        return "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, long back-references (%d distinct streams)" % n_unique, u, 256 // n_unique
+    if name == "highentropy_256x4MiB":
+        u = w.make_streams("high_entropy", n_unique, 4 << 20, 2000 + 4096 * rank)
+        return "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, high-entropy literals (%d distinct streams)" % n_unique, u, 256 // n_unique
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(unique, budget_s=12.0):
+    """CPU oracle on a bounded sample of the same streams, one stream per thread, all cores."""
+    import oracle_lib as oracle
+    L = oracle.lib()
+    cores = os.cpu_count() or 1
+    sample = (unique * ((cores + len(unique) - 1) // len(unique)))[:max(cores, min(len(unique), cores))]
+    n = len(sample)
+    ins = [ctypes.create_string_buffer(c, len(c)) for c, _, _ in sample]
+    outs = [ctypes.create_string_buffer(sz + 64) for _, sz, _ in sample]
+    a_in = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in ins])
+    a_is = (ctypes.c_size_t * n)(*[len(c) for c, _, _ in sample])
+    a_out = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in outs])
+    a_oc = (ctypes.c_size_t * n)(*[sz + 64 for _, sz, _ in sample])
+    infos = (oracle.OracleInfo * n)()
+    L.brotli_oracle_decode_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    total = sum(sz for _, sz, _ in sample)
+    best, reps, t_start = None, 0, time.time()
+    while reps < 3 or (time.time() - t_start < budget_s and reps < 50):
+        t = time.time()
+        L.brotli_oracle_decode_batch(n, a_in, a_is, a_out, a_oc, 1, cores, infos)
+        dt = time.time() - t
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    assert all(i.result == 1 for i in infos)
+    return {"value": round(total / best / 1e6, 1), "unit": "MB/s decompressed", "cores": cores, "kind": "port",
+            "sample": "%d streams of the workload (%.0f MiB), best of %d passes, one stream per thread; the Rust reference "
+                      "cannot be built in this image, this is the repo's C restatement (oracle/)" % (n, total / 2**20, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("BROTLI_BENCH_WORKLOAD", "longbackref_256x4MiB"),
+                    choices=["longbackref_256x4MiB", "highentropy_256x4MiB", "alice29x1024"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL over xGMI
+    pkg = load_pkg()
+
+    # rank 0 decides the workload and broadcasts its descriptor (the only thing that crosses xGMI before the run)
+    desc = [args.workload]
+    if world > 1:
+        dist.broadcast_object_list(desc, src=0)
+    label, unique, copies = build_workload(desc[0], rank)
+    n = len(unique) * copies
+    comp_total = sum(len(c) for c, _, _ in unique) * copies
+    raw_total = sum(sz for _, sz, _ in unique) * copies
+
+    # inputs resident in HBM: every stream gets its own compressed copy and its own output buffer
+    dev = torch.device("cuda", local_rank)
+    in_stride = max((len(c) + 255) // 256 * 256 for c, _, _ in unique)
+    out_stride = max((sz + 255) // 256 * 256 for _, sz, _ in unique)
+    d_in = torch.zeros(n * in_stride, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(n * out_stride, dtype=torch.uint8, device=dev)
+    sizes, caps = [], []
+    for i in range(n):
+        c, sz, _ = unique[i % len(unique)]
+        d_in[i * in_stride: i * in_stride + len(c)] = torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev)
+        sizes.append(len(c))
+        caps.append(sz)
+    in_ptrs = [d_in.data_ptr() + i * in_stride for i in range(n)]
+    out_ptrs = [d_out.data_ptr() + i * out_stride for i in range(n)]
+    torch.cuda.synchronize()
+
+    batch = pkg.Batch(n)
+    stream = torch.cuda.current_stream().cuda_stream
+    batch.decode_device(in_ptrs, sizes, out_ptrs, caps, pkg.FLAG_LARGE_WINDOW, stream)
+    res = batch.wait()
+    # bit-exact check of this rank's batch against the regenerated raw data (SHA-256 per stream)
+    bad = [i for i, r in enumerate(res) if r.result != 1 or r.decoded_size != caps[i]]
+    if bad:
+        raise SystemExit("decode failed on rank %d: stream %d result %d error %d" % (rank, bad[0], res[bad[0]].result, res[bad[0]].error_code))
+    host = d_out.cpu().numpy()
+    for i in range(n):
+        _, sz, sha = unique[i % len(unique)]
+        if hashlib.sha256(host[i * out_stride: i * out_stride + sz].tobytes()).hexdigest() != sha:
+            raise SystemExit("rank %d: stream %d is not bit-exact" % (rank, i))
+    del host
+
+    for _ in range(args.warmup):
+        batch.relaunch(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.relaunch(stream)
+        # HIP events recorded around the launch on the launch stream; reading them waits for this step only
+        kernel_ms.append(batch.last_kernel_ms())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    st = torch.tensor([float(raw_total), float(comp_total), float(sum(kernel_ms) / len(kernel_ms))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(st) for _ in range(world)]
+        dist.all_gather(gathered, st)  # per-rank status words
+    else:
+        gathered = [st]
+    if rank == 0:
+        elapsed_max = float(t.item())
+        total_raw = sum(float(g[0].item()) for g in gathered)
+        value = total_raw * args.steps / elapsed_max / 1e6
+        mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = (comp_total + raw_total) / (mean_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "decompressed MB/s (bit-exact vs reference fixtures; HIP decode kernel, inputs resident in HBM)",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": label, "streams_per_gpu": n, "decompressed_bytes_per_gpu": raw_total,
+                       "compressed_bytes_per_gpu": comp_total, "parallelism": "independent streams sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "brotli_amd_decode_kernel", "kernel_ms": round(mean_kernel_ms, 3),
+                         "decompressed_frac": round(raw_total / (mean_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(unique)
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -673,3 +673,8 @@ extern "C" size_t* BrotliDecoderMallocUsize(BrotliDecoderState* s, size_t size) 
   return static_cast<size_t*>(st_alloc(s, size * sizeof(size_t)));
 }
 extern "C" void BrotliDecoderFreeUsize(BrotliDecoderState* s, size_t* data, size_t) { if (s) st_free(s, data); }
+
+// Debug/profiling aid for tools/ (not part of the public headers): raw status block of stream i after Wait.
+extern "C" __attribute__((visibility("default"))) const BrotliAmdStreamStatus* brotli_amd_debug_status(BrotliAmdBatch* b, uint32_t i) {
+  return (b && i < b->n) ? &b->h_status[i] : nullptr;
+}

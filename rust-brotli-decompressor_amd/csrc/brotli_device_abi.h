@@ -22,8 +22,8 @@ extern "C" {
 typedef struct BrotliAmdResume {
   uint64_t bit_pos;       // absolute bit position in the compressed stream
   uint64_t out_pos;       // bytes produced so far
-  int32_t dist_rb[4];     // state.rs:296
-  int32_t dist_rb_idx;
+  int32_t dist_rb[4];     // last four distances, most recent first (state.rs:295-296 as a shift register)
+  int32_t dist_rb_idx;    // unused (always 0): the ring is stored already rotated
   uint32_t window_bits;   // 0 = stream header not parsed yet
   uint32_t large_window;  // stream carries the large-window header
   uint32_t rb_size_log2;  // emulated ring size (0 = not allocated yet), decode.rs:1808-1871

@@ -100,8 +100,19 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
+// Values that are the same in every lane but come out of per-lane storage (VGPRs, private memory) are passed
+// through v_readfirstlane so that the compiler keeps them, and everything computed from them, in SGPRs and
+// branches on them with scalar branches instead of exec masks.
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int32_t rfl(int32_t v) { return (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+__device__ __forceinline__ uint64_t rfl(uint64_t v) {
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);  // the builtin returns int: no sign extension
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+template <typename T>
+__device__ __forceinline__ T* rfl_ptr(T* p) { return (T*)(uintptr_t)rfl((uint64_t)(uintptr_t)p); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mask_bits(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return n ? (__brev(v) >> (32 - n)) : 0; }
@@ -121,6 +132,12 @@ struct BitReader {
   uint64_t buf;          // uniform
   uint32_t cnt;          // uniform: valid bits in buf
 
+  // after a copy out of private memory: re-establish that everything but the two window registers is uniform
+  __device__ __forceinline__ void uniformize() {
+    base = (gcu32*)(uintptr_t)rfl((uint64_t)(uintptr_t)base);
+    n_dw = rfl(n_dw); tail_mask = rfl(tail_mask); skip_bits = rfl(skip_bits); total_bits = rfl(total_bits);
+    chunk_base = rfl(chunk_base); next_dw = rfl(next_dw); buf = rfl(buf); cnt = rfl(cnt);
+  }
   __device__ __forceinline__ uint32_t load_window(uint32_t first) const {
     uint32_t i = first + lane_id();
     uint32_t v = 0;
@@ -130,7 +147,7 @@ struct BitReader {
     }
     return v;
   }
-  __device__ void seek(uint64_t bit_pos) {
+  __device__ __forceinline__ void seek(uint64_t bit_pos) {
     uint64_t abs = bit_pos + skip_bits;
     uint32_t dw = (uint32_t)(abs >> 5);
     chunk_base = dw;
@@ -176,6 +193,10 @@ struct Arena {
   uint32_t lds_limit;  // arena bytes that live in LDS (at g_smem + LDS_FIXED)
   uint32_t top;
 
+  __device__ __forceinline__ void uniformize() {
+    glb = (gu8*)(uintptr_t)rfl((uint64_t)(uintptr_t)glb);
+    lds_limit = rfl(lds_limit); top = rfl(top);
+  }
   __device__ __forceinline__ uint32_t alloc(uint32_t max_bytes) {  // object never straddles the LDS/global split
     uint32_t off = (top + 3u) & ~3u;
     if (off < lds_limit && off + max_bytes > lds_limit) off = lds_limit;
@@ -183,24 +204,30 @@ struct Arena {
     return off;
   }
   __device__ __forceinline__ void shrink_to(uint32_t off_end) { top = off_end; }
-  // uniform loads
+  // uniform loads.  LDS_ONLY = the caller knows the object is in the LDS part: the load is a plain ds_read and
+  // the wait in front of v_readfirstlane is lgkmcnt only (the two-way form must also wait for vmcnt, i.e. for
+  // every global store the wave still has in flight)
+  template <bool LDS_ONLY = false>
   __device__ __forceinline__ uint32_t ld16(uint32_t off) const {
     uint32_t v;
-    if (off < lds_limit) v = lds_ld16(LDS_FIXED + off); else v = *reinterpret_cast<gu16*>(glb + off);
+    if (LDS_ONLY || off < lds_limit) v = lds_ld16(LDS_FIXED + off); else v = *reinterpret_cast<gu16*>(glb + off);
     return rfl(v);
   }
+  template <bool LDS_ONLY = false>
   __device__ __forceinline__ uint32_t ld8(uint32_t off) const {
     uint32_t v;
-    if (off < lds_limit) v = lds_ld8(LDS_FIXED + off); else v = glb[off];
+    if (LDS_ONLY || off < lds_limit) v = lds_ld8(LDS_FIXED + off); else v = glb[off];
     return rfl(v);
   }
+  template <bool LDS_ONLY = false>
   __device__ __forceinline__ uint32_t ld32(uint32_t off) const {
     uint32_t v;
-    if (off < lds_limit) v = lds_ld32(LDS_FIXED + off); else v = *reinterpret_cast<gu32*>(glb + off);
+    if (LDS_ONLY || off < lds_limit) v = lds_ld32(LDS_FIXED + off); else v = *reinterpret_cast<gu32*>(glb + off);
     return rfl(v);
   }
   // per-lane accesses (every active lane uses its own offset)
-  __device__ __forceinline__ uint32_t ld8_lane(uint32_t off) const { return off < lds_limit ? lds_ld8(LDS_FIXED + off) : (uint32_t)glb[off]; }
+  template <bool LDS_ONLY = false>
+  __device__ __forceinline__ uint32_t ld8_lane(uint32_t off) const { return (LDS_ONLY || off < lds_limit) ? lds_ld8(LDS_FIXED + off) : (uint32_t)glb[off]; }
   __device__ __forceinline__ void st16_lane(uint32_t off, uint32_t v) const {
     if (off < lds_limit) lds_st16(LDS_FIXED + off, v); else *reinterpret_cast<gu16*>(glb + off) = (uint16_t)v;
   }
@@ -217,13 +244,14 @@ struct Arena {
 
 // table entry: (value << 4) | len.  Root entry with len > 8: value = offset of the 2nd-level table from the
 // tree base (entries), len - 8 = its depth.  2nd-level entry: len = code length - 8.
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t read_symbol(BitReader& br, const Arena& a, uint32_t tree) {
   uint32_t bits = br.peek32();
-  uint32_t e = a.ld16(tree + ((bits & 0xFFu) << 1));
+  uint32_t e = a.ld16<LDS_ONLY>(tree + ((bits & 0xFFu) << 1));
   uint32_t len = e & 15u;
   if (len > ROOT_BITS) {
     uint32_t idx = (e >> 4) + ((bits >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
-    e = a.ld16(tree + (idx << 1));
+    e = a.ld16<LDS_ONLY>(tree + (idx << 1));
     len = ROOT_BITS + (e & 15u);
   }
   br.drop(len);
@@ -263,8 +291,16 @@ struct Stream {
   uint32_t bl_vgpr;        // per-lane: block length code LUT image
   uint32_t num_metablocks;
   uint64_t num_commands;
+#ifdef BROTLI_AMD_PROFILE
+  uint64_t prof[4];
+#endif
 };
 
+#ifdef BROTLI_AMD_NO_COLD_UNIFORM
+#define COLD_UNIFORMIZE(x)
+#else
+#define COLD_UNIFORMIZE(x) x
+#endif
 #ifdef BROTLI_AMD_TRACE
 #define TRACE_STOP(br, e) do { if (lane_id() == 0) printf("stop line %d e=%d pos=%llu total=%llu\n", __LINE__, (int)(e), (unsigned long long)(br).pos(), (unsigned long long)(br).total_bits); } while (0)
 #else
@@ -396,16 +432,17 @@ __device__ __forceinline__ uint32_t log2floor_plus1(uint32_t x) { return x ? 32u
 
 // src/decode.rs:868-1013.  Reads one prefix code, builds its table at a fresh arena allocation, returns the
 // arena offset in *tree_off.  The one helper that is a real function call (7 call sites, cold).
-__device__ __noinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off) {
+__device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off) {
   struct Scope {  // register copies of the reader and the arena, stored back on every exit
     Stream& s; BitReader br; Arena ar;
-    __device__ __forceinline__ Scope(Stream& s_) : s(s_), br(s_.br), ar(s_.ar) {}
+    __device__ __forceinline__ Scope(Stream& s_) : s(s_), br(s_.br), ar(s_.ar) { COLD_UNIFORMIZE(br.uniformize(); ar.uniformize();) }
     __device__ __forceinline__ ~Scope() { s.br = br; s.ar = ar; }
   } sc(s);
   BitReader& br = sc.br;
   Arena& ar = sc.ar;
   const uint32_t lane = lane_id();
-  alphabet_size &= 0x7ffu;
+  alphabet_size = rfl(alphabet_size) & 0x7ffu;
+  max_symbol = rfl(max_symbol);
   uint32_t max_entries = max_table_entries(alphabet_size);
   uint32_t tree = ar.alloc(max_entries * 2);
   *tree_off = tree;
@@ -524,12 +561,12 @@ __device__ __noinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size,
 // go through the Stream object in memory.
 struct ColdScope {
   Stream& s; BitReader br;
-  __device__ __forceinline__ ColdScope(Stream& s_) : s(s_), br(s_.br) {}
+  __device__ __forceinline__ ColdScope(Stream& s_) : s(s_), br(s_.br) { COLD_UNIFORMIZE(br.uniformize();) }
   __device__ __forceinline__ ~ColdScope() { s.br = br; }
   __device__ __forceinline__ int huffman(uint32_t alphabet, uint32_t max_symbol, uint32_t* tree) {
     s.br = br;
-    int e = read_huffman_code(s, alphabet, max_symbol, tree);
-    br = s.br;
+    int e = rfl(read_huffman_code(s, alphabet, max_symbol, tree));
+    br = s.br; COLD_UNIFORMIZE(br.uniformize(); *tree = rfl(*tree);)
     return e;
   }
 };
@@ -587,19 +624,21 @@ __device__ __forceinline__ bool jump_to_byte_boundary(BitReader& br) {  // bit_r
 }
 
 // decode.rs:1016-1026: block length = base[code] + extra bits
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t read_block_length(BitReader& br, const Arena& ar, uint32_t bl_vgpr, uint32_t tree) {
-  uint32_t code = read_symbol(br, ar, tree);
+  uint32_t code = read_symbol<LDS_ONLY>(br, ar, tree);
   uint32_t e = rdlane(bl_vgpr, code);
   return (e & 0xFFFFu) + br.read(e >> 16);
 }
 
 // decode.rs:1469-1524.  0 = single block type, 1 = switched, 2 = needs more input
 enum { BS_SINGLE_TYPE = 0, BS_SWITCHED = 1, BS_NEEDS_INPUT = 2 };
+template <bool LDS_ONLY>
 __device__ __forceinline__ int block_switch(BitReader& br, const Arena& ar, uint32_t bl_vgpr, uint32_t bt_tree, uint32_t bl_tree, uint32_t nbt,
                                             uint32_t& block_len, uint32_t& t0, uint32_t& t1) {
   if (nbt <= 1) return BS_SINGLE_TYPE;
-  uint32_t block_type = read_symbol(br, ar, bt_tree);
-  uint32_t len = read_block_length(br, ar, bl_vgpr, bl_tree);
+  uint32_t block_type = read_symbol<LDS_ONLY>(br, ar, bt_tree);
+  uint32_t len = read_block_length<LDS_ONLY>(br, ar, bl_vgpr, bl_tree);
   if (br.over()) return BS_NEEDS_INPUT;
   block_len = len;
   if (block_type == 1) block_type = t1 + 1;
@@ -773,49 +812,59 @@ __device__ __forceinline__ uint32_t emit_dictionary_word(gcu8* dict, gu8* dst, u
   return total;
 }
 
+#ifdef BROTLI_AMD_PROFILE
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#define PROF_ADD(acc, t0) do { uint64_t _t = __builtin_amdgcn_s_memtime(); (acc) += _t - (t0); (t0) = _t; } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(acc, t0) do { } while (0)
+#endif
 // ===================================== the command loop (hot path) =====================================
 // src/decode.rs:2330-2744 with a flat output buffer.  Works entirely on register copies of the stream state
 // (SGPRs for everything uniform); the Stream object is read on entry and written on exit.
+template <bool LDS_ONLY>
 __device__ __forceinline__ int process_commands(Stream& s) {
-  BitReader br = s.br;
-  const Arena a = s.ar;
+  BitReader br = s.br; br.uniformize();
+  Arena a_ = s.ar; a_.uniformize();
+  const Arena a = a_;
   const uint32_t lane = lane_id();
-  gu8* const out = s.out;
-  gcu8* const dict = s.dict;
-  const uint64_t out_cap = s.out_cap;
-  uint64_t P = s.P, next_boundary = s.next_boundary;
-  const uint64_t rb_size = s.rb_size;
-  const bool full_ring = rb_size == (1ull << s.window_bits);
-  int32_t mlen = s.mlen;
-  const int32_t max_backward = s.max_backward;
-  int32_t d0 = s.dist_rb0, d1 = s.dist_rb1, d2 = s.dist_rb2, d3 = s.dist_rb3, didx = s.dist_rb_idx;
-  uint32_t bl0 = s.bl0, bl1 = s.bl1, bl2 = s.bl2;
-  const uint32_t nbt0 = s.nbt0, nbt1 = s.nbt1, nbt2 = s.nbt2;
+  gu8* const out = rfl_ptr(s.out);
+  gcu8* const dict = rfl_ptr(s.dict);
+  const uint64_t out_cap = rfl(s.out_cap);
+  uint64_t P = rfl(s.P), next_boundary = rfl(s.next_boundary);
+  const uint64_t rb_size = rfl(s.rb_size);
+  const bool full_ring = rb_size == (1ull << rfl(s.window_bits));
+  int32_t mlen = rfl(s.mlen);
+  const int32_t max_backward = rfl(s.max_backward);
+  // last four distances, most recent first (the reference's dist_rb/dist_rb_idx ring as a shift register: short
+  // code 0 and dictionary references leave it untouched, every other LZ77 distance is pushed; state.rs:295-296)
+  int32_t d0 = rfl(s.dist_rb0), d1 = rfl(s.dist_rb1), d2 = rfl(s.dist_rb2), d3 = rfl(s.dist_rb3);
+  uint32_t bl0 = rfl(s.bl0), bl1 = rfl(s.bl1), bl2 = rfl(s.bl2);
+  const uint32_t nbt0 = rfl(s.nbt0), nbt1 = rfl(s.nbt1), nbt2 = rfl(s.nbt2);
   uint32_t rb_l0 = 1, rb_l1 = 0, rb_c0 = 1, rb_c1 = 0, rb_d0 = 1, rb_d1 = 0;  // block type rings (state.rs:429-435)
-  const uint32_t bt_tree0 = s.bt_tree0, bt_tree1 = s.bt_tree1, bt_tree2 = s.bt_tree2;
-  const uint32_t bl_tree0 = s.bl_tree0, bl_tree1 = s.bl_tree1, bl_tree2 = s.bl_tree2;
-  const uint32_t postfix_bits = s.postfix_bits, num_direct = s.num_direct;
-  const uint32_t ctx_modes = s.ctx_modes, ctx_map = s.ctx_map, dist_ctx_map = s.dist_ctx_map;
-  const uint32_t lit_trees = s.lit_trees, cmd_trees = s.cmd_trees, dist_trees = s.dist_trees;
-  const uint32_t lut_vgpr = s.lut_vgpr, bl_vgpr = s.bl_vgpr;
-  uint64_t num_commands = s.num_commands;
+  const uint32_t bt_tree0 = rfl(s.bt_tree0), bt_tree1 = rfl(s.bt_tree1), bt_tree2 = rfl(s.bt_tree2);
+  const uint32_t bl_tree0 = rfl(s.bl_tree0), bl_tree1 = rfl(s.bl_tree1), bl_tree2 = rfl(s.bl_tree2);
+  const uint32_t postfix_bits = rfl(s.postfix_bits), num_direct = rfl(s.num_direct);
+  const uint32_t ctx_modes = rfl(s.ctx_modes), ctx_map = rfl(s.ctx_map), dist_ctx_map = rfl(s.dist_ctx_map);
+  const uint32_t lit_trees = rfl(s.lit_trees), cmd_trees = rfl(s.cmd_trees), dist_trees = rfl(s.dist_trees);
+  const uint32_t lut_vgpr = s.lut_vgpr, bl_vgpr = s.bl_vgpr;  // per-lane LUT images
+  uint64_t num_commands = rfl(s.num_commands);
   int result = E_SUCCESS;
+  uint64_t prof_cmd = 0, prof_lit = 0, prof_dist = 0, prof_copy = 0, prof_t = PROF_T();
+  (void)prof_cmd; (void)prof_lit; (void)prof_dist; (void)prof_copy; (void)prof_t;
 
-  auto dist_get = [&](int32_t i) -> int32_t { i &= 3; return i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3; };
-  auto dist_set = [&](int32_t i, int32_t v) { i &= 3; if (i == 0) d0 = v; else if (i == 1) d1 = v; else if (i == 2) d2 = v; else d3 = v; };
-
-  uint32_t cmd_tree = a.ld32(cmd_trees);
+  uint32_t cmd_tree = a.ld32<LDS_ONLY>(cmd_trees);
   uint32_t dist_ctx_slice = 0, ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT;
   // PrepareLiteralDecoding, decode.rs:1554-1570
   auto prepare_literal = [&]() {
     uint32_t bt = rb_l1;
     ctx_slice = bt << 6;
     // trivial <=> all 64 map entries of the block type are equal (DetectTrivialLiteralBlockTypes, 1525-1553)
-    uint32_t mine = a.ld8_lane(ctx_map + ctx_slice + lane);
+    uint32_t mine = a.ld8_lane<LDS_ONLY>(ctx_map + ctx_slice + lane);
     uint32_t first = rdlane(mine, 0);
     trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
-    lit_tree = a.ld32(lit_trees + first * 4);
-    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8(ctx_modes + bt) & 3u);
+    lit_tree = a.ld32<LDS_ONLY>(lit_trees + first * 4);
+    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(ctx_modes + bt) & 3u);
   };
   prepare_literal();
   // last two output bytes (context of the next literal); stream start counts as two zero bytes (decode.rs:1859-1860)
@@ -831,11 +880,11 @@ __device__ __forceinline__ int process_commands(Stream& s) {
   for (;;) {
     // ---- COMMAND_BEGIN ----
     if (bl1 == 0) {
-      int r = block_switch(br, a, bl_vgpr, bt_tree1, bl_tree1, nbt1, bl1, rb_c0, rb_c1);
+      int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree1, bl_tree1, nbt1, bl1, rb_c0, rb_c1);
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
-      if (r == BS_SWITCHED) { cmd_tree = a.ld32(cmd_trees + rb_c1 * 4); continue; }
+      if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(cmd_trees + rb_c1 * 4); continue; }
     }
-    uint32_t cmd = read_symbol(br, a, cmd_tree);
+    uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
     // kCmdLut regenerated arithmetically (RFC 7932 section 5; replaces src/prefix.rs:115-5755)
     uint32_t cell = cmd >> 6;
     uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
@@ -848,6 +897,7 @@ __device__ __forceinline__ int process_commands(Stream& s) {
     if (br.over()) STOP(E_NEEDS_MORE_INPUT);
     bl1--;
     num_commands++;
+    PROF_ADD(prof_cmd, prof_t);
 
     if (insert_len != 0) {
       mlen -= insert_len;
@@ -855,16 +905,16 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       int32_t i = insert_len;
       while (i > 0) {
         if (bl0 == 0) {
-          int r = block_switch(br, a, bl_vgpr, bt_tree0, bl_tree0, nbt0, bl0, rb_l0, rb_l1);
+          int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree0, bl_tree0, nbt0, bl0, rb_l0, rb_l1);
           if (r == BS_NEEDS_INPUT) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);
           if (r == BS_SWITCHED) prepare_literal();
         }
         uint32_t tree = lit_tree;
         if (!trivial) {
           uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
-          tree = a.ld32(lit_trees + a.ld8(ctx_map + ctx_slice + context) * 4);
+          tree = a.ld32<LDS_ONLY>(lit_trees + a.ld8<LDS_ONLY>(ctx_map + ctx_slice + context) * 4);
         }
-        uint32_t lit = read_symbol(br, a, tree);
+        uint32_t lit = read_symbol<LDS_ONLY>(br, a, tree);
         if (br.over()) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);  // decode.rs:2835-2846 + 1709-1711
         if (P >= out_cap) STOP(E_NEEDS_MORE_OUTPUT);
         p2 = p1; p1 = lit;
@@ -877,32 +927,32 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       }
       if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
     }
+    PROF_ADD(prof_lit, prof_t);
     // ---- COMMAND_POST_DECODE_LITERALS ----
     if (distance_code >= 0) {
-      distance_context = 1;  // distance_code == 0 here
-      didx--;
-      distance_code = dist_get(didx);
+      distance_context = 1;  // implicit distance: the last one, not pushed again (decode.rs:2560-2565 + 2643-2644)
+      distance_code = d0;
     } else {
       if (bl2 == 0) {
-        int r = block_switch(br, a, bl_vgpr, bt_tree2, bl_tree2, nbt2, bl2, rb_d0, rb_d1);
+        int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree2, bl_tree2, nbt2, bl2, rb_d0, rb_d1);
         if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
         if (r == BS_SWITCHED) dist_ctx_slice = rb_d1 << 2;
       }
-      uint32_t dist_tree_idx = a.ld8(dist_ctx_map + dist_ctx_slice + distance_context);
-      uint32_t dtree = a.ld32(dist_trees + dist_tree_idx * 4);
+      uint32_t dist_tree_idx = a.ld8<LDS_ONLY>(dist_ctx_map + dist_ctx_slice + distance_context);
+      uint32_t dtree = a.ld32<LDS_ONLY>(dist_trees + dist_tree_idx * 4);
       // ReadDistanceInternal, decode.rs:2066-2131
-      uint32_t code = read_symbol(br, a, dtree);
+      uint32_t code = read_symbol<LDS_ONLY>(br, a, dtree);
       distance_context = 0;
       if (code < 16) {
         if (br.over()) STOP(E_NEEDS_MORE_INPUT);
         // TakeDistanceFromRingBuffer, decode.rs:2017-2049
         if (code == 0) {
-          didx--;
-          distance_code = dist_get(didx);
+          distance_code = d0;
           distance_context = 1;
         } else {
           uint32_t sh = code << 1;
-          int32_t v = dist_get(didx + (int32_t)((0xaaafff1bu >> sh) & 3u));
+          uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);  // 0 = last distance ... 3 = fourth last
+          int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
           int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
           if (code & 1u) v += mag;
           else { v -= mag; if (v <= 0) v = 0x7fffffff; }
@@ -924,6 +974,7 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       }
       bl2--;
     }
+    PROF_ADD(prof_dist, prof_t);
     // postReadDistance, decode.rs:2583-2589
     int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
     if (distance_code > max_distance) {
@@ -933,7 +984,6 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       int32_t word_id = distance_code - max_distance - 1;
       uint32_t word_idx = (uint32_t)word_id & mask_bits(shift);
       uint32_t transform_idx = (uint32_t)word_id >> shift;
-      didx += (int32_t)distance_context;
       if (transform_idx >= BROTLI_NUM_TRANSFORMS) STOP(E_TRANSFORM);
       uint32_t offset = kDictOffsetsByLength[copy_len] + word_idx * (uint32_t)copy_len;
       uint64_t room = out_cap - P;
@@ -944,8 +994,7 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       P += out_len;
       mlen -= (int32_t)out_len;
     } else {
-      dist_set(didx, distance_code);
-      didx++;
+      if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
       mlen -= copy_len;
       if (distance_code <= 0) STOP(E_UNREACHABLE);  // wrapped large-window arithmetic, never on valid streams
       uint64_t room = out_cap - P;
@@ -957,6 +1006,7 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       P += n;
       if (clipped) STOP(E_NEEDS_MORE_OUTPUT);
     }
+    PROF_ADD(prof_copy, prof_t);
     if (P >= next_boundary) RING_CROSS();
     if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE
   }
@@ -965,24 +1015,28 @@ __device__ __forceinline__ int process_commands(Stream& s) {
 done:
   s.br = br;
   s.P = P; s.next_boundary = next_boundary; s.mlen = mlen;
-  s.dist_rb0 = d0; s.dist_rb1 = d1; s.dist_rb2 = d2; s.dist_rb3 = d3; s.dist_rb_idx = didx;
+  s.dist_rb0 = d0; s.dist_rb1 = d1; s.dist_rb2 = d2; s.dist_rb3 = d3;
   s.num_commands = num_commands;
+#ifdef BROTLI_AMD_PROFILE
+  s.prof[0] += prof_cmd; s.prof[1] += prof_lit; s.prof[2] += prof_dist; s.prof[3] += prof_copy;
+#endif
   return result;
 }
 
 // decode.rs:1754-1806: stored metablock = byte-aligned memcpy of MLEN bytes, all lanes
 __device__ __forceinline__ int copy_uncompressed(Stream& s) {
-  BitReader br = s.br;
+  BitReader br = s.br; br.uniformize();
   const uint32_t lane = lane_id();
   uint64_t byte = br.pos() >> 3;
   uint64_t in_size = br.total_bits >> 3;
   uint64_t avail = in_size > byte ? in_size - byte : 0;
-  uint64_t n = (uint64_t)(uint32_t)s.mlen < avail ? (uint64_t)(uint32_t)s.mlen : avail;
-  uint64_t room = s.out_cap - s.P;
+  const uint64_t mlen0 = (uint64_t)rfl((uint32_t)s.mlen), P0 = rfl(s.P);
+  uint64_t n = mlen0 < avail ? mlen0 : avail;
+  uint64_t room = rfl(s.out_cap) - P0;
   bool clipped = n > room;
   if (clipped) n = room;
-  gcu8* src = s.in_bytes + byte;
-  gu8* dst = s.out + s.P;
+  gcu8* src = rfl_ptr(s.in_bytes) + byte;
+  gu8* dst = rfl_ptr(s.out) + P0;
   for (uint64_t k = lane; k < n; k += 64) dst[k] = src[k];
   s.P += n;
   s.mlen -= (int32_t)n;
@@ -1116,7 +1170,8 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
         TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
         TRY(decode_tree_group(s, num_dist_codes, max_dist_symbol, s.num_dist_trees, &s.dist_trees));
-        TRY(process_commands(s));
+        // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
+        if (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) { TRY(process_commands<true>(s)); } else { TRY(process_commands<false>(s)); }
       }
     }
     // METABLOCK_DONE (decode.rs:3345-3381)
@@ -1170,6 +1225,10 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
     s.lut_vgpr = lut; s.bl_vgpr = bl;
     s.num_metablocks = 0; s.num_commands = 0;
     s.mlen = 0;
+#ifdef BROTLI_AMD_PROFILE
+    s.prof[0] = s.prof[1] = s.prof[2] = s.prof[3] = 0;
+    const uint64_t prof_start = __builtin_amdgcn_s_memtime();
+#endif
     s.is_last = 0; s.is_uncompressed = 0; s.is_metadata = 0;
     // bit reader over [in, in + in_size)
     {
@@ -1195,7 +1254,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
       if (lane == 0) st->resume = d.resume;
     } else {
       s.P = 0;
-      s.dist_rb0 = 16; s.dist_rb1 = 15; s.dist_rb2 = 11; s.dist_rb3 = 4;  // state.rs:296
+      s.dist_rb0 = 4; s.dist_rb1 = 11; s.dist_rb2 = 15; s.dist_rb3 = 16;  // state.rs:296, most recent first
       s.dist_rb_idx = 0;
       s.window_bits = 0; s.large_window = 0;
       s.rb_size = 0; s.next_boundary = 0;
@@ -1226,6 +1285,12 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
       st->num_metablocks = s.num_metablocks;
       st->num_commands = s.num_commands;
       st->reserved = 0;
+#ifdef BROTLI_AMD_PROFILE
+      // debugging aid: cycle split of the command loop in the (otherwise unused) resume block of the status
+      st->resume.bit_pos = __builtin_amdgcn_s_memtime() - prof_start;
+      st->resume.out_pos = s.prof[0];
+      st->resume.dist_rb[0] = (int32_t)(s.prof[1] >> 8); st->resume.dist_rb[1] = (int32_t)(s.prof[2] >> 8); st->resume.dist_rb[2] = (int32_t)(s.prof[3] >> 8);
+#endif
     }
   }
 }
