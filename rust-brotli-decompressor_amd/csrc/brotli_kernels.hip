@@ -85,6 +85,8 @@ typedef __attribute__((address_space(1))) uint16_t gu16;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 typedef __attribute__((address_space(1))) const uint8_t gcu8;
 typedef __attribute__((address_space(1))) const uint32_t gcu32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
 template <typename T, typename U>
 __device__ __forceinline__ T* as_global(U* p) { return (T*)(uintptr_t)p; }
 
@@ -730,63 +732,35 @@ __device__ __forceinline__ uint32_t max_distance_symbol(uint32_t ndirect, uint32
 }
 
 // ============================== output: literals, copies, dictionary words ==============================
-// out[P .. P+len) = out[P-dist .. ) with LZ77 semantics (decode.rs:2641-2720).  All 64 lanes move bytes.
-// Leaves the last two bytes in p1/p2 (read back from the lanes with v_readlane, no memory round trip).
-__device__ __forceinline__ void lz77_copy(gu8* dst, uint32_t dist, uint32_t len, uint32_t& p1, uint32_t& p2) {
-  const uint32_t lane = lane_id();
-  uint32_t last = 0, prev = 0;  // bytes of the last two 64-byte steps, per lane
-  if (dist >= 64 || dist >= len) {
-    // a 64-byte step never reads what it writes itself; a later step may read an earlier step's bytes
-    // (dist < len), which the in-order vector memory pipeline of one wave allows
-    gu8* src = dst - dist;
-    for (uint32_t k = 0; k < len; k += 64) {
-      uint32_t i = k + lane;
-      uint32_t b = 0;
-      if (i < len) { b = src[i]; dst[i] = (uint8_t)b; }
-      prev = last; last = b;
-    }
-  } else {
-    // overlapping copy with a short period: pattern fill from the `dist` bytes before P
-    gu8* pat = dst - dist;
-    uint32_t m = lane % dist;
-    uint32_t step = 64 % dist;
-    for (uint32_t k = 0; k < len; k += 64) {
-      uint32_t i = k + lane;
-      uint32_t b = 0;
-      if (i < len) { b = pat[m]; dst[i] = (uint8_t)b; }
-      m += step; if (m >= dist) m -= dist;
-      prev = last; last = b;
-    }
-  }
-  uint32_t k1 = len - 1, k2 = len - 2;  // len >= 2
-  p1 = rdlane(last, k1 & 63u);
-  p2 = ((k2 >> 6) == (k1 >> 6)) ? rdlane(last, k2 & 63u) : rdlane(prev, k2 & 63u);
+// Length and affixes of a transformed dictionary word (transform.rs:737-795), everything uniform.
+struct WordShape { uint32_t pre, plen, suf, slen, skip, wlen, t, total; };
+__device__ __forceinline__ WordShape word_shape(uint32_t len, uint32_t transform_idx) {
+  WordShape w;
+  w.pre = kTransforms[transform_idx * 3]; w.t = kTransforms[transform_idx * 3 + 1]; w.suf = kTransforms[transform_idx * 3 + 2];
+  w.plen = 0; while (kAffixPool[w.pre + w.plen]) w.plen++;
+  w.slen = 0; while (kAffixPool[w.suf + w.slen]) w.slen++;
+  w.skip = w.t < 12 ? 0 : w.t - 11;
+  if (w.skip > len) w.skip = len;
+  int32_t wl = (int32_t)(len - w.skip);
+  if (w.t <= 9) wl -= (int32_t)w.t;
+  w.wlen = wl > 0 ? (uint32_t)wl : 0;
+  w.total = w.plen + w.wlen + w.slen;
+  return w;
 }
 
-// decode.rs:2593-2640 + transform.rs:737-795.  Writes the (transformed) word at dst (at most `room` bytes),
-// returns its length; p1/p2 = its last two bytes when it has that many.
-__device__ __forceinline__ uint32_t emit_dictionary_word(gcu8* dict, gu8* dst, uint32_t offset, uint32_t len, uint32_t transform_idx,
-                                                         uint64_t room, uint32_t& p1, uint32_t& p2) {
+// decode.rs:2593-2640 + transform.rs:737-795.  Returns the bytes of the (transformed) word, one per lane.
+__device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t offset, const WordShape& w) {
   const uint32_t lane = lane_id();
-  uint32_t pre = kTransforms[transform_idx * 3], t = kTransforms[transform_idx * 3 + 1], suf = kTransforms[transform_idx * 3 + 2];
-  uint32_t plen = 0; while (kAffixPool[pre + plen]) plen++;
-  uint32_t slen = 0; while (kAffixPool[suf + slen]) slen++;
-  uint32_t skip = t < 12 ? 0 : t - 11;
-  if (skip > len) skip = len;
-  int32_t wl = (int32_t)(len - skip);
-  if (t <= 9) wl -= (int32_t)t;
-  uint32_t wlen = wl > 0 ? (uint32_t)wl : 0;
-  // stage prefix + word in LDS (bytes after the word are zero so that a stray uppercase write is harmless)
   uint32_t b = 0;
-  if (lane < plen) b = kAffixPool[pre + lane];
-  else if (lane < plen + wlen) b = dict[offset + skip + (lane - plen)];
-  lds_st8(LDS_WORD + lane, b);
-  lds_st8(LDS_WORD + 64 + lane, 0);
-  lds_sync();
-  if (t == 10 || t == 11) {  // transform.rs:720-735 -- serial over UTF-8 sequences
+  if (lane < w.plen) b = kAffixPool[w.pre + lane];
+  else if (lane < w.plen + w.wlen) b = dict[offset + w.skip + (lane - w.plen)];
+  if (w.t == 10 || w.t == 11) {  // transform.rs:720-735 -- serial over UTF-8 sequences, staged through LDS
+    lds_st8(LDS_WORD + lane, b);
+    lds_st8(LDS_WORD + 64 + lane, 0);  // bytes after the word are zero so that a stray write past it is harmless
+    lds_sync();
     if (lane == 0) {
-      uint32_t p = LDS_WORD + plen;
-      int32_t remaining = (t == 10) ? 1 : (int32_t)wlen;
+      uint32_t p = LDS_WORD + w.plen;
+      int32_t remaining = (w.t == 10) ? 1 : (int32_t)w.wlen;
       while (remaining > 0) {
         int step;
         uint32_t c0 = lds_ld8(p);
@@ -794,22 +768,15 @@ __device__ __forceinline__ uint32_t emit_dictionary_word(gcu8* dict, gu8* dst, u
         else if (c0 < 0xe0) { lds_st8(p + 1, lds_ld8(p + 1) ^ 32); step = 2; }
         else { lds_st8(p + 2, lds_ld8(p + 2) ^ 5); step = 3; }
         p += step; remaining -= step;
-        if (t == 10) break;
+        if (w.t == 10) break;
       }
     }
     lds_sync();
+    b = lds_ld8(LDS_WORD + lane);
+    lds_sync();
   }
-  uint32_t total = plen + wlen + slen;
-  uint32_t ob;
-  if (lane >= plen + wlen && lane < total) ob = kAffixPool[suf + (lane - plen - wlen)];
-  else ob = lds_ld8(LDS_WORD + lane);
-  uint32_t n = total;
-  if ((uint64_t)n > room) n = (uint32_t)room;
-  if (lane < n) dst[lane] = (uint8_t)ob;
-  if (total >= 1) p1 = rdlane(ob, total - 1);
-  if (total >= 2) p2 = rdlane(ob, total - 2);
-  lds_sync();
-  return total;
+  if (lane >= w.plen + w.wlen && lane < w.total) b = kAffixPool[w.suf + (lane - w.plen - w.wlen)];
+  return b;
 }
 
 #ifdef BROTLI_AMD_PROFILE
@@ -819,36 +786,62 @@ __device__ __forceinline__ uint32_t emit_dictionary_word(gcu8* dict, gu8* dst, u
 #define PROF_T() 0ull
 #define PROF_ADD(acc, t0) do { } while (0)
 #endif
+
 // ===================================== the command loop (hot path) =====================================
-// src/decode.rs:2330-2744 with a flat output buffer.  Works entirely on register copies of the stream state
-// (SGPRs for everything uniform); the Stream object is read on entry and written on exit.
+// Argument block of the command loop.  The loop is a real function (one per table placement) so that it gets a
+// register allocation of its own: everything uniform lives in SGPRs for the whole metablock and nothing of the
+// (large, cold) header code competes for them.
+struct HotArgs {
+  BitReader br;
+  Arena ar;
+  gu8* out; gcu8* dict;
+  uint64_t out_cap, P, next_boundary, rb_size;
+  uint32_t window_bits;
+  int32_t mlen, max_backward;
+  int32_t d0, d1, d2, d3;
+  uint32_t bl0, bl1, bl2, nbt0, nbt1, nbt2;
+  uint32_t bt_tree0, bt_tree1, bt_tree2, bl_tree0, bl_tree1, bl_tree2;
+  uint32_t postfix_bits, num_direct;
+  uint32_t ctx_modes, ctx_map, dist_ctx_map, lit_trees, cmd_trees, dist_trees;
+  uint32_t lut_vgpr, bl_vgpr;
+  uint64_t num_commands;
+  uint64_t prof[4];
+};
+
+// src/decode.rs:2330-2744 with a flat output buffer.
+//  * literals are collected one per lane (v_writelane) and stored 64 at a time;
+//  * a copy of <= 64 bytes is split in two: its load is issued when the command is decoded, its store when the
+//    next command needs the memory pipe -- the load latency overlaps the decode of the next command;
+//  * long copies move 16 bytes per lane per step when source and destination are at least a step apart;
+//  * the last two output bytes (literal context) are taken from registers where they still are, from memory
+//    only after a long copy.
 template <bool LDS_ONLY>
-__device__ __forceinline__ int process_commands(Stream& s) {
-  BitReader br = s.br; br.uniformize();
-  Arena a_ = s.ar; a_.uniformize();
+__device__ __noinline__ int process_commands(HotArgs* args) {
+  BitReader br = args->br; br.uniformize();
+  Arena a_ = args->ar; a_.uniformize();
   const Arena a = a_;
   const uint32_t lane = lane_id();
-  gu8* const out = rfl_ptr(s.out);
-  gcu8* const dict = rfl_ptr(s.dict);
-  const uint64_t out_cap = rfl(s.out_cap);
-  uint64_t P = rfl(s.P), next_boundary = rfl(s.next_boundary);
-  const uint64_t rb_size = rfl(s.rb_size);
-  const bool full_ring = rb_size == (1ull << rfl(s.window_bits));
-  int32_t mlen = rfl(s.mlen);
-  const int32_t max_backward = rfl(s.max_backward);
+  gu8* const out = rfl_ptr(args->out);
+  gcu8* const dict = rfl_ptr(args->dict);
+  const uint64_t out_cap = rfl(args->out_cap);
+  uint64_t P = rfl(args->P), next_boundary = rfl(args->next_boundary);
+  const uint64_t rb_size = rfl(args->rb_size);
+  const bool full_ring = rb_size == (1ull << rfl(args->window_bits));
+  int32_t mlen = rfl(args->mlen);
+  const int32_t max_backward = rfl(args->max_backward);
   // last four distances, most recent first (the reference's dist_rb/dist_rb_idx ring as a shift register: short
   // code 0 and dictionary references leave it untouched, every other LZ77 distance is pushed; state.rs:295-296)
-  int32_t d0 = rfl(s.dist_rb0), d1 = rfl(s.dist_rb1), d2 = rfl(s.dist_rb2), d3 = rfl(s.dist_rb3);
-  uint32_t bl0 = rfl(s.bl0), bl1 = rfl(s.bl1), bl2 = rfl(s.bl2);
-  const uint32_t nbt0 = rfl(s.nbt0), nbt1 = rfl(s.nbt1), nbt2 = rfl(s.nbt2);
+  int32_t d0 = rfl(args->d0), d1 = rfl(args->d1), d2 = rfl(args->d2), d3 = rfl(args->d3);
+  uint32_t bl0 = rfl(args->bl0), bl1 = rfl(args->bl1), bl2 = rfl(args->bl2);
+  const uint32_t nbt0 = rfl(args->nbt0), nbt1 = rfl(args->nbt1), nbt2 = rfl(args->nbt2);
   uint32_t rb_l0 = 1, rb_l1 = 0, rb_c0 = 1, rb_c1 = 0, rb_d0 = 1, rb_d1 = 0;  // block type rings (state.rs:429-435)
-  const uint32_t bt_tree0 = rfl(s.bt_tree0), bt_tree1 = rfl(s.bt_tree1), bt_tree2 = rfl(s.bt_tree2);
-  const uint32_t bl_tree0 = rfl(s.bl_tree0), bl_tree1 = rfl(s.bl_tree1), bl_tree2 = rfl(s.bl_tree2);
-  const uint32_t postfix_bits = rfl(s.postfix_bits), num_direct = rfl(s.num_direct);
-  const uint32_t ctx_modes = rfl(s.ctx_modes), ctx_map = rfl(s.ctx_map), dist_ctx_map = rfl(s.dist_ctx_map);
-  const uint32_t lit_trees = rfl(s.lit_trees), cmd_trees = rfl(s.cmd_trees), dist_trees = rfl(s.dist_trees);
-  const uint32_t lut_vgpr = s.lut_vgpr, bl_vgpr = s.bl_vgpr;  // per-lane LUT images
-  uint64_t num_commands = rfl(s.num_commands);
+  const uint32_t bt_tree0 = rfl(args->bt_tree0), bt_tree1 = rfl(args->bt_tree1), bt_tree2 = rfl(args->bt_tree2);
+  const uint32_t bl_tree0 = rfl(args->bl_tree0), bl_tree1 = rfl(args->bl_tree1), bl_tree2 = rfl(args->bl_tree2);
+  const uint32_t postfix_bits = rfl(args->postfix_bits), num_direct = rfl(args->num_direct);
+  const uint32_t ctx_modes = rfl(args->ctx_modes), ctx_map = rfl(args->ctx_map), dist_ctx_map = rfl(args->dist_ctx_map);
+  const uint32_t lit_trees = rfl(args->lit_trees), cmd_trees = rfl(args->cmd_trees), dist_trees = rfl(args->dist_trees);
+  const uint32_t lut_vgpr = args->lut_vgpr, bl_vgpr = args->bl_vgpr;  // per-lane LUT images
+  uint64_t num_commands = rfl(args->num_commands);
   int result = E_SUCCESS;
   uint64_t prof_cmd = 0, prof_lit = 0, prof_dist = 0, prof_copy = 0, prof_t = PROF_T();
   (void)prof_cmd; (void)prof_lit; (void)prof_dist; (void)prof_copy; (void)prof_t;
@@ -867,11 +860,21 @@ __device__ __forceinline__ int process_commands(Stream& s) {
     ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(ctx_modes + bt) & 3u);
   };
   prepare_literal();
-  // last two output bytes (context of the next literal); stream start counts as two zero bytes (decode.rs:1859-1860)
-  uint32_t p1 = 0, p2 = 0;
-  if (P >= 1) p1 = rfl(out[P - 1]);
-  if (P >= 2) p2 = rfl(out[P - 2]);
 
+  // ---- output side state ----
+  // literal run being collected: lane k holds literal k, lit_n of them, first one goes to out[lit_pos]
+  uint32_t lit_reg = 0, lit_n = 0; uint64_t lit_pos = P;
+  // short copy / dictionary word whose bytes are in registers (lane k = byte k) but not stored yet
+  uint32_t pend_reg = 0, pend_n = 0; uint64_t pend_pos = 0;
+  // where the two bytes before P (literal context) currently are
+  enum { CTX_REGS = 0, CTX_PEND = 1, CTX_MEMORY = 2 };
+  uint32_t ctx_src = CTX_MEMORY, ctx_len = 0;  // CTX_PEND: last ctx_len bytes of output are pend_reg[0..ctx_len)
+  uint32_t p1 = 0, p2 = 0;  // stream start counts as two zero bytes (decode.rs:1859-1860)
+  if (P == 0) ctx_src = CTX_REGS;
+
+#define FLUSH_LITERALS() do { if (lit_n) { uint64_t q_ = lit_pos + lane; if (lane < lit_n && q_ < out_cap) out[q_] = (uint8_t)lit_reg; \
+                                lit_pos += lit_n; lit_n = 0; } } while (0)
+#define FLUSH_PENDING() do { if (pend_n) { uint64_t q_ = pend_pos + lane; if (lane < pend_n && q_ < out_cap) out[q_] = (uint8_t)pend_reg; pend_n = 0; } } while (0)
 #define STOP(e) do { result = (e); goto done; } while (0)
   // ring-buffer flush points (decode.rs:1693-1738, 3299-3344): crossing one with a negative remaining length is
   // BLOCK_LENGTH_1; the last crossed one is what the caller has received when an error is reported
@@ -902,6 +905,22 @@ __device__ __forceinline__ int process_commands(Stream& s) {
     if (insert_len != 0) {
       mlen -= insert_len;
       // ---- COMMAND_INNER: literals ----
+      if (lit_n == 0) lit_pos = P;
+      // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose only literal
+      // block type is trivial, otherwise always (a block switch inside the run may make the very next literal
+      // context-modelled)
+      if (!(trivial && nbt0 <= 1) && ctx_src != CTX_REGS) {
+        if (ctx_src == CTX_PEND) {
+          uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
+          p2 = ctx_len >= 2 ? rdlane(pend_reg, ctx_len - 2) : p1;
+          p1 = q1;
+        } else {
+          FLUSH_PENDING();
+          p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u;
+          p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u;
+        }
+      }
+      if (!(trivial && nbt0 <= 1)) ctx_src = CTX_REGS;
       int32_t i = insert_len;
       while (i > 0) {
         if (bl0 == 0) {
@@ -916,10 +935,14 @@ __device__ __forceinline__ int process_commands(Stream& s) {
         }
         uint32_t lit = read_symbol<LDS_ONLY>(br, a, tree);
         if (br.over()) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);  // decode.rs:2835-2846 + 1709-1711
-        if (P >= out_cap) STOP(E_NEEDS_MORE_OUTPUT);
+        // a full output buffer is only an error while the metablock is still within its declared length; past it
+        // the stream is already invalid and the remaining literals are decoded without being stored
+        if (P >= out_cap && mlen >= 0) STOP(E_NEEDS_MORE_OUTPUT);
         p2 = p1; p1 = lit;
-        if (lane == 0) out[P] = (uint8_t)lit;
+        lit_reg = (lane == lit_n) ? lit : lit_reg;
+        lit_n++;
         P++;
+        if (lit_n == 64) FLUSH_LITERALS();
         if (bl0 == 0) STOP(E_WINDOW_BITS);  // decode.rs:2434-2439
         bl0--;
         i--;
@@ -986,23 +1009,83 @@ __device__ __forceinline__ int process_commands(Stream& s) {
       uint32_t transform_idx = (uint32_t)word_id >> shift;
       if (transform_idx >= BROTLI_NUM_TRANSFORMS) STOP(E_TRANSFORM);
       uint32_t offset = kDictOffsetsByLength[copy_len] + word_idx * (uint32_t)copy_len;
-      uint64_t room = out_cap - P;
-      uint32_t q1 = p1, q2 = p2;
-      uint32_t out_len = emit_dictionary_word(dict, out + P, offset, (uint32_t)copy_len, transform_idx, room, q1, q2);
-      if ((uint64_t)out_len > room) { P = out_cap; STOP(E_NEEDS_MORE_OUTPUT); }
-      if (out_len >= 2) { p1 = q1; p2 = q2; } else if (out_len == 1) { p2 = p1; p1 = q1; }
-      P += out_len;
-      mlen -= (int32_t)out_len;
+      WordShape w = word_shape((uint32_t)copy_len, transform_idx);
+      mlen -= (int32_t)w.total;
+      if (mlen < 0) STOP(P + w.total >= next_boundary ? E_BLOCK_LENGTH_1 : E_BLOCK_LENGTH_2);  // decode.rs:2621-2625, 3356-3359
+      if (w.total != 0) {
+        if (P + w.total > out_cap) {  // clip: deliver what fits, then report the full buffer
+          FLUSH_LITERALS(); FLUSH_PENDING();
+          uint32_t ob = dictionary_word_bytes(dict, offset, w);
+          uint64_t q = P + lane;
+          if (lane < w.total && q < out_cap) out[q] = (uint8_t)ob;
+          P = out_cap;
+          STOP(E_NEEDS_MORE_OUTPUT);
+        }
+        FLUSH_LITERALS();
+        if (ctx_src == CTX_PEND && w.total == 1) { p1 = rdlane(pend_reg, ctx_len - 1); ctx_src = CTX_REGS; }
+        FLUSH_PENDING();
+        uint32_t ob = dictionary_word_bytes(dict, offset, w);
+        if (w.total == 1) {  // context = this byte and the one before it
+          if (ctx_src == CTX_MEMORY) { p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u; }
+          p2 = p1; p1 = rdlane(ob, 0); ctx_src = CTX_REGS;
+        } else { ctx_src = CTX_PEND; ctx_len = w.total; }
+        pend_reg = ob; pend_n = w.total; pend_pos = P;
+        P += w.total;
+      }
     } else {
       if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
       mlen -= copy_len;
+      // a copy that overshoots MLEN ends the stream whatever it copies (decode.rs:2690-2720 + 1709-1711 / 3356-3359)
+      if (mlen < 0) STOP(P + (uint32_t)copy_len >= next_boundary ? E_BLOCK_LENGTH_1 : E_BLOCK_LENGTH_2);
       if (distance_code <= 0) STOP(E_UNREACHABLE);  // wrapped large-window arithmetic, never on valid streams
+      const uint32_t dist = (uint32_t)distance_code;
       uint64_t room = out_cap - P;
       uint32_t n = (uint32_t)copy_len;
-      bool clipped = (uint64_t)n > room;
+      const bool clipped = (uint64_t)n > room;
       if (clipped) n = (uint32_t)room;
-      if (n >= 2) lz77_copy(out + P, (uint32_t)distance_code, n, p1, p2);
-      else if (n == 1) { uint32_t b = rfl(out[P - (uint32_t)distance_code]); if (lane == 0) out[P] = (uint8_t)b; p2 = p1; p1 = b; }
+      // every earlier byte must be in memory (or at least ordered before the loads below in the wave's in-order
+      // vector memory pipeline)
+      FLUSH_LITERALS();
+      FLUSH_PENDING();
+      gu8* dst = out + P;
+      if (n <= 64 && dist >= n) {
+        // short, non-overlapping: load now, store when the next command comes here (or at exit)
+        uint32_t b = 0;
+        if (lane < n) b = (dst - dist)[lane];
+        pend_reg = b; pend_n = n; pend_pos = P;
+        if (n >= 2) { ctx_src = CTX_PEND; ctx_len = n; }
+        else if (n == 1) { if (ctx_src == CTX_MEMORY) p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u; p2 = p1; p1 = rdlane(b, 0); ctx_src = CTX_REGS; }
+      } else if (dist >= n || dist >= 1024) {
+        // long: 16 bytes per lane and step; steps are >= 1 KiB apart from their source or do not overlap at all
+        gu8* src = dst - dist;
+        uint32_t n16 = n >> 4;
+        for (uint32_t c = lane; c < n16; c += 64) {
+          u32x4 v = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);  // any alignment: global accesses are byte-addressed
+          *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = v;
+        }
+        uint32_t tail = n16 << 4;
+        if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+        ctx_src = CTX_MEMORY;
+      } else if (dist >= 64) {
+        // overlapping at a distance of 64..1023: 64 bytes per step, a step reads what earlier steps wrote
+        gu8* src = dst - dist;
+        for (uint32_t k = 0; k < n; k += 64) {
+          uint32_t i = k + lane;
+          if (i < n) dst[i] = src[i];
+        }
+        ctx_src = CTX_MEMORY;
+      } else {
+        // overlapping with a short period: pattern fill from the `dist` bytes before P
+        gu8* pat = dst - dist;
+        uint32_t m = lane % dist;
+        uint32_t step = 64 % dist;
+        for (uint32_t k = 0; k < n; k += 64) {
+          uint32_t i = k + lane;
+          if (i < n) dst[i] = pat[m];
+          m += step; if (m >= dist) m -= dist;
+        }
+        ctx_src = CTX_MEMORY;
+      }
       P += n;
       if (clipped) STOP(E_NEEDS_MORE_OUTPUT);
     }
@@ -1013,14 +1096,47 @@ __device__ __forceinline__ int process_commands(Stream& s) {
 #undef STOP
 #undef RING_CROSS
 done:
-  s.br = br;
-  s.P = P; s.next_boundary = next_boundary; s.mlen = mlen;
-  s.dist_rb0 = d0; s.dist_rb1 = d1; s.dist_rb2 = d2; s.dist_rb3 = d3;
-  s.num_commands = num_commands;
+  FLUSH_LITERALS();
+  FLUSH_PENDING();
+#undef FLUSH_LITERALS
+#undef FLUSH_PENDING
+  args->br = br;
+  args->P = P; args->next_boundary = next_boundary; args->mlen = mlen;
+  args->d0 = d0; args->d1 = d1; args->d2 = d2; args->d3 = d3;
+  args->num_commands = num_commands;
 #ifdef BROTLI_AMD_PROFILE
-  s.prof[0] += prof_cmd; s.prof[1] += prof_lit; s.prof[2] += prof_dist; s.prof[3] += prof_copy;
+  args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
 #endif
   return result;
+}
+
+// Marshals the stream state into the argument block, runs the loop, takes the results back.
+__device__ __forceinline__ int run_commands(Stream& s) {
+  HotArgs h;
+  h.br = s.br; h.ar = s.ar; h.out = s.out; h.dict = s.dict;
+  h.out_cap = s.out_cap; h.P = s.P; h.next_boundary = s.next_boundary; h.rb_size = s.rb_size;
+  h.window_bits = s.window_bits; h.mlen = s.mlen; h.max_backward = s.max_backward;
+  h.d0 = s.dist_rb0; h.d1 = s.dist_rb1; h.d2 = s.dist_rb2; h.d3 = s.dist_rb3;
+  h.bl0 = s.bl0; h.bl1 = s.bl1; h.bl2 = s.bl2; h.nbt0 = s.nbt0; h.nbt1 = s.nbt1; h.nbt2 = s.nbt2;
+  h.bt_tree0 = s.bt_tree0; h.bt_tree1 = s.bt_tree1; h.bt_tree2 = s.bt_tree2;
+  h.bl_tree0 = s.bl_tree0; h.bl_tree1 = s.bl_tree1; h.bl_tree2 = s.bl_tree2;
+  h.postfix_bits = s.postfix_bits; h.num_direct = s.num_direct;
+  h.ctx_modes = s.ctx_modes; h.ctx_map = s.ctx_map; h.dist_ctx_map = s.dist_ctx_map;
+  h.lit_trees = s.lit_trees; h.cmd_trees = s.cmd_trees; h.dist_trees = s.dist_trees;
+  h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
+  h.num_commands = s.num_commands;
+  h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = 0;
+  // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
+  int e = (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) ? process_commands<true>(&h) : process_commands<false>(&h);
+  e = rfl(e);
+  s.br = h.br; s.br.uniformize();
+  s.P = rfl(h.P); s.next_boundary = rfl(h.next_boundary); s.mlen = rfl(h.mlen);
+  s.dist_rb0 = rfl(h.d0); s.dist_rb1 = rfl(h.d1); s.dist_rb2 = rfl(h.d2); s.dist_rb3 = rfl(h.d3);
+  s.num_commands = rfl(h.num_commands);
+#ifdef BROTLI_AMD_PROFILE
+  s.prof[0] += h.prof[0]; s.prof[1] += h.prof[1]; s.prof[2] += h.prof[2]; s.prof[3] += h.prof[3];
+#endif
+  return e;
 }
 
 // decode.rs:1754-1806: stored metablock = byte-aligned memcpy of MLEN bytes, all lanes
@@ -1170,8 +1286,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
         TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
         TRY(decode_tree_group(s, num_dist_codes, max_dist_symbol, s.num_dist_trees, &s.dist_trees));
-        // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
-        if (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) { TRY(process_commands<true>(s)); } else { TRY(process_commands<false>(s)); }
+        TRY(run_commands(s));
       }
     }
     // METABLOCK_DONE (decode.rs:3345-3381)
