@@ -184,6 +184,23 @@ struct BitReader {
     cnt -= n;
     return v;
   }
+  // k-th dword after the ones already shifted into buf (k = 0, 1), without consuming it
+  __device__ __forceinline__ uint32_t peek_dword(uint32_t k) const {
+    uint32_t idx = next_dw + k - chunk_base;  // < 128: one window ahead is always loaded
+    return idx < 64 ? rdlane(cur, idx) : rdlane(nxt, idx - 64);
+  }
+  // 128-bit view of the stream from the current position: at least cnt + 64 >= 96 valid bits (needs cnt >= 32)
+  __device__ __forceinline__ void window128(uint64_t& lo, uint64_t& hi) const {
+    uint64_t e = (uint64_t)peek_dword(0) | ((uint64_t)peek_dword(1) << 32);
+    lo = buf | (e << cnt);         // 32 <= cnt <= 63
+    hi = e >> (64 - cnt);
+  }
+  __device__ __forceinline__ void advance(uint32_t n) {  // n <= 96
+    if (n <= cnt) { drop(n); return; }
+    n -= cnt; buf = 0; cnt = 0;
+    next_dw += n >> 5; n &= 31;
+    if (n) { pull(); drop(n); }
+  }
   __device__ __forceinline__ uint64_t pos() const { return (uint64_t)next_dw * 32 - cnt - skip_bits; }
   __device__ __forceinline__ bool over() const { return pos() > total_bits; }
 };
@@ -294,7 +311,7 @@ struct Stream {
   uint32_t num_metablocks;
   uint64_t num_commands;
 #ifdef BROTLI_AMD_PROFILE
-  uint64_t prof[4];
+  uint64_t prof[6];
 #endif
 };
 
@@ -805,7 +822,7 @@ struct HotArgs {
   uint32_t ctx_modes, ctx_map, dist_ctx_map, lit_trees, cmd_trees, dist_trees;
   uint32_t lut_vgpr, bl_vgpr;
   uint64_t num_commands;
-  uint64_t prof[4];
+  uint64_t prof[6];
 };
 
 // src/decode.rs:2330-2744 with a flat output buffer.
@@ -845,6 +862,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   int result = E_SUCCESS;
   uint64_t prof_cmd = 0, prof_lit = 0, prof_dist = 0, prof_copy = 0, prof_t = PROF_T();
   (void)prof_cmd; (void)prof_lit; (void)prof_dist; (void)prof_copy; (void)prof_t;
+  uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
 
   uint32_t cmd_tree = a.ld32<LDS_ONLY>(cmd_trees);
   uint32_t dist_ctx_slice = 0, ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT;
@@ -905,7 +923,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     if (insert_len != 0) {
       mlen -= insert_len;
       // ---- COMMAND_INNER: literals ----
-      if (lit_n == 0) lit_pos = P;
       // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose only literal
       // block type is trivial, otherwise always (a block switch inside the run may make the very next literal
       // context-modelled)
@@ -922,7 +939,69 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       }
       if (!(trivial && nbt0 <= 1)) ctx_src = CTX_REGS;
       int32_t i = insert_len;
+      // ---- wave-parallel literal decode (trivial context: one prefix code for the whole run) ----
+      // Every lane decodes the symbol that would start at bit offset `lane` of a 64-bit window (one gathered table
+      // lookup for all 64 candidates); a short scalar walk over the code lengths then picks the offsets that really
+      // are symbol boundaries, and the surviving lanes store their bytes with one coalesced instruction.
+#ifdef BROTLI_AMD_PROFILE
+      if (prof_fast_syms == 0) prof_fast_syms = 0x100000u | (LDS_ONLY ? 1u : 0u) | (trivial ? 2u : 0u) | (mlen >= 0 ? 4u : 0u) | (i >= 8 ? 8u : 0u) | (bl0 >= 8 ? 16u : 0u) | (out_cap - P >= 8 ? 32u : 0u);
+#endif
+      if (LDS_ONLY && trivial && mlen >= 0) {
+        while (i >= 8 && bl0 >= 8) {
+          uint64_t room = out_cap - P;
+          uint32_t lim = (uint32_t)i < bl0 ? (uint32_t)i : bl0;
+          if (lim > 64) lim = 64;
+          if ((uint64_t)lim > room) lim = (uint32_t)room;
+          if (lim < 8) break;
+          br.need32();
+          uint64_t wlo, whi;
+          br.window128(wlo, whi);
+          // bits that really exist from here on (pos <= total here), saturated to 32 bits: the walk below compares
+          // in 32 bits (hipcc 7.2 miscompiles a select fed by a uniform 64-bit unsigned compare in this loop)
+          uint64_t avail64 = br.total_bits - br.pos();
+          uint32_t avail = (avail64 >> 16) ? 0xFFFFu : (uint32_t)avail64;
+          uint32_t w0 = (uint32_t)wlo, w1 = (uint32_t)(wlo >> 32), w2 = (uint32_t)whi;
+          uint32_t x = lane < 32 ? __builtin_amdgcn_alignbit(w1, w0, lane) : __builtin_amdgcn_alignbit(w2, w1, lane - 32);
+          uint32_t e = lds_ld16(LDS_FIXED + lit_tree + ((x & 0xFFu) << 1));
+          uint32_t L = e & 15u;
+          if (L > ROOT_BITS) {
+            uint32_t idx = (e >> 4) + ((x >> ROOT_BITS) & mask_bits(L - ROOT_BITS));
+            e = lds_ld16(LDS_FIXED + lit_tree + (idx << 1));
+            L = ROOT_BITS + (e & 15u);
+          }
+          uint32_t sym = e >> 4;
+          if (rdlane(L, 0) == 0) break;  // single-symbol code (zero bits per literal): the scalar loop handles it
+          uint64_t starts = 0;
+          uint32_t off = 0, left = lim;
+          do {
+            uint32_t l = rdlane(L, off);
+            if (off + l > avail) break;
+            starts |= 1ull << off;
+            off += l;
+            left--;
+          } while (left != 0 && off < 64);
+#ifdef BROTLI_AMD_TRACE
+          if (lane == 0 && num_commands < 3) printf("batch lim %u avail %llu L0 %u x0 %08x starts %llx off %u cnt %u w0 %08x w1 %08x w2 %08x tree %u\n", lim, avail, rdlane(L, 0), rdlane(x, 0), (unsigned long long)starts, off, br.cnt, w0, w1, w2, lit_tree);
+#endif
+          if (starts == 0) break;
+          uint32_t n = (uint32_t)__popcll(starts);
+          FLUSH_LITERALS();
+          if ((starts >> lane) & 1ull) out[P + (uint32_t)__popcll(starts & ((1ull << lane) - 1ull))] = (uint8_t)sym;
+          uint32_t last = 63u - (uint32_t)__clzll((long long)starts);
+          uint64_t rest = starts & ~(1ull << last);
+          uint32_t q1 = rdlane(sym, last);
+          p2 = rest ? rdlane(sym, 63u - (uint32_t)__clzll((long long)rest)) : p1;
+          p1 = q1;
+          br.advance(off);
+          P += n; i -= (int32_t)n; bl0 -= n;
+#ifdef BROTLI_AMD_PROFILE
+          prof_fast_batches++; prof_fast_syms += n;
+#endif
+          if (P >= next_boundary) RING_CROSS();
+        }
+      }
       while (i > 0) {
+        if (lit_n == 0) lit_pos = P;
         if (bl0 == 0) {
           int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree0, bl_tree0, nbt0, bl0, rb_l0, rb_l1);
           if (r == BS_NEEDS_INPUT) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);
@@ -1106,6 +1185,7 @@ done:
   args->num_commands = num_commands;
 #ifdef BROTLI_AMD_PROFILE
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
+  args->prof[4] = prof_fast_batches; args->prof[5] = prof_fast_syms;
 #endif
   return result;
 }
@@ -1125,7 +1205,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
   h.lit_trees = s.lit_trees; h.cmd_trees = s.cmd_trees; h.dist_trees = s.dist_trees;
   h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
   h.num_commands = s.num_commands;
-  h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = 0;
+  h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
   int e = (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) ? process_commands<true>(&h) : process_commands<false>(&h);
   e = rfl(e);
@@ -1134,7 +1214,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
   s.dist_rb0 = rfl(h.d0); s.dist_rb1 = rfl(h.d1); s.dist_rb2 = rfl(h.d2); s.dist_rb3 = rfl(h.d3);
   s.num_commands = rfl(h.num_commands);
 #ifdef BROTLI_AMD_PROFILE
-  s.prof[0] += h.prof[0]; s.prof[1] += h.prof[1]; s.prof[2] += h.prof[2]; s.prof[3] += h.prof[3];
+  s.prof[0] += h.prof[0]; s.prof[1] += h.prof[1]; s.prof[2] += h.prof[2]; s.prof[3] += h.prof[3]; s.prof[4] += h.prof[4]; s.prof[5] += h.prof[5];
 #endif
   return e;
 }
@@ -1341,7 +1421,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
     s.num_metablocks = 0; s.num_commands = 0;
     s.mlen = 0;
 #ifdef BROTLI_AMD_PROFILE
-    s.prof[0] = s.prof[1] = s.prof[2] = s.prof[3] = 0;
+    s.prof[0] = s.prof[1] = s.prof[2] = s.prof[3] = s.prof[4] = s.prof[5] = 0;
     const uint64_t prof_start = __builtin_amdgcn_s_memtime();
 #endif
     s.is_last = 0; s.is_uncompressed = 0; s.is_metadata = 0;
@@ -1405,6 +1485,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
       st->resume.bit_pos = __builtin_amdgcn_s_memtime() - prof_start;
       st->resume.out_pos = s.prof[0];
       st->resume.dist_rb[0] = (int32_t)(s.prof[1] >> 8); st->resume.dist_rb[1] = (int32_t)(s.prof[2] >> 8); st->resume.dist_rb[2] = (int32_t)(s.prof[3] >> 8);
+      st->resume.dist_rb[3] = (int32_t)s.prof[4]; st->resume.dist_rb_idx = (int32_t)s.prof[5];
 #endif
     }
   }

@@ -15,7 +15,8 @@ RESULT_ERROR, RESULT_SUCCESS, RESULT_NEEDS_MORE_INPUT, RESULT_NEEDS_MORE_OUTPUT 
 class OracleInfo(ctypes.Structure):
     _fields_ = [("result", ctypes.c_int32), ("error_code", ctypes.c_int32), ("decoded_size", ctypes.c_uint64),
                 ("consumed", ctypes.c_uint64), ("produced", ctypes.c_uint64), ("window_bits", ctypes.c_uint32),
-                ("num_metablocks", ctypes.c_uint32), ("num_commands", ctypes.c_uint64), ("num_literals", ctypes.c_uint64)]
+                ("num_metablocks", ctypes.c_uint32), ("num_commands", ctypes.c_uint64), ("num_literals", ctypes.c_uint64),
+                ("num_context_literals", ctypes.c_uint64), ("max_literal_trees", ctypes.c_uint32), ("max_block_types", ctypes.c_uint32)]
 
 
 def build():

@@ -34,3 +34,4 @@ cmd, lit, dist, cp = st.resume.out_pos, st.resume.dist_rb[0] << 8, st.resume.dis
 print(name, "n", n, "kernel ms %.3f" % ms, "result", st.result, "cmds", st.ncmd)
 print("cycles total %d (%.1f MHz eff)  cmd %d  lit %d  dist %d  copy %d  other %d" % (tot, tot / ms / 1e3, cmd, lit, dist, cp, tot - cmd - lit - dist - cp))
 if st.ncmd: print("per command: total %.0f cmd %.0f lit %.0f dist %.0f copy %.0f" % (tot / st.ncmd, cmd / st.ncmd, lit / st.ncmd, dist / st.ncmd, cp / st.ncmd))
+print("fast batches", st.resume.dist_rb[3], "fast syms", st.resume.dist_rb_idx)

@@ -28,3 +28,4 @@ tot, cmd, lit, dist, cp = st.resume.bit_pos, st.resume.out_pos, st.resume.dist_r
 print(kind, "n", n, "kernel ms %.3f" % ms, "result", st.result, "cmds", st.ncmd, "csize", len(c))
 print("ticks total %d: cmd %.1f%%  lit %.1f%%  dist %.1f%%  copy %.1f%%  other %.1f%%" % (tot, 100 * cmd / tot, 100 * lit / tot, 100 * dist / tot, 100 * cp / tot, 100 * (tot - cmd - lit - dist - cp) / tot))
 print("per command ticks: total %.0f cmd %.0f lit %.0f dist %.0f copy %.0f" % (tot / st.ncmd, cmd / st.ncmd, lit / st.ncmd, dist / st.ncmd, cp / st.ncmd))
+print("fast batches", st.resume.dist_rb[3], "fast syms", st.resume.idx)
