@@ -1,0 +1,192 @@
+"""The streaming and one-shot entry points of the C ABI on a real MI355X (reference: src/ffi/mod.rs,
+src/bin/integration_tests.rs, src/bin/tests.rs, src/bin/error_handling_tests.rs, src/reader.rs, src/writer.rs)."""
+import hashlib
+import io
+import json
+import os
+import subprocess
+
+import pytest
+
+import oracle_lib as oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+MANIFEST = {e["name"]: e for e in json.load(open(os.path.join(GOLD, "manifest.json")))}
+
+
+def _data(name):
+    return open(os.path.join(GOLD, "testdata", name), "rb").read()
+
+
+def _stream_decode(pkg, data, in_chunk, out_chunk, large_window=False, max_calls=200000):
+    """the loop of the reference's decompress_internal (src/bin/integration_tests.rs:122-216)"""
+    st = pkg.DecoderState(large_window=large_window)
+    out = bytearray()
+    pos, calls = 0, 0
+    pending = b""
+    result = pkg.RESULT_NEEDS_MORE_INPUT
+    while True:
+        if not pending and result == pkg.RESULT_NEEDS_MORE_INPUT:
+            if pos >= len(data):
+                break
+            pending = data[pos:pos + in_chunk]
+            pos += len(pending)
+        result, used, got = st.decompress_stream(pending, out_chunk)
+        pending = pending[used:]
+        out += got
+        calls += 1
+        assert calls < max_calls
+        if result in (pkg.RESULT_SUCCESS, pkg.RESULT_ERROR):
+            break
+    code = st.error_code()
+    finished = st.is_finished()
+    st.close()
+    return result, code, bytes(out), finished, pos - len(pending)
+
+
+BIG = ["alice29.txt.compressed", "metablock_reset.compressed", "mapsdatazrh.compressed", "random_then_unicode.compressed"]
+SMALL = ["10x10y.compressed", "64x.compressed", "ukkonooa.compressed", "monkey.compressed", "x.compressed.03", "xyzzy.compressed",
+         "quickfox.compressed", "ends_with_truncated_dictionary.compressed", "empty.compressed", "empty.compressed.16", "random1024.br",
+         "zeros.compressed", "fuzz502.compressed"]
+
+
+@pytest.mark.parametrize("name", BIG)
+@pytest.mark.parametrize("chunks", [(65536, 65536), (4096, 517), (517, 65536), (12345, 181)])
+def test_streaming_big_fixtures(pkg, name, chunks):
+    data = _data(name)
+    result, code, out, finished, consumed = _stream_decode(pkg, data, *chunks)
+    assert (result, code) == (1, 1) and finished
+    assert hashlib.sha256(out).hexdigest() == MANIFEST[name]["sha256"]
+    assert consumed == len(data)
+
+
+@pytest.mark.parametrize("name", SMALL)
+@pytest.mark.parametrize("chunks", [(65536, 65536), (1, 65536), (65536, 1), (1, 1), (3, 3), (12, 1)])
+def test_streaming_small_fixtures_adversarial_chunks(pkg, name, chunks):
+    """the buffer-size pairs of src/bin/integration_tests.rs:528-1006"""
+    if MANIFEST[name].get("size", 0) > 20000 and chunks[1] <= 3:
+        pytest.skip("one output byte per call on a large output is only slow")
+    data = _data(name)
+    result, code, out, finished, consumed = _stream_decode(pkg, data, *chunks)
+    assert (result, code) == (1, 1) and finished
+    assert hashlib.sha256(out).hexdigest() == MANIFEST[name]["sha256"]
+
+
+def test_streaming_errors_latch_and_trailing_input(pkg):
+    # corrupt stream: same code as the one-shot path; later calls keep failing (decode.rs:2796-2798)
+    bad = bytes.fromhex("1b3000e08dd4592d39ffb5024810952a9aea420e51a416b9cbf5f85c64b92fc96a3fb1dca8e03507")
+    st = pkg.DecoderState()
+    r, used, out = st.decompress_stream(bad, 4096)
+    assert (r, st.error_code(), st.error_string()) == (0, -8, "ERROR_FORMAT_CONTEXT_MAP_REPEAT")
+    assert st.decompress_stream(b"", 16)[0] == 0
+    st.close()
+    # "hello\n" followed by garbage: 10 of 18 bytes consumed (src/reader.rs:359, src/writer.rs:385)
+    hello = pkg.load_library()  # noqa: F841
+    import libbrotli_ref as ref
+    if ref.encoder_available():
+        comp = ref.encode(b"hello\n", 5, 22)
+        st = pkg.DecoderState()
+        r, used, out = st.decompress_stream(comp + b"\x01\x02\x03garbage", 64)
+        assert (r, out, used) == (1, b"hello\n", len(comp))
+        assert st.is_finished() and st.is_used()
+        st.close()
+    # large-window streams are rejected by instances until the parameter is set (ffi/mod.rs:127, 743-750)
+    lw = _data("rnd_chunk.br")
+    st = pkg.DecoderState(large_window=False)
+    assert st.decompress_stream(lw, 16)[0] == 0 and st.error_code() == -13
+    st.close()
+    # parameters can only be set before the first byte
+    L = pkg.load_library()
+    st = pkg.DecoderState()
+    st.decompress_stream(b"\x0b", 16)
+    assert L.BrotliDecoderSetParameter(st._h, pkg.PARAM_LARGE_WINDOW, 1) == 0
+    st.close()
+
+
+def test_one_byte_streams_through_the_reader(pkg):
+    """src/bin/tests.rs:76-98: exactly these one-byte inputs are complete streams"""
+    ok = []
+    for b in range(256):
+        try:
+            if pkg.Decompressor(io.BytesIO(bytes([b])), 8, large_window=False).read() == b"":
+                ok.append(b)
+        except ValueError:
+            pass
+    assert ok == [6, 26, 51, 53, 55, 57, 59, 61, 63]
+
+
+def test_reader_and_writer_adapters(pkg):
+    """src/bin/integration_tests.rs:294-415: 178-byte reads with 181/121/8192-byte buffers; 517-byte writer buffer"""
+    data, want = _data("alice29.txt.compressed"), MANIFEST["alice29.txt.compressed"]["sha256"]
+    for bufsize in (181, 8192):
+        r = pkg.Decompressor(io.BytesIO(data), bufsize)
+        got = bytearray()
+        while True:
+            c = r.read(178 if bufsize == 8192 else 4000)
+            if not c:
+                break
+            got += c
+        assert hashlib.sha256(got).hexdigest() == want
+    sink = io.BytesIO()
+    w = pkg.DecompressorWriter(sink, 517)
+    for i in range(0, len(data), 512):
+        assert w.write(data[i:i + 512]) == len(data[i:i + 512])
+    w.close()
+    assert hashlib.sha256(sink.getvalue()).hexdigest() == want
+    # truncated input: into_inner()/close() is an error
+    w = pkg.DecompressorWriter(io.BytesIO(), 517)
+    w.write(data[:1000])
+    with pytest.raises(ValueError):
+        w.close()
+    with pytest.raises(ValueError):
+        pkg.Decompressor(io.BytesIO(data[:1000]), 4096).read()
+
+
+def test_one_shot_matches_oracle_including_small_outputs(pkg):
+    """BrotliDecoderDecompressWithReturnInfo == the reference's brotli_decode (lib.rs:447-468), also when the output
+    buffer is too small: what is reported then depends on the stream up to the next ring-buffer flush point"""
+    cases = []
+    for name in ("alice29.txt.compressed", "zeros.compressed", "metablock_reset.compressed", "64x.compressed", "borked.compressed"):
+        d = _data(name)
+        size = MANIFEST[name].get("size", 64)
+        for cap in sorted({0, 1, 10, size // 2, max(size - 1, 0), size, size + 100}):
+            cases.append((name, d, cap))
+    # corrupt tail after a too-small buffer: the error wins over NEEDS_MORE_OUTPUT iff it comes before the flush point
+    d = bytearray(_data("alice29.txt.compressed"))
+    d[40000] ^= 0x10
+    cases.append(("alice29 corrupt", bytes(d), 1000))
+    for name, d, cap in cases:
+        info, out = pkg.brotli_decode(d, cap)
+        oinfo, oout = oracle.decode(d, cap, oracle.FLAG_LARGE_WINDOW)
+        assert (info.result, info.code, info.decoded_size, out) == (oinfo.result, oinfo.error_code, oinfo.decoded_size, oout), (name, cap)
+        assert info.error.decode() == pkg.load_library().BrotliDecoderErrorString(info.code).decode()
+
+
+def _native(target):
+    path = os.path.join(ROOT, "tests", "native", target)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "native")])
+    return path
+
+
+def test_c_acceptance_program(pkg):
+    exe = _native("abi_acceptance")
+    data = _data("alice29.txt.compressed")
+    p = subprocess.run([exe, "--stream"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    assert hashlib.sha256(p.stdout).hexdigest() == MANIFEST["alice29.txt.compressed"]["sha256"]
+    p = subprocess.run([exe, "--stream"], input=data[:20000], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 2 and b"Unexpected EOF" in p.stderr
+
+
+def test_cpp_reader_writer_adapters(pkg, tmp_path):
+    exe = _native("wrappers_test")
+    for name, read_size, buf in (("alice29.txt.compressed", 178, 181), ("alice29.txt.compressed", 4096, 8192), ("monkey.compressed", 1, 1),
+                                 ("quickfox_repeated.compressed", 3, 121)):
+        comp = os.path.join(GOLD, "testdata", name)
+        raw = tmp_path / (name + ".raw")
+        info, out = oracle.decode(_data(name), MANIFEST[name]["size"] + 16)
+        raw.write_bytes(out)
+        p = subprocess.run([exe, comp, str(raw), str(read_size), str(buf)], stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, (name, p.stderr.decode())
