@@ -128,6 +128,7 @@ struct BitReader {
   uint32_t tail_mask;    // valid bytes of the last dword
   uint32_t skip_bits;    // 8 * (stream start & 3)
   uint64_t total_bits;   // 8 * in_size
+  uint32_t end_dw;       // index of the dword that contains the first bit after the stream
   uint32_t cur, nxt;     // per-lane dword of window [chunk_base, +64) and [chunk_base+64, +128)
   uint32_t chunk_base;   // uniform
   uint32_t next_dw;      // uniform: next dword to shift into buf
@@ -137,23 +138,25 @@ struct BitReader {
   // after a copy out of private memory: re-establish that everything but the two window registers is uniform
   __device__ __forceinline__ void uniformize() {
     base = (gcu32*)(uintptr_t)rfl((uint64_t)(uintptr_t)base);
-    n_dw = rfl(n_dw); tail_mask = rfl(tail_mask); skip_bits = rfl(skip_bits); total_bits = rfl(total_bits);
+    n_dw = rfl(n_dw); tail_mask = rfl(tail_mask); skip_bits = rfl(skip_bits); total_bits = rfl(total_bits); end_dw = rfl(end_dw);
     chunk_base = rfl(chunk_base); next_dw = rfl(next_dw); buf = rfl(buf); cnt = rfl(cnt);
   }
+  // raw window load: no use of the loaded value here, so the load stays in flight until the window is needed
   __device__ __forceinline__ uint32_t load_window(uint32_t first) const {
     uint32_t i = first + lane_id();
     uint32_t v = 0;
-    if (i < n_dw) {
-      v = base[i];
-      if (i == n_dw - 1) v &= tail_mask;
-    }
+    if (i < n_dw) v = base[i];
     return v;
+  }
+  // bytes of the last dword that lie beyond the stream read as zero
+  __device__ __forceinline__ uint32_t fix_tail(uint32_t v, uint32_t first) const {
+    return (first + lane_id() == n_dw - 1) ? (v & tail_mask) : v;
   }
   __device__ __forceinline__ void seek(uint64_t bit_pos) {
     uint64_t abs = bit_pos + skip_bits;
     uint32_t dw = (uint32_t)(abs >> 5);
     chunk_base = dw;
-    cur = load_window(dw);
+    cur = fix_tail(load_window(dw), dw);
     nxt = load_window(dw + 64);
     next_dw = dw;
     buf = 0; cnt = 0;
@@ -164,8 +167,8 @@ struct BitReader {
   __device__ __forceinline__ void pull() {  // shift one more dword in (cnt <= 32 on entry)
     uint32_t idx = next_dw - chunk_base;
     if (idx >= 64) {
-      cur = nxt;
       chunk_base += 64;
+      cur = fix_tail(nxt, chunk_base);
       nxt = load_window(chunk_base + 64);
       idx -= 64;
     }
@@ -187,7 +190,7 @@ struct BitReader {
   // k-th dword after the ones already shifted into buf (k = 0, 1), without consuming it
   __device__ __forceinline__ uint32_t peek_dword(uint32_t k) const {
     uint32_t idx = next_dw + k - chunk_base;  // < 128: one window ahead is always loaded
-    return idx < 64 ? rdlane(cur, idx) : rdlane(nxt, idx - 64);
+    return idx < 64 ? rdlane(cur, idx) : rdlane(fix_tail(nxt, chunk_base + 64), idx - 64);
   }
   // 128-bit view of the stream from the current position: at least cnt + 64 >= 96 valid bits (needs cnt >= 32)
   __device__ __forceinline__ void window128(uint64_t& lo, uint64_t& hi) const {
@@ -202,7 +205,8 @@ struct BitReader {
     if (n) { pull(); drop(n); }
   }
   __device__ __forceinline__ uint64_t pos() const { return (uint64_t)next_dw * 32 - cnt - skip_bits; }
-  __device__ __forceinline__ bool over() const { return pos() > total_bits; }
+  // bits consumed beyond the end of the input?  Only possible once the dword that holds the end has been pulled.
+  __device__ __forceinline__ bool over() const { return next_dw > end_dw && pos() > total_bits; }
 };
 
 // ============================================= arena =============================================
@@ -878,21 +882,30 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(ctx_modes + bt) & 3u);
   };
   prepare_literal();
+  // Literal context never matters in this metablock when every literal block type has a trivial context map
+  // (then p1/p2 need not be tracked at all, which saves reading back the tail of every long copy).
+  bool ctx_never = true;
+  for (uint32_t bt = 0; bt < nbt0; bt++) {
+    uint32_t mine = a.ld8_lane<LDS_ONLY>(ctx_map + (bt << 6) + lane);
+    if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
+  }
 
   // ---- output side state ----
   // literal run being collected: lane k holds literal k, lit_n of them, first one goes to out[lit_pos]
   uint32_t lit_reg = 0, lit_n = 0; uint64_t lit_pos = P;
   // short copy / dictionary word whose bytes are in registers (lane k = byte k) but not stored yet
   uint32_t pend_reg = 0, pend_n = 0; uint64_t pend_pos = 0;
+  // the same for a copy of up to 1 KiB: 16 bytes per lane (its sub-16-byte tail goes through pend_reg)
+  u32x4 pendv = {0, 0, 0, 0}; uint32_t pendv_n16 = 0; uint64_t pendv_pos = 0;
   // where the two bytes before P (literal context) currently are
   enum { CTX_REGS = 0, CTX_PEND = 1, CTX_MEMORY = 2 };
   uint32_t ctx_src = CTX_MEMORY, ctx_len = 0;  // CTX_PEND: last ctx_len bytes of output are pend_reg[0..ctx_len)
   uint32_t p1 = 0, p2 = 0;  // stream start counts as two zero bytes (decode.rs:1859-1860)
   if (P == 0) ctx_src = CTX_REGS;
 
-#define FLUSH_LITERALS() do { if (lit_n) { uint64_t q_ = lit_pos + lane; if (lane < lit_n && q_ < out_cap) out[q_] = (uint8_t)lit_reg; \
-                                lit_pos += lit_n; lit_n = 0; } } while (0)
-#define FLUSH_PENDING() do { if (pend_n) { uint64_t q_ = pend_pos + lane; if (lane < pend_n && q_ < out_cap) out[q_] = (uint8_t)pend_reg; pend_n = 0; } } while (0)
+#define FLUSH_LITERALS() do { if (lit_n) { if (lane < lit_n) out[lit_pos + lane] = (uint8_t)lit_reg; lit_pos += lit_n; lit_n = 0; } } while (0)
+#define FLUSH_PENDING() do { if (pendv_n16) { if (lane < pendv_n16) *reinterpret_cast<gu32x4*>(out + pendv_pos + (uint64_t)lane * 16) = pendv; pendv_n16 = 0; } \
+                             if (pend_n) { if (lane < pend_n) out[pend_pos + lane] = (uint8_t)pend_reg; pend_n = 0; } } while (0)
 #define STOP(e) do { result = (e); goto done; } while (0)
   // ring-buffer flush points (decode.rs:1693-1738, 3299-3344): crossing one with a negative remaining length is
   // BLOCK_LENGTH_1; the last crossed one is what the caller has received when an error is reported
@@ -926,7 +939,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose only literal
       // block type is trivial, otherwise always (a block switch inside the run may make the very next literal
       // context-modelled)
-      if (!(trivial && nbt0 <= 1) && ctx_src != CTX_REGS) {
+      if (!ctx_never && ctx_src != CTX_REGS) {
         if (ctx_src == CTX_PEND) {
           uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
           p2 = ctx_len >= 2 ? rdlane(pend_reg, ctx_len - 2) : p1;
@@ -937,7 +950,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u;
         }
       }
-      if (!(trivial && nbt0 <= 1)) ctx_src = CTX_REGS;
+      if (!ctx_never) ctx_src = CTX_REGS;
       int32_t i = insert_len;
       // ---- wave-parallel literal decode (trivial context: one prefix code for the whole run) ----
       // Every lane decodes the symbol that would start at bit offset `lane` of a 64-bit window (one gathered table
@@ -971,18 +984,22 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           }
           uint32_t sym = e >> 4;
           if (rdlane(L, 0) == 0) break;  // single-symbol code (zero bits per literal): the scalar loop handles it
-          uint64_t starts = 0;
-          uint32_t off = 0, left = lim;
-          do {
-            uint32_t l = rdlane(L, off);
-            if (off + l > avail) break;
-            starts |= 1ull << off;
-            off += l;
-            left--;
-          } while (left != 0 && off < 64);
-#ifdef BROTLI_AMD_TRACE
-          if (lane == 0 && num_commands < 3) printf("batch lim %u avail %llu L0 %u x0 %08x starts %llx off %u cnt %u w0 %08x w1 %08x w2 %08x tree %u\n", lim, avail, rdlane(L, 0), rdlane(x, 0), (unsigned long long)starts, off, br.cnt, w0, w1, w2, lit_tree);
-#endif
+          // Candidates that would run past the end of the input end the walk: give them a length that jumps out of
+          // the window, and cut the result at the first such start afterwards.
+          uint64_t vmask = __ballot(lane + L <= avail);
+          uint32_t Lw = ((vmask >> lane) & 1ull) ? L : 64u;
+          uint64_t starts; uint32_t off, tmp;
+          // off = 0; do { starts |= 1 << off; off += Lw[off]; } while (off < 64);   -- 5 instructions per symbol
+          asm volatile("s_mov_b64 %0, 0\n\ts_mov_b32 %1, 0\n"
+                       "1:\n\ts_nop 3\n\tv_readlane_b32 %2, %3, %1\n\ts_bitset1_b64 %0, %1\n\ts_add_u32 %1, %1, %2\n\ts_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b\n"
+                       : "=&s"(starts), "=&s"(off), "=&s"(tmp) : "v"(Lw) : "scc");
+          uint64_t bad = starts & ~vmask;
+          if (bad) { off = (uint32_t)__builtin_ctzll(bad); starts &= (1ull << off) - 1ull; }
+          // no more symbols than the run (and the block) has left
+          for (uint32_t cnt_ = (uint32_t)__popcll(starts); cnt_ > lim; cnt_--) {
+            off = 63u - (uint32_t)__clzll((long long)starts);
+            starts &= ~(1ull << off);
+          }
           if (starts == 0) break;
           uint32_t n = (uint32_t)__popcll(starts);
           FLUSH_LITERALS();
@@ -1018,10 +1035,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         // the stream is already invalid and the remaining literals are decoded without being stored
         if (P >= out_cap && mlen >= 0) STOP(E_NEEDS_MORE_OUTPUT);
         p2 = p1; p1 = lit;
-        lit_reg = (lane == lit_n) ? lit : lit_reg;
-        lit_n++;
+        if (P < out_cap) {  // (past the end only while the stream is already invalid: decoded, not stored)
+          lit_reg = (lane == lit_n) ? lit : lit_reg;
+          lit_n++;
+          if (lit_n == 64) FLUSH_LITERALS();
+        }
         P++;
-        if (lit_n == 64) FLUSH_LITERALS();
         if (bl0 == 0) STOP(E_WINDOW_BITS);  // decode.rs:2434-2439
         bl0--;
         i--;
@@ -1134,6 +1153,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         pend_reg = b; pend_n = n; pend_pos = P;
         if (n >= 2) { ctx_src = CTX_PEND; ctx_len = n; }
         else if (n == 1) { if (ctx_src == CTX_MEMORY) p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u; p2 = p1; p1 = rdlane(b, 0); ctx_src = CTX_REGS; }
+      } else if (dist >= n && n <= 1024) {
+        // up to 1 KiB, not overlapping itself: same split as above with 16 bytes per lane (+ a byte tail)
+        gu8* src = dst - dist;
+        uint32_t n16 = n >> 4, rem = n & 15u;
+        u32x4 v = {0, 0, 0, 0};
+        if (lane < n16) v = *reinterpret_cast<gu32x4*>(src + (uint64_t)lane * 16);
+        uint32_t b = 0;
+        if (lane < rem) b = src[(n16 << 4) + lane];
+        pendv = v; pendv_n16 = n16; pendv_pos = P;
+        pend_reg = b; pend_n = rem; pend_pos = P + (n16 << 4);
+        ctx_src = CTX_MEMORY;
       } else if (dist >= n || dist >= 1024) {
         // long: 16 bytes per lane and step; steps are >= 1 KiB apart from their source or do not overlap at all
         gu8* src = dst - dist;
@@ -1436,6 +1466,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
       s.br.tail_mask = tail ? ((1u << (tail * 8)) - 1u) : 0xFFFFFFFFu;
       s.br.skip_bits = mis * 8;
       s.br.total_bits = d.in_size * 8;
+      s.br.end_dw = (uint32_t)((d.in_size * 8 + mis * 8) >> 5);
     }
     const bool resume = (d.flags & BROTLI_AMD_FLAG_RESUME) && d.resume.window_bits != 0;
     if (resume) {

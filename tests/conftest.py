@@ -23,6 +23,14 @@ def load_pkg():
     name = "rust_brotli_decompressor_amd"
     if name in sys.modules:
         return sys.modules[name]
+    # torch ships its own copy of the HIP runtime; when it is going to be used in this process it has to be the
+    # first one to initialise (a second runtime initialised later reports "No HIP GPUs are available")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     path = os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py")
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
