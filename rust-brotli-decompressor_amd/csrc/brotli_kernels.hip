@@ -807,6 +807,14 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 #define PROF_T() 0ull
 #define PROF_ADD(acc, t0) do { } while (0)
 #endif
+// BROTLI_AMD_PROFILE_LIT: the dist / copy slots report the batched / one-by-one literal loops instead
+#ifdef BROTLI_AMD_PROFILE_LIT
+#define PROF_LIT(acc, t0) PROF_ADD(acc, t0)
+#define PROF_REST(acc, t0) PROF_ADD(prof_cmd, t0)
+#else
+#define PROF_LIT(acc, t0) do { } while (0)
+#define PROF_REST(acc, t0) PROF_ADD(acc, t0)
+#endif
 
 // ===================================== the command loop (hot path) =====================================
 // Argument block of the command loop.  The loop is a real function (one per table placement) so that it gets a
@@ -836,7 +844,7 @@ struct HotArgs {
 //  * long copies move 16 bytes per lane per step when source and destination are at least a step apart;
 //  * the last two output bytes (literal context) are taken from registers where they still are, from memory
 //    only after a long copy.
-template <bool LDS_ONLY>
+template <bool LDS_ONLY, bool CTX_NEVER>
 __device__ __noinline__ int process_commands(HotArgs* args) {
   BitReader br = args->br; br.uniformize();
   Arena a_ = args->ar; a_.uniformize();
@@ -869,7 +877,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
 
   uint32_t cmd_tree = a.ld32<LDS_ONLY>(cmd_trees);
-  uint32_t dist_ctx_slice = 0, ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT;
+  uint32_t dist_ctx_slice = 0, ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0;
   // PrepareLiteralDecoding, decode.rs:1554-1570
   auto prepare_literal = [&]() {
     uint32_t bt = rb_l1;
@@ -880,15 +888,30 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
     lit_tree = a.ld32<LDS_ONLY>(lit_trees + first * 4);
     ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(ctx_modes + bt) & 3u);
+    if (LDS_ONLY) lit_zero = (rfl(lds_ld16(LDS_FIXED + lit_tree)) & 15u) == 0u ? 1u : 0u;  // one-symbol code: zero bits per literal
   };
   prepare_literal();
   // Literal context never matters in this metablock when every literal block type has a trivial context map
-  // (then p1/p2 need not be tracked at all, which saves reading back the tail of every long copy).
-  bool ctx_never = true;
-  for (uint32_t bt = 0; bt < nbt0; bt++) {
-    uint32_t mine = a.ld8_lane<LDS_ONLY>(ctx_map + (bt << 6) + lane);
-    if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
-  }
+  // (CTX_NEVER, found by the caller): then p1/p2 need not be tracked at all, which saves reading back the tail of
+  // every long copy, and the lean stages below apply.
+  constexpr bool ctx_never = CTX_NEVER;
+
+  // ---- lean commands ----
+  // A command whose whole effect stays clear of every limit (declared metablock length, end of the output buffer,
+  // next ring-buffer flush point, current literal block, end of the input) runs through stages that do not check
+  // any of them again: `quota` is the number of bytes that can be produced before the first of the output-side
+  // limits, recomputed after every command that went through the checked stages.
+  constexpr bool lean_mb = LDS_ONLY && CTX_NEVER;
+  const uint32_t safe_dw = br.end_dw > 32u ? br.end_dw - 32u : 0u;  // literals take at most 15 bits (half a dword) each
+  uint32_t quota = 0;
+#define RECOMPUTE_QUOTA() do { \
+    uint64_t room_ = out_cap - P; \
+    uint64_t q_ = room_ > 16 ? room_ - 16 : 0; \
+    uint64_t rb_ = next_boundary > P ? next_boundary - P : 0; \
+    if (rb_ < q_) q_ = rb_; \
+    uint32_t m_ = mlen > 0 ? (uint32_t)mlen : 0u; \
+    quota = q_ < (uint64_t)m_ ? (uint32_t)q_ : m_; } while (0)
+  if (lean_mb) RECOMPUTE_QUOTA();
 
   // ---- output side state ----
   // literal run being collected: lane k holds literal k, lit_n of them, first one goes to out[lit_pos]
@@ -932,8 +955,69 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     bl1--;
     num_commands++;
     PROF_ADD(prof_cmd, prof_t);
+    const uint32_t tot = (uint32_t)insert_len + (uint32_t)copy_len;
+    bool lean = lean_mb && tot < quota && (uint32_t)insert_len <= bl0 && !lit_zero && br.next_dw + ((uint32_t)insert_len >> 1) < safe_dw;
 
-    if (insert_len != 0) {
+    if (insert_len != 0 && lean) {
+      // ---- literals of a lean command: one prefix code, no limit can be hit ----
+      mlen -= insert_len;
+      bl0 -= (uint32_t)insert_len;
+      gu8* wp = out + P;
+      P += (uint32_t)insert_len;
+      uint32_t i = (uint32_t)insert_len;
+      do {
+        if (i <= 2) {  // one or two literals: cheaper one by one
+          do {
+            uint32_t lit = read_symbol<true>(br, a, lit_tree);
+            if (lane == 0) *wp = (uint8_t)lit;
+            wp++;
+          } while (--i);
+          break;
+        }
+        // 64 candidate symbols, one per bit offset of the next 64 bits (see the checked variant below)
+        br.need32();
+        uint32_t idx = br.next_dw - br.chunk_base;
+        uint32_t e0, e1;
+        if (idx < 63u) { e0 = rdlane(br.cur, idx); e1 = rdlane(br.cur, idx + 1u); }
+        else { e0 = br.peek_dword(0); e1 = br.peek_dword(1); }
+        const uint64_t e = (uint64_t)e0 | ((uint64_t)e1 << 32);
+        const uint64_t wlo = br.buf | (e << br.cnt);   // 32 <= cnt <= 63
+        const uint64_t whi = e >> (64u - br.cnt);
+        uint32_t w0 = (uint32_t)wlo, w1 = (uint32_t)(wlo >> 32), w2 = (uint32_t)whi;
+        uint32_t x = lane < 32 ? __builtin_amdgcn_alignbit(w1, w0, lane) : __builtin_amdgcn_alignbit(w2, w1, lane - 32);
+        uint32_t en = lds_ld16(LDS_FIXED + lit_tree + ((x & 0xFFu) << 1));
+        uint32_t L = en & 15u;
+        if (L > ROOT_BITS) {
+          uint32_t k2 = (en >> 4) + ((x >> ROOT_BITS) & mask_bits(L - ROOT_BITS));
+          en = lds_ld16(LDS_FIXED + lit_tree + (k2 << 1));
+          L = ROOT_BITS + (en & 15u);
+        }
+        uint32_t sym = en >> 4;
+        // offsets the run cannot reach (15 bits per literal at most) end the walk
+        uint32_t Lw = lane < i * 15u ? L : 64u;
+        uint64_t starts; uint32_t off, tmp;
+        asm volatile("s_mov_b64 %0, 0\n\ts_mov_b32 %1, 0\n"
+                     "1:\n\ts_nop 3\n\tv_readlane_b32 %2, %3, %1\n\ts_bitset1_b64 %0, %1\n\ts_add_u32 %1, %1, %2\n\ts_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b\n"
+                     : "=&s"(starts), "=&s"(off), "=&s"(tmp) : "v"(Lw) : "scc");
+        uint32_t n = (uint32_t)__popcll(starts);
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+        if (n > i) {  // the run ends inside the window: cut at the start that would be literal number i
+          uint64_t cut = __ballot(rank == i) & starts;
+          off = (uint32_t)__builtin_ctzll(cut);
+          starts &= (1ull << off) - 1ull;
+          n = i;
+        }
+        // lanes that hold a real symbol store it at its rank
+        asm volatile("s_mov_b64 exec, %0\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, -1"
+                     :: "s"(starts), "v"(rank), "v"(sym), "s"(wp) : "memory");
+        if (off <= br.cnt) { br.buf >>= off; br.cnt -= off; }
+        else { uint32_t nsk = off - br.cnt; br.buf = e >> nsk; br.cnt = 64u - nsk; br.next_dw += 2u; }
+        wp += n; i -= n;
+#ifdef BROTLI_AMD_PROFILE
+        prof_fast_batches++; prof_fast_syms += n;
+#endif
+      } while (i > 0);
+    } else if (insert_len != 0) {
       mlen -= insert_len;
       // ---- COMMAND_INNER: literals ----
       // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose only literal
@@ -959,6 +1043,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #ifdef BROTLI_AMD_PROFILE
       if (prof_fast_syms == 0) prof_fast_syms = 0x100000u | (LDS_ONLY ? 1u : 0u) | (trivial ? 2u : 0u) | (mlen >= 0 ? 4u : 0u) | (i >= 8 ? 8u : 0u) | (bl0 >= 8 ? 16u : 0u) | (out_cap - P >= 8 ? 32u : 0u);
 #endif
+      PROF_LIT(prof_lit, prof_t);
       if (LDS_ONLY && trivial && mlen >= 0) {
         while (i >= 8 && bl0 >= 8) {
           uint64_t room = out_cap - P;
@@ -1017,6 +1102,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           if (P >= next_boundary) RING_CROSS();
         }
       }
+      PROF_LIT(prof_dist, prof_t);
       while (i > 0) {
         if (lit_n == 0) lit_pos = P;
         if (bl0 == 0) {
@@ -1046,6 +1132,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         i--;
         if (P >= next_boundary) RING_CROSS();
       }
+      PROF_LIT(prof_copy, prof_t);
       if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
     }
     PROF_ADD(prof_lit, prof_t);
@@ -1095,7 +1182,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       }
       bl2--;
     }
-    PROF_ADD(prof_dist, prof_t);
+    PROF_REST(prof_dist, prof_t);
     // postReadDistance, decode.rs:2583-2589
     int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
     if (distance_code > max_distance) {
@@ -1137,6 +1224,25 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (mlen < 0) STOP(P + (uint32_t)copy_len >= next_boundary ? E_BLOCK_LENGTH_1 : E_BLOCK_LENGTH_2);
       if (distance_code <= 0) STOP(E_UNREACHABLE);  // wrapped large-window arithmetic, never on valid streams
       const uint32_t dist = (uint32_t)distance_code;
+      if (lean && dist >= (uint32_t)copy_len && (uint32_t)copy_len <= 1024u) {
+        // lean copy: fits, does not overlap itself; 16 bytes per lane plus a byte tail, stored when the next
+        // command gets here (its source may be what this one writes)
+        FLUSH_LITERALS();
+        FLUSH_PENDING();
+        const uint32_t n = (uint32_t)copy_len;
+        gu8* src = out + P - dist;
+        uint32_t n16 = n >> 4, rem = n & 15u;
+        u32x4 v = {0, 0, 0, 0};
+        if (lane < n16) v = *reinterpret_cast<gu32x4*>(src + (uint64_t)lane * 16);
+        uint32_t b = 0;
+        if (lane < rem) b = src[(n16 << 4) + lane];
+        pendv = v; pendv_n16 = n16; pendv_pos = P;
+        pend_reg = b; pend_n = rem; pend_pos = P + (n16 << 4);
+        P += n;
+        quota -= tot;
+        PROF_REST(prof_copy, prof_t);
+        continue;
+      }
       uint64_t room = out_cap - P;
       uint32_t n = (uint32_t)copy_len;
       const bool clipped = (uint64_t)n > room;
@@ -1198,10 +1304,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       P += n;
       if (clipped) STOP(E_NEEDS_MORE_OUTPUT);
     }
-    PROF_ADD(prof_copy, prof_t);
+    PROF_REST(prof_copy, prof_t);
     if (P >= next_boundary) RING_CROSS();
     if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE
+    if (lean_mb) RECOMPUTE_QUOTA();
   }
+#undef RECOMPUTE_QUOTA
 #undef STOP
 #undef RING_CROSS
 done:
@@ -1237,7 +1345,19 @@ __device__ __forceinline__ int run_commands(Stream& s) {
   h.num_commands = s.num_commands;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
-  int e = (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) ? process_commands<true>(&h) : process_commands<false>(&h);
+  int e;
+  if (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) {
+    // every literal block type with a constant context map (DetectTrivialLiteralBlockTypes, decode.rs:1525-1553)?
+    bool ctx_never = true;
+    const uint32_t nbt0 = rfl(s.nbt0), ctx_map = rfl(s.ctx_map);
+    for (uint32_t bt = 0; bt < nbt0; bt++) {
+      uint32_t mine = lds_ld8(LDS_FIXED + ctx_map + (bt << 6) + lane_id());
+      if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
+    }
+    e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
+  } else {
+    e = process_commands<false, false>(&h);
+  }
   e = rfl(e);
   s.br = h.br; s.br.uniformize();
   s.P = rfl(h.P); s.next_boundary = rfl(h.next_boundary); s.mlen = rfl(h.mlen);
