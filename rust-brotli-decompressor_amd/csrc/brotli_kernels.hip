@@ -955,10 +955,10 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     bl1--;
     num_commands++;
     PROF_ADD(prof_cmd, prof_t);
-    const uint32_t tot = (uint32_t)insert_len + (uint32_t)copy_len;
-    bool lean = lean_mb && tot < quota && (uint32_t)insert_len <= bl0 && !lit_zero && br.next_dw + ((uint32_t)insert_len >> 1) < safe_dw;
+    const bool lean_lit = lean_mb && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0 && !lit_zero &&
+                          br.next_dw + ((uint32_t)insert_len >> 1) < safe_dw;
 
-    if (insert_len != 0 && lean) {
+    if (insert_len != 0 && lean_lit) {
       // ---- literals of a lean command: one prefix code, no limit can be hit ----
       mlen -= insert_len;
       bl0 -= (uint32_t)insert_len;
@@ -1017,6 +1017,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         prof_fast_batches++; prof_fast_syms += n;
 #endif
       } while (i > 0);
+      quota -= (uint32_t)insert_len;
+      if (quota == 0) {  // exactly at a limit: end of the metablock, flush point, or (nearly) full output buffer
+        if (P >= next_boundary) RING_CROSS();
+        if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
+        RECOMPUTE_QUOTA();
+      }
     } else if (insert_len != 0) {
       mlen -= insert_len;
       // ---- COMMAND_INNER: literals ----
@@ -1134,6 +1140,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       }
       PROF_LIT(prof_copy, prof_t);
       if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
+      if (lean_mb) RECOMPUTE_QUOTA();
     }
     PROF_ADD(prof_lit, prof_t);
     // ---- COMMAND_POST_DECODE_LITERALS ----
@@ -1224,7 +1231,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (mlen < 0) STOP(P + (uint32_t)copy_len >= next_boundary ? E_BLOCK_LENGTH_1 : E_BLOCK_LENGTH_2);
       if (distance_code <= 0) STOP(E_UNREACHABLE);  // wrapped large-window arithmetic, never on valid streams
       const uint32_t dist = (uint32_t)distance_code;
-      if (lean && dist >= (uint32_t)copy_len && (uint32_t)copy_len <= 1024u) {
+      if (lean_mb && (uint32_t)copy_len <= quota && dist >= (uint32_t)copy_len && (uint32_t)copy_len <= 1024u) {
         // lean copy: fits, does not overlap itself; 16 bytes per lane plus a byte tail, stored when the next
         // command gets here (its source may be what this one writes)
         FLUSH_LITERALS();
@@ -1239,9 +1246,10 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         pendv = v; pendv_n16 = n16; pendv_pos = P;
         pend_reg = b; pend_n = rem; pend_pos = P + (n16 << 4);
         P += n;
-        quota -= tot;
+        quota -= n;
         PROF_REST(prof_copy, prof_t);
-        continue;
+        if (quota != 0) continue;
+        goto command_done;
       }
       uint64_t room = out_cap - P;
       uint32_t n = (uint32_t)copy_len;
@@ -1305,6 +1313,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (clipped) STOP(E_NEEDS_MORE_OUTPUT);
     }
     PROF_REST(prof_copy, prof_t);
+command_done:
     if (P >= next_boundary) RING_CROSS();
     if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE
     if (lean_mb) RECOMPUTE_QUOTA();
@@ -1323,7 +1332,11 @@ done:
   args->num_commands = num_commands;
 #ifdef BROTLI_AMD_PROFILE
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
+#ifdef BROTLI_AMD_PROFILE_HDR
+  args->prof[4] = 0; args->prof[5] = prof_fast_syms;
+#else
   args->prof[4] = prof_fast_batches; args->prof[5] = prof_fast_syms;
+#endif
 #endif
   return result;
 }
@@ -1459,6 +1472,9 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 
   for (;;) {
     // METABLOCK_BEGIN (state.rs:422-450)
+#ifdef BROTLI_AMD_PROFILE_HDR
+    const uint64_t hdr_t0 = __builtin_amdgcn_s_memtime();
+#endif
     s.bl0 = s.bl1 = s.bl2 = 1u << 24;
     s.nbt0 = s.nbt1 = s.nbt2 = 1;
     s.ar.top = 0;
@@ -1516,7 +1532,17 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
         TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
         TRY(decode_tree_group(s, num_dist_codes, max_dist_symbol, s.num_dist_trees, &s.dist_trees));
+#ifdef BROTLI_AMD_PROFILE_HDR
+        s.prof[4] += __builtin_amdgcn_s_memtime() - hdr_t0;
+#endif
+#ifdef BROTLI_AMD_PROFILE_HDR
+        const uint64_t run_t0 = __builtin_amdgcn_s_memtime();
+        int run_e = run_commands(s);
+        s.prof[5] = (s.prof[5] & 0xFFFFFu) + ((__builtin_amdgcn_s_memtime() - run_t0) >> 8);
+        TRY(run_e);
+#else
         TRY(run_commands(s));
+#endif
       }
     }
     // METABLOCK_DONE (decode.rs:3345-3381)
