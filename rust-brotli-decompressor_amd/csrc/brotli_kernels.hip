@@ -73,7 +73,8 @@ constexpr uint32_t LDS_SUBBASE = LDS_SUBDEPTH + 256;        // 512: its base off
 constexpr uint32_t LDS_LENINFO = LDS_SUBBASE + 512;         // 128: spare
 constexpr uint32_t LDS_WORD = LDS_LENINFO + 128;            // 128: dictionary word staging
 constexpr uint32_t LDS_MTF = LDS_WORD + 128;                // 256: inverse move-to-front list
-constexpr uint32_t LDS_FIXED = LDS_MTF + 256;               // = 4480, 16-byte aligned
+constexpr uint32_t LDS_INWIN = LDS_MTF + 256;               // 1024: compressed-input ring, four 256-byte halves filled by LDS-DMA
+constexpr uint32_t LDS_FIXED = LDS_INWIN + 1024;            // = 5504, 16-byte aligned
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -120,8 +121,11 @@ __device__ __forceinline__ uint32_t mask_bits(uint32_t n) { return n >= 32 ? 0xF
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return n ? (__brev(v) >> (32 - n)) : 0; }
 
 // =========================================== bit reader ===========================================
-// Replaces src/bit_reader/mod.rs: same values, different mechanics.  The compressed stream is fetched in
-// 256-byte windows, one dword per lane, one coalesced load per window, the next window always in flight.
+// Replaces src/bit_reader/mod.rs: same values, different mechanics.  The compressed stream is fetched 256 bytes
+// (one dword per lane) at a time straight into a four-slot ring in LDS (global_load_lds: no register destination,
+// nothing for the compiler to wait on in the decode loops); the wave takes its 64-dword register window `cur`
+// out of the ring at whatever dword the reader has reached, and only there waits for the transfers -- which were
+// issued one or two windows earlier.
 struct BitReader {
   gcu32* base;           // stream start rounded down to 4 bytes
   uint32_t n_dw;         // dwords that contain stream bytes
@@ -129,36 +133,51 @@ struct BitReader {
   uint32_t skip_bits;    // 8 * (stream start & 3)
   uint64_t total_bits;   // 8 * in_size
   uint32_t end_dw;       // index of the dword that contains the first bit after the stream
-  uint32_t cur, nxt;     // per-lane dword of window [chunk_base, +64) and [chunk_base+64, +128)
+  uint32_t cur;          // per-lane dword of the window [chunk_base, chunk_base + 64)
   uint32_t chunk_base;   // uniform
+  uint32_t issued_half;  // uniform: 64-dword pieces of the stream below this index have been requested into the ring
   uint32_t next_dw;      // uniform: next dword to shift into buf
   uint64_t buf;          // uniform
   uint32_t cnt;          // uniform: valid bits in buf
 
-  // after a copy out of private memory: re-establish that everything but the two window registers is uniform
+  // after a copy out of private memory: re-establish that everything but the window register is uniform
   __device__ __forceinline__ void uniformize() {
     base = (gcu32*)(uintptr_t)rfl((uint64_t)(uintptr_t)base);
     n_dw = rfl(n_dw); tail_mask = rfl(tail_mask); skip_bits = rfl(skip_bits); total_bits = rfl(total_bits); end_dw = rfl(end_dw);
-    chunk_base = rfl(chunk_base); next_dw = rfl(next_dw); buf = rfl(buf); cnt = rfl(cnt);
+    chunk_base = rfl(chunk_base); issued_half = rfl(issued_half); next_dw = rfl(next_dw); buf = rfl(buf); cnt = rfl(cnt);
   }
-  // raw window load: no use of the loaded value here, so the load stays in flight until the window is needed
-  __device__ __forceinline__ uint32_t load_window(uint32_t first) const {
-    uint32_t i = first + lane_id();
-    uint32_t v = 0;
-    if (i < n_dw) v = base[i];
-    return v;
+  // request dwords [64 h, 64 h + 64) of the stream into ring slot h & 3 (asynchronous; counted by vmcnt only)
+  __device__ __forceinline__ void dma_half(uint32_t h) const {
+    uint32_t i = (h << 6) + lane_id();
+    uint32_t lds_dst = rfl((uint32_t)(uintptr_t)(&g_smem[LDS_INWIN]) + ((h & 3u) << 8));
+    uint64_t active = __ballot(i < n_dw);  // lanes past the end of the stream request nothing
+    if (active) {
+      gcu32* src = base + i;
+      uint32_t keep_m0; uint64_t keep_exec;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %4\n\t"
+                   "global_load_lds_dword %2, off\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(src), "s"(lds_dst), "s"(active) : "memory");
+    }
   }
-  // bytes of the last dword that lie beyond the stream read as zero
-  __device__ __forceinline__ uint32_t fix_tail(uint32_t v, uint32_t first) const {
-    return (first + lane_id() == n_dw - 1) ? (v & tail_mask) : v;
+  // move the register window to [next_dw, next_dw + 64)
+  __device__ __forceinline__ void rebase() {
+    const uint32_t a = next_dw >> 6;
+    while (issued_half <= a + 1u) { dma_half(issued_half); issued_half++; }  // normally requested long ago
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t j = next_dw + lane_id();
+    uint32_t v = lds_ld32(LDS_INWIN + ((j & 255u) << 2));
+    v = j < n_dw ? v : 0u;                       // beyond the stream: zero bits
+    if (j == n_dw - 1u) v &= tail_mask;          // bytes of the last dword that lie beyond the stream read as zero
+    cur = v;
+    chunk_base = next_dw;
+    while (issued_half <= a + 2u) { dma_half(issued_half); issued_half++; }  // slots of pieces below a - 1 are dead
   }
   __device__ __forceinline__ void seek(uint64_t bit_pos) {
     uint64_t abs = bit_pos + skip_bits;
     uint32_t dw = (uint32_t)(abs >> 5);
-    chunk_base = dw;
-    cur = fix_tail(load_window(dw), dw);
-    nxt = load_window(dw + 64);
     next_dw = dw;
+    issued_half = dw >> 6;
+    rebase();
     buf = 0; cnt = 0;
     pull();
     uint32_t r = (uint32_t)(abs & 31);
@@ -166,12 +185,7 @@ struct BitReader {
   }
   __device__ __forceinline__ void pull() {  // shift one more dword in (cnt <= 32 on entry)
     uint32_t idx = next_dw - chunk_base;
-    if (idx >= 64) {
-      chunk_base += 64;
-      cur = fix_tail(nxt, chunk_base);
-      nxt = load_window(chunk_base + 64);
-      idx -= 64;
-    }
+    if (idx >= 64) { rebase(); idx = 0; }
     uint32_t dw = rdlane(cur, idx);
     buf |= (uint64_t)dw << cnt;
     cnt += 32;
@@ -187,14 +201,17 @@ struct BitReader {
     cnt -= n;
     return v;
   }
-  // k-th dword after the ones already shifted into buf (k = 0, 1), without consuming it
-  __device__ __forceinline__ uint32_t peek_dword(uint32_t k) const {
-    uint32_t idx = next_dw + k - chunk_base;  // < 128: one window ahead is always loaded
-    return idx < 64 ? rdlane(cur, idx) : rdlane(fix_tail(nxt, chunk_base + 64), idx - 64);
+  // the window holds at least `k` dwords that have not been shifted into buf yet (k <= 4)
+  __device__ __forceinline__ void ensure_dwords(uint32_t k) { if (next_dw - chunk_base > 64u - k) rebase(); }
+  // the two dwords after the ones already shifted into buf, without consuming them (after ensure_dwords(2))
+  __device__ __forceinline__ uint64_t peek64() const {
+    uint32_t idx = next_dw - chunk_base;
+    return (uint64_t)rdlane(cur, idx) | ((uint64_t)rdlane(cur, idx + 1u) << 32);
   }
   // 128-bit view of the stream from the current position: at least cnt + 64 >= 96 valid bits (needs cnt >= 32)
-  __device__ __forceinline__ void window128(uint64_t& lo, uint64_t& hi) const {
-    uint64_t e = (uint64_t)peek_dword(0) | ((uint64_t)peek_dword(1) << 32);
+  __device__ __forceinline__ void window128(uint64_t& lo, uint64_t& hi) {
+    ensure_dwords(2);
+    uint64_t e = peek64();
     lo = buf | (e << cnt);         // 32 <= cnt <= 63
     hi = e >> (64 - cnt);
   }
@@ -975,12 +992,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           break;
         }
         // 64 candidate symbols, one per bit offset of the next 64 bits (see the checked variant below)
-        br.need32();
-        uint32_t idx = br.next_dw - br.chunk_base;
-        uint32_t e0, e1;
-        if (idx < 63u) { e0 = rdlane(br.cur, idx); e1 = rdlane(br.cur, idx + 1u); }
-        else { e0 = br.peek_dword(0); e1 = br.peek_dword(1); }
-        const uint64_t e = (uint64_t)e0 | ((uint64_t)e1 << 32);
+        br.ensure_dwords(3);
+        if (br.cnt < 32) {  // pull() without the window check
+          uint32_t dw = rdlane(br.cur, br.next_dw - br.chunk_base);
+          br.buf |= (uint64_t)dw << br.cnt; br.cnt += 32; br.next_dw++;
+        }
+        const uint64_t e = br.peek64();
         const uint64_t wlo = br.buf | (e << br.cnt);   // 32 <= cnt <= 63
         const uint64_t whi = e >> (64u - br.cnt);
         uint32_t w0 = (uint32_t)wlo, w1 = (uint32_t)(wlo >> 32), w2 = (uint32_t)whi;
