@@ -149,7 +149,7 @@ struct BitReader {
   // request dwords [64 h, 64 h + 64) of the stream into ring slot h & 3 (asynchronous; counted by vmcnt only)
   __device__ __forceinline__ void dma_half(uint32_t h) const {
     uint32_t i = (h << 6) + lane_id();
-    uint32_t lds_dst = rfl((uint32_t)(uintptr_t)(&g_smem[LDS_INWIN]) + ((h & 3u) << 8));
+    uint32_t lds_dst = rfl((uint32_t)(uintptr_t)&g_smem[LDS_INWIN] + ((h & 3u) << 8));
     uint64_t active = __ballot(i < n_dw);  // lanes past the end of the stream request nothing
     if (active) {
       gcu32* src = base + i;
@@ -982,58 +982,127 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       gu8* wp = out + P;
       P += (uint32_t)insert_len;
       uint32_t i = (uint32_t)insert_len;
-      do {
-        if (i <= 2) {  // one or two literals: cheaper one by one
-          do {
-            uint32_t lit = read_symbol<true>(br, a, lit_tree);
-            if (lane == 0) *wp = (uint8_t)lit;
-            wp++;
-          } while (--i);
-          break;
-        }
-        // 64 candidate symbols, one per bit offset of the next 64 bits (see the checked variant below)
-        br.ensure_dwords(3);
-        if (br.cnt < 32) {  // pull() without the window check
-          uint32_t dw = rdlane(br.cur, br.next_dw - br.chunk_base);
-          br.buf |= (uint64_t)dw << br.cnt; br.cnt += 32; br.next_dw++;
-        }
-        const uint64_t e = br.peek64();
-        const uint64_t wlo = br.buf | (e << br.cnt);   // 32 <= cnt <= 63
-        const uint64_t whi = e >> (64u - br.cnt);
-        uint32_t w0 = (uint32_t)wlo, w1 = (uint32_t)(wlo >> 32), w2 = (uint32_t)whi;
-        uint32_t x = lane < 32 ? __builtin_amdgcn_alignbit(w1, w0, lane) : __builtin_amdgcn_alignbit(w2, w1, lane - 32);
-        uint32_t en = lds_ld16(LDS_FIXED + lit_tree + ((x & 0xFFu) << 1));
-        uint32_t L = en & 15u;
-        if (L > ROOT_BITS) {
-          uint32_t k2 = (en >> 4) + ((x >> ROOT_BITS) & mask_bits(L - ROOT_BITS));
-          en = lds_ld16(LDS_FIXED + lit_tree + (k2 << 1));
-          L = ROOT_BITS + (en & 15u);
-        }
-        uint32_t sym = en >> 4;
-        // offsets the run cannot reach (15 bits per literal at most) end the walk
-        uint32_t Lw = lane < i * 15u ? L : 64u;
-        uint64_t starts; uint32_t off, tmp;
-        asm volatile("s_mov_b64 %0, 0\n\ts_mov_b32 %1, 0\n"
-                     "1:\n\ts_nop 3\n\tv_readlane_b32 %2, %3, %1\n\ts_bitset1_b64 %0, %1\n\ts_add_u32 %1, %1, %2\n\ts_cmp_lt_u32 %1, 64\n\ts_cbranch_scc1 1b\n"
-                     : "=&s"(starts), "=&s"(off), "=&s"(tmp) : "v"(Lw) : "scc");
-        uint32_t n = (uint32_t)__popcll(starts);
-        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
-        if (n > i) {  // the run ends inside the window: cut at the start that would be literal number i
-          uint64_t cut = __ballot(rank == i) & starts;
-          off = (uint32_t)__builtin_ctzll(cut);
-          starts &= (1ull << off) - 1ull;
-          n = i;
-        }
-        // lanes that hold a real symbol store it at its rank
-        asm volatile("s_mov_b64 exec, %0\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, -1"
-                     :: "s"(starts), "v"(rank), "v"(sym), "s"(wp) : "memory");
-        if (off <= br.cnt) { br.buf >>= off; br.cnt -= off; }
-        else { uint32_t nsk = off - br.cnt; br.buf = e >> nsk; br.cnt = 64u - nsk; br.next_dw += 2u; }
-        wp += n; i -= n;
-#ifdef BROTLI_AMD_PROFILE
-        prof_fast_batches++; prof_fast_syms += n;
-#endif
-      } while (i > 0);
+      if (i > 2) {
+        // Batches of up to 64 bits: every lane decodes the symbol that would start at bit offset `lane` of the next
+        // 64 bits (one gathered table lookup for all 64 candidates), a scalar walk over the code lengths picks the
+        // offsets that really are symbol boundaries, the surviving lanes store their bytes at their rank.  The loop
+        // is hand-scheduled: one wave issues about one instruction per 8 clocks whatever it is, so instructions are
+        // what this costs (about 55 + 4 per literal).  It leaves when fewer than 3 literals remain or the register
+        // window runs out of dwords.
+        const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
+        const uint32_t tree_addr = rfl((uint32_t)(uintptr_t)&g_smem[LDS_FIXED + lit_tree]);
+        uint32_t woff = 0;
+        do {
+          br.ensure_dwords(3);
+          uint32_t v0, v1, v2, v3, v4, t0, t1, off, n;
+          asm volatile(
+              "s_nop 4\n"
+              "1:\n\t"
+              "s_cmp_gt_u32 %[cnt], 31\n\t"
+              "s_cbranch_scc1 2f\n\t"
+              "s_sub_u32 %[t0], %[ndw], %[cb]\n\t"
+              "v_readlane_b32 s90, %[cur], %[t0]\n\t"
+              "s_mov_b32 s91, 0\n\t"
+              "s_lshl_b64 vcc, s[90:91], %[cnt]\n\t"
+              "s_or_b64 %[buf], %[buf], vcc\n\t"
+              "s_add_u32 %[cnt], %[cnt], 32\n\t"
+              "s_add_u32 %[ndw], %[ndw], 1\n"
+              "2:\n\t"
+              "s_sub_u32 %[t0], %[ndw], %[cb]\n\t"
+              "s_add_u32 %[t1], %[t0], 1\n\t"
+              "v_readlane_b32 s90, %[cur], %[t0]\n\t"
+              "v_readlane_b32 s91, %[cur], %[t1]\n\t"
+              "s_lshl_b64 vcc, s[90:91], %[cnt]\n\t"
+              "s_or_b64 s[92:93], %[buf], vcc\n\t"
+              "s_sub_u32 %[t0], 64, %[cnt]\n\t"
+              "s_lshr_b64 s[94:95], s[90:91], %[t0]\n\t"
+              "v_mov_b32 %[v0], s92\n\t"
+              "v_mov_b32 %[v1], s93\n\t"
+              "v_alignbit_b32 %[v0], s93, %[v0], %[lane]\n\t"
+              "v_alignbit_b32 %[v1], s94, %[v1], %[lane]\n\t"
+              "v_bfi_b32 %[v0], %[lomask], %[v0], %[v1]\n\t"
+              "v_and_b32 %[v1], 0xff, %[v0]\n\t"
+              "v_lshl_add_u32 %[v1], %[v1], 1, %[tree]\n\t"
+              "ds_read_u16 %[v2], %[v1]\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "v_and_b32 %[v3], 15, %[v2]\n\t"
+              "v_cmp_lt_u32 vcc, 8, %[v3]\n\t"
+              "s_cbranch_vccz 3f\n\t"
+              "s_and_saveexec_b64 s[94:95], vcc\n\t"
+              "v_lshrrev_b32 %[v1], 8, %[v0]\n\t"
+              "v_add_u32 %[v3], -8, %[v3]\n\t"
+              "v_bfe_u32 %[v1], %[v1], 0, %[v3]\n\t"
+              "v_lshrrev_b32 %[v4], 4, %[v2]\n\t"
+              "v_add_u32 %[v1], %[v1], %[v4]\n\t"
+              "v_lshl_add_u32 %[v1], %[v1], 1, %[tree]\n\t"
+              "ds_read_u16 %[v2], %[v1]\n\t"
+              "s_waitcnt lgkmcnt(0)\n\t"
+              "v_and_b32 %[v3], 15, %[v2]\n\t"
+              "v_add_u32 %[v3], 8, %[v3]\n\t"
+              "s_mov_b64 exec, s[94:95]\n"
+              "3:\n\t"
+              "s_mul_i32 %[t0], %[i], 15\n\t"
+              "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"
+              "s_nop 1\n\t"
+              "v_cndmask_b32 %[v3], 64, %[v3], vcc\n\t"
+              "s_mov_b64 s[92:93], 0\n\t"
+              "s_mov_b32 %[off], 0xffffffc0\n"
+              "4:\n\t"
+              "v_readlane_b32 %[t1], %[v3], %[off]\n\t"
+              "s_bitset1_b64 s[92:93], %[off]\n\t"
+              "s_add_u32 %[off], %[off], %[t1]\n\t"
+              "s_cbranch_scc0 4b\n\t"
+              "s_add_u32 %[off], %[off], 64\n\t"
+              "s_bcnt1_i32_b64 %[n], s[92:93]\n\t"
+              "v_mbcnt_lo_u32_b32 %[v4], s92, 0\n\t"
+              "v_mbcnt_hi_u32_b32 %[v4], s93, %[v4]\n\t"
+              "s_cmp_le_u32 %[n], %[i]\n\t"
+              "s_cbranch_scc1 5f\n\t"
+              "v_cmp_eq_u32 vcc, %[i], %[v4]\n\t"
+              "s_and_b64 vcc, vcc, s[92:93]\n\t"
+              "s_ff1_i32_b64 %[off], vcc\n\t"
+              "s_lshl_b64 vcc, -1, %[off]\n\t"
+              "s_andn2_b64 s[92:93], s[92:93], vcc\n\t"
+              "s_mov_b32 %[n], %[i]\n"
+              "5:\n\t"
+              "v_lshrrev_b32 %[v2], 4, %[v2]\n\t"
+              "v_add_u32 %[v4], %[woff], %[v4]\n\t"
+              "s_mov_b64 exec, s[92:93]\n\t"
+              "global_store_byte %[v4], %[v2], %[wp]\n\t"
+              "s_mov_b64 exec, -1\n\t"
+              "s_cmp_le_u32 %[off], %[cnt]\n\t"
+              "s_cbranch_scc1 6f\n\t"
+              "s_sub_u32 %[t0], %[off], %[cnt]\n\t"
+              "s_lshr_b64 %[buf], s[90:91], %[t0]\n\t"
+              "s_sub_u32 %[cnt], 64, %[t0]\n\t"
+              "s_add_u32 %[ndw], %[ndw], 2\n\t"
+              "s_branch 7f\n"
+              "6:\n\t"
+              "s_lshr_b64 %[buf], %[buf], %[off]\n\t"
+              "s_sub_u32 %[cnt], %[cnt], %[off]\n"
+              "7:\n\t"
+              "s_add_u32 %[woff], %[woff], %[n]\n\t"
+              "s_sub_u32 %[i], %[i], %[n]\n\t"
+              "s_cmp_lt_u32 %[i], 3\n\t"
+              "s_cbranch_scc1 8f\n\t"
+              "s_sub_u32 %[t0], %[ndw], %[cb]\n\t"
+              "s_cmp_lt_u32 %[t0], 62\n\t"
+              "s_cbranch_scc1 1b\n"
+              "8:\n\t"
+              "s_nop 4\n"
+              : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [i] "+s"(i), [woff] "+s"(woff),
+                [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4),
+                [t0] "=&s"(t0), [t1] "=&s"(t1), [off] "=&s"(off), [n] "=&s"(n)
+              : [cur] "v"(br.cur), [lane] "v"(lane), [lomask] "v"(lomask), [tree] "s"(tree_addr), [cb] "s"(br.chunk_base), [wp] "s"(wp)
+              : "memory", "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
+        } while (i > 2);
+        wp += woff;
+      }
+      while (i > 0) {  // one or two literals: cheaper one by one
+        uint32_t lit = read_symbol<true>(br, a, lit_tree);
+        if (lane == 0) *wp = (uint8_t)lit;
+        wp++; i--;
+      }
       quota -= (uint32_t)insert_len;
       if (quota == 0) {  // exactly at a limit: end of the metablock, flush point, or (nearly) full output buffer
         if (P >= next_boundary) RING_CROSS();
