@@ -919,11 +919,11 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // any of them again: `quota` is the number of bytes that can be produced before the first of the output-side
   // limits, recomputed after every command that went through the checked stages.
   constexpr bool lean_mb = LDS_ONLY && CTX_NEVER;
-  const uint32_t safe_dw = br.end_dw > 32u ? br.end_dw - 32u : 0u;  // literals take at most 15 bits (half a dword) each
+  const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;  // a 64-dword register window that starts below lies inside the stream
   uint32_t quota = 0;
 #define RECOMPUTE_QUOTA() do { \
     uint64_t room_ = out_cap - P; \
-    uint64_t q_ = room_ > 16 ? room_ - 16 : 0; \
+    uint64_t q_ = room_; \
     uint64_t rb_ = next_boundary > P ? next_boundary - P : 0; \
     if (rb_ < q_) q_ = rb_; \
     uint32_t m_ = mlen > 0 ? (uint32_t)mlen : 0u; \
@@ -972,17 +972,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     bl1--;
     num_commands++;
     PROF_ADD(prof_cmd, prof_t);
-    const bool lean_lit = lean_mb && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0 && !lit_zero &&
-                          br.next_dw + ((uint32_t)insert_len >> 1) < safe_dw;
+    const bool lean_lit = lean_mb && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0 && !lit_zero;
+    int32_t lits_left = insert_len;  // literals of this command that are still to be decoded
 
     if (insert_len != 0 && lean_lit) {
-      // ---- literals of a lean command: one prefix code, no limit can be hit ----
+      // ---- literals of a lean command: one prefix code, no output-side limit can be hit ----
+      // (the input side is checked per register window: a window that lies inside the stream with a margin cannot
+      // run past its end; what is left of the run near the end of the input goes through the checked loops)
       mlen -= insert_len;
-      bl0 -= (uint32_t)insert_len;
       gu8* wp = out + P;
-      P += (uint32_t)insert_len;
       uint32_t i = (uint32_t)insert_len;
-      if (i > 2) {
+      if (i > 2 && br.next_dw < safe_dw) {
         // Batches of up to 64 bits: every lane decodes the symbol that would start at bit offset `lane` of the next
         // 64 bits (one gathered table lookup for all 64 candidates), a scalar walk over the code lengths picks the
         // offsets that really are symbol boundaries, the surviving lanes store their bytes at their rank.  The loop
@@ -1095,22 +1095,26 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
                 [t0] "=&s"(t0), [t1] "=&s"(t1), [off] "=&s"(off), [n] "=&s"(n)
               : [cur] "v"(br.cur), [lane] "v"(lane), [lomask] "v"(lomask), [tree] "s"(tree_addr), [cb] "s"(br.chunk_base), [wp] "s"(wp)
               : "memory", "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
-        } while (i > 2);
+        } while (i > 2 && br.next_dw < safe_dw);
         wp += woff;
       }
-      while (i > 0) {  // one or two literals: cheaper one by one
+      while (i > 0 && i <= 2 && br.next_dw < safe_dw) {  // one or two literals: cheaper one by one
         uint32_t lit = read_symbol<true>(br, a, lit_tree);
         if (lane == 0) *wp = (uint8_t)lit;
         wp++; i--;
       }
-      quota -= (uint32_t)insert_len;
-      if (quota == 0) {  // exactly at a limit: end of the metablock, flush point, or (nearly) full output buffer
+      const uint32_t done = (uint32_t)insert_len - i;
+      P += done; bl0 -= done; quota -= done;
+      lits_left = (int32_t)i;
+      if (quota == 0 && i == 0) {  // exactly at a limit: end of the metablock, flush point, or full output buffer
         if (P >= next_boundary) RING_CROSS();
         if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
         RECOMPUTE_QUOTA();
       }
     } else if (insert_len != 0) {
       mlen -= insert_len;
+    }
+    if (lits_left != 0) {
       // ---- COMMAND_INNER: literals ----
       // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose only literal
       // block type is trivial, otherwise always (a block switch inside the run may make the very next literal
@@ -1127,7 +1131,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         }
       }
       if (!ctx_never) ctx_src = CTX_REGS;
-      int32_t i = insert_len;
+      int32_t i = lits_left;
       // ---- wave-parallel literal decode (trivial context: one prefix code for the whole run) ----
       // Every lane decodes the symbol that would start at bit offset `lane` of a 64-bit window (one gathered table
       // lookup for all 64 candidates); a short scalar walk over the code lengths then picks the offsets that really
