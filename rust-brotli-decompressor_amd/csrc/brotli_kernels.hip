@@ -74,7 +74,9 @@ constexpr uint32_t LDS_LENINFO = LDS_SUBBASE + 512;         // 128: spare
 constexpr uint32_t LDS_WORD = LDS_LENINFO + 128;            // 128: dictionary word staging
 constexpr uint32_t LDS_MTF = LDS_WORD + 128;                // 256: inverse move-to-front list
 constexpr uint32_t LDS_INWIN = LDS_MTF + 256;               // 1024: compressed-input ring, four 256-byte halves filled by LDS-DMA
-constexpr uint32_t LDS_FIXED = LDS_INWIN + 1024;            // = 5504, 16-byte aligned
+constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit reader needs only when it moves its window (BitReader)
+constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
+constexpr uint32_t LDS_FIXED = LDS_HOT + 96;                // = 5632, 16-byte aligned
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -127,11 +129,17 @@ __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return n 
 // out of the ring at whatever dword the reader has reached, and only there waits for the transfers -- which were
 // issued one or two windows earlier.
 struct BitReader {
-  gcu32* base;           // stream start rounded down to 4 bytes
-  uint32_t n_dw;         // dwords that contain stream bytes
-  uint32_t tail_mask;    // valid bytes of the last dword
-  uint32_t skip_bits;    // 8 * (stream start & 3)
-  uint64_t total_bits;   // 8 * in_size
+  // Per-stream constants that only matter when the window moves or the end of the input is near live in LDS
+  // (written by set_input), not in registers: the command loop is short of SGPRs, not of LDS reads on cold paths.
+  //   LDS_BR + 0: stream start rounded down to 4 bytes (u64)   + 8: dwords that contain stream bytes
+  //   + 12: valid bytes of the last dword (mask)   + 16: 8 * (stream start & 3)   + 24: 8 * in_size (u64)
+  __device__ __forceinline__ static gcu32* base() {
+    return (gcu32*)(uintptr_t)rfl(*reinterpret_cast<const uint64_t*>(&g_smem[LDS_BR]));
+  }
+  __device__ __forceinline__ static uint32_t n_dw() { return rfl(lds_ld32(LDS_BR + 8)); }
+  __device__ __forceinline__ static uint32_t tail_mask() { return rfl(lds_ld32(LDS_BR + 12)); }
+  __device__ __forceinline__ static uint32_t skip_bits() { return rfl(lds_ld32(LDS_BR + 16)); }
+  __device__ __forceinline__ static uint64_t total_bits() { return rfl(*reinterpret_cast<const uint64_t*>(&g_smem[LDS_BR + 24])); }
   uint32_t end_dw;       // index of the dword that contains the first bit after the stream
   uint32_t cur;          // per-lane dword of the window [chunk_base, chunk_base + 64)
   uint32_t chunk_base;   // uniform
@@ -142,21 +150,39 @@ struct BitReader {
 
   // after a copy out of private memory: re-establish that everything but the window register is uniform
   __device__ __forceinline__ void uniformize() {
-    base = (gcu32*)(uintptr_t)rfl((uint64_t)(uintptr_t)base);
-    n_dw = rfl(n_dw); tail_mask = rfl(tail_mask); skip_bits = rfl(skip_bits); total_bits = rfl(total_bits); end_dw = rfl(end_dw);
+    end_dw = rfl(end_dw);
     chunk_base = rfl(chunk_base); issued_half = rfl(issued_half); next_dw = rfl(next_dw); buf = rfl(buf); cnt = rfl(cnt);
+  }
+  // bit reader over [in, in + in_size)
+  __device__ __forceinline__ void set_input(uint64_t addr, uint64_t in_size) {
+    uint32_t mis = (uint32_t)(addr & 3u);
+    uint64_t span = (uint64_t)mis + in_size;
+    uint32_t tail = (uint32_t)(span & 3u);
+    lds_sync();
+    if (lane_id() == 0) {
+      *reinterpret_cast<uint64_t*>(&g_smem[LDS_BR]) = addr - mis;
+      lds_st32(LDS_BR + 8, (uint32_t)((span + 3) >> 2));
+      lds_st32(LDS_BR + 12, tail ? ((1u << (tail * 8)) - 1u) : 0xFFFFFFFFu);
+      lds_st32(LDS_BR + 16, mis * 8);
+      *reinterpret_cast<uint64_t*>(&g_smem[LDS_BR + 24]) = in_size * 8;
+    }
+    lds_sync();
+    end_dw = (uint32_t)((in_size * 8 + mis * 8) >> 5);
   }
   // request dwords [64 h, 64 h + 64) of the stream into ring slot h & 3 (asynchronous; counted by vmcnt only)
   __device__ __forceinline__ void dma_half(uint32_t h) const {
     uint32_t i = (h << 6) + lane_id();
-    uint32_t lds_dst = rfl((uint32_t)(uintptr_t)&g_smem[LDS_INWIN] + ((h & 3u) << 8));
-    uint64_t active = __ballot(i < n_dw);  // lanes past the end of the stream request nothing
-    if (active) {
-      gcu32* src = base + i;
-      uint32_t keep_m0; uint64_t keep_exec;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %4\n\t"
-                   "global_load_lds_dword %2, off\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep_m0), "=&s"(keep_exec) : "v"(src), "s"(lds_dst), "s"(active) : "memory");
+    uint32_t lds_dst = (uint32_t)(uintptr_t)&g_smem[LDS_INWIN] + ((h & 3u) << 8);
+    uint32_t ndw = n_dw();
+    if (__ballot(i < ndw)) {  // lanes past the end of the stream request nothing
+      gcu32* src = base() + i;
+      uint32_t keep_m0, t; uint64_t keep_exec;
+      // (the operands are made uniform inside the statement: in code whose control flow the compiler takes for
+      // divergent it would hand over VGPRs for "s" operands)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\tv_readfirstlane_b32 %2, %4\n\tv_cmp_gt_u32 vcc, %5, %6\n\t"
+                   "s_mov_b32 m0, %2\n\ts_mov_b64 exec, vcc\n\t"
+                   "global_load_lds_dword %3, off\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0), "=&s"(keep_exec), "=&s"(t) : "v"(src), "v"(lds_dst), "v"(ndw), "v"(i) : "memory", "vcc");
     }
   }
   // move the register window to [next_dw, next_dw + 64)
@@ -166,14 +192,15 @@ struct BitReader {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t j = next_dw + lane_id();
     uint32_t v = lds_ld32(LDS_INWIN + ((j & 255u) << 2));
-    v = j < n_dw ? v : 0u;                       // beyond the stream: zero bits
-    if (j == n_dw - 1u) v &= tail_mask;          // bytes of the last dword that lie beyond the stream read as zero
+    const uint32_t ndw = n_dw();
+    v = j < ndw ? v : 0u;                        // beyond the stream: zero bits
+    if (j == ndw - 1u) v &= tail_mask();          // bytes of the last dword that lie beyond the stream read as zero
     cur = v;
     chunk_base = next_dw;
     while (issued_half <= a + 2u) { dma_half(issued_half); issued_half++; }  // slots of pieces below a - 1 are dead
   }
   __device__ __forceinline__ void seek(uint64_t bit_pos) {
-    uint64_t abs = bit_pos + skip_bits;
+    uint64_t abs = bit_pos + skip_bits();
     uint32_t dw = (uint32_t)(abs >> 5);
     next_dw = dw;
     issued_half = dw >> 6;
@@ -221,9 +248,9 @@ struct BitReader {
     next_dw += n >> 5; n &= 31;
     if (n) { pull(); drop(n); }
   }
-  __device__ __forceinline__ uint64_t pos() const { return (uint64_t)next_dw * 32 - cnt - skip_bits; }
+  __device__ __forceinline__ uint64_t pos() const { return (uint64_t)next_dw * 32 - cnt - skip_bits(); }
   // bits consumed beyond the end of the input?  Only possible once the dword that holds the end has been pulled.
-  __device__ __forceinline__ bool over() const { return next_dw > end_dw && pos() > total_bits; }
+  __device__ __forceinline__ bool over() const { return next_dw > end_dw && pos() > total_bits(); }
 };
 
 // ============================================= arena =============================================
@@ -375,7 +402,7 @@ struct Stream {
 #define COLD_UNIFORMIZE(x) x
 #endif
 #ifdef BROTLI_AMD_TRACE
-#define TRACE_STOP(br, e) do { if (lane_id() == 0) printf("stop line %d e=%d pos=%llu total=%llu\n", __LINE__, (int)(e), (unsigned long long)(br).pos(), (unsigned long long)(br).total_bits); } while (0)
+#define TRACE_STOP(br, e) do { if (lane_id() == 0) printf("stop line %d e=%d pos=%llu total=%llu\n", __LINE__, (int)(e), (unsigned long long)(br).pos(), (unsigned long long)(br).total_bits()); } while (0)
 #else
 #define TRACE_STOP(br, e) do { } while (0)
 #endif
@@ -735,7 +762,7 @@ __device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint
   { const Arena ar = s.ar; for (uint32_t i = lane; i < size; i += 64) ar.st8_lane(map + i, 0); }
   lds_sync();
   if (n <= 1) return E_SUCCESS;
-  if (br.pos() + 5 > br.total_bits) return E_NEEDS_MORE_INPUT;  // SafeGetBits(5), decode.rs:1311
+  if (br.pos() + 5 > br.total_bits()) return E_NEEDS_MORE_INPUT;  // SafeGetBits(5), decode.rs:1311
   uint32_t bits = br.peek32() & 31u;
   uint32_t max_rle;
   if (bits & 1u) { max_rle = (bits >> 1) + 1; br.drop(5); } else { max_rle = 0; br.drop(1); }
@@ -907,10 +934,8 @@ struct HotArgs {
   uint32_t window_bits;
   int32_t mlen, max_backward;
   int32_t d0, d1, d2, d3;
-  uint32_t bl0, bl1, bl2, nbt0, nbt1, nbt2;
-  uint32_t bt_tree0, bt_tree1, bt_tree2, bl_tree0, bl_tree1, bl_tree2;
+  uint32_t bl0, bl1, bl2;
   uint32_t postfix_bits, num_direct;
-  uint32_t ctx_modes, ctx_map, dist_ctx_map, lit_trees, cmd_trees, dist_trees;
   uint32_t bl_vgpr;
   uint64_t num_commands;
   uint64_t prof[6];
@@ -941,13 +966,19 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // code 0 and dictionary references leave it untouched, every other LZ77 distance is pushed; state.rs:295-296)
   int32_t d0 = rfl(args->d0), d1 = rfl(args->d1), d2 = rfl(args->d2), d3 = rfl(args->d3);
   uint32_t bl0 = rfl(args->bl0), bl1 = rfl(args->bl1), bl2 = rfl(args->bl2);
-  const uint32_t nbt0 = rfl(args->nbt0), nbt1 = rfl(args->nbt1), nbt2 = rfl(args->nbt2);
-  uint32_t rb_l0 = 1, rb_l1 = 0, rb_c0 = 1, rb_c1 = 0, rb_d0 = 1, rb_d1 = 0;  // block type rings (state.rs:429-435)
-  const uint32_t bt_tree0 = rfl(args->bt_tree0), bt_tree1 = rfl(args->bt_tree1), bt_tree2 = rfl(args->bt_tree2);
-  const uint32_t bl_tree0 = rfl(args->bl_tree0), bl_tree1 = rfl(args->bl_tree1), bl_tree2 = rfl(args->bl_tree2);
+  // What only block switches need (block-type and block-length trees, number of block types, the block-type rings
+  // of state.rs:429-435, where the tree groups and maps are) stays in LDS, put there by run_commands():
+  enum { H_BT_TREE = 0, H_BL_TREE = 3, H_NBT = 6, H_CTX_MODES = 9, H_CTX_MAP = 10, H_DIST_CTX_MAP = 11, H_LIT_TREES = 12, H_CMD_TREES = 13,
+         H_DIST_TREES = 14, H_RING = 15 /* + 2 * category: second last, last block type */ };
+#define HOTC(k) rfl(lds_ld32(LDS_HOT + 4u * (uint32_t)(k)))
+#define BLOCK_SWITCH(cat, bl, res) do { \
+    uint32_t t0_ = HOTC(H_RING + 2 * (cat)), t1_ = HOTC(H_RING + 2 * (cat) + 1); \
+    (res) = block_switch<LDS_ONLY>(br, a, bl_vgpr, HOTC(H_BT_TREE + (cat)), HOTC(H_BL_TREE + (cat)), HOTC(H_NBT + (cat)), bl, t0_, t1_); \
+    if ((res) == BS_SWITCHED) { if (lane == 0) { lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat)), t0_); lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat) + 1), t1_); } lds_sync(); } \
+  } while (0)
   const uint32_t postfix_bits = rfl(args->postfix_bits), num_direct = rfl(args->num_direct);
-  const uint32_t ctx_modes = rfl(args->ctx_modes), ctx_map = rfl(args->ctx_map), dist_ctx_map = rfl(args->dist_ctx_map);
-  const uint32_t lit_trees = rfl(args->lit_trees), cmd_trees = rfl(args->cmd_trees), dist_trees = rfl(args->dist_trees);
+  // (the context map and the literal tree group are looked at for every context-modelled literal)
+  const uint32_t ctx_map = CTX_NEVER ? 0u : HOTC(H_CTX_MAP), lit_trees = CTX_NEVER ? 0u : HOTC(H_LIT_TREES);
   const uint32_t bl_vgpr = args->bl_vgpr;  // per-lane image of the block length code LUT
   uint64_t num_commands = rfl(args->num_commands);
   int result = E_SUCCESS;
@@ -955,21 +986,29 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   (void)prof_cmd; (void)prof_lit; (void)prof_dist; (void)prof_copy; (void)prof_t;
   uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
 
-  uint32_t cmd_tree = a.ld32<LDS_ONLY>(cmd_trees);
-  uint32_t dist_ctx_slice = 0, ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0;
+  uint32_t cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4);
+  uint32_t ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0;
   // PrepareLiteralDecoding, decode.rs:1554-1570
   auto prepare_literal = [&]() {
-    uint32_t bt = rb_l1;
+    uint32_t bt = HOTC(H_RING + 1);
     ctx_slice = bt << 6;
     // trivial <=> all 64 map entries of the block type are equal (DetectTrivialLiteralBlockTypes, 1525-1553)
-    uint32_t mine = a.ld8_lane<LDS_ONLY>(ctx_map + ctx_slice + lane);
+    uint32_t mine = a.ld8_lane<LDS_ONLY>(HOTC(H_CTX_MAP) + ctx_slice + lane);
     uint32_t first = rdlane(mine, 0);
     trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
-    lit_tree = a.ld32<LDS_ONLY>(lit_trees + first * 4);
-    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(ctx_modes + bt) & 3u);
+    lit_tree = a.ld32<LDS_ONLY>(HOTC(H_LIT_TREES) + first * 4);
+    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(HOTC(H_CTX_MODES) + bt) & 3u);
     if (LDS_ONLY) lit_zero = (rfl(lds_ld16(LDS_FIXED + lit_tree)) & 15u) == 0u ? 1u : 0u;  // one-symbol code: zero bits per literal
   };
   prepare_literal();
+  // the four distance trees of the current distance block type, one per distance context (decode.rs:2566-2570)
+  uint32_t dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0;
+  auto prepare_distance = [&]() {
+    uint32_t m = HOTC(H_DIST_CTX_MAP) + (HOTC(H_RING + 5) << 2), g = HOTC(H_DIST_TREES);
+    dt0 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 0) * 4); dt1 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 1) * 4);
+    dt2 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 2) * 4); dt3 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 3) * 4);
+  };
+  prepare_distance();
   // Literal context never matters in this metablock when every literal block type has a trivial context map
   // (CTX_NEVER, found by the caller): then p1/p2 need not be tracked at all, which saves reading back the tail of
   // every long copy, and the lean stages below apply.
@@ -1016,9 +1055,10 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   for (;;) {
     // ---- COMMAND_BEGIN ----
     if (bl1 == 0) {
-      int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree1, bl_tree1, nbt1, bl1, rb_c0, rb_c1);
+      int r;
+      BLOCK_SWITCH(1, bl1, r);
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
-      if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(cmd_trees + rb_c1 * 4); continue; }
+      if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
     }
     uint32_t clo, chi;
     read_command<LDS_ONLY>(br, a, cmd_tree, clo, chi);
@@ -1210,7 +1250,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           br.window128(wlo, whi);
           // bits that really exist from here on (pos <= total here), saturated to 32 bits: the walk below compares
           // in 32 bits (hipcc 7.2 miscompiles a select fed by a uniform 64-bit unsigned compare in this loop)
-          uint64_t avail64 = br.total_bits - br.pos();
+          uint64_t avail64 = br.total_bits() - br.pos();
           uint32_t avail = (avail64 >> 16) ? 0xFFFFu : (uint32_t)avail64;
           uint32_t w0 = (uint32_t)wlo, w1 = (uint32_t)(wlo >> 32), w2 = (uint32_t)whi;
           uint32_t x = lane < 32 ? __builtin_amdgcn_alignbit(w1, w0, lane) : __builtin_amdgcn_alignbit(w2, w1, lane - 32);
@@ -1260,12 +1300,13 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       while (i > 0) {
         if (lit_n == 0) lit_pos = P;
         if (bl0 == 0) {
-          int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree0, bl_tree0, nbt0, bl0, rb_l0, rb_l1);
+          int r;
+          BLOCK_SWITCH(0, bl0, r);
           if (r == BS_NEEDS_INPUT) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);
           if (r == BS_SWITCHED) prepare_literal();
         }
         uint32_t tree = lit_tree;
-        if (!trivial) {
+        if (!CTX_NEVER && !trivial) {
           uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
           tree = a.ld32<LDS_ONLY>(lit_trees + a.ld8<LDS_ONLY>(ctx_map + ctx_slice + context) * 4);
         }
@@ -1297,12 +1338,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       distance_code = d0;
     } else {
       if (bl2 == 0) {
-        int r = block_switch<LDS_ONLY>(br, a, bl_vgpr, bt_tree2, bl_tree2, nbt2, bl2, rb_d0, rb_d1);
+        int r;
+        BLOCK_SWITCH(2, bl2, r);
         if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
-        if (r == BS_SWITCHED) dist_ctx_slice = rb_d1 << 2;
+        if (r == BS_SWITCHED) prepare_distance();
       }
-      uint32_t dist_tree_idx = a.ld8<LDS_ONLY>(dist_ctx_map + dist_ctx_slice + distance_context);
-      uint32_t dtree = a.ld32<LDS_ONLY>(dist_trees + dist_tree_idx * 4);
+      uint32_t dtree = distance_context == 0 ? dt0 : distance_context == 1 ? dt1 : distance_context == 2 ? dt2 : dt3;
       // ReadDistanceInternal, decode.rs:2066-2131
       uint32_t code = read_symbol<LDS_ONLY>(br, a, dtree);
       distance_context = 0;
@@ -1467,6 +1508,8 @@ command_done:
     if (lean_mb) RECOMPUTE_QUOTA();
   }
 #undef RECOMPUTE_QUOTA
+#undef BLOCK_SWITCH
+#undef HOTC
 #undef STOP
 #undef RING_CROSS
 done:
@@ -1496,12 +1539,15 @@ __device__ __forceinline__ int run_commands(Stream& s) {
   h.out_cap = s.out_cap; h.P = s.P; h.next_boundary = s.next_boundary; h.rb_size = s.rb_size;
   h.window_bits = s.window_bits; h.mlen = s.mlen; h.max_backward = s.max_backward;
   h.d0 = s.dist_rb0; h.d1 = s.dist_rb1; h.d2 = s.dist_rb2; h.d3 = s.dist_rb3;
-  h.bl0 = s.bl0; h.bl1 = s.bl1; h.bl2 = s.bl2; h.nbt0 = s.nbt0; h.nbt1 = s.nbt1; h.nbt2 = s.nbt2;
-  h.bt_tree0 = s.bt_tree0; h.bt_tree1 = s.bt_tree1; h.bt_tree2 = s.bt_tree2;
-  h.bl_tree0 = s.bl_tree0; h.bl_tree1 = s.bl_tree1; h.bl_tree2 = s.bl_tree2;
+  h.bl0 = s.bl0; h.bl1 = s.bl1; h.bl2 = s.bl2;
   h.postfix_bits = s.postfix_bits; h.num_direct = s.num_direct;
-  h.ctx_modes = s.ctx_modes; h.ctx_map = s.ctx_map; h.dist_ctx_map = s.dist_ctx_map;
-  h.lit_trees = s.lit_trees; h.cmd_trees = s.cmd_trees; h.dist_trees = s.dist_trees;
+  lds_sync();
+  if (lane_id() == 0) {  // the cold part of the loop's state (see HOTC in process_commands)
+    const uint32_t cold[21] = {s.bt_tree0, s.bt_tree1, s.bt_tree2, s.bl_tree0, s.bl_tree1, s.bl_tree2, s.nbt0, s.nbt1, s.nbt2,
+                               s.ctx_modes, s.ctx_map, s.dist_ctx_map, s.lit_trees, s.cmd_trees, s.dist_trees, 1, 0, 1, 0, 1, 0};
+    for (int k = 0; k < 21; k++) lds_st32(LDS_HOT + 4u * (uint32_t)k, cold[k]);
+  }
+  lds_sync();
   h.bl_vgpr = s.bl_vgpr;
   h.num_commands = s.num_commands;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
@@ -1535,7 +1581,7 @@ __device__ __forceinline__ int copy_uncompressed(Stream& s) {
   BitReader br = s.br; br.uniformize();
   const uint32_t lane = lane_id();
   uint64_t byte = br.pos() >> 3;
-  uint64_t in_size = br.total_bits >> 3;
+  uint64_t in_size = br.total_bits() >> 3;
   uint64_t avail = in_size > byte ? in_size - byte : 0;
   const uint64_t mlen0 = (uint64_t)rfl((uint32_t)s.mlen), P0 = rfl(s.P);
   uint64_t n = mlen0 < avail ? mlen0 : avail;
@@ -1562,7 +1608,7 @@ __device__ __forceinline__ void allocate_ring(Stream& s, const BitReader& br) {
   uint64_t rb = 1ull << s.window_bits;
   if (s.is_uncompressed) {
     uint64_t byte = (br.pos() >> 3) + (uint64_t)(uint32_t)s.mlen;
-    if (byte < (br.total_bits >> 3)) {
+    if (byte < (br.total_bits() >> 3)) {
       uint32_t b = rfl(s.in_bytes[byte]);
       if ((b & 3u) == 3u) is_last = 1;
     }
@@ -1634,7 +1680,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
       if ((s.is_metadata || s.is_uncompressed) && !jump_to_byte_boundary(br)) return E_PADDING_2;  // decode.rs:2990-2994
       if (s.is_metadata) {
         // skip MLEN bytes (decode.rs:3031-3045)
-        uint64_t byte = br.pos() >> 3, isz = br.total_bits >> 3;
+        uint64_t byte = br.pos() >> 3, isz = br.total_bits() >> 3;
         uint64_t avail = isz > byte ? isz - byte : 0;
         if ((uint64_t)(uint32_t)s.mlen > avail) { br.seek(isz * 8 + 8); return E_NEEDS_MORE_INPUT; }
         br.seek((byte + (uint32_t)s.mlen) * 8);
@@ -1747,19 +1793,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
     const uint64_t prof_start = __builtin_amdgcn_s_memtime();
 #endif
     s.is_last = 0; s.is_uncompressed = 0; s.is_metadata = 0;
-    // bit reader over [in, in + in_size)
-    {
-      uint64_t addr = (uint64_t)d.in;
-      uint32_t mis = (uint32_t)(addr & 3u);
-      s.br.base = (gcu32*)(uintptr_t)(addr - mis);
-      uint64_t span = (uint64_t)mis + d.in_size;
-      s.br.n_dw = (uint32_t)((span + 3) >> 2);
-      uint32_t tail = (uint32_t)(span & 3u);
-      s.br.tail_mask = tail ? ((1u << (tail * 8)) - 1u) : 0xFFFFFFFFu;
-      s.br.skip_bits = mis * 8;
-      s.br.total_bits = d.in_size * 8;
-      s.br.end_dw = (uint32_t)((d.in_size * 8 + mis * 8) >> 5);
-    }
+    s.br.set_input((uint64_t)d.in, d.in_size);
     const bool resume = (d.flags & BROTLI_AMD_FLAG_RESUME) && d.resume.window_bits != 0;
     if (resume) {
       s.P = d.resume.out_pos;
