@@ -977,8 +977,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     if ((res) == BS_SWITCHED) { if (lane == 0) { lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat)), t0_); lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat) + 1), t1_); } lds_sync(); } \
   } while (0)
   const uint32_t postfix_bits = rfl(args->postfix_bits), num_direct = rfl(args->num_direct);
-  // (the context map and the literal tree group are looked at for every context-modelled literal)
-  const uint32_t ctx_map = CTX_NEVER ? 0u : HOTC(H_CTX_MAP), lit_trees = CTX_NEVER ? 0u : HOTC(H_LIT_TREES);
   const uint32_t bl_vgpr = args->bl_vgpr;  // per-lane image of the block length code LUT
   uint64_t num_commands = rfl(args->num_commands);
   int result = E_SUCCESS;
@@ -987,7 +985,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
 
   uint32_t cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4);
-  uint32_t ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0;
+  uint32_t ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0, ctx_tree_v = 0;
   // PrepareLiteralDecoding, decode.rs:1554-1570
   auto prepare_literal = [&]() {
     uint32_t bt = HOTC(H_RING + 1);
@@ -997,6 +995,11 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     uint32_t first = rdlane(mine, 0);
     trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
     lit_tree = a.ld32<LDS_ONLY>(HOTC(H_LIT_TREES) + first * 4);
+    // lane c: the tree of literal context c in this block type (context map and tree group folded into one readlane)
+    if (!CTX_NEVER) {
+      uint32_t toff = HOTC(H_LIT_TREES) + mine * 4;
+      ctx_tree_v = (LDS_ONLY || toff < a.lds_limit) ? lds_ld32(LDS_FIXED + toff) : (uint32_t)*reinterpret_cast<gu32*>(a.glb + toff);
+    }
     ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(HOTC(H_CTX_MODES) + bt) & 3u);
     if (LDS_ONLY) lit_zero = (rfl(lds_ld16(LDS_FIXED + lit_tree)) & 15u) == 0u ? 1u : 0u;  // one-symbol code: zero bits per literal
   };
@@ -1308,7 +1311,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         uint32_t tree = lit_tree;
         if (!CTX_NEVER && !trivial) {
           uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
-          tree = a.ld32<LDS_ONLY>(lit_trees + a.ld8<LDS_ONLY>(ctx_map + ctx_slice + context) * 4);
+          tree = rdlane(ctx_tree_v, context);
         }
         uint32_t lit = read_symbol<LDS_ONLY>(br, a, tree);
         if (br.over()) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);  // decode.rs:2835-2846 + 1709-1711
