@@ -82,7 +82,13 @@ static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
 // and every global access through address-space-1 pointers (global_load/global_store).  Generic pointers would
 // become FLAT instructions, and the hardware does not order a FLAT access to LDS against a DS access.
-extern __shared__ __attribute__((aligned(16))) uint8_t g_smem[];
+// The kernel has no static LDS, so its dynamic LDS starts at LDS address 0 and everything below addresses LDS
+// absolutely: `g_smem` is a macro for address-space-3 address 0, not a symbol.  (A reference to an
+// `extern __shared__` symbol from a non-inlined device function makes hipcc look its address up in a table in
+// constant memory -- an s_load in front of table lookups in the command loop.)  The kernel checks the assumption.
+extern __shared__ __attribute__((aligned(16))) uint8_t g_dynamic_lds[];
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+#define g_smem (reinterpret_cast<lds_u8*>(0u))
 typedef __attribute__((address_space(1))) uint8_t gu8;
 typedef __attribute__((address_space(1))) uint16_t gu16;
 typedef __attribute__((address_space(1))) uint32_t gu32;
@@ -94,11 +100,11 @@ template <typename T, typename U>
 __device__ __forceinline__ T* as_global(U* p) { return (T*)(uintptr_t)p; }
 
 __device__ __forceinline__ uint32_t lds_ld8(uint32_t off) { return g_smem[off]; }
-__device__ __forceinline__ uint32_t lds_ld16(uint32_t off) { return *reinterpret_cast<const uint16_t*>(&g_smem[off]); }
-__device__ __forceinline__ uint32_t lds_ld32(uint32_t off) { return *reinterpret_cast<const uint32_t*>(&g_smem[off]); }
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t off) { return *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(&g_smem[off]); }
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t off) { return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>(&g_smem[off]); }
 __device__ __forceinline__ void lds_st8(uint32_t off, uint32_t v) { g_smem[off] = (uint8_t)v; }
-__device__ __forceinline__ void lds_st16(uint32_t off, uint32_t v) { *reinterpret_cast<uint16_t*>(&g_smem[off]) = (uint16_t)v; }
-__device__ __forceinline__ void lds_st32(uint32_t off, uint32_t v) { *reinterpret_cast<uint32_t*>(&g_smem[off]) = v; }
+__device__ __forceinline__ void lds_st16(uint32_t off, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint16_t*>(&g_smem[off]) = (uint16_t)v; }
+__device__ __forceinline__ void lds_st32(uint32_t off, uint32_t v) { *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(&g_smem[off]) = v; }
 // LDS operations of one wave execute in order; this only stops the compiler from moving accesses across it
 __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -134,12 +140,12 @@ struct BitReader {
   //   LDS_BR + 0: stream start rounded down to 4 bytes (u64)   + 8: dwords that contain stream bytes
   //   + 12: valid bytes of the last dword (mask)   + 16: 8 * (stream start & 3)   + 24: 8 * in_size (u64)
   __device__ __forceinline__ static gcu32* base() {
-    return (gcu32*)(uintptr_t)rfl(*reinterpret_cast<const uint64_t*>(&g_smem[LDS_BR]));
+    return (gcu32*)(uintptr_t)rfl(*reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_BR]));
   }
   __device__ __forceinline__ static uint32_t n_dw() { return rfl(lds_ld32(LDS_BR + 8)); }
   __device__ __forceinline__ static uint32_t tail_mask() { return rfl(lds_ld32(LDS_BR + 12)); }
   __device__ __forceinline__ static uint32_t skip_bits() { return rfl(lds_ld32(LDS_BR + 16)); }
-  __device__ __forceinline__ static uint64_t total_bits() { return rfl(*reinterpret_cast<const uint64_t*>(&g_smem[LDS_BR + 24])); }
+  __device__ __forceinline__ static uint64_t total_bits() { return rfl(*reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_BR + 24])); }
   uint32_t end_dw;       // index of the dword that contains the first bit after the stream
   uint32_t cur;          // per-lane dword of the window [chunk_base, chunk_base + 64)
   uint32_t chunk_base;   // uniform
@@ -160,11 +166,11 @@ struct BitReader {
     uint32_t tail = (uint32_t)(span & 3u);
     lds_sync();
     if (lane_id() == 0) {
-      *reinterpret_cast<uint64_t*>(&g_smem[LDS_BR]) = addr - mis;
+      *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_BR]) = addr - mis;
       lds_st32(LDS_BR + 8, (uint32_t)((span + 3) >> 2));
       lds_st32(LDS_BR + 12, tail ? ((1u << (tail * 8)) - 1u) : 0xFFFFFFFFu);
       lds_st32(LDS_BR + 16, mis * 8);
-      *reinterpret_cast<uint64_t*>(&g_smem[LDS_BR + 24]) = in_size * 8;
+      *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_BR + 24]) = in_size * 8;
     }
     lds_sync();
     end_dw = (uint32_t)((in_size * 8 + mis * 8) >> 5);
@@ -172,7 +178,7 @@ struct BitReader {
   // request dwords [64 h, 64 h + 64) of the stream into ring slot h & 3 (asynchronous; counted by vmcnt only)
   __device__ __forceinline__ void dma_half(uint32_t h) const {
     uint32_t i = (h << 6) + lane_id();
-    uint32_t lds_dst = (uint32_t)(uintptr_t)&g_smem[LDS_INWIN] + ((h & 3u) << 8);
+    uint32_t lds_dst = LDS_INWIN + ((h & 3u) << 8);
     uint32_t ndw = n_dw();
     if (__ballot(i < ndw)) {  // lanes past the end of the stream request nothing
       gcu32* src = base() + i;
@@ -279,13 +285,13 @@ struct Arena {
   template <bool LDS_ONLY = false>
   __device__ __forceinline__ void ld64(uint32_t off, uint32_t& lo, uint32_t& hi) const {
     uint64_t v;
-    if (LDS_ONLY || off < lds_limit) v = *reinterpret_cast<const uint64_t*>(&g_smem[LDS_FIXED + off]);
+    if (LDS_ONLY || off < lds_limit) v = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_FIXED + off]);
     else v = *reinterpret_cast<__attribute__((address_space(1))) const uint64_t*>(glb + off);
     lo = rfl((uint32_t)v); hi = rfl((uint32_t)(v >> 32));
   }
   __device__ __forceinline__ void st64_lane(uint32_t off, uint32_t lo, uint32_t hi) const {
     uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
-    if (off < lds_limit) *reinterpret_cast<uint64_t*>(&g_smem[LDS_FIXED + off]) = v;
+    if (off < lds_limit) *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_FIXED + off]) = v;
     else *reinterpret_cast<__attribute__((address_space(1))) uint64_t*>(glb + off) = v;
   }
   // uniform loads.  LDS_ONLY = the caller knows the object is in the LDS part: the load is a plain ds_read and
@@ -468,13 +474,12 @@ __device__ __forceinline__ uint32_t build_tree(const Arena& a, uint32_t tree, ui
       } else {
         uint32_t d = c.len - ROOT_BITS;
         uint32_t p = c.code >> d;
-        uint32_t* w = reinterpret_cast<uint32_t*>(&g_smem[LDS_SUBDEPTH + (p & ~3u)]);
+        __attribute__((address_space(3))) uint32_t* w = reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(&g_smem[LDS_SUBDEPTH + (p & ~3u)]);
         uint32_t sh = (p & 3u) * 8;
         uint32_t old = *w;
-        while (((old >> sh) & 0xFFu) < d) {
-          uint32_t prev = atomicCAS(w, old, (old & ~(0xFFu << sh)) | (d << sh));
-          if (prev == old) break;
-          old = prev;
+        while (((old >> sh) & 0xFFu) < d) {  // on failure `old` is refreshed with what is there
+          if (__hip_atomic_compare_exchange_strong(w, &old, (old & ~(0xFFu << sh)) | (d << sh), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         }
       }
     }
@@ -1091,7 +1096,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         // what this costs (about 55 + 4 per literal).  It leaves when fewer than 3 literals remain or the register
         // window runs out of dwords.
         const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
-        const uint32_t tree_addr = rfl((uint32_t)(uintptr_t)&g_smem[LDS_FIXED + lit_tree]);
+        const uint32_t tree_addr = LDS_FIXED + lit_tree;
         uint32_t woff = 0;
         do {
           br.ensure_dwords(3);
@@ -1765,6 +1770,8 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
+  // all LDS addressing is absolute (see g_smem): the dynamic LDS block must start at LDS address 0
+  if ((uint32_t)(uintptr_t)g_dynamic_lds != 0u) __builtin_trap();
   // literal context LUT -> LDS once per block
   for (uint32_t i = lane; i < 2048; i += 64) lds_st8(LDS_CTX_LUT + i, kContextLookup[i]);
   // per-lane LUT images
