@@ -1027,7 +1027,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // next ring-buffer flush point, current literal block, end of the input) runs through stages that do not check
   // any of them again: `quota` is the number of bytes that can be produced before the first of the output-side
   // limits, recomputed after every command that went through the checked stages.
-  constexpr bool lean_mb = LDS_ONLY && CTX_NEVER;
+  constexpr bool lean_mb = LDS_ONLY && CTX_NEVER;   // lean literal batches: one prefix code per block type
+  constexpr bool quota_mb = LDS_ONLY;              // lean copies and lean context-modelled literals
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;  // a 64-dword register window that starts below lies inside the stream
   uint32_t quota = 0;
 #define RECOMPUTE_QUOTA() do { \
@@ -1037,7 +1038,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     if (rb_ < q_) q_ = rb_; \
     uint32_t m_ = mlen > 0 ? (uint32_t)mlen : 0u; \
     quota = q_ < (uint64_t)m_ ? (uint32_t)q_ : m_; } while (0)
-  if (lean_mb) RECOMPUTE_QUOTA();
+  if (quota_mb) RECOMPUTE_QUOTA();
 
   // ---- output side state ----
   // literal run being collected: lane k holds literal k, lit_n of them, first one goes to out[lit_pos]
@@ -1080,6 +1081,24 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     PROF_ADD(prof_cmd, prof_t);
     const bool lean_lit = lean_mb && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0 && !lit_zero;
     int32_t lits_left = insert_len;  // literals of this command that are still to be decoded
+
+    // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose literal block
+    // types are all trivial, otherwise always (a block switch inside the run may make the very next literal
+    // context-modelled)
+    if (!ctx_never && insert_len != 0) {
+      if (ctx_src != CTX_REGS) {
+        if (ctx_src == CTX_PEND) {
+          uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
+          p2 = ctx_len >= 2 ? rdlane(pend_reg, ctx_len - 2) : p1;
+          p1 = q1;
+        } else {
+          FLUSH_PENDING();
+          p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u;
+          p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u;
+        }
+      }
+      ctx_src = CTX_REGS;
+    }
 
     if (insert_len != 0 && lean_lit) {
       // ---- literals of a lean command: one prefix code, no output-side limit can be hit ----
@@ -1217,26 +1236,38 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
         RECOMPUTE_QUOTA();
       }
+    } else if (insert_len != 0 && quota_mb && !CTX_NEVER && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0) {
+      // ---- context-modelled literals of a command that stays clear of every output-side limit and of the end of
+      // its literal block: one at a time (the tree depends on the two bytes before), nothing to check but the input
+      mlen -= insert_len;
+      uint32_t i = (uint32_t)insert_len;
+      if (lit_n == 0) lit_pos = P;
+      while (i > 0 && br.next_dw < safe_dw) {
+        uint32_t tree = lit_tree;
+        if (!trivial) {
+          uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
+          tree = rdlane(ctx_tree_v, context);
+        }
+        uint32_t lit = read_symbol<true>(br, a, tree);
+        p2 = p1; p1 = lit;
+        lit_reg = (lane == lit_n) ? lit : lit_reg;
+        lit_n++;
+        if (lit_n == 64) FLUSH_LITERALS();
+        i--;
+      }
+      const uint32_t done = (uint32_t)insert_len - i;
+      P += done; bl0 -= done; quota -= done;
+      lits_left = (int32_t)i;
+      if (quota == 0 && i == 0) {
+        if (P >= next_boundary) RING_CROSS();
+        if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
+        RECOMPUTE_QUOTA();
+      }
     } else if (insert_len != 0) {
       mlen -= insert_len;
     }
     if (lits_left != 0) {
-      // ---- COMMAND_INNER: literals ----
-      // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose only literal
-      // block type is trivial, otherwise always (a block switch inside the run may make the very next literal
-      // context-modelled)
-      if (!ctx_never && ctx_src != CTX_REGS) {
-        if (ctx_src == CTX_PEND) {
-          uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
-          p2 = ctx_len >= 2 ? rdlane(pend_reg, ctx_len - 2) : p1;
-          p1 = q1;
-        } else {
-          FLUSH_PENDING();
-          p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u;
-          p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u;
-        }
-      }
-      if (!ctx_never) ctx_src = CTX_REGS;
+      // ---- COMMAND_INNER: literals, every limit checked ----
       int32_t i = lits_left;
       // ---- wave-parallel literal decode (trivial context: one prefix code for the whole run) ----
       // Every lane decodes the symbol that would start at bit offset `lane` of a 64-bit window (one gathered table
@@ -1337,7 +1368,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       }
       PROF_LIT(prof_copy, prof_t);
       if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
-      if (lean_mb) RECOMPUTE_QUOTA();
+      if (quota_mb) RECOMPUTE_QUOTA();
     }
     PROF_ADD(prof_lit, prof_t);
     // ---- COMMAND_POST_DECODE_LITERALS ----
@@ -1428,7 +1459,24 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (mlen < 0) STOP(P + (uint32_t)copy_len >= next_boundary ? E_BLOCK_LENGTH_1 : E_BLOCK_LENGTH_2);
       if (distance_code <= 0) STOP(E_UNREACHABLE);  // wrapped large-window arithmetic, never on valid streams
       const uint32_t dist = (uint32_t)distance_code;
-      if (lean_mb && (uint32_t)copy_len <= quota && dist >= (uint32_t)copy_len && (uint32_t)copy_len <= 1024u) {
+      if (quota_mb && !CTX_NEVER && (uint32_t)copy_len <= 64u && (uint32_t)copy_len <= quota && dist >= (uint32_t)copy_len) {
+        // lean short copy where literal context matters: one byte per lane, so that the next literal can take the two
+        // bytes before it straight from the register (copy lengths start at 2)
+        FLUSH_LITERALS();
+        FLUSH_PENDING();
+        const uint32_t n = (uint32_t)copy_len;
+        uint32_t b = 0;
+        if (lane < n) b = (out + P - dist)[lane];
+        pend_reg = b; pend_n = n; pend_pos = P;
+        ctx_src = CTX_PEND; ctx_len = n;
+        P += n;
+        quota -= n;
+        PROF_REST(prof_copy, prof_t);
+        if (quota != 0) continue;
+        goto command_done;
+      }
+      if (quota_mb && (uint32_t)copy_len <= quota && dist >= (uint32_t)copy_len && (uint32_t)copy_len <= 1024u &&
+          (CTX_NEVER || (uint32_t)copy_len > 64u)) {
         // lean copy: fits, does not overlap itself; 16 bytes per lane plus a byte tail, stored when the next
         // command gets here (its source may be what this one writes)
         FLUSH_LITERALS();
@@ -1442,6 +1490,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         if (lane < rem) b = src[(n16 << 4) + lane];
         pendv = v; pendv_n16 = n16; pendv_pos = P;
         pend_reg = b; pend_n = rem; pend_pos = P + (n16 << 4);
+        if (!CTX_NEVER) ctx_src = CTX_MEMORY;
         P += n;
         quota -= n;
         PROF_REST(prof_copy, prof_t);
@@ -1513,7 +1562,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 command_done:
     if (P >= next_boundary) RING_CROSS();
     if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE
-    if (lean_mb) RECOMPUTE_QUOTA();
+    if (quota_mb) RECOMPUTE_QUOTA();
   }
 #undef RECOMPUTE_QUOTA
 #undef BLOCK_SWITCH
