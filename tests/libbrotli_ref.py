@@ -74,3 +74,53 @@ def encode(data: bytes, quality: int = 5, lgwin: int = 22, mode: int = 0) -> byt
     if not ok:
         raise RuntimeError("BrotliEncoderCompress failed")
     return out.raw[:n.value]
+
+
+# ---- streaming encoder with explicit parameters (brotli/encode.h of 1.0.9) ----
+PARAM_MODE, PARAM_QUALITY, PARAM_LGWIN, PARAM_LGBLOCK, PARAM_NO_LITERAL_CONTEXT, PARAM_SIZE_HINT, PARAM_LARGE_WINDOW, PARAM_NPOSTFIX, \
+    PARAM_NDIRECT = range(9)
+OP_PROCESS, OP_FLUSH, OP_FINISH, OP_EMIT_METADATA = range(4)
+
+if _enc is not None:
+    _enc.BrotliEncoderCreateInstance.restype = ctypes.c_void_p
+    _enc.BrotliEncoderCreateInstance.argtypes = [ctypes.c_void_p] * 3
+    _enc.BrotliEncoderDestroyInstance.argtypes = [ctypes.c_void_p]
+    _enc.BrotliEncoderSetParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32]
+    _enc.BrotliEncoderCompressStream.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p),
+                                                 ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    _enc.BrotliEncoderIsFinished.argtypes = [ctypes.c_void_p]
+    _enc.BrotliEncoderHasMoreOutput.argtypes = [ctypes.c_void_p]
+
+
+def encode_stream(chunks, params=None, ops=None) -> bytes:
+    """Compress `chunks` (list of bytes) with the streaming encoder.  params: {PARAM_*: value}.  ops: one operation per
+    chunk (OP_PROCESS / OP_FLUSH / OP_EMIT_METADATA; a metadata chunk must be at most 16 bytes); the stream is always
+    finished at the end.  Flushes give several metablocks, metadata chunks give metadata metablocks."""
+    st = _enc.BrotliEncoderCreateInstance(None, None, None)
+    try:
+        for k, v in (params or {}).items():
+            if not _enc.BrotliEncoderSetParameter(st, k, v):
+                raise ValueError("BrotliEncoderSetParameter(%d, %d) refused" % (k, v))
+        out = bytearray()
+        obuf = ctypes.create_string_buffer(1 << 16)
+
+        def pump(op, data):
+            ibuf = ctypes.create_string_buffer(data, max(1, len(data)))
+            avail_in = ctypes.c_size_t(len(data))
+            next_in = ctypes.c_void_p(ctypes.addressof(ibuf))
+            while True:
+                avail_out = ctypes.c_size_t(len(obuf))
+                next_out = ctypes.c_void_p(ctypes.addressof(obuf))
+                if not _enc.BrotliEncoderCompressStream(st, op, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                                        ctypes.byref(next_out), None):
+                    raise RuntimeError("BrotliEncoderCompressStream failed")
+                out.extend(obuf.raw[:len(obuf) - avail_out.value])
+                if avail_in.value == 0 and not _enc.BrotliEncoderHasMoreOutput(st):
+                    break
+        ops = ops or [OP_PROCESS] * len(chunks)
+        for c, op in zip(chunks, ops):
+            pump(op, c)
+        pump(OP_FINISH, b"")
+        return bytes(out)
+    finally:
+        _enc.BrotliEncoderDestroyInstance(st)

@@ -164,3 +164,44 @@ def test_unaligned_device_inputs(pkg):
 
 def test_tiny_inputs(pkg):
     _check_against_oracle(pkg, [b"", b"\x06", b"\x00", b"\x01"], [16, 16, 16, 0], 1, "tiny")
+
+
+def test_parameterised_encoder_corpus(pkg):
+    """streams with NPOSTFIX/NDIRECT != 0, every context mode, many block types, every window size (standard and
+    large), flushes and metadata blocks: bit-exact, and every status field equal to the oracle's"""
+    import param_corpus
+    streams = param_corpus.corpus()
+    if not streams:
+        pytest.skip("libbrotlienc not available")
+    datas = [c for _, c, _ in streams]
+    caps = [len(r) + 16 for _, _, r in streams]
+    batch = pkg.Batch(len(streams))
+    results, outs = batch.decode_host(datas, caps, pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    for (label, comp, raw), r, out in zip(streams, results, outs):
+        assert (r.result, r.error_code, r.decoded_size, r.consumed) == (1, 1, len(raw), len(comp)), label
+        assert out == raw, label
+    _check_against_oracle(pkg, datas, caps, 1, "corpus")
+    # exact-fit and too-small output buffers
+    _check_against_oracle(pkg, datas, [len(r) for _, _, r in streams], 1, "corpus exact fit")
+    _check_against_oracle(pkg, datas, [len(r) // 2 for _, _, r in streams], 1, "corpus half")
+
+
+@pytest.mark.parametrize("arena", [256, 4096])
+def test_tables_that_do_not_fit_lds(pkg, arena):
+    """the spill policy: with an LDS arena this small most prefix-code tables of a metablock live in the block's
+    global scratch (the generic instantiation of the command loop); results must not change"""
+    import param_corpus
+    m = [e for e in _manifest() if e["name"] != "rnd_chunk.br"]
+    datas = [_data(e["name"]) for e in m]
+    caps = [e.get("size", 1 << 16) + 16 for e in m]
+    for label, comp, raw in param_corpus.corpus()[::3]:
+        datas.append(comp)
+        caps.append(len(raw) + 16)
+    batch = pkg.Batch(len(datas), lds_arena_bytes=arena)
+    results, outs = batch.decode_host(datas, caps, pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    for i, (d, cap) in enumerate(zip(datas, caps)):
+        info, exp = oracle.decode(d, cap, 1)
+        r = results[i]
+        assert (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp), (i, arena)

@@ -193,3 +193,23 @@ def test_differential_vs_libbrotlidec(seed):
         if not same:
             diffs.append((len(d), cap, lw, info.result, info.error_code, info.decoded_size, res, code, len(rout)))
     assert not diffs, repr(diffs[:5])
+
+
+def test_parameterised_encoder_corpus():
+    """NPOSTFIX/NDIRECT != 0, all context modes, many block types, all window sizes, flushes and metadata blocks
+    (what the reference's fixtures leave unpinned): the oracle reproduces the raw data"""
+    import param_corpus
+    streams = param_corpus.corpus()
+    if not streams:
+        pytest.skip("libbrotlienc not available")
+    seen_np = False
+    for label, comp, raw in streams:
+        info, out = oracle.decode(comp, len(raw) + 16, oracle.FLAG_LARGE_WINDOW)
+        assert (info.result, info.error_code, info.decoded_size) == (1, 1, len(raw)), label
+        assert out == raw, label
+        assert info.consumed == len(comp), label
+        # standard-window streams are also accepted without the large-window flag, large-window ones are not
+        info2, _ = oracle.decode(comp, len(raw) + 16, 0)
+        assert (info2.result == 1) == (not label.startswith("large-")), label
+        seen_np = seen_np or label.startswith("np3-")
+    assert seen_np
