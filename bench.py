@@ -19,6 +19,7 @@ import ctypes
 import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -47,6 +48,12 @@ def build_workload(name, rank):
     if name == "alice29x1024" or not w.encoder_available():
         return "1024 x alice29.txt.compressed (reference fixture, wbits 22)", w.fixture_streams("alice29.txt.compressed"), 1024
     n_unique = int(os.environ.get("BROTLI_BENCH_UNIQUE", "32"))
+    m = re.fullmatch(r"(longbackref|highentropy)_(\d+)x(\d+)(KiB|MiB)", name)
+    if m and name not in ("longbackref_256x4MiB", "highentropy_256x4MiB"):
+        # occupancy sweeps: the same total volume cut into more, smaller streams (still wbits 22)
+        kind, n, size = m.group(1), int(m.group(2)), int(m.group(3)) << (10 if m.group(4) == "KiB" else 20)
+        u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", n_unique, size, 3000 + 4096 * rank)
+        return "%d x %d KiB streams, wbits 22, brotli -q5, %s (%d distinct streams)" % (n, size >> 10, kind, n_unique), u, max(1, n // n_unique)
     if name == "longbackref_256x4MiB":
         u = w.make_streams("long_backref", n_unique, 4 << 20, 1000 + 4096 * rank)
         return "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, long back-references (%d distinct streams)" % n_unique, u, 256 // n_unique
@@ -92,7 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("BROTLI_BENCH_WORKLOAD", "longbackref_256x4MiB"),
-                    choices=["longbackref_256x4MiB", "highentropy_256x4MiB", "alice29x1024"])
+                    help="longbackref_256x4MiB (default, the metric's configuration), highentropy_256x4MiB, alice29x1024, or "
+                         "<longbackref|highentropy>_<streams>x<size><KiB|MiB> for occupancy sweeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,7 +143,7 @@ def main():
     out_ptrs = [d_out.data_ptr() + i * out_stride for i in range(n)]
     torch.cuda.synchronize()
 
-    batch = pkg.Batch(n)
+    batch = pkg.Batch(n, lds_arena_bytes=int(os.environ.get("BROTLI_BENCH_LDS_ARENA", "0")))
     stream = torch.cuda.current_stream().cuda_stream
     batch.decode_device(in_ptrs, sizes, out_ptrs, caps, pkg.FLAG_LARGE_WINDOW, stream)
     res = batch.wait()

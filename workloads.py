@@ -47,7 +47,7 @@ def long_backref_stream(seed: int, size: int = 4 << 20) -> bytes:
     ranks = np.arange(1, 65, dtype=np.float64)
     p = (1.0 / ranks) / np.sum(1.0 / ranks)
     out = np.empty(size, dtype=np.uint8)
-    seed_len = min(size, 512 << 10)
+    seed_len = min(size, max(1024, size >> 3))  # 512 KiB of a 4 MiB stream
     out[:seed_len] = (rng.choice(64, size=seed_len, p=p) + 32).astype(np.uint8)
     pos = seed_len
     max_back = (4 << 20) - 16
@@ -55,7 +55,7 @@ def long_backref_stream(seed: int, size: int = 4 << 20) -> bytes:
         if rng.random() < 0.9:
             n = int(rng.integers(32, 4096))
             hi = min(pos, max_back)
-            d = int(rng.integers(min(64 << 10, hi - 1), hi)) if hi > 1 else 1
+            d = int(rng.integers(min(64 << 10, hi // 2), hi)) if hi > 1 else 1
             n = min(n, size - pos, d)
             out[pos:pos + n] = out[pos - d:pos - d + n]
         else:
