@@ -32,7 +32,7 @@ typedef struct BrotliAmdResult {
   uint64_t consumed;     /* input bytes consumed */
   uint64_t produced;     /* bytes written to the output buffer (>= decoded_size after an error) */
   uint32_t num_metablocks;
-  uint32_t reserved;
+  uint32_t spilled_metablocks; /* metablocks whose tables did not fit the LDS arena (slower path; raise lds_arena_bytes) */
   uint64_t num_commands;
 } BrotliAmdResult;
 

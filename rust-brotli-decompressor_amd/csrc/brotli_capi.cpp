@@ -201,7 +201,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
       const BrotliAmdStreamStatus& s = b->h_status[i];
       BrotliAmdResult& r = results[i];
       r.result = s.result; r.error_code = s.error_code; r.decoded_size = s.decoded_size; r.consumed = s.consumed;
-      r.produced = s.produced; r.num_metablocks = s.num_metablocks; r.reserved = 0; r.num_commands = s.num_commands;
+      r.produced = s.produced; r.num_metablocks = s.num_metablocks; r.spilled_metablocks = s.spilled_metablocks; r.num_commands = s.num_commands;
     }
   }
   return 0;

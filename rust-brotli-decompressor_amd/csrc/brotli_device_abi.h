@@ -48,7 +48,7 @@ typedef struct BrotliAmdStreamStatus {
   uint64_t consumed;      // input bytes consumed
   uint64_t produced;      // bytes written to `out` (>= decoded_size on errors)
   uint32_t num_metablocks;
-  uint32_t reserved;
+  uint32_t spilled_metablocks;  // metablocks whose tables did not fit the LDS part of the arena
   uint64_t num_commands;
   BrotliAmdResume resume; // last completed metablock boundary
 } BrotliAmdStreamStatus;

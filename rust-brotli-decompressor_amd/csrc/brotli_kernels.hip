@@ -276,24 +276,7 @@ struct Arena {
     top = off + max_bytes;
     return off;
   }
-  __device__ __forceinline__ uint32_t alloc8(uint32_t max_bytes) {  // same, 8-byte aligned
-    top = (top + 7u) & ~7u;
-    return alloc(max_bytes);
-  }
   __device__ __forceinline__ void shrink_to(uint32_t off_end) { top = off_end; }
-  // uniform 64-bit load (8-byte aligned object)
-  template <bool LDS_ONLY = false>
-  __device__ __forceinline__ void ld64(uint32_t off, uint32_t& lo, uint32_t& hi) const {
-    uint64_t v;
-    if (LDS_ONLY || off < lds_limit) v = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_FIXED + off]);
-    else v = *reinterpret_cast<__attribute__((address_space(1))) const uint64_t*>(glb + off);
-    lo = rfl((uint32_t)v); hi = rfl((uint32_t)(v >> 32));
-  }
-  __device__ __forceinline__ void st64_lane(uint32_t off, uint32_t lo, uint32_t hi) const {
-    uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
-    if (off < lds_limit) *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_FIXED + off]) = v;
-    else *reinterpret_cast<__attribute__((address_space(1))) uint64_t*>(glb + off) = v;
-  }
   // uniform loads.  LDS_ONLY = the caller knows the object is in the LDS part: the load is a plain ds_read and
   // the wait in front of v_readfirstlane is lgkmcnt only (the two-way form must also wait for vmcnt, i.e. for
   // every global store the wave still has in flight)
@@ -348,23 +331,6 @@ __device__ __forceinline__ uint32_t read_symbol(BitReader& br, const Arena& a, u
   return e >> 4;
 }
 
-// Insert-and-copy trees use 8-byte entries that carry what src/prefix.rs:115-5755 (kCmdLut) would be looked up for
-// after the symbol: lo = len:4 | insert extra bits:5 | copy extra bits:5 | distance context:2 | implicit distance:1,
-// hi = insert base:16 | copy base:16.  Root entries that point down keep the (offset << 4) | (8 + depth) layout in lo.
-constexpr uint32_t CMD_IMPLICIT_DISTANCE = 1u << 16;
-template <bool LDS_ONLY = false>
-__device__ __forceinline__ void read_command(BitReader& br, const Arena& a, uint32_t tree, uint32_t& lo, uint32_t& hi) {
-  uint32_t bits = br.peek32();
-  a.ld64<LDS_ONLY>(tree + ((bits & 0xFFu) << 3), lo, hi);
-  uint32_t len = lo & 15u;
-  if (len > ROOT_BITS) {
-    uint32_t idx = (lo >> 4) + ((bits >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
-    a.ld64<LDS_ONLY>(tree + (idx << 3), lo, hi);
-    len = ROOT_BITS + (lo & 15u);
-  }
-  br.drop(len);
-}
-
 // ========================================== decoder state ==========================================
 // Everything one stream carries (reference: BrotliState, src/state.rs:156-278).  The object itself may live
 // in private memory (its address is handed to the one non-inlined helper); every function works on register
@@ -394,8 +360,9 @@ struct Stream {
   uint32_t ctx_modes, ctx_map, dist_ctx_map;          // arena offsets
   uint32_t lit_trees, cmd_trees, dist_trees;          // arena offsets of u32 arrays of tree offsets
   uint32_t num_lit_trees, num_dist_trees;
+  uint32_t lut_vgpr;       // per-lane: insert/copy code LUT image
   uint32_t bl_vgpr;        // per-lane: block length code LUT image
-  uint32_t num_metablocks;
+  uint32_t num_metablocks, num_spilled;
   uint64_t num_commands;
 #ifdef BROTLI_AMD_PROFILE
   uint64_t prof[6];
@@ -812,41 +779,12 @@ __device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint
 }
 
 // decode.rs:1130-1219: `ntrees` prefix codes; their arena offsets go to a u32 array
-template <bool COMMANDS = false>
 __device__ __forceinline__ int decode_tree_group(Stream& s, uint32_t alphabet, uint32_t max_symbol, uint32_t ntrees, uint32_t* group_off) {
   uint32_t g = s.ar.alloc(ntrees * 4);
   *group_off = g;
   for (uint32_t t = 0; t < ntrees; t++) {
     uint32_t tree;
-    if (!COMMANDS) {
-      TRY(read_huffman_code(s, alphabet, max_symbol, &tree));
-    } else {
-      // the 2-byte table is built behind the place of the 8-byte one and expanded into it (see read_command)
-      uint32_t wide = rfl(s.ar.alloc8(max_table_entries(704) * 8));
-      uint32_t narrow;
-      TRY(read_huffman_code(s, alphabet, max_symbol, &narrow));
-      narrow = rfl(narrow);
-      const uint32_t size = (rfl(s.ar.top) - narrow) >> 1;
-      Arena ar = s.ar; ar.uniformize();
-      for (uint32_t k = lane_id(); k < size; k += 64) {
-        uint32_t e = (narrow + 2 * k < ar.lds_limit) ? lds_ld16(LDS_FIXED + narrow + 2 * k) : (uint32_t)*reinterpret_cast<gu16*>(ar.glb + narrow + 2 * k);
-        uint32_t lo = e, hi = 0;
-        if (!(k < 256 && (e & 15u) > ROOT_BITS)) {
-          uint32_t cmd = e >> 4;
-          uint32_t cell = cmd >> 6;  // RFC 7932 section 5: the 11 cells of the insert-and-copy alphabet
-          uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
-          uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);         // {0,1,0,1,0,1,2,0,2,1,2}
-          uint32_t dctx = copy_code > 2 ? 3u : copy_code;
-          lo = (e & 15u) | ((uint32_t)kInsExtra[ins_code] << 4) | ((uint32_t)kCopyExtra[copy_code] << 9) | (dctx << 14) |
-               (cmd < 128 ? CMD_IMPLICIT_DISTANCE : 0u);
-          hi = (uint32_t)kInsBase[ins_code] | ((uint32_t)kCopyBase[copy_code] << 16);
-        }
-        ar.st64_lane(wide + 8 * k, lo, hi);
-      }
-      lds_sync();
-      s.ar.shrink_to(wide + size * 8);
-      tree = wide;
-    }
+    TRY(read_huffman_code(s, alphabet, max_symbol, &tree));
     s.ar.st32(g + t * 4, tree);
   }
   lds_sync();
@@ -941,7 +879,7 @@ struct HotArgs {
   int32_t d0, d1, d2, d3;
   uint32_t bl0, bl1, bl2;
   uint32_t postfix_bits, num_direct;
-  uint32_t bl_vgpr;
+  uint32_t lut_vgpr, bl_vgpr;
   uint64_t num_commands;
   uint64_t prof[6];
 };
@@ -982,7 +920,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     if ((res) == BS_SWITCHED) { if (lane == 0) { lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat)), t0_); lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat) + 1), t1_); } lds_sync(); } \
   } while (0)
   const uint32_t postfix_bits = rfl(args->postfix_bits), num_direct = rfl(args->num_direct);
-  const uint32_t bl_vgpr = args->bl_vgpr;  // per-lane image of the block length code LUT
+  const uint32_t lut_vgpr = args->lut_vgpr, bl_vgpr = args->bl_vgpr;  // per-lane LUT images
   uint64_t num_commands = rfl(args->num_commands);
   int result = E_SUCCESS;
   uint64_t prof_cmd = 0, prof_lit = 0, prof_dist = 0, prof_copy = 0, prof_t = PROF_T();
@@ -1069,12 +1007,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
       if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
     }
-    uint32_t clo, chi;
-    read_command<LDS_ONLY>(br, a, cmd_tree, clo, chi);
-    int32_t distance_code = (clo & CMD_IMPLICIT_DISTANCE) ? 0 : -1;
-    uint32_t distance_context = (clo >> 14) & 3u;
-    int32_t insert_len = (int32_t)((chi & 0xFFFFu) + br.read((clo >> 4) & 31u));
-    int32_t copy_len = (int32_t)((chi >> 16) + br.read((clo >> 9) & 31u));
+    uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
+    // kCmdLut regenerated arithmetically (RFC 7932 section 5; replaces src/prefix.rs:115-5755); 2-byte tree entries:
+    // 8-byte entries carrying these fields were measured 1 % faster but cost 3.3 KB of LDS per command tree
+    uint32_t cell = cmd >> 6;
+    uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
+    uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);         // {0,1,0,1,0,1,2,0,2,1,2}
+    uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
+    int32_t distance_code = cmd < 128 ? 0 : -1;
+    uint32_t distance_context = copy_code > 2 ? 3u : copy_code;
+    int32_t insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
+    int32_t copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
     if (br.over()) STOP(E_NEEDS_MORE_INPUT);
     bl1--;
     num_commands++;
@@ -1605,7 +1548,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     for (int k = 0; k < 21; k++) lds_st32(LDS_HOT + 4u * (uint32_t)k, cold[k]);
   }
   lds_sync();
-  h.bl_vgpr = s.bl_vgpr;
+  h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
   h.num_commands = s.num_commands;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
@@ -1620,6 +1563,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
   } else {
+    s.num_spilled++;
     e = process_commands<false, false>(&h);
   }
   e = rfl(e);
@@ -1781,7 +1725,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         uint32_t max_dist_symbol = s.large_window ? max_distance_symbol(ndirect, s.postfix_bits) : num_dist_codes;
         TRY(decode_context_map(s, s.nbt2 << 2, &s.num_dist_trees, &s.dist_ctx_map));
         TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
-        TRY(decode_tree_group<true>(s, 704, 704, s.nbt1, &s.cmd_trees));
+        TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
         TRY(decode_tree_group(s, num_dist_codes, max_dist_symbol, s.num_dist_trees, &s.dist_trees));
 #ifdef BROTLI_AMD_PROFILE_HDR
         s.prof[4] += __builtin_amdgcn_s_memtime() - hdr_t0;
@@ -1824,7 +1768,9 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
   // literal context LUT -> LDS once per block
   for (uint32_t i = lane; i < 2048; i += 64) lds_st8(LDS_CTX_LUT + i, kContextLookup[i]);
   // per-lane LUT images
-  uint32_t bl = 0;
+  uint32_t lut = 0, bl = 0;
+  if (lane < 24) lut = (uint32_t)kInsBase[lane] | ((uint32_t)kInsExtra[lane] << 16);
+  else if (lane >= 32 && lane < 56) lut = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
   if (lane < 26) bl = (uint32_t)kBlockLenBase[lane] | ((uint32_t)kBlockLenExtra[lane] << 16);
   lds_sync();
 
@@ -1844,8 +1790,8 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
     s.dict = as_global<gcu8>(dict);
     s.in_bytes = as_global<gcu8>(d.in);
     s.flags = d.flags;
-    s.bl_vgpr = bl;
-    s.num_metablocks = 0; s.num_commands = 0;
+    s.lut_vgpr = lut; s.bl_vgpr = bl;
+    s.num_metablocks = 0; s.num_spilled = 0; s.num_commands = 0;
     s.mlen = 0;
 #ifdef BROTLI_AMD_PROFILE
     s.prof[0] = s.prof[1] = s.prof[2] = s.prof[3] = s.prof[4] = s.prof[5] = 0;
@@ -1895,7 +1841,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
       st->produced = s.P;
       st->num_metablocks = s.num_metablocks;
       st->num_commands = s.num_commands;
-      st->reserved = 0;
+      st->spilled_metablocks = s.num_spilled;
 #ifdef BROTLI_AMD_PROFILE
       // debugging aid: cycle split of the command loop in the (otherwise unused) resume block of the status
       st->resume.bit_pos = __builtin_amdgcn_s_memtime() - prof_start;
