@@ -76,7 +76,8 @@ constexpr uint32_t LDS_MTF = LDS_WORD + 128;                // 256: inverse move
 constexpr uint32_t LDS_INWIN = LDS_MTF + 256;               // 1024: compressed-input ring, four 256-byte halves filled by LDS-DMA
 constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit reader needs only when it moves its window (BitReader)
 constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
-constexpr uint32_t LDS_FIXED = LDS_HOT + 96;                // = 5632, 16-byte aligned
+constexpr uint32_t LDS_LEAN = LDS_HOT + 96;                 // 192: state handed between process_commands and lean_commands
+constexpr uint32_t LDS_FIXED = LDS_LEAN + 192;              // = 5824, 16-byte aligned
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -865,6 +866,275 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 #define PROF_REST(acc, t0) PROF_ADD(acc, t0)
 #endif
 
+// One hand-scheduled pass of the literal batch loop (operands: see its two users).
+#define LITERAL_BATCH_ASM \
+  "s_nop 4\n" \
+  "1:\n\t" \
+  "s_cmp_gt_u32 %[cnt], 31\n\t" \
+  "s_cbranch_scc1 2f\n\t" \
+  "s_sub_u32 %[t0], %[ndw], %[cb]\n\t" \
+  "v_readlane_b32 s90, %[cur], %[t0]\n\t" \
+  "s_mov_b32 s91, 0\n\t" \
+  "s_lshl_b64 vcc, s[90:91], %[cnt]\n\t" \
+  "s_or_b64 %[buf], %[buf], vcc\n\t" \
+  "s_add_u32 %[cnt], %[cnt], 32\n\t" \
+  "s_add_u32 %[ndw], %[ndw], 1\n" \
+  "2:\n\t" \
+  "s_sub_u32 %[t0], %[ndw], %[cb]\n\t" \
+  "s_add_u32 %[t1], %[t0], 1\n\t" \
+  "v_readlane_b32 s90, %[cur], %[t0]\n\t" \
+  "v_readlane_b32 s91, %[cur], %[t1]\n\t" \
+  "s_lshl_b64 vcc, s[90:91], %[cnt]\n\t" \
+  "s_or_b64 s[92:93], %[buf], vcc\n\t" \
+  "s_sub_u32 %[t0], 64, %[cnt]\n\t" \
+  "s_lshr_b64 s[94:95], s[90:91], %[t0]\n\t" \
+  "v_mov_b32 %[v0], s92\n\t" \
+  "v_mov_b32 %[v1], s93\n\t" \
+  "v_alignbit_b32 %[v0], s93, %[v0], %[lane]\n\t" \
+  "v_alignbit_b32 %[v1], s94, %[v1], %[lane]\n\t" \
+  "v_bfi_b32 %[v0], %[lomask], %[v0], %[v1]\n\t" \
+  "v_and_b32 %[v1], 0xff, %[v0]\n\t" \
+  "v_lshl_add_u32 %[v1], %[v1], 1, %[tree]\n\t" \
+  "ds_read_u16 %[v2], %[v1]\n\t" \
+  "s_waitcnt lgkmcnt(0)\n\t" \
+  "v_and_b32 %[v3], 15, %[v2]\n\t" \
+  "v_cmp_lt_u32 vcc, 8, %[v3]\n\t" \
+  "s_cbranch_vccz 3f\n\t" \
+  "s_and_saveexec_b64 s[94:95], vcc\n\t" \
+  "v_lshrrev_b32 %[v1], 8, %[v0]\n\t" \
+  "v_add_u32 %[v3], -8, %[v3]\n\t" \
+  "v_bfe_u32 %[v1], %[v1], 0, %[v3]\n\t" \
+  "v_lshrrev_b32 %[v4], 4, %[v2]\n\t" \
+  "v_add_u32 %[v1], %[v1], %[v4]\n\t" \
+  "v_lshl_add_u32 %[v1], %[v1], 1, %[tree]\n\t" \
+  "ds_read_u16 %[v2], %[v1]\n\t" \
+  "s_waitcnt lgkmcnt(0)\n\t" \
+  "v_and_b32 %[v3], 15, %[v2]\n\t" \
+  "v_add_u32 %[v3], 8, %[v3]\n\t" \
+  "s_mov_b64 exec, s[94:95]\n" \
+  "3:\n\t" \
+  "s_mul_i32 %[t0], %[i], 15\n\t" \
+  "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t" \
+  "s_nop 1\n\t" \
+  "v_cndmask_b32 %[v3], 64, %[v3], vcc\n\t" \
+  "s_mov_b64 s[92:93], 0\n\t" \
+  "s_mov_b32 %[off], 0xffffffc0\n" \
+  "4:\n\t" \
+  "v_readlane_b32 %[t1], %[v3], %[off]\n\t" \
+  "s_bitset1_b64 s[92:93], %[off]\n\t" \
+  "s_add_u32 %[off], %[off], %[t1]\n\t" \
+  "s_cbranch_scc0 4b\n\t" \
+  "s_add_u32 %[off], %[off], 64\n\t" \
+  "s_bcnt1_i32_b64 %[n], s[92:93]\n\t" \
+  "v_mbcnt_lo_u32_b32 %[v4], s92, 0\n\t" \
+  "v_mbcnt_hi_u32_b32 %[v4], s93, %[v4]\n\t" \
+  "s_cmp_le_u32 %[n], %[i]\n\t" \
+  "s_cbranch_scc1 5f\n\t" \
+  "v_cmp_eq_u32 vcc, %[i], %[v4]\n\t" \
+  "s_and_b64 vcc, vcc, s[92:93]\n\t" \
+  "s_ff1_i32_b64 %[off], vcc\n\t" \
+  "s_lshl_b64 vcc, -1, %[off]\n\t" \
+  "s_andn2_b64 s[92:93], s[92:93], vcc\n\t" \
+  "s_mov_b32 %[n], %[i]\n" \
+  "5:\n\t" \
+  "v_lshrrev_b32 %[v2], 4, %[v2]\n\t" \
+  "v_add_u32 %[v4], %[woff], %[v4]\n\t" \
+  "s_mov_b64 exec, s[92:93]\n\t" \
+  "global_store_byte %[v4], %[v2], %[wp]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "s_cmp_le_u32 %[off], %[cnt]\n\t" \
+  "s_cbranch_scc1 6f\n\t" \
+  "s_sub_u32 %[t0], %[off], %[cnt]\n\t" \
+  "s_lshr_b64 %[buf], s[90:91], %[t0]\n\t" \
+  "s_sub_u32 %[cnt], 64, %[t0]\n\t" \
+  "s_add_u32 %[ndw], %[ndw], 2\n\t" \
+  "s_branch 7f\n" \
+  "6:\n\t" \
+  "s_lshr_b64 %[buf], %[buf], %[off]\n\t" \
+  "s_sub_u32 %[cnt], %[cnt], %[off]\n" \
+  "7:\n\t" \
+  "s_add_u32 %[woff], %[woff], %[n]\n\t" \
+  "s_sub_u32 %[i], %[i], %[n]\n\t" \
+  "s_cmp_lt_u32 %[i], 3\n\t" \
+  "s_cbranch_scc1 8f\n\t" \
+  "s_sub_u32 %[t0], %[ndw], %[cb]\n\t" \
+  "s_cmp_lt_u32 %[t0], 62\n\t" \
+  "s_cbranch_scc1 1b\n" \
+  "8:\n\t" \
+  "s_nop 4\n"
+
+// ===================================== lean command loop =====================================
+// The common case of the command loop as a function of its own: commands of a metablock whose literal block types
+// all have a constant context map, while every stage stays clear of the limits (see `quota` in process_commands).
+// It owns only the state such commands touch -- its register allocation is not shared with the checked stages and
+// their error handling -- and hands a command over at the first stage it cannot take (L_STAGE); process_commands
+// finishes that command and comes back.  State crosses through LDS_LEAN (uniform values) and function arguments.
+enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI, L_QUOTA, L_MLEN, L_BL0, L_BL1, L_BL2, L_D0, L_D1, L_D2,
+       L_D3, L_NCMD_LO, L_NCMD_HI, L_CMD_TREE, L_LIT_TREE, L_DT0, L_DT1, L_DT2, L_DT3, L_MAX_BACKWARD, L_POSTFIX, L_NUM_DIRECT, L_OUT_LO,
+       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_COUNT };
+static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
+enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
+       LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7 };
+#define LEAN_LD(k) rfl(lds_ld32(LDS_LEAN + 4u * (uint32_t)(k)))
+#define LEAN_ST(k, v) lds_st32(LDS_LEAN + 4u * (uint32_t)(k), (uint32_t)(v))
+
+__device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
+  const uint32_t lane = lane_id();
+  const Arena a = {nullptr, 0xFFFFFFFFu, 0u};  // every table of the metablock is in LDS: the arena fields are not looked at
+  BitReader br;
+  br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+  br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
+  br.chunk_base = 0; br.cur = 0;
+  br.rebase();
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
+  uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+  uint32_t quota = LEAN_LD(L_QUOTA);
+  int32_t mlen = (int32_t)LEAN_LD(L_MLEN);
+  uint32_t bl0 = LEAN_LD(L_BL0), bl1 = LEAN_LD(L_BL1), bl2 = LEAN_LD(L_BL2);
+  int32_t d0 = (int32_t)LEAN_LD(L_D0), d1 = (int32_t)LEAN_LD(L_D1), d2 = (int32_t)LEAN_LD(L_D2), d3 = (int32_t)LEAN_LD(L_D3);
+  uint32_t ncmd = 0;
+  const uint32_t cmd_tree = LEAN_LD(L_CMD_TREE), lit_tree = LEAN_LD(L_LIT_TREE);
+  const uint32_t dt0 = LEAN_LD(L_DT0), dt1 = LEAN_LD(L_DT1), dt2 = LEAN_LD(L_DT2), dt3 = LEAN_LD(L_DT3);
+  const int32_t max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
+  const uint32_t postfix_bits = LEAN_LD(L_POSTFIX), num_direct = LEAN_LD(L_NUM_DIRECT);
+  const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
+  const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
+  const uint32_t tree_addr = LDS_FIXED + lit_tree;
+  // copy whose bytes are in registers but not stored yet (16 bytes per lane + a byte tail)
+  u32x4 pendv = {0, 0, 0, 0}; uint32_t pendv_n16 = 0, pend_reg = 0, pend_n = 0; uint64_t pend_pos = 0;
+#define LEAN_FLUSH() do { if (pendv_n16) { if (lane < pendv_n16) *reinterpret_cast<gu32x4*>(out + pend_pos + (uint64_t)lane * 16) = pendv; } \
+                          if (pend_n) { if (lane < pend_n) out[pend_pos + ((uint64_t)pendv_n16 << 4) + lane] = (uint8_t)pend_reg; } \
+                          pendv_n16 = 0; pend_n = 0; } while (0)
+  uint32_t stage = LS_BEGIN;
+  int32_t insert_len = 0, copy_len = 0, distance_code = 0;
+  uint32_t distance_context = 0, lits_left = 0;
+
+  for (;;) {
+    if (bl1 == 0 || br.next_dw >= safe_dw) { stage = LS_BEGIN; break; }  // block switch due, or close to the end of the input
+    uint32_t cmd = read_symbol<true>(br, a, cmd_tree);
+    uint32_t cell = cmd >> 6;  // RFC 7932 section 5 (see process_commands)
+    uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
+    uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+    uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
+    distance_code = cmd < 128 ? 0 : -1;
+    distance_context = copy_code > 2 ? 3u : copy_code;
+    insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
+    copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
+    bl1--;
+    ncmd++;
+    lits_left = (uint32_t)insert_len;
+    if (insert_len != 0) {
+      if ((uint32_t)insert_len > quota || (uint32_t)insert_len > bl0) { stage = LS_AFTER_HEAD; break; }
+      mlen -= insert_len;
+      gu8* wp = out + P;
+      uint32_t i = (uint32_t)insert_len;
+      if (i > 2 && br.next_dw < safe_dw) {
+        uint32_t woff = 0;
+        do {
+          br.ensure_dwords(3);
+          uint32_t v0, v1, v2, v3, v4, t0, t1, off, n;
+          asm volatile(LITERAL_BATCH_ASM
+              : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [i] "+s"(i), [woff] "+s"(woff),
+                [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4),
+                [t0] "=&s"(t0), [t1] "=&s"(t1), [off] "=&s"(off), [n] "=&s"(n)
+              : [cur] "v"(br.cur), [lane] "v"(lane), [lomask] "v"(lomask), [tree] "s"(tree_addr), [cb] "s"(br.chunk_base), [wp] "s"(wp)
+              : "memory", "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
+        } while (i > 2 && br.next_dw < safe_dw);
+        wp += woff;
+      }
+      while (i > 0 && i <= 2 && br.next_dw < safe_dw) {  // one or two literals: cheaper one by one
+        uint32_t lit = read_symbol<true>(br, a, lit_tree);
+        if (lane == 0) *wp = (uint8_t)lit;
+        wp++; i--;
+      }
+      const uint32_t done = (uint32_t)insert_len - i;
+      P += done; bl0 -= done; quota -= done;
+      lits_left = i;
+      if (i != 0) { stage = LS_LITERALS_REST; break; }
+      if (quota == 0) { stage = LS_LITERALS_AT_LIMIT; break; }
+    }
+    // ---- distance (ReadDistanceInternal, decode.rs:2066-2131; see process_commands) ----
+    if (distance_code >= 0) {
+      distance_context = 1;
+      distance_code = d0;
+    } else {
+      if (bl2 == 0) { stage = LS_DISTANCE; break; }
+      uint32_t dtree = distance_context == 0 ? dt0 : distance_context == 1 ? dt1 : distance_context == 2 ? dt2 : dt3;
+      uint32_t code = read_symbol<true>(br, a, dtree);
+      distance_context = 0;
+      if (code < 16) {
+        if (code == 0) {
+          distance_code = d0;
+          distance_context = 1;
+        } else {
+          uint32_t sh = code << 1;
+          uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
+          int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
+          int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+          if (code & 1u) v += mag;
+          else { v -= mag; if (v <= 0) v = 0x7fffffff; }
+          distance_code = v;
+        }
+      } else {
+        int32_t distval = (int32_t)code - (int32_t)num_direct;
+        int32_t dc = (int32_t)code;
+        if (distval >= 0) {
+          int32_t postfix = distval & (int32_t)mask_bits(postfix_bits);
+          distval >>= postfix_bits;
+          uint32_t nbits = ((uint32_t)distval >> 1) + 1;
+          uint32_t bits = br.read(nbits);
+          int64_t offset = (int64_t)(int32_t)((((uint32_t)(distval & 1) + 2u) << nbits) - 4u);
+          dc = (int32_t)(((offset + (int64_t)bits) << postfix_bits) + postfix + (int64_t)num_direct);
+        }
+        distance_code = (int32_t)((uint32_t)dc - 16u + 1u);
+      }
+      bl2--;
+      if (br.next_dw > br.end_dw) { stage = LS_NEEDS_INPUT; break; }  // (cannot happen below safe_dw; literal runs are what moves far)
+    }
+    // ---- copy: an LZ77 reference (not the dictionary) inside the quota that does not overlap itself, <= 1 KiB ----
+    {
+      const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
+      const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
+      if (distance_code > max_distance || distance_code <= 0 || n > quota || dist < n) { stage = LS_POST_DISTANCE; break; }
+      if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
+      mlen -= copy_len;
+      LEAN_FLUSH();
+      gu8* src = out + P - dist;
+      uint32_t n16 = n >> 4, rem = n & 15u;
+      if (n > 1024u) {  // long: all but the last (partial) KiB right away, 16 bytes per lane and step
+        gu8* dst = out + P;
+        const uint32_t whole = (n16 - 1u) & ~63u;  // 16-byte pieces in whole steps, at least one piece is left for below
+        for (uint32_t c = lane; c < whole; c += 64) {
+          u32x4 t = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+          *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t;
+        }
+        src += (uint64_t)whole * 16; P += (uint64_t)whole * 16; quota -= whole * 16; n16 -= whole;
+      }
+      // the load is issued now, the store when the next command gets here (its source may be what this one writes)
+      u32x4 v = {0, 0, 0, 0};
+      if (lane < n16) v = *reinterpret_cast<gu32x4*>(src + (uint64_t)lane * 16);
+      uint32_t b = 0;
+      if (lane < rem) b = src[(n16 << 4) + lane];
+      pendv = v; pendv_n16 = n16; pend_reg = b; pend_n = rem; pend_pos = P;
+      P += (n16 << 4) + rem;
+      quota -= (n16 << 4) + rem;
+      if (quota == 0) { stage = LS_COMMAND_DONE; break; }
+    }
+  }
+  LEAN_FLUSH();
+#undef LEAN_FLUSH
+  if (lane == 0) {
+    LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+    LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
+    LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
+    LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
+    LEAN_ST(L_INSERT, insert_len); LEAN_ST(L_COPY, copy_len); LEAN_ST(L_DCODE, distance_code); LEAN_ST(L_DCTX, distance_context);
+    LEAN_ST(L_LITS_LEFT, lits_left);
+  }
+  lds_sync();
+  return rfl(stage);
+}
+
 // ===================================== the command loop (hot path) =====================================
 // Argument block of the command loop.  The loop is a real function (one per table placement) so that it gets a
 // register allocation of its own: everything uniform lives in SGPRs for the whole metablock and nothing of the
@@ -926,6 +1196,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t prof_cmd = 0, prof_lit = 0, prof_dist = 0, prof_copy = 0, prof_t = PROF_T();
   (void)prof_cmd; (void)prof_lit; (void)prof_dist; (void)prof_copy; (void)prof_t;
   uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
+  uint32_t prof_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)prof_stage;
 
   uint32_t cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4);
   uint32_t ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0, ctx_tree_v = 0;
@@ -999,7 +1270,58 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // BLOCK_LENGTH_1; the last crossed one is what the caller has received when an error is reported
 #define RING_CROSS() do { while (P >= next_boundary) { if (mlen < 0) STOP(E_BLOCK_LENGTH_1); if (!full_ring) STOP(E_UNREACHABLE); next_boundary += rb_size; } } while (0)
 
+  // per-command values (declared out here so that the lean loop's hand-over can jump to any stage below)
+  int32_t insert_len = 0, copy_len = 0, distance_code = 0, lits_left = 0, max_distance = 0;
+  uint32_t distance_context = 0;
+
+  if (LDS_ONLY && CTX_NEVER && lane == 0) {  // what lean_commands needs and never changes in this metablock
+    LEAN_ST(L_END_DW, br.end_dw); LEAN_ST(L_MAX_BACKWARD, max_backward); LEAN_ST(L_POSTFIX, postfix_bits); LEAN_ST(L_NUM_DIRECT, num_direct);
+    LEAN_ST(L_OUT_LO, (uint32_t)(uintptr_t)out); LEAN_ST(L_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
+  }
+
   for (;;) {
+    if (LDS_ONLY && CTX_NEVER && bl1 != 0 && quota != 0 && !lit_zero && br.next_dw < safe_dw) {
+      // ---- the lean loop takes over until a stage needs the checked code below ----
+      FLUSH_LITERALS();
+      FLUSH_PENDING();
+      lds_sync();
+      if (lane == 0) {
+        LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+        LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
+        LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
+        LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3);
+        LEAN_ST(L_CMD_TREE, cmd_tree); LEAN_ST(L_LIT_TREE, lit_tree);
+        LEAN_ST(L_DT0, dt0); LEAN_ST(L_DT1, dt1); LEAN_ST(L_DT2, dt2); LEAN_ST(L_DT3, dt3);
+      }
+      lds_sync();
+      const uint32_t stage = rfl(lean_commands(lut_vgpr));
+      br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+      br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
+      br.rebase();
+      P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+      quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
+      bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
+      d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
+      num_commands += LEAN_LD(L_NCMD_LO);
+#ifdef BROTLI_AMD_PROFILE
+      prof_fast_batches++; prof_fast_syms += LEAN_LD(L_NCMD_LO);  // (lean entries, commands run lean)
+      prof_stage[stage & 7]++;
+#endif
+      insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
+      distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
+      if (stage == LS_AFTER_HEAD) goto after_head;
+      if (stage == LS_LITERALS_REST) goto general_literals_rest;
+      if (stage == LS_LITERALS_AT_LIMIT) {  // exactly at a limit: end of the metablock, flush point, or full output buffer
+        if (P >= next_boundary) RING_CROSS();
+        if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
+        RECOMPUTE_QUOTA();
+        goto general_distance;
+      }
+      if (stage == LS_DISTANCE) goto general_distance;
+      if (stage == LS_POST_DISTANCE) goto general_post_distance;
+      if (stage == LS_COMMAND_DONE) goto command_done;
+      if (stage == LS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
+    }
     // ---- COMMAND_BEGIN ----
     if (bl1 == 0) {
       int r;
@@ -1007,6 +1329,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
       if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
     }
+    {
     uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
     // kCmdLut regenerated arithmetically (RFC 7932 section 5; replaces src/prefix.rs:115-5755); 2-byte tree entries:
     // 8-byte entries carrying these fields were measured 1 % faster but cost 3.3 KB of LDS per command tree
@@ -1014,16 +1337,19 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
     uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);         // {0,1,0,1,0,1,2,0,2,1,2}
     uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
-    int32_t distance_code = cmd < 128 ? 0 : -1;
-    uint32_t distance_context = copy_code > 2 ? 3u : copy_code;
-    int32_t insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
-    int32_t copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
+    distance_code = cmd < 128 ? 0 : -1;
+    distance_context = copy_code > 2 ? 3u : copy_code;
+    insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
+    copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
+    }
     if (br.over()) STOP(E_NEEDS_MORE_INPUT);
     bl1--;
     num_commands++;
     PROF_ADD(prof_cmd, prof_t);
+    lits_left = insert_len;  // literals of this command that are still to be decoded
+after_head:
+    {
     const bool lean_lit = lean_mb && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0 && !lit_zero;
-    int32_t lits_left = insert_len;  // literals of this command that are still to be decoded
 
     // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose literal block
     // types are all trivial, otherwise always (a block switch inside the run may make the very next literal
@@ -1064,100 +1390,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           br.ensure_dwords(3);
           uint32_t v0, v1, v2, v3, v4, t0, t1, off, n;
           asm volatile(
-              "s_nop 4\n"
-              "1:\n\t"
-              "s_cmp_gt_u32 %[cnt], 31\n\t"
-              "s_cbranch_scc1 2f\n\t"
-              "s_sub_u32 %[t0], %[ndw], %[cb]\n\t"
-              "v_readlane_b32 s90, %[cur], %[t0]\n\t"
-              "s_mov_b32 s91, 0\n\t"
-              "s_lshl_b64 vcc, s[90:91], %[cnt]\n\t"
-              "s_or_b64 %[buf], %[buf], vcc\n\t"
-              "s_add_u32 %[cnt], %[cnt], 32\n\t"
-              "s_add_u32 %[ndw], %[ndw], 1\n"
-              "2:\n\t"
-              "s_sub_u32 %[t0], %[ndw], %[cb]\n\t"
-              "s_add_u32 %[t1], %[t0], 1\n\t"
-              "v_readlane_b32 s90, %[cur], %[t0]\n\t"
-              "v_readlane_b32 s91, %[cur], %[t1]\n\t"
-              "s_lshl_b64 vcc, s[90:91], %[cnt]\n\t"
-              "s_or_b64 s[92:93], %[buf], vcc\n\t"
-              "s_sub_u32 %[t0], 64, %[cnt]\n\t"
-              "s_lshr_b64 s[94:95], s[90:91], %[t0]\n\t"
-              "v_mov_b32 %[v0], s92\n\t"
-              "v_mov_b32 %[v1], s93\n\t"
-              "v_alignbit_b32 %[v0], s93, %[v0], %[lane]\n\t"
-              "v_alignbit_b32 %[v1], s94, %[v1], %[lane]\n\t"
-              "v_bfi_b32 %[v0], %[lomask], %[v0], %[v1]\n\t"
-              "v_and_b32 %[v1], 0xff, %[v0]\n\t"
-              "v_lshl_add_u32 %[v1], %[v1], 1, %[tree]\n\t"
-              "ds_read_u16 %[v2], %[v1]\n\t"
-              "s_waitcnt lgkmcnt(0)\n\t"
-              "v_and_b32 %[v3], 15, %[v2]\n\t"
-              "v_cmp_lt_u32 vcc, 8, %[v3]\n\t"
-              "s_cbranch_vccz 3f\n\t"
-              "s_and_saveexec_b64 s[94:95], vcc\n\t"
-              "v_lshrrev_b32 %[v1], 8, %[v0]\n\t"
-              "v_add_u32 %[v3], -8, %[v3]\n\t"
-              "v_bfe_u32 %[v1], %[v1], 0, %[v3]\n\t"
-              "v_lshrrev_b32 %[v4], 4, %[v2]\n\t"
-              "v_add_u32 %[v1], %[v1], %[v4]\n\t"
-              "v_lshl_add_u32 %[v1], %[v1], 1, %[tree]\n\t"
-              "ds_read_u16 %[v2], %[v1]\n\t"
-              "s_waitcnt lgkmcnt(0)\n\t"
-              "v_and_b32 %[v3], 15, %[v2]\n\t"
-              "v_add_u32 %[v3], 8, %[v3]\n\t"
-              "s_mov_b64 exec, s[94:95]\n"
-              "3:\n\t"
-              "s_mul_i32 %[t0], %[i], 15\n\t"
-              "v_cmp_gt_u32 vcc, %[t0], %[lane]\n\t"
-              "s_nop 1\n\t"
-              "v_cndmask_b32 %[v3], 64, %[v3], vcc\n\t"
-              "s_mov_b64 s[92:93], 0\n\t"
-              "s_mov_b32 %[off], 0xffffffc0\n"
-              "4:\n\t"
-              "v_readlane_b32 %[t1], %[v3], %[off]\n\t"
-              "s_bitset1_b64 s[92:93], %[off]\n\t"
-              "s_add_u32 %[off], %[off], %[t1]\n\t"
-              "s_cbranch_scc0 4b\n\t"
-              "s_add_u32 %[off], %[off], 64\n\t"
-              "s_bcnt1_i32_b64 %[n], s[92:93]\n\t"
-              "v_mbcnt_lo_u32_b32 %[v4], s92, 0\n\t"
-              "v_mbcnt_hi_u32_b32 %[v4], s93, %[v4]\n\t"
-              "s_cmp_le_u32 %[n], %[i]\n\t"
-              "s_cbranch_scc1 5f\n\t"
-              "v_cmp_eq_u32 vcc, %[i], %[v4]\n\t"
-              "s_and_b64 vcc, vcc, s[92:93]\n\t"
-              "s_ff1_i32_b64 %[off], vcc\n\t"
-              "s_lshl_b64 vcc, -1, %[off]\n\t"
-              "s_andn2_b64 s[92:93], s[92:93], vcc\n\t"
-              "s_mov_b32 %[n], %[i]\n"
-              "5:\n\t"
-              "v_lshrrev_b32 %[v2], 4, %[v2]\n\t"
-              "v_add_u32 %[v4], %[woff], %[v4]\n\t"
-              "s_mov_b64 exec, s[92:93]\n\t"
-              "global_store_byte %[v4], %[v2], %[wp]\n\t"
-              "s_mov_b64 exec, -1\n\t"
-              "s_cmp_le_u32 %[off], %[cnt]\n\t"
-              "s_cbranch_scc1 6f\n\t"
-              "s_sub_u32 %[t0], %[off], %[cnt]\n\t"
-              "s_lshr_b64 %[buf], s[90:91], %[t0]\n\t"
-              "s_sub_u32 %[cnt], 64, %[t0]\n\t"
-              "s_add_u32 %[ndw], %[ndw], 2\n\t"
-              "s_branch 7f\n"
-              "6:\n\t"
-              "s_lshr_b64 %[buf], %[buf], %[off]\n\t"
-              "s_sub_u32 %[cnt], %[cnt], %[off]\n"
-              "7:\n\t"
-              "s_add_u32 %[woff], %[woff], %[n]\n\t"
-              "s_sub_u32 %[i], %[i], %[n]\n\t"
-              "s_cmp_lt_u32 %[i], 3\n\t"
-              "s_cbranch_scc1 8f\n\t"
-              "s_sub_u32 %[t0], %[ndw], %[cb]\n\t"
-              "s_cmp_lt_u32 %[t0], 62\n\t"
-              "s_cbranch_scc1 1b\n"
-              "8:\n\t"
-              "s_nop 4\n"
+              LITERAL_BATCH_ASM
               : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [i] "+s"(i), [woff] "+s"(woff),
                 [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4),
                 [t0] "=&s"(t0), [t1] "=&s"(t1), [off] "=&s"(off), [n] "=&s"(n)
@@ -1209,6 +1442,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     } else if (insert_len != 0) {
       mlen -= insert_len;
     }
+    }
+general_literals_rest:
     if (lits_left != 0) {
       // ---- COMMAND_INNER: literals, every limit checked ----
       int32_t i = lits_left;
@@ -1315,6 +1550,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     }
     PROF_ADD(prof_lit, prof_t);
     // ---- COMMAND_POST_DECODE_LITERALS ----
+general_distance:
     if (distance_code >= 0) {
       distance_context = 1;  // implicit distance: the last one, not pushed again (decode.rs:2560-2565 + 2643-2644)
       distance_code = d0;
@@ -1362,7 +1598,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     }
     PROF_REST(prof_dist, prof_t);
     // postReadDistance, decode.rs:2583-2589
-    int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
+general_post_distance:
+    max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
     if (distance_code > max_distance) {
       if (distance_code > 0x7FFFFFFC) STOP(E_DISTANCE);
       if (copy_len < 4 || copy_len > 24) STOP(E_DICTIONARY);
@@ -1522,6 +1759,7 @@ done:
   args->d0 = d0; args->d1 = d1; args->d2 = d2; args->d3 = d3;
   args->num_commands = num_commands;
 #ifdef BROTLI_AMD_PROFILE
+  if (lane == 0 && blockIdx.x == 0) printf("lean exits by stage: %u %u %u %u %u %u %u %u\n", prof_stage[0], prof_stage[1], prof_stage[2], prof_stage[3], prof_stage[4], prof_stage[5], prof_stage[6], prof_stage[7]);
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
 #ifdef BROTLI_AMD_PROFILE_HDR
   args->prof[4] = 0; args->prof[5] = prof_fast_syms;
