@@ -1009,9 +1009,25 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
   int32_t insert_len = 0, copy_len = 0, distance_code = 0;
   uint32_t distance_context = 0, lits_left = 0;
 
+  // The root entry of the next command's prefix code is requested as soon as its bit position is known (before the
+  // copy of the current command is issued) and picked up at the top of the loop: one LDS round trip off the chain.
+  br.need32();
+  uint32_t next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+
   for (;;) {
     if (bl1 == 0 || br.next_dw >= safe_dw) { stage = LS_BEGIN; break; }  // block switch due, or close to the end of the input
-    uint32_t cmd = read_symbol<true>(br, a, cmd_tree);
+    uint32_t cmd;
+    {  // read_symbol() with the root lookup already under way (cnt >= 32 here)
+      uint32_t e = rfl(next_root);
+      uint32_t len = e & 15u;
+      if (len > ROOT_BITS) {
+        uint32_t idx = (e >> 4) + (((uint32_t)br.buf >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
+        e = rfl(lds_ld16(LDS_FIXED + cmd_tree + (idx << 1)));
+        len = ROOT_BITS + (e & 15u);
+      }
+      br.drop(len);
+      cmd = e >> 4;
+    }
     uint32_t cell = cmd >> 6;  // RFC 7932 section 5 (see process_commands)
     uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
     uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
@@ -1091,7 +1107,9 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
       bl2--;
       if (br.next_dw > br.end_dw) { stage = LS_NEEDS_INPUT; break; }  // (cannot happen below safe_dw; literal runs are what moves far)
     }
-    // ---- copy: an LZ77 reference (not the dictionary) inside the quota that does not overlap itself, <= 1 KiB ----
+    br.need32();
+    next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+    // ---- copy: an LZ77 reference (not the dictionary) inside the quota that does not overlap itself ----
     {
       const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
       const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
