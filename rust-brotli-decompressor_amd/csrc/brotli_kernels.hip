@@ -1254,7 +1254,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // next ring-buffer flush point, current literal block, end of the input) runs through stages that do not check
   // any of them again: `quota` is the number of bytes that can be produced before the first of the output-side
   // limits, recomputed after every command that went through the checked stages.
-  constexpr bool lean_mb = LDS_ONLY && CTX_NEVER;   // lean literal batches: one prefix code per block type
   constexpr bool quota_mb = LDS_ONLY;              // lean copies and lean context-modelled literals
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;  // a 64-dword register window that starts below lies inside the stream
   uint32_t quota = 0;
@@ -1367,7 +1366,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     lits_left = insert_len;  // literals of this command that are still to be decoded
 after_head:
     {
-    const bool lean_lit = lean_mb && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0 && !lit_zero;
 
     // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose literal block
     // types are all trivial, otherwise always (a block switch inside the run may make the very next literal
@@ -1387,50 +1385,7 @@ after_head:
       ctx_src = CTX_REGS;
     }
 
-    if (insert_len != 0 && lean_lit) {
-      // ---- literals of a lean command: one prefix code, no output-side limit can be hit ----
-      // (the input side is checked per register window: a window that lies inside the stream with a margin cannot
-      // run past its end; what is left of the run near the end of the input goes through the checked loops)
-      mlen -= insert_len;
-      gu8* wp = out + P;
-      uint32_t i = (uint32_t)insert_len;
-      if (i > 2 && br.next_dw < safe_dw) {
-        // Batches of up to 64 bits: every lane decodes the symbol that would start at bit offset `lane` of the next
-        // 64 bits (one gathered table lookup for all 64 candidates), a scalar walk over the code lengths picks the
-        // offsets that really are symbol boundaries, the surviving lanes store their bytes at their rank.  The loop
-        // is hand-scheduled: one wave issues about one instruction per 8 clocks whatever it is, so instructions are
-        // what this costs (about 55 + 4 per literal).  It leaves when fewer than 3 literals remain or the register
-        // window runs out of dwords.
-        const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
-        const uint32_t tree_addr = LDS_FIXED + lit_tree;
-        uint32_t woff = 0;
-        do {
-          br.ensure_dwords(3);
-          uint32_t v0, v1, v2, v3, v4, t0, t1, off, n;
-          asm volatile(
-              LITERAL_BATCH_ASM
-              : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [i] "+s"(i), [woff] "+s"(woff),
-                [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4),
-                [t0] "=&s"(t0), [t1] "=&s"(t1), [off] "=&s"(off), [n] "=&s"(n)
-              : [cur] "v"(br.cur), [lane] "v"(lane), [lomask] "v"(lomask), [tree] "s"(tree_addr), [cb] "s"(br.chunk_base), [wp] "s"(wp)
-              : "memory", "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
-        } while (i > 2 && br.next_dw < safe_dw);
-        wp += woff;
-      }
-      while (i > 0 && i <= 2 && br.next_dw < safe_dw) {  // one or two literals: cheaper one by one
-        uint32_t lit = read_symbol<true>(br, a, lit_tree);
-        if (lane == 0) *wp = (uint8_t)lit;
-        wp++; i--;
-      }
-      const uint32_t done = (uint32_t)insert_len - i;
-      P += done; bl0 -= done; quota -= done;
-      lits_left = (int32_t)i;
-      if (quota == 0 && i == 0) {  // exactly at a limit: end of the metablock, flush point, or full output buffer
-        if (P >= next_boundary) RING_CROSS();
-        if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)
-        RECOMPUTE_QUOTA();
-      }
-    } else if (insert_len != 0 && quota_mb && !CTX_NEVER && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0) {
+    if (insert_len != 0 && quota_mb && !CTX_NEVER && (uint32_t)insert_len <= quota && (uint32_t)insert_len <= bl0) {
       // ---- context-modelled literals of a command that stays clear of every output-side limit and of the end of
       // its literal block: one at a time (the tree depends on the two bytes before), nothing to check but the input
       mlen -= insert_len;
