@@ -971,14 +971,15 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 // finishes that command and comes back.  State crosses through LDS_LEAN (uniform values) and function arguments.
 enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI, L_QUOTA, L_MLEN, L_BL0, L_BL1, L_BL2, L_D0, L_D1, L_D2,
        L_D3, L_NCMD_LO, L_NCMD_HI, L_CMD_TREE, L_LIT_TREE, L_DT0, L_DT1, L_DT2, L_DT3, L_MAX_BACKWARD, L_POSTFIX, L_NUM_DIRECT, L_OUT_LO,
-       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_COUNT };
+       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_COUNT };
 static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
 enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
        LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7 };
 #define LEAN_LD(k) rfl(lds_ld32(LDS_LEAN + 4u * (uint32_t)(k)))
 #define LEAN_ST(k, v) lds_st32(LDS_LEAN + 4u * (uint32_t)(k), (uint32_t)(v))
 
-__device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
+template <bool CTX_NEVER>
+__device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   const uint32_t lane = lane_id();
   const Arena a = {nullptr, 0xFFFFFFFFu, 0u};  // every table of the metablock is in LDS: the arena fields are not looked at
   BitReader br;
@@ -1002,7 +1003,14 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
   const uint32_t tree_addr = LDS_FIXED + lit_tree;
   // copy whose bytes are in registers but not stored yet (16 bytes per lane + a byte tail)
   u32x4 pendv = {0, 0, 0, 0}; uint32_t pendv_n16 = 0, pend_reg = 0, pend_n = 0; uint64_t pend_pos = 0;
-#define LEAN_FLUSH() do { if (pendv_n16) { if (lane < pendv_n16) *reinterpret_cast<gu32x4*>(out + pend_pos + (uint64_t)lane * 16) = pendv; } \
+  // context-modelled metablocks: literals collected one per lane (stored 64 at a time or before the next copy), the
+  // two bytes before P in p1/p2 when ctx_regs, else in the pending short copy (ctx_pend) or in memory
+  uint32_t lit_reg = 0, lit_n = 0; uint64_t lit_pos = P;
+  uint32_t p1 = CTX_NEVER ? 0u : LEAN_LD(L_P1), p2 = CTX_NEVER ? 0u : LEAN_LD(L_P2);
+  bool ctx_regs = CTX_NEVER ? true : LEAN_LD(L_CTX_REGS) != 0u, ctx_pend = false;
+  const uint32_t trivial = CTX_NEVER ? 1u : LEAN_LD(L_TRIVIAL), ctx_lut = CTX_NEVER ? 0u : LEAN_LD(L_CTX_LUT);
+#define LEAN_FLUSH() do { if (!CTX_NEVER && lit_n) { if (lane < lit_n) out[lit_pos + lane] = (uint8_t)lit_reg; lit_n = 0; } \
+                          if (pendv_n16) { if (lane < pendv_n16) *reinterpret_cast<gu32x4*>(out + pend_pos + (uint64_t)lane * 16) = pendv; } \
                           if (pend_n) { if (lane < pend_n) out[pend_pos + ((uint64_t)pendv_n16 << 4) + lane] = (uint8_t)pend_reg; } \
                           pendv_n16 = 0; pend_n = 0; } while (0)
   uint32_t stage = LS_BEGIN;
@@ -1042,9 +1050,36 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
     if (insert_len != 0) {
       if ((uint32_t)insert_len > quota || (uint32_t)insert_len > bl0) { stage = LS_AFTER_HEAD; break; }
       mlen -= insert_len;
-      gu8* wp = out + P;
       uint32_t i = (uint32_t)insert_len;
-      if (i > 2 && br.next_dw < safe_dw) {
+      if (!CTX_NEVER) {
+        // ---- context-modelled: one at a time, the tree depends on the two bytes before ----
+        if (!ctx_regs) {
+          if (ctx_pend) {  // they are the tail of the short copy still in pend_reg (copy lengths start at 2)
+            p1 = rdlane(pend_reg, pend_n - 1u); p2 = rdlane(pend_reg, pend_n - 2u);
+          } else {
+            LEAN_FLUSH();
+            p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u;
+            p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u;
+          }
+          ctx_regs = true;
+        }
+        if (lit_n == 0) lit_pos = P;
+        while (i > 0 && br.next_dw < safe_dw) {
+          uint32_t tree = lit_tree;
+          if (!trivial) {
+            uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
+            tree = rdlane(ctx_tree_v, context);
+          }
+          uint32_t lit = read_symbol<true>(br, a, tree);
+          p2 = p1; p1 = lit;
+          lit_reg = (lane == lit_n) ? lit : lit_reg;
+          lit_n++;
+          if (lit_n == 64) { if (lane < 64) out[lit_pos + lane] = (uint8_t)lit_reg; lit_pos += 64; lit_n = 0; }
+          i--;
+        }
+      }
+      gu8* wp = out + P;
+      if (CTX_NEVER && i > 2 && br.next_dw < safe_dw) {
         uint32_t woff = 0;
         do {
           br.ensure_dwords(3);
@@ -1058,7 +1093,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
         } while (i > 2 && br.next_dw < safe_dw);
         wp += woff;
       }
-      while (i > 0 && i <= 2 && br.next_dw < safe_dw) {  // one or two literals: cheaper one by one
+      while (CTX_NEVER && i > 0 && i <= 2 && br.next_dw < safe_dw) {  // one or two literals: cheaper one by one
         uint32_t lit = read_symbol<true>(br, a, lit_tree);
         if (lane == 0) *wp = (uint8_t)lit;
         wp++; i--;
@@ -1113,10 +1148,28 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
     {
       const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
       const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
-      if (distance_code > max_distance || distance_code <= 0 || n > quota || dist < n) { stage = LS_POST_DISTANCE; break; }
+      if (distance_code > max_distance || distance_code <= 0 || n > quota) { stage = LS_POST_DISTANCE; break; }
+      if (!CTX_NEVER && n <= 64u) {
+        // short copy where literal context matters: one byte per lane (pattern when it overlaps itself), so that the
+        // next literal can take the two bytes before it straight from the register
+        if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
+        mlen -= copy_len;
+        LEAN_FLUSH();
+        gu8* src = out + P - dist;
+        uint32_t b = 0;
+        if (lane < n) b = src[dist >= n ? lane : lane % dist];
+        pend_reg = b; pend_n = n; pend_pos = P;
+        ctx_regs = false; ctx_pend = true;
+        P += n;
+        quota -= n;
+        if (quota == 0) { stage = LS_COMMAND_DONE; break; }
+        continue;
+      }
+      if (dist < n) { stage = LS_POST_DISTANCE; break; }
       if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
       mlen -= copy_len;
       LEAN_FLUSH();
+      if (!CTX_NEVER) { ctx_regs = false; ctx_pend = false; }
       gu8* src = out + P - dist;
       uint32_t n16 = n >> 4, rem = n & 15u;
       if (n > 1024u) {  // long: all but the last (partial) KiB right away, 16 bytes per lane and step
@@ -1139,9 +1192,11 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr) {
       if (quota == 0) { stage = LS_COMMAND_DONE; break; }
     }
   }
+  if (!CTX_NEVER && !ctx_regs && ctx_pend) { p1 = rdlane(pend_reg, pend_n - 1u); p2 = rdlane(pend_reg, pend_n - 2u); ctx_regs = true; }
   LEAN_FLUSH();
 #undef LEAN_FLUSH
   if (lane == 0) {
+    if (!CTX_NEVER) { LEAN_ST(L_P1, p1); LEAN_ST(L_P2, p2); LEAN_ST(L_CTX_REGS, ctx_regs ? 1u : 0u); }
     LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
     LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
     LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
@@ -1291,14 +1346,20 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   int32_t insert_len = 0, copy_len = 0, distance_code = 0, lits_left = 0, max_distance = 0;
   uint32_t distance_context = 0;
 
-  if (LDS_ONLY && CTX_NEVER && lane == 0) {  // what lean_commands needs and never changes in this metablock
+  if (LDS_ONLY && lane == 0) {  // what lean_commands needs and never changes in this metablock
     LEAN_ST(L_END_DW, br.end_dw); LEAN_ST(L_MAX_BACKWARD, max_backward); LEAN_ST(L_POSTFIX, postfix_bits); LEAN_ST(L_NUM_DIRECT, num_direct);
     LEAN_ST(L_OUT_LO, (uint32_t)(uintptr_t)out); LEAN_ST(L_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
   }
 
   for (;;) {
-    if (LDS_ONLY && CTX_NEVER && bl1 != 0 && quota != 0 && !lit_zero && br.next_dw < safe_dw) {
+    if (LDS_ONLY && bl1 != 0 && quota != 0 && !(CTX_NEVER && lit_zero) && br.next_dw < safe_dw) {
       // ---- the lean loop takes over until a stage needs the checked code below ----
+      if (!CTX_NEVER && ctx_src == CTX_PEND) {  // the context bytes leave the pending copy before it is stored
+        uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
+        p2 = ctx_len >= 2 ? rdlane(pend_reg, ctx_len - 2) : p1;
+        p1 = q1;
+        ctx_src = CTX_REGS;
+      }
       FLUSH_LITERALS();
       FLUSH_PENDING();
       lds_sync();
@@ -1309,9 +1370,13 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3);
         LEAN_ST(L_CMD_TREE, cmd_tree); LEAN_ST(L_LIT_TREE, lit_tree);
         LEAN_ST(L_DT0, dt0); LEAN_ST(L_DT1, dt1); LEAN_ST(L_DT2, dt2); LEAN_ST(L_DT3, dt3);
+        if (!CTX_NEVER) {
+          LEAN_ST(L_P1, p1); LEAN_ST(L_P2, p2); LEAN_ST(L_CTX_REGS, ctx_src == CTX_REGS ? 1u : 0u); LEAN_ST(L_TRIVIAL, trivial);
+          LEAN_ST(L_CTX_LUT, ctx_lut);
+        }
       }
       lds_sync();
-      const uint32_t stage = rfl(lean_commands(lut_vgpr));
+      const uint32_t stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
       br.rebase();
@@ -1320,6 +1385,10 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
       d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
       num_commands += LEAN_LD(L_NCMD_LO);
+      if (!CTX_NEVER) {
+        if (LEAN_LD(L_CTX_REGS)) { p1 = LEAN_LD(L_P1); p2 = LEAN_LD(L_P2); ctx_src = CTX_REGS; }
+        else ctx_src = CTX_MEMORY;
+      }
 #ifdef BROTLI_AMD_PROFILE
       prof_fast_batches++; prof_fast_syms += LEAN_LD(L_NCMD_LO);  // (lean entries, commands run lean)
       prof_stage[stage & 7]++;
