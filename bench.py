@@ -210,7 +210,7 @@ def main():
                          "kernel": "brotli_amd_decode_kernel", "kernel_ms": round(mean_kernel_ms, 3),
                          "decompressed_frac": round(raw_total / (mean_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (a host-side baseline: rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(unique)
         print(json.dumps(out))
     batch.close()
