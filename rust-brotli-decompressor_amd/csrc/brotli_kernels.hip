@@ -1,30 +1,33 @@
 // brotli_kernels.hip -- the Brotli decode hot path as hand-written HIP for gfx950 (MI355X / CDNA4).
 //
 // What this replaces in the reference (paths relative to /root/reference):
-//   src/decode.rs:2330-2744   ProcessCommandsInternal (command loop)          -> process_commands()
-//   src/decode.rs:378-500     DecodeSymbol / ReadSymbol                       -> read_symbol()
-//   src/decode.rs:2017-2189   distance / command readers                      -> inline in process_commands()
+//   src/decode.rs:2330-2744   ProcessCommandsInternal (command loop)          -> lean_commands() (common case) +
+//                                                                                process_commands() (every check)
+//   src/decode.rs:378-500     DecodeSymbol / ReadSymbol                       -> read_symbol(), LITERAL_BATCH_ASM
+//   src/decode.rs:2017-2189   distance / command readers                      -> inline in both command functions
 //   src/decode.rs:1469-1524   block switches                                  -> block_switch()
 //   src/decode.rs:1754-1806   CopyUncompressedBlockToOutput                   -> copy_uncompressed()
-//   src/bit_reader/mod.rs     64-bit window + BrotliFillBitWindow             -> struct BitReader (coalesced 256-B chunks)
+//   src/bit_reader/mod.rs     64-bit window + BrotliFillBitWindow             -> struct BitReader (LDS-DMA input ring)
 //   src/huffman/mod.rs        table builders                                  -> build_tree() (lane-parallel)
-//   src/transform.rs:720-795  TransformDictionaryWord                          -> emit_dictionary_word()
+//   src/transform.rs:720-795  TransformDictionaryWord                          -> dictionary_word_bytes()
 //   src/decode.rs:152-372, 516-1465, 2921-3288  stream/metablock headers       -> decode_stream() (must run on device:
 //                             a metablock's compressed extent is only known after decoding it)
 //
-// Execution model (v1): ONE WAVEFRONT PER STREAM, fully fused.  The entropy decode of a Brotli stream is a
-// serial dependent chain, so all 64 lanes of the wave execute it uniformly (values live in SGPRs; table
-// entries come back from LDS through v_readfirstlane) and the lanes are used for everything that is data
-// parallel inside one stream:
-//   * input: each lane keeps one dword of a 256-byte window of the compressed stream in a VGPR (two windows,
-//     double buffered, loaded with one coalesced global_load per 256 B); the 64-bit bit buffer is refilled with
-//     v_readlane -- no memory latency on the serial chain;
-//   * small LUTs (insert/copy code ranges, block-length code, the 32-entry code-length code) live one entry
-//     per lane in VGPRs and are indexed with v_readlane;
+// Execution model: ONE WAVEFRONT PER STREAM, fully fused.  The entropy decode of a Brotli stream is a serial
+// dependent chain, so all 64 lanes of the wave execute it uniformly (values live in SGPRs; table entries come back
+// from LDS through v_readfirstlane) and the lanes are used for everything that is data parallel inside one stream:
+//   * input: 256-byte pieces of the compressed stream go straight into an LDS ring (global_load_lds); the wave takes
+//     a 64-dword register window out of it and refills its 64-bit bit buffer with v_readlane -- no memory latency on
+//     the serial chain;
+//   * literal runs with one prefix code: all 64 bit offsets of the next 64 bits are decoded at once (gathered table
+//     lookup), a scalar walk over the code lengths finds the real symbol boundaries, one masked store writes them;
+//   * small LUTs (insert/copy code ranges, block-length code, the 32-entry code-length code, the context -> tree map
+//     of the current literal block type) live one entry per lane in VGPRs and are indexed with v_readlane;
 //   * Huffman tables are built lane-parallel (ballot counting sort + parallel replicate) into an LDS arena;
 //     objects that do not fit the LDS arena spill to a per-block global scratch area (never straddling);
-//   * LZ77 copies, dictionary words and stored metablocks are moved by all 64 lanes, 64 bytes per step,
-//     overlapping copies as pattern fills (out[pos+k] = out[pos-dist + k mod dist]).
+//   * LZ77 copies, dictionary words and stored metablocks are moved by all 64 lanes (16 bytes per lane and step where
+//     source and destination are far enough apart), overlapping copies as pattern fills.
+// What bounds it is the instruction issue rate of one wave (about one instruction per 8 clocks): see DESIGN.md.
 // Blocks are persistent: each pulls stream indices from an atomic queue until the batch is empty.
 //
 // Roofline that bounds it: HBM traffic is (compressed bytes read + decompressed bytes written); there is no
@@ -1416,17 +1419,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
     }
     {
-    uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
-    // kCmdLut regenerated arithmetically (RFC 7932 section 5; replaces src/prefix.rs:115-5755); 2-byte tree entries:
-    // 8-byte entries carrying these fields were measured 1 % faster but cost 3.3 KB of LDS per command tree
-    uint32_t cell = cmd >> 6;
-    uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
-    uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);         // {0,1,0,1,0,1,2,0,2,1,2}
-    uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
-    distance_code = cmd < 128 ? 0 : -1;
-    distance_context = copy_code > 2 ? 3u : copy_code;
-    insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
-    copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
+      uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
+      // kCmdLut regenerated arithmetically (RFC 7932 section 5; replaces src/prefix.rs:115-5755); 2-byte tree entries:
+      // 8-byte entries carrying these fields were measured 1 % faster but cost 3.3 KB of LDS per command tree
+      uint32_t cell = cmd >> 6;
+      uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);   // {0,0,0,0,1,1,0,2,1,2,2}
+      uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);         // {0,1,0,1,0,1,2,0,2,1,2}
+      uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
+      distance_code = cmd < 128 ? 0 : -1;
+      distance_context = copy_code > 2 ? 3u : copy_code;
+      insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
+      copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
     }
     if (br.over()) STOP(E_NEEDS_MORE_INPUT);
     bl1--;
@@ -1434,8 +1437,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     PROF_ADD(prof_cmd, prof_t);
     lits_left = insert_len;  // literals of this command that are still to be decoded
 after_head:
-    {
-
     // p1/p2 must be right whenever a literal's context can matter: not at all in a metablock whose literal block
     // types are all trivial, otherwise always (a block switch inside the run may make the very next literal
     // context-modelled)
@@ -1483,7 +1484,6 @@ after_head:
       }
     } else if (insert_len != 0) {
       mlen -= insert_len;
-    }
     }
 general_literals_rest:
     if (lits_left != 0) {
