@@ -268,17 +268,23 @@ struct BitReader {
 struct Arena {
   gu8* glb;            // this block's global scratch, addressed with the same offsets as the LDS part
   uint32_t lds_limit;  // arena bytes that live in LDS (at g_smem + LDS_FIXED)
-  uint32_t top;
+  uint32_t top;        // hot objects (prefix-code tables of literals, commands, distances) grow up from 0
+  uint32_t cold;       // cold objects (what only block switches read: block-type/length trees, context maps, tree
+                       // groups) grow down from the end of the global scratch and never take LDS
 
   __device__ __forceinline__ void uniformize() {
     glb = (gu8*)(uintptr_t)rfl((uint64_t)(uintptr_t)glb);
-    lds_limit = rfl(lds_limit); top = rfl(top);
+    lds_limit = rfl(lds_limit); top = rfl(top); cold = rfl(cold);
   }
   __device__ __forceinline__ uint32_t alloc(uint32_t max_bytes) {  // object never straddles the LDS/global split
     uint32_t off = (top + 3u) & ~3u;
     if (off < lds_limit && off + max_bytes > lds_limit) off = lds_limit;
     top = off + max_bytes;
     return off;
+  }
+  __device__ __forceinline__ uint32_t alloc_cold(uint32_t bytes) {
+    cold = (cold - bytes) & ~3u;
+    return cold;
   }
   __device__ __forceinline__ void shrink_to(uint32_t off_end) { top = off_end; }
   // uniform loads.  LDS_ONLY = the caller knows the object is in the LDS part: the load is a plain ds_read and
@@ -342,6 +348,7 @@ __device__ __forceinline__ uint32_t read_symbol(BitReader& br, const Arena& a, u
 struct Stream {
   BitReader br;
   Arena ar;
+  uint32_t ar_end;         // size of the block's global scratch = where the cold objects start growing down
   gu8* out;
   uint64_t out_cap;
   uint64_t P;              // bytes produced
@@ -508,7 +515,7 @@ __device__ __forceinline__ uint32_t log2floor_plus1(uint32_t x) { return x ? 32u
 
 // src/decode.rs:868-1013.  Reads one prefix code, builds its table at a fresh arena allocation, returns the
 // arena offset in *tree_off.  The one helper that is a real function call (7 call sites, cold).
-__device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off) {
+__device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off, bool cold = false) {
   struct Scope {  // register copies of the reader and the arena, stored back on every exit
     Stream& s; BitReader br; Arena ar;
     __device__ __forceinline__ Scope(Stream& s_) : s(s_), br(s_.br), ar(s_.ar) { COLD_UNIFORMIZE(br.uniformize(); ar.uniformize();) }
@@ -520,7 +527,7 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
   alphabet_size = rfl(alphabet_size) & 0x7ffu;
   max_symbol = rfl(max_symbol);
   uint32_t max_entries = max_table_entries(alphabet_size);
-  uint32_t tree = ar.alloc(max_entries * 2);
+  uint32_t tree = cold ? ar.alloc_cold(max_entries * 2) : ar.alloc(max_entries * 2);
   *tree_off = tree;
   uint32_t hskip = br.read(2); NEED_INPUT(br);
   for (uint32_t i = lane; i < MAX_ALPHABET; i += 64) lds_st8(LDS_LENGTHS + i, 0);
@@ -629,7 +636,7 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
     lds_sync();
     size = build_tree(ar, tree, max_symbol);
   }
-  ar.shrink_to(tree + size * 2);
+  if (!cold) ar.shrink_to(tree + size * 2);
   return E_SUCCESS;
 }
 
@@ -639,9 +646,9 @@ struct ColdScope {
   Stream& s; BitReader br;
   __device__ __forceinline__ ColdScope(Stream& s_) : s(s_), br(s_.br) { COLD_UNIFORMIZE(br.uniformize();) }
   __device__ __forceinline__ ~ColdScope() { s.br = br; }
-  __device__ __forceinline__ int huffman(uint32_t alphabet, uint32_t max_symbol, uint32_t* tree) {
+  __device__ __forceinline__ int huffman(uint32_t alphabet, uint32_t max_symbol, uint32_t* tree, bool cold = false) {
     s.br = br;
-    int e = rfl(read_huffman_code(s, alphabet, max_symbol, tree));
+    int e = rfl(read_huffman_code(s, alphabet, max_symbol, tree, cold));
     br = s.br; COLD_UNIFORMIZE(br.uniformize(); *tree = rfl(*tree);)
     return e;
   }
@@ -733,11 +740,14 @@ __device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint
   uint32_t n;
   TRY(decode_varlen_uint8(br, &n));
   n += 1; *num_trees = n;
+  // decoded where it is fast to work on (arena top, LDS while there is room), then parked with the cold objects
+  const uint32_t hot_top = s.ar.top;
   uint32_t map = s.ar.alloc(size);
-  *map_off = map;
-  { const Arena ar = s.ar; for (uint32_t i = lane; i < size; i += 64) ar.st8_lane(map + i, 0); }
+  const uint32_t parked = s.ar.alloc_cold(size);
+  *map_off = parked;
+  { const Arena ar = s.ar; for (uint32_t i = lane; i < size; i += 64) { ar.st8_lane(map + i, 0); ar.st8_lane(parked + i, 0); } }
   lds_sync();
-  if (n <= 1) return E_SUCCESS;
+  if (n <= 1) { s.ar.top = hot_top; return E_SUCCESS; }
   if (br.pos() + 5 > br.total_bits()) return E_NEEDS_MORE_INPUT;  // SafeGetBits(5), decode.rs:1311
   uint32_t bits = br.peek32() & 31u;
   uint32_t max_rle;
@@ -777,14 +787,18 @@ __device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint
       lds_sync();
     }
   }
-  // the context-map prefix code is dead now; give its arena space back
-  if (tree >= saved_top) s.ar.top = saved_top;
+  // park the map; its working copy and its prefix code are dead now: give their arena space back
+  lds_sync();
+  for (uint32_t i = lane; i < size; i += 64) ar.st8_lane(parked + i, ar.ld8_lane(map + i));
+  lds_sync();
+  (void)saved_top;
+  s.ar.top = hot_top;
   return E_SUCCESS;
 }
 
 // decode.rs:1130-1219: `ntrees` prefix codes; their arena offsets go to a u32 array
 __device__ __forceinline__ int decode_tree_group(Stream& s, uint32_t alphabet, uint32_t max_symbol, uint32_t ntrees, uint32_t* group_off) {
-  uint32_t g = s.ar.alloc(ntrees * 4);
+  uint32_t g = s.ar.alloc_cold(ntrees * 4);
   *group_off = g;
   for (uint32_t t = 0; t < ntrees; t++) {
     uint32_t tree;
@@ -1262,7 +1276,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #define HOTC(k) rfl(lds_ld32(LDS_HOT + 4u * (uint32_t)(k)))
 #define BLOCK_SWITCH(cat, bl, res) do { \
     uint32_t t0_ = HOTC(H_RING + 2 * (cat)), t1_ = HOTC(H_RING + 2 * (cat) + 1); \
-    (res) = block_switch<LDS_ONLY>(br, a, bl_vgpr, HOTC(H_BT_TREE + (cat)), HOTC(H_BL_TREE + (cat)), HOTC(H_NBT + (cat)), bl, t0_, t1_); \
+    (res) = block_switch<false>(br, a, bl_vgpr, HOTC(H_BT_TREE + (cat)), HOTC(H_BL_TREE + (cat)), HOTC(H_NBT + (cat)), bl, t0_, t1_); \
     if ((res) == BS_SWITCHED) { if (lane == 0) { lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat)), t0_); lds_st32(LDS_HOT + 4u * (H_RING + 2 * (cat) + 1), t1_); } lds_sync(); } \
   } while (0)
   const uint32_t postfix_bits = rfl(args->postfix_bits), num_direct = rfl(args->num_direct);
@@ -1274,23 +1288,23 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
   uint32_t prof_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)prof_stage;
 
-  uint32_t cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4);
+  uint32_t cmd_tree = a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4);
   uint32_t ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0, ctx_tree_v = 0;
   // PrepareLiteralDecoding, decode.rs:1554-1570
   auto prepare_literal = [&]() {
     uint32_t bt = HOTC(H_RING + 1);
     ctx_slice = bt << 6;
     // trivial <=> all 64 map entries of the block type are equal (DetectTrivialLiteralBlockTypes, 1525-1553)
-    uint32_t mine = a.ld8_lane<LDS_ONLY>(HOTC(H_CTX_MAP) + ctx_slice + lane);
+    uint32_t mine = a.ld8_lane<false>(HOTC(H_CTX_MAP) + ctx_slice + lane);
     uint32_t first = rdlane(mine, 0);
     trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
-    lit_tree = a.ld32<LDS_ONLY>(HOTC(H_LIT_TREES) + first * 4);
+    lit_tree = a.ld32<false>(HOTC(H_LIT_TREES) + first * 4);
     // lane c: the tree of literal context c in this block type (context map and tree group folded into one readlane)
     if (!CTX_NEVER) {
       uint32_t toff = HOTC(H_LIT_TREES) + mine * 4;
-      ctx_tree_v = (LDS_ONLY || toff < a.lds_limit) ? lds_ld32(LDS_FIXED + toff) : (uint32_t)*reinterpret_cast<gu32*>(a.glb + toff);
+      ctx_tree_v = toff < a.lds_limit ? lds_ld32(LDS_FIXED + toff) : (uint32_t)*reinterpret_cast<gu32*>(a.glb + toff);
     }
-    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<LDS_ONLY>(HOTC(H_CTX_MODES) + bt) & 3u);
+    ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<false>(HOTC(H_CTX_MODES) + bt) & 3u);
     if (LDS_ONLY) lit_zero = (rfl(lds_ld16(LDS_FIXED + lit_tree)) & 15u) == 0u ? 1u : 0u;  // one-symbol code: zero bits per literal
   };
   prepare_literal();
@@ -1298,8 +1312,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint32_t dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0;
   auto prepare_distance = [&]() {
     uint32_t m = HOTC(H_DIST_CTX_MAP) + (HOTC(H_RING + 5) << 2), g = HOTC(H_DIST_TREES);
-    dt0 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 0) * 4); dt1 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 1) * 4);
-    dt2 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 2) * 4); dt3 = a.ld32<LDS_ONLY>(g + a.ld8<LDS_ONLY>(m + 3) * 4);
+    dt0 = a.ld32<false>(g + a.ld8<false>(m + 0) * 4); dt1 = a.ld32<false>(g + a.ld8<false>(m + 1) * 4);
+    dt2 = a.ld32<false>(g + a.ld8<false>(m + 2) * 4); dt3 = a.ld32<false>(g + a.ld8<false>(m + 3) * 4);
   };
   prepare_distance();
   // Literal context never matters in this metablock when every literal block type has a trivial context map
@@ -1416,7 +1430,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       int r;
       BLOCK_SWITCH(1, bl1, r);
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
-      if (r == BS_SWITCHED) { cmd_tree = a.ld32<LDS_ONLY>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
+      if (r == BS_SWITCHED) { cmd_tree = a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
     }
     {
       uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
@@ -1837,8 +1851,9 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     // every literal block type with a constant context map (DetectTrivialLiteralBlockTypes, decode.rs:1525-1553)?
     bool ctx_never = true;
     const uint32_t nbt0 = rfl(s.nbt0), ctx_map = rfl(s.ctx_map);
+    Arena ar_ = s.ar; ar_.uniformize();
     for (uint32_t bt = 0; bt < nbt0; bt++) {
-      uint32_t mine = lds_ld8(LDS_FIXED + ctx_map + (bt << 6) + lane_id());
+      uint32_t mine = ar_.ld8_lane<false>(ctx_map + (bt << 6) + lane_id());
       if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
@@ -1953,6 +1968,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
     s.bl0 = s.bl1 = s.bl2 = 1u << 24;
     s.nbt0 = s.nbt1 = s.nbt2 = 1;
     s.ar.top = 0;
+    s.ar.cold = s.ar_end;
     {
       ColdScope c(s);
       BitReader& br = c.br;
@@ -1985,8 +2001,8 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
             if (k == 0) s.nbt0 = nbt; else if (k == 1) s.nbt1 = nbt; else s.nbt2 = nbt;
             if (nbt < 2) continue;
             uint32_t tt, tl;
-            TRY(c.huffman(nbt + 2, nbt + 2, &tt));
-            TRY(c.huffman(26, 26, &tl));
+            TRY(c.huffman(nbt + 2, nbt + 2, &tt, true));
+            TRY(c.huffman(26, 26, &tl, true));
             uint32_t len = read_block_length(br, s.ar, s.bl_vgpr, tl); NEED_INPUT(br);
             if (k == 0) { s.bl0 = len; s.bt_tree0 = tt; s.bl_tree0 = tl; }
             else if (k == 1) { s.bl1 = len; s.bt_tree1 = tt; s.bl_tree1 = tl; }
@@ -1996,7 +2012,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
           uint32_t bits = br.read(6); NEED_INPUT(br);
           s.postfix_bits = bits & 3u;
           s.num_direct = 16 + ((bits >> 2) << s.postfix_bits);
-          s.ctx_modes = s.ar.alloc(s.nbt0);
+          s.ctx_modes = s.ar.alloc_cold(s.nbt0);
           for (uint32_t k = 0; k < s.nbt0; k++) { uint32_t m = br.read(2); NEED_INPUT(br); s.ar.st8(s.ctx_modes + k, m); }
         }
         TRY(decode_context_map(s, s.nbt0 << 6, &s.num_lit_trees, &s.ctx_map));
@@ -2066,6 +2082,8 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
     s.ar.glb = as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block);
     s.ar.lds_limit = lds_arena_bytes;
     s.ar.top = 0;
+    s.ar_end = (uint32_t)scratch_per_block & ~3u;
+    s.ar.cold = s.ar_end;
     s.out = as_global<gu8>(d.out); s.out_cap = d.out_cap;
     s.dict = as_global<gcu8>(dict);
     s.in_bytes = as_global<gcu8>(d.in);
