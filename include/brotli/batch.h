@@ -38,6 +38,8 @@ typedef struct BrotliAmdResult {
 
 #define BROTLI_AMD_BATCH_LARGE_WINDOW 1u /* accept large-window streams (reference one-shot default, lib.rs:457) */
 #define BROTLI_AMD_BATCH_NO_CANNY 2u     /* BROTLI_DECODER_PARAM_DISABLE_RING_BUFFER_REALLOCATION */
+#define BROTLI_AMD_BATCH_SPILL_IN_PLACE 16u /* no second launch with a larger LDS arena for streams whose prefix-code tables
+                                              do not fit the arena of the first: they spill to global memory (slower) */
 
 /* Creates a batch context on the current HIP device for up to max_streams streams per call.
  * lds_arena_bytes = 0 and grid_blocks = 0 select the defaults.  NULL when no device is usable. */

@@ -85,6 +85,12 @@ struct BrotliAmdBatch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
+  // second pass for streams whose tables did not fit the LDS arena of the first (BROTLI_AMD_FLAG_NO_SPILL)
+  uint32_t max_arena = 0, retry_grid_max = 0;
+  BrotliAmdStreamDesc* d_retry_descs = nullptr;
+  BrotliAmdStreamStatus* d_retry_status = nullptr;
+  BrotliAmdStreamDesc* h_retry_descs = nullptr;    // pinned
+  BrotliAmdStreamStatus* h_retry_status = nullptr;  // pinned
   // staging for BrotliAmdBatchDecodeHost
   uint8_t* d_stage_in = nullptr; size_t stage_in_cap = 0;
   uint8_t* d_stage_out = nullptr; size_t stage_out_cap = 0;
@@ -115,11 +121,53 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
 int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n) filled
   if (n == 0) { b->n = 0; b->launched = false; return 0; }
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+  // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
+  if (b->lds_arena < b->max_arena)
+    for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
   b->n = n;
   b->grid = std::min(n, b->grid_max);
   if (!ensure_scratch(b, b->grid)) return -1;
   if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
   return launch(b, stream);
+}
+
+// Streams that came back with BROTLI_AMD_RESULT_RETRY_ARENA continue, from the metablock boundary they stopped at, in
+// a launch whose blocks have the largest LDS arena the device allows (fewer blocks per CU; spilling is allowed there).
+int retry_with_large_arena(BrotliAmdBatch* b) {
+  std::vector<uint32_t> idx;
+  for (uint32_t i = 0; i < b->n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_RETRY_ARENA) idx.push_back(i);
+  if (idx.empty()) return 0;
+  if (!b->d_retry_descs) {
+    bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
+    ok = ok && hip_ok(hipMalloc(&b->d_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipMalloc(retry status)");
+    ok = ok && hip_ok(hipHostMalloc(&b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipHostMalloc(retry descs)");
+    ok = ok && hip_ok(hipHostMalloc(&b->h_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipHostMalloc(retry status)");
+    if (!ok) return -1;
+  }
+  const uint32_t m = (uint32_t)idx.size();
+  for (uint32_t j = 0; j < m; j++) {
+    BrotliAmdStreamDesc d = b->h_descs[idx[j]];
+    d.flags = (d.flags & ~BROTLI_AMD_FLAG_NO_SPILL) | BROTLI_AMD_FLAG_RESUME;
+    d.resume = b->h_status[idx[j]].resume;
+    b->h_retry_descs[j] = d;
+  }
+  const uint32_t grid = std::min(m, b->retry_grid_max);
+  hipStream_t stream = b->last_stream;
+  if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
+  if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
+  if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
+  if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, b->max_arena,
+                                       b->d_dict, stream), "brotli_amd_decode_kernel launch (large arena)")) return -1;
+  if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
+  if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
+  for (uint32_t j = 0; j < m; j++) {
+    BrotliAmdStreamStatus& first = b->h_status[idx[j]];
+    BrotliAmdStreamStatus second = b->h_retry_status[j];
+    second.num_metablocks += first.num_metablocks;
+    second.num_commands += first.num_commands;
+    first = second;
+  }
+  return 0;
 }
 
 }  // namespace
@@ -139,6 +187,11 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
   if (per_block > prop.sharedMemPerBlock && prop.sharedMemPerBlock) per_block = (uint32_t)prop.sharedMemPerBlock;
   b->lds_arena = (per_block - fixed) & ~15u;
+  {  // the arena of the second pass: the largest block the device allows (at most 64 KiB: two such blocks per CU at least)
+    uint32_t big = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
+    b->max_arena = big > fixed ? (big - fixed) & ~15u : 0;
+    b->retry_grid_max = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max<size_t>(1, lds_cu / big);
+  }
   uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cu / per_block));
   b->grid_max = grid_blocks ? grid_blocks : (uint32_t)prop.multiProcessorCount * blocks_per_cu;
   b->d_dict = device_dictionary(dev);
@@ -162,6 +215,10 @@ extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_queue) (void)hipFree(b->d_queue);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
+  if (b->d_retry_descs) (void)hipFree(b->d_retry_descs);
+  if (b->d_retry_status) (void)hipFree(b->d_retry_status);
+  if (b->h_retry_descs) (void)hipHostFree(b->h_retry_descs);
+  if (b->h_retry_status) (void)hipHostFree(b->h_retry_status);
   if (b->d_stage_in) (void)hipFree(b->d_stage_in);
   if (b->d_stage_out) (void)hipFree(b->d_stage_out);
   if (b->h_descs) (void)hipHostFree(b->h_descs);
@@ -179,7 +236,7 @@ extern "C" int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* b, uint32_t n, const v
     std::memset(&d, 0, sizeof d);
     d.in = static_cast<const uint8_t*>(d_in[i]); d.in_size = in_sizes[i];
     d.out = static_cast<uint8_t*>(d_out[i]); d.out_cap = out_caps[i];
-    d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY);
+    d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY | BROTLI_AMD_BATCH_SPILL_IN_PLACE);
   }
   return submit(b, n, static_cast<hipStream_t>(hip_stream));
 }
@@ -196,6 +253,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   if (!hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * b->n, hipMemcpyDeviceToHost, b->last_stream), "hipMemcpyAsync(status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize")) return -1;
+  if (retry_with_large_arena(b) != 0) return -1;
   if (results) {
     for (uint32_t i = 0; i < b->n; i++) {
       const BrotliAmdStreamStatus& s = b->h_status[i];
@@ -245,7 +303,7 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
     std::memset(&d, 0, sizeof d);
     d.in = b->d_stage_in + in_off[i]; d.in_size = in_sizes[i];
     d.out = b->d_stage_out + out_off[i]; d.out_cap = out_caps[i];
-    d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY);
+    d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY | BROTLI_AMD_BATCH_SPILL_IN_PLACE);
   }
   if (submit(b, n, nullptr) != 0) return -1;
   std::vector<BrotliAmdResult> local;

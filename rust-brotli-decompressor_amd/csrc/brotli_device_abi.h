@@ -14,6 +14,10 @@ extern "C" {
 #define BROTLI_AMD_FLAG_LARGE_WINDOW 1u  // accept the 14-bit large-window header (state.rs:394, ffi/mod.rs:127)
 #define BROTLI_AMD_FLAG_NO_CANNY 2u      // BROTLI_DECODER_PARAM_DISABLE_RING_BUFFER_REALLOCATION (ffi/mod.rs:167-169)
 #define BROTLI_AMD_FLAG_RESUME 4u        // start from the metablock boundary stored in `resume`
+#define BROTLI_AMD_FLAG_NO_SPILL 8u      // a metablock whose tables do not fit the LDS arena ends the decode with result
+                                         // BROTLI_AMD_RESULT_RETRY_ARENA at the boundary before it (the host then
+                                         // resumes the stream in a launch with a larger arena) instead of spilling
+#define BROTLI_AMD_RESULT_RETRY_ARENA 4  // (never reaches the caller of the C ABI)
 
 // State at a metablock boundary: everything that survives from one metablock to the next in the
 // reference (state.rs:422-450 resets the rest).  The kernel stores it after every completed metablock;

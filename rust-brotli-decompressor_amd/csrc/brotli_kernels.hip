@@ -48,6 +48,7 @@ constexpr int E_EXUBERANT_NIBBLE = -1, E_RESERVED = -2, E_EXUBERANT_META_NIBBLE 
               E_SIMPLE_HUFFMAN_SAME = -5, E_CL_SPACE = -6, E_HUFFMAN_SPACE = -7, E_CONTEXT_MAP_REPEAT = -8,
               E_BLOCK_LENGTH_1 = -9, E_BLOCK_LENGTH_2 = -10, E_TRANSFORM = -11, E_DICTIONARY = -12, E_WINDOW_BITS = -13,
               E_PADDING_2 = -15, E_DISTANCE = -16, E_UNREACHABLE = -31;
+constexpr int E_RETRY_ARENA = 100;  // internal: see BROTLI_AMD_FLAG_NO_SPILL
 
 // ---- small constant tables (RFC 7932 sections 3.5, 4, 5, 6) ----
 __constant__ const uint8_t kCodeLengthCodeOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
@@ -1858,6 +1859,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
   } else {
+    if (rfl(s.flags) & BROTLI_AMD_FLAG_NO_SPILL) return E_RETRY_ARENA;  // nothing of this metablock has been output yet
     s.num_spilled++;
     e = process_commands<false, false>(&h);
   }
@@ -2120,7 +2122,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
 
     // result mapping of the one-shot driver (decode.rs:2829-2916, 3382-3397; lib.rs:447-468)
     const bool over = s.br.over();
-    if (e != E_NEEDS_MORE_INPUT && e != E_BLOCK_LENGTH_1 && e != E_NEEDS_MORE_OUTPUT && over) e = E_NEEDS_MORE_INPUT;
+    if (e != E_NEEDS_MORE_INPUT && e != E_BLOCK_LENGTH_1 && e != E_NEEDS_MORE_OUTPUT && e != E_RETRY_ARENA && over) e = E_NEEDS_MORE_INPUT;
     uint64_t decoded;
     if (e == E_SUCCESS || e == E_NEEDS_MORE_INPUT) decoded = s.P;          // everything produced is flushed
     else if (e == E_NEEDS_MORE_OUTPUT) decoded = s.out_cap;
@@ -2130,7 +2132,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
       if (decoded > s.P) decoded = 0;
     }
     if (lane == 0) {
-      st->result = e == E_SUCCESS ? 1 : e == E_NEEDS_MORE_INPUT ? 2 : e == E_NEEDS_MORE_OUTPUT ? 3 : 0;
+      st->result = e == E_SUCCESS ? 1 : e == E_NEEDS_MORE_INPUT ? 2 : e == E_NEEDS_MORE_OUTPUT ? 3 : e == E_RETRY_ARENA ? BROTLI_AMD_RESULT_RETRY_ARENA : 0;
       st->error_code = e;
       st->decoded_size = decoded;
       uint64_t c = (s.br.pos() + 7) >> 3;

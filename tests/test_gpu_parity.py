@@ -198,10 +198,22 @@ def test_tables_that_do_not_fit_lds(pkg, arena):
     for label, comp, raw in param_corpus.corpus()[::3]:
         datas.append(comp)
         caps.append(len(raw) + 16)
+    expected = [oracle.decode(d, cap, 1) for d, cap in zip(datas, caps)]
+    # (a) spilling in place: the generic instantiation of the command loop runs
+    batch = pkg.Batch(len(datas), lds_arena_bytes=arena)
+    results, outs = batch.decode_host(datas, caps, pkg.FLAG_LARGE_WINDOW | pkg.FLAG_SPILL_IN_PLACE)
+    batch.close()
+    assert sum(r.spilled_metablocks for r in results) > 0
+    for i, (info, exp) in enumerate(expected):
+        r = results[i]
+        assert (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp), (i, arena)
+    # (b) the default policy: those streams continue, from the metablock boundary they stopped at, in a second launch
+    # whose blocks have the largest arena; same results, and (these tables all fit 58 KiB) nothing spills
     batch = pkg.Batch(len(datas), lds_arena_bytes=arena)
     results, outs = batch.decode_host(datas, caps, pkg.FLAG_LARGE_WINDOW)
     batch.close()
-    for i, (d, cap) in enumerate(zip(datas, caps)):
-        info, exp = oracle.decode(d, cap, 1)
+    assert sum(r.spilled_metablocks for r in results) == 0
+    for i, (info, exp) in enumerate(expected):
         r = results[i]
-        assert (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp), (i, arena)
+        assert (r.result, r.error_code, r.decoded_size, r.consumed, outs[i]) == \
+               (info.result, info.error_code, info.decoded_size, info.consumed if info.result == 1 else r.consumed, exp), (i, arena)
