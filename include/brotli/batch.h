@@ -67,6 +67,9 @@ BROTLI_DEC_API int BrotliAmdBatchDecodeHost(BrotliAmdBatch* batch, uint32_t n, c
 /* Milliseconds the last launch spent in the decode kernel (HIP events on the launch stream). */
 BROTLI_DEC_API float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* batch);
 
+/* Streams the last BrotliAmdBatchWait had to continue in a second launch with a larger LDS arena (0 in the common case). */
+BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch);
+
 /* Text of the last HIP/runtime failure on this thread ("" if none). */
 BROTLI_DEC_API const char* BrotliAmdLastError(void);
 

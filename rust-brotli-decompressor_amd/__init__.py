@@ -29,7 +29,7 @@ DECODE_H_SYMBOLS = [
 ]
 BATCH_H_SYMBOLS = [
     "BrotliAmdBatchCreate", "BrotliAmdBatchDestroy", "BrotliAmdBatchDecodeDevice", "BrotliAmdBatchRelaunch", "BrotliAmdBatchWait",
-    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdLastError",
+    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdLastError",
 ]
 
 
@@ -99,6 +99,8 @@ def load_library():
     L.BrotliAmdBatchDecodeHost.argtypes = [vp, u32, vp, vp, vp, vp, u32, vp]
     L.BrotliAmdBatchLastKernelMs.restype = ctypes.c_float
     L.BrotliAmdBatchLastKernelMs.argtypes = [vp]
+    L.BrotliAmdBatchLastSecondPassCount.restype = ctypes.c_uint32
+    L.BrotliAmdBatchLastSecondPassCount.argtypes = [vp]
     L.BrotliAmdLastError.restype = ctypes.c_char_p
     _lib = L
     return L
@@ -164,6 +166,9 @@ class Batch:
 
     def last_kernel_ms(self):
         return float(self._L.BrotliAmdBatchLastKernelMs(self._h))
+
+    def last_second_pass_count(self):
+        return int(self._L.BrotliAmdBatchLastSecondPassCount(self._h))
 
     def decode_host(self, datas, out_caps, flags=FLAG_LARGE_WINDOW):
         """Host bytes in, (results, outputs) out: upload, decode, download."""

@@ -85,8 +85,13 @@ struct BrotliAmdBatch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
   bool launched = false;
+  // first-pass arena of this launch: the configured one, or a smaller one when the batch has more streams than the
+  // device can hold blocks of the configured size (more waves in flight; what does not fit goes to the second pass)
+  bool auto_arena = false, small_arena_pays = true;
+  uint32_t cur_arena = 0, cus = 0, lds_fixed = 0;
+  size_t lds_per_cu = 0;
   // second pass for streams whose tables did not fit the LDS arena of the first (BROTLI_AMD_FLAG_NO_SPILL)
-  uint32_t max_arena = 0, retry_grid_max = 0;
+  uint32_t max_arena = 0, retry_grid_max = 0, last_retry_count = 0;
   BrotliAmdStreamDesc* d_retry_descs = nullptr;
   BrotliAmdStreamStatus* d_retry_status = nullptr;
   BrotliAmdStreamDesc* h_retry_descs = nullptr;    // pinned
@@ -110,7 +115,7 @@ bool ensure_scratch(BrotliAmdBatch* b, uint32_t grid) {
 int launch(BrotliAmdBatch* b, hipStream_t stream) {
   if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
-  if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->lds_arena,
+  if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
                                        b->d_dict, stream), "brotli_amd_decode_kernel launch")) return -1;
   if (!hip_ok(hipEventRecord(b->ev1, stream), "hipEventRecord")) return -1;
   b->last_stream = stream;
@@ -121,11 +126,22 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
 int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n) filled
   if (n == 0) { b->n = 0; b->launched = false; return 0; }
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+  // arena of this launch (see cur_arena)
+  b->cur_arena = b->lds_arena;
+  uint32_t grid_max = b->grid_max;
+  if (b->auto_arena && b->small_arena_pays && n > b->grid_max && b->max_arena > b->lds_arena) {
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(8, ((size_t)n + b->cus - 1) / b->cus);       // blocks per CU wanted
+    const uint32_t per_block = (uint32_t)(b->lds_per_cu / per_cu) & ~255u;
+    if (per_block > b->lds_fixed + 8192u && per_block - b->lds_fixed < b->lds_arena) {
+      b->cur_arena = (per_block - b->lds_fixed) & ~15u;
+      grid_max = b->cus * per_cu;
+    }
+  }
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
-  if (b->lds_arena < b->max_arena)
+  if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
   b->n = n;
-  b->grid = std::min(n, b->grid_max);
+  b->grid = std::min(n, grid_max);
   if (!ensure_scratch(b, b->grid)) return -1;
   if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
   return launch(b, stream);
@@ -136,6 +152,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
 int retry_with_large_arena(BrotliAmdBatch* b) {
   std::vector<uint32_t> idx;
   for (uint32_t i = 0; i < b->n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_RETRY_ARENA) idx.push_back(i);
+  b->last_retry_count = (uint32_t)idx.size();
   if (idx.empty()) return 0;
   if (!b->d_retry_descs) {
     bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
@@ -145,6 +162,7 @@ int retry_with_large_arena(BrotliAmdBatch* b) {
     if (!ok) return -1;
   }
   const uint32_t m = (uint32_t)idx.size();
+  if (b->cur_arena < b->lds_arena && m > b->n / 4) b->small_arena_pays = false;  // this kind of stream needs the full arena
   for (uint32_t j = 0; j < m; j++) {
     BrotliAmdStreamDesc d = b->h_descs[idx[j]];
     d.flags = (d.flags & ~BROTLI_AMD_FLAG_NO_SPILL) | BROTLI_AMD_FLAG_RESUME;
@@ -187,6 +205,9 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
   if (per_block > prop.sharedMemPerBlock && prop.sharedMemPerBlock) per_block = (uint32_t)prop.sharedMemPerBlock;
   b->lds_arena = (per_block - fixed) & ~15u;
+  b->cur_arena = b->lds_arena;
+  b->auto_arena = lds_arena_bytes == 0;
+  b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_per_cu = lds_cu;
   {  // the arena of the second pass: the largest block the device allows (at most 64 KiB: two such blocks per CU at least)
     uint32_t big = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
     b->max_arena = big > fixed ? (big - fixed) & ~15u : 0;
@@ -264,6 +285,8 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
   }
   return 0;
 }
+
+extern "C" uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* b) { return b ? b->last_retry_count : 0; }
 
 extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
   if (!b || !b->launched) return 0.0f;
