@@ -217,3 +217,33 @@ def test_tables_that_do_not_fit_lds(pkg, arena):
         r = results[i]
         assert (r.result, r.error_code, r.decoded_size, r.consumed, outs[i]) == \
                (info.result, info.error_code, info.decoded_size, info.consumed if info.result == 1 else r.consumed, exp), (i, arena)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_mutated_corpus_streams_match_oracle(pkg, seed):
+    """truncations, bit flips and insertions applied to the parameterised corpus (every window size, NPOSTFIX/NDIRECT,
+    context modes, flushes, metadata): result, error code, delivered size and bytes equal the oracle's"""
+    import param_corpus
+    streams = [(c, len(r)) for _, c, r in param_corpus.corpus() if len(c) < 60000]
+    if not streams:
+        pytest.skip("libbrotlienc not available")
+    rnd = random.Random(seed)
+    datas, caps = [], []
+    for _ in range(1200):
+        c, n = rnd.choice(streams)
+        d = bytearray(c)
+        k = rnd.random()
+        if k < 0.25 and len(d) > 1:
+            d = d[:rnd.randrange(0, len(d))]
+        elif k < 0.85:
+            for _ in range(rnd.choice([1, 1, 2, 3])):
+                pos = rnd.randrange(0, min(len(d), rnd.choice([16, 128, 2048, 1 << 20])))
+                d[pos] ^= 1 << rnd.randrange(8)
+        else:
+            pos = rnd.randrange(0, len(d) + 1)
+            d[pos:pos] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 4)))
+        datas.append(bytes(d))
+        # (room for whatever a damaged stream produces: with a buffer that fills up the batch entry points report
+        # NEEDS_MORE_OUTPUT at once, the reference at its next ring-buffer flush -- DESIGN.md section 5)
+        caps.append(1 << 20)
+    _check_against_oracle(pkg, datas, caps, 1, "mutated corpus seed %d" % seed)
