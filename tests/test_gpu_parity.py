@@ -247,3 +247,32 @@ def test_mutated_corpus_streams_match_oracle(pkg, seed):
         # NEEDS_MORE_OUTPUT at once, the reference at its next ring-buffer flush -- DESIGN.md section 5)
         caps.append(1 << 20)
     _check_against_oracle(pkg, datas, caps, 1, "mutated corpus seed %d" % seed)
+
+
+def test_bench_workload_streams_tight_buffers_and_damage(pkg):
+    """the bench workloads' own streams (long literal runs, copies of more than 1 KiB: the lean loop's limits): valid
+    streams with output buffers that are exact, one short, half, ...; damaged streams with roomy buffers"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    if not w.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    rnd = random.Random(7)
+    streams = w.make_streams("long_backref", 2, 4 << 20, 5000) + w.make_streams("high_entropy", 1, 4 << 20, 6000) + \
+        w.make_streams("long_backref", 2, 1 << 20, 7000) + w.make_streams("high_entropy", 1, 256 << 10, 8000)
+    datas, caps = [], []
+    for c, n, _ in streams:
+        for cap in (n, n - 1, n // 2, n // 3 + 17, rnd.randrange(1, n), n + 1000):
+            datas.append(c)
+            caps.append(cap)
+        for _ in range(16):
+            d = bytearray(c)
+            if rnd.random() < 0.3:
+                d = d[:rnd.randrange(1, len(d))]
+            else:
+                for _ in range(rnd.choice([1, 1, 2, 4])):
+                    pos = rnd.randrange(0, min(len(d), rnd.choice([64, 4096, 1 << 22])))
+                    d[pos] ^= 1 << rnd.randrange(8)
+            datas.append(bytes(d))
+            caps.append(8 << 20)
+    _check_against_oracle(pkg, datas, caps, 1, "bench workload streams")
