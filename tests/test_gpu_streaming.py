@@ -190,3 +190,23 @@ def test_cpp_reader_writer_adapters(pkg, tmp_path):
         raw.write_bytes(out)
         p = subprocess.run([exe, comp, str(raw), str(read_size), str(buf)], stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, (name, p.stderr.decode())
+
+
+def test_streaming_parameterised_corpus_random_chunks(pkg):
+    """every fifth stream of the parameterised corpus (window sizes, NPOSTFIX/NDIRECT, flushes, metadata blocks, large
+    windows) through BrotliDecoderDecompressStream with random input and output chunk sizes"""
+    import random
+    import param_corpus
+    streams = param_corpus.corpus()[::5]
+    if not streams:
+        pytest.skip("libbrotlienc not available")
+    rnd = random.Random(5)
+    for label, comp, raw in streams:
+        chunks = (rnd.choice([1, 7, 64, 517, 4096, 65536]), rnd.choice([1, 13, 181, 4096, 65536]))
+        if len(raw) > 30000 and chunks[1] < 100:
+            chunks = (chunks[0], 4096)
+        if len(comp) > 30000 and chunks[0] < 64:
+            chunks = (517, chunks[1])
+        result, code, out, finished, consumed = _stream_decode(pkg, comp, *chunks, large_window=label.startswith("large-"))
+        assert (result, code, finished, consumed) == (1, 1, True, len(comp)), (label, chunks)
+        assert out == raw, (label, chunks)
