@@ -210,3 +210,14 @@ def test_streaming_parameterised_corpus_random_chunks(pkg):
         result, code, out, finished, consumed = _stream_decode(pkg, comp, *chunks, large_window=label.startswith("large-"))
         assert (result, code, finished, consumed) == (1, 1, True, len(comp)), (label, chunks)
         assert out == raw, (label, chunks)
+
+
+def test_command_line_tool(pkg, tmp_path):
+    """tools/cli: the reference's brotli-decompressor binary (src/bin/brotli-decompressor.rs) over reader.hpp"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools", "cli")])
+    exe = os.path.join(ROOT, "tools", "cli", "brotli-decompressor")
+    out = tmp_path / "alice29.txt"
+    subprocess.check_call([exe, os.path.join(GOLD, "testdata", "alice29.txt.compressed"), str(out)], timeout=300)
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == MANIFEST["alice29.txt.compressed"]["sha256"]
+    p = subprocess.run([exe], input=_data("alice29.txt.compressed")[:1000], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 1 and b"Unexpected EOF" in p.stderr
