@@ -239,6 +239,13 @@ struct BitReader {
     cnt -= n;
     return v;
   }
+  __device__ __forceinline__ uint32_t read24(uint32_t n) {  // n in 0..24: no n == 32 case to care about
+    need32();
+    uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+    buf >>= n;
+    cnt -= n;
+    return v;
+  }
   // the window holds at least `k` dwords that have not been shifted into buf yet (k <= 4)
   __device__ __forceinline__ void ensure_dwords(uint32_t k) { if (next_dw - chunk_base > 64u - k) rebase(); }
   // the two dwords after the ones already shifted into buf, without consuming them (after ensure_dwords(2))
@@ -1060,8 +1067,8 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
     uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
     distance_code = cmd < 128 ? 0 : -1;
     distance_context = copy_code > 2 ? 3u : copy_code;
-    insert_len = (int32_t)((ie & 0xFFFFu) + br.read(ie >> 16));
-    copy_len = (int32_t)((ce & 0xFFFFu) + br.read(ce >> 16));
+    insert_len = (int32_t)((ie & 0xFFFFu) + br.read24(ie >> 16));
+    copy_len = (int32_t)((ce & 0xFFFFu) + br.read24(ce >> 16));
     bl1--;
     ncmd++;
     lits_left = (uint32_t)insert_len;
