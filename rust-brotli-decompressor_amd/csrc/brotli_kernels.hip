@@ -81,7 +81,8 @@ constexpr uint32_t LDS_INWIN = LDS_MTF + 256;               // 1024: compressed-
 constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit reader needs only when it moves its window (BitReader)
 constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
 constexpr uint32_t LDS_LEAN = LDS_HOT + 96;                 // 192: state handed between process_commands and lean_commands
-constexpr uint32_t LDS_FIXED = LDS_LEAN + 192;              // = 5824, 16-byte aligned
+constexpr uint32_t LDS_LEANWIN = LDS_LEAN + 192;            // 256: the reader's register window, handed over with the state
+constexpr uint32_t LDS_FIXED = LDS_LEANWIN + 256;           // = 6080, 16-byte aligned
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -996,7 +997,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 // finishes that command and comes back.  State crosses through LDS_LEAN (uniform values) and function arguments.
 enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI, L_QUOTA, L_MLEN, L_BL0, L_BL1, L_BL2, L_D0, L_D1, L_D2,
        L_D3, L_NCMD_LO, L_NCMD_HI, L_CMD_TREE, L_LIT_TREE, L_DT0, L_DT1, L_DT2, L_DT3, L_MAX_BACKWARD, L_POSTFIX, L_NUM_DIRECT, L_OUT_LO,
-       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_COUNT };
+       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_CHUNK_BASE, L_COUNT };
 static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
 enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
        LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7 };
@@ -1010,8 +1011,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
   BitReader br;
   br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
   br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
-  br.chunk_base = 0; br.cur = 0;
-  br.rebase();
+  br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);  // (the caller's window, as it is)
   gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
   uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
   uint32_t quota = LEAN_LD(L_QUOTA);
@@ -1220,7 +1220,9 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
   if (!CTX_NEVER && !ctx_regs && ctx_pend) { p1 = rdlane(pend_reg, pend_n - 1u); p2 = rdlane(pend_reg, pend_n - 2u); ctx_regs = true; }
   LEAN_FLUSH();
 #undef LEAN_FLUSH
+  lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
   if (lane == 0) {
+    LEAN_ST(L_CHUNK_BASE, br.chunk_base);
     if (!CTX_NEVER) { LEAN_ST(L_P1, p1); LEAN_ST(L_P2, p2); LEAN_ST(L_CTX_REGS, ctx_regs ? 1u : 0u); }
     LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
     LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
@@ -1388,7 +1390,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       FLUSH_LITERALS();
       FLUSH_PENDING();
       lds_sync();
+      lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
       if (lane == 0) {
+        LEAN_ST(L_CHUNK_BASE, br.chunk_base);
         LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
         LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
         LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
@@ -1404,7 +1408,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       const uint32_t stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
-      br.rebase();
+      br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
       P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
       quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
       bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
