@@ -276,3 +276,28 @@ def test_bench_workload_streams_tight_buffers_and_damage(pkg):
             datas.append(bytes(d))
             caps.append(8 << 20)
     _check_against_oracle(pkg, datas, caps, 1, "bench workload streams")
+
+
+def test_sharded_decode_single_rank(pkg):
+    """sharding.decode_sharded with the real device decode as its per-rank function (world size 1 here; the 2-rank
+    partition/collective logic runs on CPU under gloo in test_sharding_gloo.py)"""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("brotli_amd_sharding", os.path.join(ROOT, "rust-brotli-decompressor_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    m = [e for e in _manifest() if e["name"] != "rnd_chunk.br" and not e.get("must_fail")][:20]
+    datas = [_data(e["name"]) for e in m]
+    caps = [e["size"] + 16 for e in m]
+
+    def decode_fn(streams, out_caps):
+        batch = pkg.Batch(max(1, len(streams)))
+        results, outs = batch.decode_host(streams, out_caps, pkg.FLAG_LARGE_WINDOW)
+        batch.close()
+        return np.array([[r.result, r.error_code, r.decoded_size, r.consumed] for r in results], dtype=np.int64).reshape(-1, 4), outs
+
+    mine, outs, status = sharding.decode_sharded(datas, caps, decode_fn, weights=[e["size"] for e in m])
+    assert mine == list(range(len(m)))
+    for e, out, row in zip(m, outs, status):
+        assert (int(row[0]), int(row[2]), int(row[3])) == (1, e["size"], e["csize"]), e["name"]
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e["name"]
