@@ -82,9 +82,7 @@ constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit 
 constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
 constexpr uint32_t LDS_LEAN = LDS_HOT + 96;                 // 192: state handed between process_commands and lean_commands
 constexpr uint32_t LDS_LEANWIN = LDS_LEAN + 192;            // 256: the reader's register window, handed over with the state
-constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 64: mailbox between the decoding wave and the helper wave
-constexpr uint32_t LDS_HRING = LDS_HCTL + 64;               // 3072: 8 windows x 3 alphabets x 64 table entries made by the helper
-constexpr uint32_t LDS_FIXED = LDS_HRING + 3072;            // = 9216, 16-byte aligned
+constexpr uint32_t LDS_FIXED = LDS_LEANWIN + 256;           // = 6080, 16-byte aligned
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -894,96 +892,6 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 #define PROF_REST(acc, t0) PROF_ADD(acc, t0)
 #endif
 
-// ===================================== helper wave =====================================
-// A block is two waves.  Wave 0 decodes its stream; wave 1 serves it table lookups.  Where the next symbol starts
-// depends on the one before -- but which symbol *would* start at a given bit does not.  So, for the part of a
-// metablock that piped_commands() decodes, the helper walks the stream in 64-bit windows from the bit it was given
-// and leaves, for every bit offset, the (second level resolved) table entry of each of the three alphabets in an LDS
-// ring; the decoding wave takes a window's 3 x 64 entries into registers and is left with v_readlane where it had
-// LDS round trips on its serial chain.
-//   HCTL words: 0 job sequence number   1 job kind (1 = windows, 2 = exit)   2 first dword   3 bit offset in it
-//   4-6 LDS addresses of the command / literal / distance tree   7 helpers unusable (a wait timed out)
-//   8 windows consumed   9 stop   10-11 windows finished by helper 0 / 1   12-13 last job finished by helper 0 / 1
-enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE_C = 4, HC_TREE_L = 5, HC_TREE_D = 6, HC_DEAD = 7, HC_CONSUMED = 8,
-       HC_STOP = 9, HC_PRODUCED = 10 /* + helper */, HC_DONE = 12 /* + helper */ };
-constexpr uint32_t NUM_HELPERS = 2;  // helper h makes the windows k with k % NUM_HELPERS == h
-constexpr uint32_t HELPER_RING = 8;  // windows
-typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
-typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
-__device__ __forceinline__ uint32_t hc_ld(uint32_t w) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w])); }
-__device__ __forceinline__ void hc_st(uint32_t w, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w]) = v; }
-__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-
-// table entry (value << 4 | length) of the symbol that starts with the bits in x, second level resolved
-__device__ __forceinline__ uint32_t helper_lookup(uint32_t tree_addr, uint32_t x) {
-  uint32_t e = *reinterpret_cast<lds_cu16*>(&g_smem[tree_addr + ((x & 0xFFu) << 1)]);
-  uint32_t L = e & 15u;
-  if (L > ROOT_BITS) {
-    uint32_t idx = (e >> 4) + ((x >> ROOT_BITS) & ((1u << (L - ROOT_BITS)) - 1u));
-    uint32_t f = *reinterpret_cast<lds_cu16*>(&g_smem[tree_addr + (idx << 1)]);
-    e = (f & ~15u) | (ROOT_BITS + (f & 15u));
-  }
-  return e;
-}
-
-__device__ __noinline__ void helper_wave(const uint32_t me) {
-  const uint32_t lane = lane_id();
-  const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
-  uint32_t seq = 0;
-  for (;;) {
-    uint32_t j;
-    for (;;) {  // idle until the decoding wave posts a job (it always posts `exit` at the end)
-      j = hc_ld(HC_SEQ);
-      if (j != seq) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
-    seq = j;
-    lds_acquire();
-    if (hc_ld(HC_KIND) != 1u) return;
-    const uint32_t dw0 = hc_ld(HC_DW0), sh = hc_ld(HC_SHIFT);
-    const uint32_t tc = hc_ld(HC_TREE_C), tl = hc_ld(HC_TREE_L), td = hc_ld(HC_TREE_D);
-    gcu32* const base = BitReader::base();
-    const uint32_t ndw = BitReader::n_dw(), tmask = BitReader::tail_mask();
-    uint32_t hb = 0xFFFFFFFFu, hcur = 0;  // the helper's own 64-dword register window over the stream
-    uint32_t k = me, consumed = 0;
-    for (;;) {
-      // (consumed | stop << 32) in one read; its latency hides behind the table lookups below
-      const uint64_t cs = *reinterpret_cast<volatile __attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_HCTL + 4u * HC_CONSUMED]);
-      if (k - consumed >= HELPER_RING) {  // ring full as far as known: look again
-        consumed = rfl((uint32_t)cs);
-        if (rfl((uint32_t)(cs >> 32)) != 0u) break;
-        if (k - consumed >= HELPER_RING) { __builtin_amdgcn_s_sleep(1); continue; }
-      }
-      const uint32_t d = dw0 + 2u * k;  // window k = stream bits [32 d + sh, +64); lookups reach 31 + 15 bits further
-      if (hb == 0xFFFFFFFFu || d + 3u - hb >= 64u) {
-        hb = d;
-        uint32_t idx = hb + lane;
-        uint32_t v = 0;
-        if (idx < ndw) v = base[idx];
-        if (idx == ndw - 1u) v &= tmask;
-        hcur = v;
-      }
-      const uint32_t q = d - hb;
-      const uint64_t p01 = (uint64_t)rdlane(hcur, q) | ((uint64_t)rdlane(hcur, q + 1u) << 32);
-      const uint64_t p23 = (uint64_t)rdlane(hcur, q + 2u) | ((uint64_t)rdlane(hcur, q + 3u) << 32);
-      const uint64_t p12 = (p01 >> 32) | (p23 << 32);
-      const uint32_t w0 = (uint32_t)(p01 >> sh), w1 = (uint32_t)(p12 >> sh), w2 = (uint32_t)(p23 >> sh);
-      const uint32_t x = (__builtin_amdgcn_alignbit(w1, w0, lane) & lomask) | (__builtin_amdgcn_alignbit(w2, w1, lane) & ~lomask);
-      const uint32_t ec = helper_lookup(tc, x), el = helper_lookup(tl, x), ed = helper_lookup(td, x);
-      const uint32_t slot = LDS_HRING + (k & (HELPER_RING - 1u)) * 384u + lane * 2u;
-      lds_st16(slot, ec); lds_st16(slot + 128u, el); lds_st16(slot + 256u, ed);
-      lds_release();
-      k += NUM_HELPERS;
-      hc_st(HC_PRODUCED + me, k);  // every window of mine below k is in the ring
-      if (rfl((uint32_t)(cs >> 32)) != 0u) break;  // told to stop
-      consumed = rfl((uint32_t)cs);
-    }
-    lds_release();
-    hc_st(HC_DONE + me, seq);
-  }
-}
-
 // One hand-scheduled pass of the literal batch loop (operands: see its two users).
 #define LITERAL_BATCH_ASM \
   "s_nop 4\n" \
@@ -1327,226 +1235,6 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
   return rfl(stage);
 }
 
-// ===================================== piped command loop =====================================
-// lean_commands for metablocks without literal context modelling whose four distance contexts share one tree (what
-// encoders below quality 10 emit), with the helper wave doing the table lookups: every symbol -- command, literal,
-// distance -- comes out of the window entries the helper has left in LDS for the bit it starts at (v_readlane after
-// three ds_reads per 64 bits of stream) instead of costing an LDS round trip on the serial chain; literal runs are
-// walked window by window.  Extra bits still come from the bit reader, which moves along.  Same state hand-over and
-// stage codes as lean_commands.
-__device__ __noinline__ uint32_t piped_commands(uint32_t lut_vgpr) {
-  const uint32_t lane = lane_id();
-  BitReader br;
-  br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
-  br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
-  br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
-  gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
-  uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
-  uint32_t quota = LEAN_LD(L_QUOTA);
-  int32_t mlen = (int32_t)LEAN_LD(L_MLEN);
-  uint32_t bl0 = LEAN_LD(L_BL0), bl1 = LEAN_LD(L_BL1), bl2 = LEAN_LD(L_BL2);
-  int32_t d0 = (int32_t)LEAN_LD(L_D0), d1 = (int32_t)LEAN_LD(L_D1), d2 = (int32_t)LEAN_LD(L_D2), d3 = (int32_t)LEAN_LD(L_D3);
-  uint32_t ncmd = 0;
-  const int32_t max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
-  const uint32_t postfix_bits = LEAN_LD(L_POSTFIX), num_direct = LEAN_LD(L_NUM_DIRECT);
-  const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
-  u32x4 pendv = {0, 0, 0, 0}; uint32_t pendv_n16 = 0, pend_reg = 0, pend_n = 0; uint64_t pend_pos = 0;
-#define PIPE_FLUSH() do { if (pendv_n16) { if (lane < pendv_n16) *reinterpret_cast<gu32x4*>(out + pend_pos + (uint64_t)lane * 16) = pendv; } \
-                          if (pend_n) { if (lane < pend_n) out[pend_pos + ((uint64_t)pendv_n16 << 4) + lane] = (uint8_t)pend_reg; } \
-                          pendv_n16 = 0; pend_n = 0; } while (0)
-  uint32_t stage = LS_BEGIN;
-  int32_t insert_len = 0, copy_len = 0, distance_code = 0;
-  uint32_t distance_context = 0, lits_left = 0;
-
-  // ---- the job: window entries of the three trees from the bit the reader stands at ----
-  const uint64_t abs0 = br.pos() + BitReader::skip_bits();
-  const uint32_t seq = hc_ld(HC_SEQ) + 1u;
-  hc_st(HC_DW0, (uint32_t)(abs0 >> 5)); hc_st(HC_SHIFT, (uint32_t)abs0 & 31u);
-  hc_st(HC_TREE_C, LDS_FIXED + LEAN_LD(L_CMD_TREE)); hc_st(HC_TREE_L, LDS_FIXED + LEAN_LD(L_LIT_TREE)); hc_st(HC_TREE_D, LDS_FIXED + LEAN_LD(L_DT0));
-  hc_st(HC_PRODUCED, 0); hc_st(HC_PRODUCED + 1u, 1); hc_st(HC_CONSUMED, 0); hc_st(HC_STOP, 0); hc_st(HC_KIND, 1);
-  lds_release();
-  hc_st(HC_SEQ, seq);
-  uint32_t g = 0;            // bits consumed since abs0
-  uint32_t wk = 0xFFFFFFFFu;  // window whose entries are in Ec / El / Ed
-  uint32_t Ec = 0, El = 0, Ed = 0, avail = 0;
-  bool lost = false;
-  // the entries of the window the reader stands in, from the ring into registers (waiting for the helper if need be;
-  // bounded: a helper that never answers must not hang the GPU -- the command then goes to the checked stages)
-#define PIPE_WINDOW() do { \
-    const uint32_t k_ = g >> 6; \
-    if (k_ != wk) { \
-      if (k_ >= avail) { /* (avail: every window below it is known to be in the ring) */ \
-        uint32_t polls_ = 0; \
-        for (;;) { \
-          const uint32_t p0_ = hc_ld(HC_PRODUCED), p1_ = hc_ld(HC_PRODUCED + 1u);  /* helper h has finished its windows below p_h */ \
-          avail = p0_ < p1_ ? p0_ : p1_; \
-          if (avail > k_ || (k_ & 1u ? p1_ : p0_) > k_) break; \
-          if (++polls_ > (1u << 20)) { lost = true; break; } \
-          __builtin_amdgcn_s_sleep(1); \
-        } \
-        lds_acquire(); \
-      } \
-      if (!lost) { \
-        const uint32_t slot_ = LDS_HRING + (k_ & (HELPER_RING - 1u)) * 384u + lane * 2u; \
-        Ec = lds_ld16(slot_); El = lds_ld16(slot_ + 128u); Ed = lds_ld16(slot_ + 256u); \
-        wk = k_; \
-        hc_st(HC_CONSUMED, k_); \
-      } \
-    } } while (0)
-
-  for (;;) {
-    if (bl1 == 0 || br.next_dw >= safe_dw) { stage = LS_BEGIN; break; }
-    PIPE_WINDOW();
-    if (lost) { stage = LS_BEGIN; break; }
-    // ---- head ----
-    uint32_t ie, ce;
-    {
-      const uint32_t e = rdlane(Ec, g & 63u);
-      const uint32_t len = e & 15u, cmd = e >> 4;
-      br.need32(); br.drop(len); g += len;
-      const uint32_t cell = cmd >> 6;  // RFC 7932 section 5 (see process_commands)
-      const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
-      const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
-      ie = rdlane(lut_vgpr, ins_code); ce = rdlane(lut_vgpr, 32u + copy_code);
-      distance_code = cmd < 128 ? 0 : -1;
-      distance_context = copy_code > 2 ? 3u : copy_code;
-    }
-    insert_len = (int32_t)((ie & 0xFFFFu) + br.read24(ie >> 16));
-    copy_len = (int32_t)((ce & 0xFFFFu) + br.read24(ce >> 16));
-    g += (ie >> 16) + (ce >> 16);
-    bl1--;
-    ncmd++;
-    lits_left = (uint32_t)insert_len;
-    // ---- literals: window by window, walk from the bit the run has reached, store at rank ----
-    if (insert_len != 0) {
-      if ((uint32_t)insert_len > quota || (uint32_t)insert_len > bl0) { stage = LS_AFTER_HEAD; break; }
-      mlen -= insert_len;
-      uint32_t i = (uint32_t)insert_len;
-      while (i > 0 && br.next_dw < safe_dw) {
-        PIPE_WINDOW();
-        if (lost) break;
-        const uint32_t cur = g & 63u;
-        const uint32_t Lw = lane < cur + i * 15u ? (El & 15u) : 64u;  // (offsets the run cannot reach end the walk)
-        uint64_t starts; uint32_t woff, t1;
-        asm volatile("s_mov_b64 %0, 0\n\ts_add_u32 %1, %4, 0xffffffc0\n"
-                     "1:\n\tv_readlane_b32 %2, %3, %1\n\ts_bitset1_b64 %0, %1\n\ts_add_u32 %1, %1, %2\n\ts_cbranch_scc0 1b\n\t"
-                     "s_add_u32 %1, %1, 64\n"
-                     : "=&s"(starts), "=&s"(woff), "=&s"(t1) : "v"(Lw), "s"(cur) : "scc");
-        uint32_t n = (uint32_t)__popcll(starts);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
-        if (n > i) {  // the run ends inside this window: cut at the start that would be literal number i
-          const uint64_t cut = __ballot(rank == i) & starts;
-          woff = (uint32_t)__builtin_ctzll(cut);
-          starts &= (1ull << woff) - 1ull;
-          n = i;
-        }
-        gu8* wq = out + P;
-        const uint32_t symv = El >> 4;
-        asm volatile("s_mov_b64 exec, %0\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, -1"
-                     :: "s"(starts), "v"(rank), "v"(symv), "s"(wq) : "memory");
-        const uint32_t adv = woff - cur;
-        br.advance(adv); g += adv;
-        P += n; bl0 -= n; quota -= n; i -= n;
-      }
-      lits_left = i;
-      if (i != 0) { stage = LS_LITERALS_REST; break; }
-      if (quota == 0) { stage = LS_LITERALS_AT_LIMIT; break; }
-    }
-    // ---- distance (ReadDistanceInternal, decode.rs:2066-2131; see process_commands) ----
-    if (distance_code >= 0) {
-      distance_context = 1;
-      distance_code = d0;
-    } else {
-      if (bl2 == 0) { stage = LS_DISTANCE; break; }
-      PIPE_WINDOW();
-      if (lost) { stage = LS_DISTANCE; break; }
-      const uint32_t e = rdlane(Ed, g & 63u);
-      const uint32_t dlen = e & 15u, code = e >> 4;
-      br.need32(); br.drop(dlen); g += dlen;
-      distance_context = 0;
-      if (code < 16) {
-        if (code == 0) {
-          distance_code = d0;
-          distance_context = 1;
-        } else {
-          uint32_t sh = code << 1;
-          uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
-          int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
-          int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
-          if (code & 1u) v += mag;
-          else { v -= mag; if (v <= 0) v = 0x7fffffff; }
-          distance_code = v;
-        }
-      } else {
-        int32_t distval = (int32_t)code - (int32_t)num_direct;
-        int32_t dc = (int32_t)code;
-        if (distval >= 0) {
-          int32_t postfix = distval & (int32_t)mask_bits(postfix_bits);
-          distval >>= postfix_bits;
-          uint32_t nbits = ((uint32_t)distval >> 1) + 1;
-          uint32_t bits = br.read(nbits); g += nbits;
-          int64_t offset = (int64_t)(int32_t)((((uint32_t)(distval & 1) + 2u) << nbits) - 4u);
-          dc = (int32_t)(((offset + (int64_t)bits) << postfix_bits) + postfix + (int64_t)num_direct);
-        }
-        distance_code = (int32_t)((uint32_t)dc - 16u + 1u);
-      }
-      bl2--;
-      if (br.next_dw > br.end_dw) { stage = LS_NEEDS_INPUT; break; }
-    }
-    // ---- copy: an LZ77 reference (not the dictionary) inside the quota that does not overlap itself ----
-    {
-      const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
-      const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
-      if (distance_code > max_distance || distance_code <= 0 || n > quota || dist < n) { stage = LS_POST_DISTANCE; break; }
-      if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
-      mlen -= copy_len;
-      PIPE_FLUSH();
-      gu8* src = out + P - dist;
-      uint32_t n16 = n >> 4, rem = n & 15u;
-      if (n > 1024u) {  // long: all but the last (partial) KiB right away, 16 bytes per lane and step
-        gu8* dst = out + P;
-        const uint32_t whole = (n16 - 1u) & ~63u;
-        for (uint32_t c = lane; c < whole; c += 64) {
-          u32x4 t = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-          *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t;
-        }
-        src += (uint64_t)whole * 16; P += (uint64_t)whole * 16; quota -= whole * 16; n16 -= whole;
-      }
-      // the load is issued now, the store when the next command gets here (its source may be what this one writes)
-      u32x4 v = {0, 0, 0, 0};
-      if (lane < n16) v = *reinterpret_cast<gu32x4*>(src + (uint64_t)lane * 16);
-      uint32_t b = 0;
-      if (lane < rem) b = src[(n16 << 4) + lane];
-      pendv = v; pendv_n16 = n16; pend_reg = b; pend_n = rem; pend_pos = P;
-      P += (n16 << 4) + rem;
-      quota -= (n16 << 4) + rem;
-      if (quota == 0) { stage = LS_COMMAND_DONE; break; }
-    }
-  }
-  // the helper must be out of the tables and the ring before this wave moves on
-  hc_st(HC_STOP, 1);
-  {
-    uint32_t polls = 0;
-    while (hc_ld(HC_DONE) != seq || hc_ld(HC_DONE + 1u) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
-  }
-  if (lost) hc_st(HC_DEAD, 1);
-  PIPE_FLUSH();
-#undef PIPE_FLUSH
-#undef PIPE_WINDOW
-  lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
-  if (lane == 0) {
-    LEAN_ST(L_CHUNK_BASE, br.chunk_base);
-    LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
-    LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
-    LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
-    LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
-    LEAN_ST(L_INSERT, insert_len); LEAN_ST(L_COPY, copy_len); LEAN_ST(L_DCODE, distance_code); LEAN_ST(L_DCTX, distance_context);
-    LEAN_ST(L_LITS_LEFT, lits_left);
-  }
-  lds_sync();
-  return rfl(stage);
-}
-
 // ===================================== the command loop (hot path) =====================================
 // Argument block of the command loop.  The loop is a real function (one per table placement) so that it gets a
 // register allocation of its own: everything uniform lives in SGPRs for the whole metablock and nothing of the
@@ -1717,10 +1405,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         }
       }
       lds_sync();
-      // (one distance tree for all four distance contexts -- what encoders below quality 10 emit -- and a helper wave
-      // that answers: the table lookups go to the helper)
-      const bool piped = CTX_NEVER && dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && hc_ld(HC_DEAD) == 0u;
-      const uint32_t stage = rfl(piped ? piped_commands(lut_vgpr) : lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+      const uint32_t stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
       br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
@@ -2381,7 +2066,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 }  // namespace
 
 // One wave per stream; persistent blocks pull stream indices from `queue`.
-extern "C" __global__ __launch_bounds__(192) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
+extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
@@ -2389,10 +2074,6 @@ extern "C" __global__ __launch_bounds__(192) void brotli_amd_decode_kernel(const
   const uint32_t lane = lane_id();
   // all LDS addressing is absolute (see g_smem): the dynamic LDS block must start at LDS address 0
   if ((uint32_t)(uintptr_t)g_dynamic_lds != 0u) __builtin_trap();
-  // waves 1 and 2 are the helpers (see helper_wave); their mailbox is cleared before the three part ways
-  if (threadIdx.x < 16u) lds_st32(LDS_HCTL + 4u * threadIdx.x, 0u);
-  __syncthreads();
-  if (rfl(threadIdx.x >> 6) != 0u) { helper_wave(rfl(threadIdx.x >> 6) - 1u); return; }
   // literal context LUT -> LDS once per block
   for (uint32_t i = lane; i < 2048; i += 64) lds_st8(LDS_CTX_LUT + i, kContextLookup[i]);
   // per-lane LUT images
@@ -2481,10 +2162,6 @@ extern "C" __global__ __launch_bounds__(192) void brotli_amd_decode_kernel(const
 #endif
     }
   }
-  // no more streams: the helper wave may go
-  hc_st(HC_KIND, 2);
-  lds_release();
-  hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
 }
 
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
@@ -2494,7 +2171,7 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   size_t smem = (size_t)LDS_FIXED + lds_arena_bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(192), smem, stream, descs, status, n_streams, queue, scratch,
+  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(64), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
   return hipGetLastError();
 }
