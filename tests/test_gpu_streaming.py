@@ -221,3 +221,62 @@ def test_command_line_tool(pkg, tmp_path):
     assert hashlib.sha256(out.read_bytes()).hexdigest() == MANIFEST["alice29.txt.compressed"]["sha256"]
     p = subprocess.run([exe], input=_data("alice29.txt.compressed")[:1000], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 1 and b"Unexpected EOF" in p.stderr
+
+
+def test_less_common_entry_points(pkg):
+    """BrotliDecoderDecompressPrealloc (ffi/mod.rs:179), BrotliDecoderDecompressStreaming (:467), HasMoreOutput /
+    TakeOutput (:546-565) on the reference's alice29 fixture"""
+    import ctypes
+    L = pkg.load_library()
+    data, size, sha = _data("alice29.txt.compressed"), MANIFEST["alice29.txt.compressed"]["size"], MANIFEST["alice29.txt.compressed"]["sha256"]
+    # Prealloc: same result as the one-shot function; the scratch arrays are only validated
+    L.BrotliDecoderDecompressPrealloc.restype = pkg.ReturnInfo
+    L.BrotliDecoderDecompressPrealloc.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                  ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    out = ctypes.create_string_buffer(size + 16)
+    s8, s32, shc = ctypes.create_string_buffer(1 << 16), (ctypes.c_uint32 * 4096)(), ctypes.create_string_buffer(4 * 65536)
+    info = L.BrotliDecoderDecompressPrealloc(len(data), data, size + 16, out, len(s8), s8, 4096, s32, 65536, shc)
+    assert (info.result, info.code, info.decoded_size) == (1, 1, size)
+    assert hashlib.sha256(out.raw[:size]).hexdigest() == sha
+    # DecompressStreaming: pointers by value, counters by reference
+    L.BrotliDecoderCreateInstance.restype = ctypes.c_void_p
+    L.BrotliDecoderCreateInstance.argtypes = [ctypes.c_void_p] * 3
+    L.BrotliDecoderDestroyInstance.argtypes = [ctypes.c_void_p]
+    L.BrotliDecoderDecompressStreaming.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
+    st = L.BrotliDecoderCreateInstance(None, None, None)
+    got, pos = bytearray(), 0
+    obuf = ctypes.create_string_buffer(8192)
+    while True:
+        chunk = data[pos:pos + 3000]
+        ain, aout = ctypes.c_size_t(len(chunk)), ctypes.c_size_t(len(obuf))
+        r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), chunk, ctypes.byref(aout), obuf)
+        pos += len(chunk) - ain.value
+        got += obuf.raw[:len(obuf) - aout.value]
+        assert r != 0
+        if r == 1:
+            break
+    L.BrotliDecoderDestroyInstance(st)
+    assert hashlib.sha256(got).hexdigest() == sha and pos == len(data)
+    # TakeOutput: feed everything with no output room, then take what the decoder holds (ffi/mod.rs:552-565)
+    L.BrotliDecoderDecompressStream.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_char_p),
+                                                ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    L.BrotliDecoderHasMoreOutput.argtypes = [ctypes.c_void_p]
+    L.BrotliDecoderTakeOutput.restype = ctypes.c_void_p
+    L.BrotliDecoderTakeOutput.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    st = L.BrotliDecoderCreateInstance(None, None, None)
+    ain, nin = ctypes.c_size_t(len(data)), ctypes.c_char_p(data)
+    aout, nout = ctypes.c_size_t(0), ctypes.c_void_p(None)
+    r = L.BrotliDecoderDecompressStream(st, ctypes.byref(ain), ctypes.byref(nin), ctypes.byref(aout), ctypes.byref(nout), None)
+    assert r == 3 and L.BrotliDecoderHasMoreOutput(st)
+    got = bytearray()
+    for _ in range(10000):
+        if not L.BrotliDecoderHasMoreOutput(st):
+            r = L.BrotliDecoderDecompressStream(st, ctypes.byref(ain), ctypes.byref(nin), ctypes.byref(aout), ctypes.byref(nout), None)
+            if r == 1 and not L.BrotliDecoderHasMoreOutput(st):
+                break
+            continue
+        n = ctypes.c_size_t(4096)  # at most this much; 0 would mean "all there is"
+        p = L.BrotliDecoderTakeOutput(st, ctypes.byref(n))
+        got += ctypes.string_at(p, n.value)
+    L.BrotliDecoderDestroyInstance(st)
+    assert hashlib.sha256(got).hexdigest() == sha
