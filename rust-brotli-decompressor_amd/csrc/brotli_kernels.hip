@@ -2072,8 +2072,21 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
-  // all LDS addressing is absolute (see g_smem): the dynamic LDS block must start at LDS address 0
-  if ((uint32_t)(uintptr_t)g_dynamic_lds != 0u) __builtin_trap();
+  // all LDS addressing is absolute (see g_smem): the dynamic LDS block must start at LDS address 0.  If a toolchain
+  // ever puts it elsewhere nothing below may touch LDS: every stream of this block is reported as failed instead.
+  if (rfl((uint32_t)(uintptr_t)g_dynamic_lds) != 0u) {
+    for (;;) {
+      uint32_t idx = 0;
+      if (lane == 0) idx = atomicAdd(queue, 1u);
+      idx = rfl(idx);
+      if (idx >= n_streams) return;
+      if (lane == 0) {
+        BrotliAmdStreamStatus* st = status + idx;
+        st->result = 0; st->error_code = E_UNREACHABLE; st->decoded_size = 0; st->consumed = 0; st->produced = 0;
+        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0;
+      }
+    }
+  }
   // literal context LUT -> LDS once per block
   for (uint32_t i = lane; i < 2048; i += 64) lds_st8(LDS_CTX_LUT + i, kContextLookup[i]);
   // per-lane LUT images
