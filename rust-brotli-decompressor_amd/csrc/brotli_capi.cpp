@@ -33,8 +33,8 @@ extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictiona
 namespace {
 
 constexpr size_t kDictSize = 122784;
-constexpr uint64_t kScratchPerBlock = 2u << 20;  // worst-case table arena of one metablock
-constexpr uint32_t kDefaultLdsPerBlock = 32 * 1024;
+constexpr uint64_t kScratchPerBlock = (2u << 20) + BROTLI_AMD_SPEC_SCRATCH;  // worst-case table arena of one metablock + helper scratch
+constexpr uint32_t kDefaultLdsPerBlock = 36 * 1024;
 
 thread_local std::string g_last_error;
 

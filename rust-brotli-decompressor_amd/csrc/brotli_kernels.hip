@@ -35,6 +35,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "brotli_device_abi.h"
 #define BROTLI_TABLE_QUAL __constant__ const
@@ -82,7 +83,11 @@ constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit 
 constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
 constexpr uint32_t LDS_LEAN = LDS_HOT + 96;                 // 192: state handed between process_commands and lean_commands
 constexpr uint32_t LDS_LEANWIN = LDS_LEAN + 192;            // 256: the reader's register window, handed over with the state
-constexpr uint32_t LDS_FIXED = LDS_LEANWIN + 256;           // = 6080, 16-byte aligned
+constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 64: mailbox between the decoding wave and its three helper waves
+constexpr uint32_t LDS_HMASK = LDS_HCTL + 64;               // 4 x 256: per wave and window of its chunk, which bit offsets start a literal
+constexpr uint32_t LDS_HCUM = LDS_HMASK + 1024;             // 4 x 128: per wave and window, literals in the chunk's windows before it
+constexpr uint32_t LDS_HFIRST = LDS_HCUM + 512;             // 4 x 256: code lengths and symbols of all offsets of a chunk's first two windows
+constexpr uint32_t LDS_FIXED = LDS_HFIRST + 1024;           // = 8704, 16-byte aligned
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -892,6 +897,111 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 #define PROF_REST(acc, t0) PROF_ADD(acc, t0)
 #endif
 
+// ===================================== helper waves: speculative literal runs =====================================
+// A block is four waves: wave 0 decodes its stream, waves 1-3 wait for work in an LDS mailbox.  The work: a long run
+// of literals with one prefix code (high-entropy data: tens of thousands of literals between two copies).  A round
+// is 4 chunks of 2048 stream bits; the decoding wave takes the first, whose first bit is known to start a literal,
+// each helper decodes one of the others *as if* a literal started at its first bit.  It usually does not -- but
+// prefix codes re-synchronise: after a few symbols the helper's chain of literal starts falls in with the true one.
+// The decoding wave then walks the true chain from where the chunk before ended only until it steps on a start the
+// helper has marked too; from there on the helper's literals are the stream's.  Per window a helper records the
+// start mask and the running literal count (LDS), its literals go to a scratch area in global memory and are moved
+// into place once their position is known; for a chunk's first two windows it also leaves code length and symbol of
+// every bit offset, which is all the decoding wave needs to walk there.  No chunk that fails to fall in within two
+// windows is used: the round ends in front of it.
+//   HCTL words: 0 round number   1 kind (1 = round, 2 = exit)   2 first dword of the round   3 bit offset in it
+//   4 LDS address of the literal tree   5-7 round finished by helper 1-3   8-11 literals in chunk 0-3
+//   12-15 bit offset into the next chunk at which the chain of chunk 0-3 ends
+enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_DONE = 5, HC_N = 8, HC_EXIT = 12 };
+constexpr uint32_t SPEC_WINDOWS = 32;          // windows of 64 bits per chunk
+constexpr uint32_t SPEC_ROUND_MIN = 16384;     // literals a run must still have for a round (a round holds at most 8192)
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+__device__ __forceinline__ uint32_t hc_ld(uint32_t w) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w])); }
+__device__ __forceinline__ void hc_st(uint32_t w, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w]) = v; }
+__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// walk over code lengths from bit `entry` of a window: which offsets start a symbol, and where the chain leaves it
+#define SPEC_WALK(Lw, entry, starts, woff) do { uint32_t t1_; \
+    asm volatile("s_mov_b64 %0, 0\n\ts_add_u32 %1, %4, 0xffffffc0\n" \
+                 "1:\n\tv_readlane_b32 %2, %3, %1\n\ts_bitset1_b64 %0, %1\n\ts_add_u32 %1, %1, %2\n\ts_cbranch_scc0 1b\n\t" \
+                 "s_add_u32 %1, %1, 64\n" \
+                 : "=&s"(starts), "=&s"(woff), "=&s"(t1_) : "v"(Lw), "s"(entry) : "scc"); } while (0)
+// lanes of `mask` store their byte at out[rank]
+#define SPEC_STORE(mask, rank, val, ptr) asm volatile("s_mov_b64 exec, %0\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, -1" \
+                                                      :: "s"(mask), "v"(rank), "v"(val), "s"(ptr) : "memory")
+
+// One chunk: SPEC_WINDOWS windows from stream dword dw0 (+ sh bits), chain entered at bit `entry` of the first window.
+// Literals go to symout[0..n), per-window start masks / running counts to the LDS areas of wave slot w.
+__device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, uint32_t tree, gu8* symout, uint32_t entry) {
+  const uint32_t lane = lane_id();
+  const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
+  w = rfl(w); dw0 = rfl(dw0); sh = rfl(sh); tree = rfl(tree); entry = rfl(entry);
+  symout = rfl_ptr(symout);
+  gcu32* const base = BitReader::base();
+  const uint32_t ndw = BitReader::n_dw(), tmask = BitReader::tail_mask();
+  uint32_t hc0, hc1;  // dwords [dw0, dw0 + 64) and [dw0 + 64, dw0 + 128) of the stream, one per lane
+  {
+    uint32_t i0 = dw0 + lane, i1 = dw0 + 64u + lane, v0 = 0, v1 = 0;
+    if (i0 < ndw) v0 = base[i0];
+    if (i1 < ndw) v1 = base[i1];
+    if (i0 == ndw - 1u) v0 &= tmask;
+    if (i1 == ndw - 1u) v1 &= tmask;
+    hc0 = v0; hc1 = v1;
+  }
+  uint32_t cnt = 0, e = entry;
+  for (uint32_t j = 0; j < SPEC_WINDOWS; j++) {
+    const uint32_t q = 2u * j;
+    const uint32_t a0 = rdlane(hc0, q), a1 = rdlane(hc0, q + 1u);
+    const uint32_t a2 = q + 2u < 64u ? rdlane(hc0, q + 2u) : rdlane(hc1, q + 2u - 64u);
+    const uint32_t a3 = q + 3u < 64u ? rdlane(hc0, q + 3u) : rdlane(hc1, q + 3u - 64u);
+    const uint64_t p01 = (uint64_t)a0 | ((uint64_t)a1 << 32), p12 = (uint64_t)a1 | ((uint64_t)a2 << 32), p23 = (uint64_t)a2 | ((uint64_t)a3 << 32);
+    const uint32_t w0 = (uint32_t)(p01 >> sh), w1 = (uint32_t)(p12 >> sh), w2 = (uint32_t)(p23 >> sh);
+    const uint32_t x = (__builtin_amdgcn_alignbit(w1, w0, lane) & lomask) | (__builtin_amdgcn_alignbit(w2, w1, lane) & ~lomask);
+    uint32_t en = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(&g_smem[tree + ((x & 0xFFu) << 1)]);
+    uint32_t L = en & 15u;
+    if (L > ROOT_BITS) {
+      uint32_t idx = (en >> 4) + ((x >> ROOT_BITS) & ((1u << (L - ROOT_BITS)) - 1u));
+      en = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(&g_smem[tree + (idx << 1)]);
+      L = ROOT_BITS + (en & 15u);
+    }
+    const uint32_t sym = en >> 4;
+    if (j < 2u) { lds_st8(LDS_HFIRST + w * 256u + j * 128u + lane, L); lds_st8(LDS_HFIRST + w * 256u + j * 128u + 64u + lane, sym); }
+    uint64_t starts; uint32_t woff;
+    SPEC_WALK(L, e, starts, woff);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
+    gu8* so = symout + cnt;
+    SPEC_STORE(starts, rank, sym, so);
+    if (lane == 0) {
+      *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_HMASK + w * 256u + j * 8u]) = starts;
+      lds_st32(LDS_HCUM + w * 128u + j * 4u, cnt);
+    }
+    cnt += (uint32_t)__popcll(starts);
+    e = woff - 64u;
+  }
+  hc_st(HC_N + w, cnt);
+  hc_st(HC_EXIT + w, e);
+}
+
+__device__ __noinline__ void helper_wave(const uint32_t me /* 1..3 */, gu8* scratch_sym) {
+  uint32_t seq = 0;
+  for (;;) {
+    uint32_t j;
+    for (;;) {  // idle until the decoding wave posts a round (it always posts `exit` at the end)
+      j = hc_ld(HC_SEQ);
+      if (j != seq) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    seq = j;
+    lds_acquire();
+    if (hc_ld(HC_KIND) != 1u) return;
+    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), scratch_sym + (me - 1u) * 2048u, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the literals are in memory before the round is reported done
+    lds_release();
+    hc_st(HC_DONE + me - 1u, seq);
+  }
+}
+
 // One hand-scheduled pass of the literal batch loop (operands: see its two users).
 #define LITERAL_BATCH_ASM \
   "s_nop 4\n" \
@@ -997,12 +1107,98 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 // finishes that command and comes back.  State crosses through LDS_LEAN (uniform values) and function arguments.
 enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI, L_QUOTA, L_MLEN, L_BL0, L_BL1, L_BL2, L_D0, L_D1, L_D2,
        L_D3, L_NCMD_LO, L_NCMD_HI, L_CMD_TREE, L_LIT_TREE, L_DT0, L_DT1, L_DT2, L_DT3, L_MAX_BACKWARD, L_POSTFIX, L_NUM_DIRECT, L_OUT_LO,
-       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_CHUNK_BASE, L_COUNT };
+       L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_CHUNK_BASE, L_SPEC_LO, L_SPEC_HI, L_COUNT };
 static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
 enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
        LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7 };
 #define LEAN_LD(k) rfl(lds_ld32(LDS_LEAN + 4u * (uint32_t)(k)))
 #define LEAN_ST(k, v) lds_st32(LDS_LEAN + 4u * (uint32_t)(k), (uint32_t)(v))
+
+// Rounds of a long literal run (see the helper waves above); state through LDS_LEAN like the lean function's.
+__device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
+  const uint32_t lane = lane_id();
+  tree_addr = rfl(tree_addr);
+  BitReader br;
+  br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+  br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
+  br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
+  uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+  uint32_t i = LEAN_LD(L_LITS_LEFT);
+  const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
+        while (i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw && hc_ld(HC_KIND) != 3u) {
+          const uint64_t run_pos = br.pos();
+          const uint64_t abs0 = run_pos + BitReader::skip_bits();
+          const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
+          const uint32_t seq = hc_ld(HC_SEQ) + 1u;
+          hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1);
+          lds_release();
+          hc_st(HC_SEQ, seq);
+          spec_chunk(0, dw0, sh, tree_addr, out + P, 0);  // the first chunk: its first bit does start a literal
+          uint64_t Pc = P + hc_ld(HC_N);
+          uint32_t e = hc_ld(HC_EXIT);
+          uint32_t bits_done = SPEC_WINDOWS * 64u + e;
+          bool lost = false;
+          for (uint32_t w = 1; w < 4; w++) {  // (bounded: helpers that never answer must not hang the GPU)
+            uint32_t polls = 0;
+            while (hc_ld(HC_DONE + w - 1u) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
+            if (lost) break;
+          }
+          lds_acquire();
+          gu8* const spec = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_SPEC_LO) | ((uint64_t)LEAN_LD(L_SPEC_HI) << 32));
+          for (uint32_t w = 1; w < 4 && !lost; w++) {
+            // walk the true chain into chunk w until it steps on a start the helper marked too
+            bool synced = false;
+            uint32_t skip = 0;
+            for (uint32_t j = 0; j < 2u && !synced; j++) {
+              const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_HMASK + w * 256u + j * 8u]);
+              const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
+              const uint32_t Lv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + lane), sv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + 64u + lane);
+              uint64_t tstarts; uint32_t woff;
+              SPEC_WALK(Lv, e, tstarts, woff);
+              const uint64_t common = tstarts & smask;
+              uint64_t mine = tstarts;  // literals of this window that only the true chain has
+              if (common) {
+                const uint32_t p = (uint32_t)__builtin_ctzll(common);
+                mine = tstarts & ((1ull << p) - 1ull);
+                skip = rfl(lds_ld32(LDS_HCUM + w * 128u + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
+                synced = true;
+              }
+              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+              gu8* wq = out + Pc;
+              SPEC_STORE(mine, rank, sv, wq);
+              Pc += (uint32_t)__popcll(mine);
+              if (!synced) { e = woff - 64u; bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + e; }
+            }
+            if (!synced) break;  // no common start within two windows: the round ends here, the run goes on from there
+            // the helper's literals from the common start on are the stream's: into place
+            const uint32_t nw = hc_ld(HC_N + w), valid = nw - skip;
+            gu8* src = spec + (w - 1u) * 2048u + skip;
+            gu8* dst = out + Pc;
+            const uint32_t n16 = valid >> 4;
+            for (uint32_t c = lane; c < n16; c += 64) {
+              u32x4 t = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+              *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t;
+            }
+            if (lane < (valid & 15u)) dst[(n16 << 4) + lane] = src[(n16 << 4) + lane];
+            Pc += valid;
+            e = hc_ld(HC_EXIT + w);
+            bits_done = (w + 1u) * SPEC_WINDOWS * 64u + e;
+          }
+          if (lost) hc_st(HC_KIND, 3);  // helpers unusable from now on
+          const uint32_t got = (uint32_t)(Pc - P);
+          P = Pc; i -= got;
+          br.seek(run_pos + bits_done);
+        }
+  lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
+  if (lane == 0) {
+    LEAN_ST(L_CHUNK_BASE, br.chunk_base);
+    LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+    LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32));
+    LEAN_ST(L_LITS_LEFT, i);
+  }
+  lds_sync();
+}
 
 template <bool CTX_NEVER>
 __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
@@ -1103,6 +1299,26 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
           i--;
         }
       }
+      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw) {
+        // ---- long run: rounds of four chunks, three of them decoded speculatively by the helper waves (spec_rounds) ----
+        LEAN_FLUSH();
+        lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
+        if (lane == 0) {
+          LEAN_ST(L_CHUNK_BASE, br.chunk_base);
+          LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+          LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32));
+          LEAN_ST(L_LITS_LEFT, i);
+        }
+        lds_sync();
+        spec_rounds(tree_addr);
+        br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+        br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
+        br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
+        P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+        const uint32_t left = LEAN_LD(L_LITS_LEFT), got = i - left;
+        i = left; bl0 -= got; quota -= got;
+      }
+      const uint32_t run_rest = i;  // what the batches below still have to decode
       gu8* wp = out + P;
       if (CTX_NEVER && i > 2 && br.next_dw < safe_dw) {
         uint32_t woff = 0;
@@ -1123,7 +1339,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
         if (lane == 0) *wp = (uint8_t)lit;
         wp++; i--;
       }
-      const uint32_t done = (uint32_t)insert_len - i;
+      const uint32_t done = (CTX_NEVER ? run_rest : (uint32_t)insert_len) - i;
       P += done; bl0 -= done; quota -= done;
       lits_left = i;
       if (i != 0) { stage = LS_LITERALS_REST; break; }
@@ -1250,6 +1466,7 @@ struct HotArgs {
   uint32_t bl0, bl1, bl2;
   uint32_t postfix_bits, num_direct;
   uint32_t lut_vgpr, bl_vgpr;
+  uint64_t spec_scratch;   // global address of the helper waves' literal scratch
   uint64_t num_commands;
   uint64_t prof[6];
 };
@@ -1376,6 +1593,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   if (LDS_ONLY && lane == 0) {  // what lean_commands needs and never changes in this metablock
     LEAN_ST(L_END_DW, br.end_dw); LEAN_ST(L_MAX_BACKWARD, max_backward); LEAN_ST(L_POSTFIX, postfix_bits); LEAN_ST(L_NUM_DIRECT, num_direct);
     LEAN_ST(L_OUT_LO, (uint32_t)(uintptr_t)out); LEAN_ST(L_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
+    LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32));
   }
 
   for (;;) {
@@ -1855,6 +2073,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
   }
   lds_sync();
   h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
+  h.spec_scratch = (uint64_t)(uintptr_t)(s.ar.glb + s.ar_end);
   h.num_commands = s.num_commands;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
@@ -2066,12 +2285,20 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 }  // namespace
 
 // One wave per stream; persistent blocks pull stream indices from `queue`.
-extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
+extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
+  // waves 1-3 are helpers (see helper_wave); their mailbox is cleared before the four part ways
+  if (threadIdx.x < 16u && (uint32_t)(uintptr_t)g_dynamic_lds == 0u) lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && blockDim.x < 256u ? 3u : 0u);  // (launched without helper waves: no rounds)
+  __syncthreads();
+  if (rfl(threadIdx.x >> 6) != 0u) {
+    if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u)
+      helper_wave(rfl(threadIdx.x >> 6), as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block + (scratch_per_block - BROTLI_AMD_SPEC_SCRATCH)));
+    return;
+  }
   // all LDS addressing is absolute (see g_smem): the dynamic LDS block must start at LDS address 0.  If a toolchain
   // ever puts it elsewhere nothing below may touch LDS: every stream of this block is reported as failed instead.
   if (rfl((uint32_t)(uintptr_t)g_dynamic_lds) != 0u) {
@@ -2108,7 +2335,7 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
     s.ar.glb = as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block);
     s.ar.lds_limit = lds_arena_bytes;
     s.ar.top = 0;
-    s.ar_end = (uint32_t)scratch_per_block & ~3u;
+    s.ar_end = (uint32_t)(scratch_per_block - BROTLI_AMD_SPEC_SCRATCH) & ~3u;
     s.ar.cold = s.ar_end;
     s.out = as_global<gu8>(d.out); s.out_cap = d.out_cap;
     s.dict = as_global<gcu8>(dict);
@@ -2175,6 +2402,10 @@ extern "C" __global__ __launch_bounds__(64) void brotli_amd_decode_kernel(const 
 #endif
     }
   }
+  // no more streams: the helper waves may go
+  hc_st(HC_KIND, 2);
+  lds_release();
+  hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
 }
 
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
@@ -2184,7 +2415,8 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   size_t smem = (size_t)LDS_FIXED + lds_arena_bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(64), smem, stream, descs, status, n_streams, queue, scratch,
+  static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
+  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(no_helpers ? 64 : 256), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
   return hipGetLastError();
 }

@@ -301,3 +301,34 @@ def test_sharded_decode_single_rank(pkg):
     for e, out, row in zip(m, outs, status):
         assert (int(row[0]), int(row[2]), int(row[3])) == (1, e["size"], e["csize"]), e["name"]
         assert hashlib.sha256(out).hexdigest() == e["sha256"], e["name"]
+
+
+def test_helper_rounds_with_a_code_that_never_resynchronises(pkg):
+    """Long literal runs are decoded in rounds whose later chunks the helper waves decode speculatively from a guessed
+    literal boundary, counting on prefix codes to re-synchronise.  This data's optimal code has lengths 6, 9, 12 and 15
+    only (253 symbols with probabilities 2^-6 ... 2^-15), so a chain that starts off the grid of multiples of three
+    never meets the true one: every round must end after its first chunk, and the output must not care.  A second
+    stream (lengths 7..9) is the usual case where the helpers' chunks do fall in."""
+    import numpy as np
+    import libbrotli_ref as ref
+    if not ref.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    rng = np.random.Generator(np.random.PCG64(99))
+    syms = rng.permutation(256)[:253].astype(np.uint8)
+    block = np.concatenate([np.repeat(syms[:60], 512), np.repeat(syms[60:89], 64), np.repeat(syms[89:93], 8), syms[93:253]])
+    assert len(block) == 32768
+    grid3 = np.concatenate([rng.permutation(block) for _ in range(8)]).tobytes()  # 256 KiB of literals, no repeats to speak of
+    usual = rng.choice(256, size=300000, p=(np.arange(1, 257) ** -0.3) / np.sum(np.arange(1, 257) ** -0.3)).astype(np.uint8).tobytes()
+    datas, raws = [], []
+    for raw in (grid3, usual):
+        raw = raw + raw[:50000]  # a long copy at the end
+        datas.append(ref.encode(raw, 5, 22))
+        raws.append(raw)
+        info, out = oracle.decode(datas[-1], len(raw) + 16, 1)
+        assert info.result == 1 and out == raw and info.num_literals > 200000 and info.num_commands < 64  # long runs indeed
+    batch = pkg.Batch(2)
+    results, outs = batch.decode_host(datas, [len(r) + 16 for r in raws], pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    for r, out, raw, d in zip(results, outs, raws, datas):
+        assert (r.result, r.error_code, r.decoded_size, r.consumed) == (1, 1, len(raw), len(d))
+        assert out == raw
