@@ -13,7 +13,9 @@
 //   src/decode.rs:152-372, 516-1465, 2921-3288  stream/metablock headers       -> decode_stream() (must run on device:
 //                             a metablock's compressed extent is only known after decoding it)
 //
-// Execution model: ONE WAVEFRONT PER STREAM, fully fused.  The entropy decode of a Brotli stream is a serial
+// Execution model: ONE DECODING WAVEFRONT PER STREAM (wave 0 of a 256-thread block), fully fused; waves 1-3 of the block
+// are helpers that decode chunks of long literal runs speculatively (spec_rounds / spec_chunk / helper_wave) and
+// sleep otherwise.  The entropy decode of a Brotli stream is a serial
 // dependent chain, so all 64 lanes of the wave execute it uniformly (values live in SGPRs; table entries come back
 // from LDS through v_readfirstlane) and the lanes are used for everything that is data parallel inside one stream:
 //   * input: 256-byte pieces of the compressed stream go straight into an LDS ring (global_load_lds); the wave takes
@@ -25,6 +27,9 @@
 //     of the current literal block type) live one entry per lane in VGPRs and are indexed with v_readlane;
 //   * Huffman tables are built lane-parallel (ballot counting sort + parallel replicate) into an LDS arena;
 //     objects that do not fit the LDS arena spill to a per-block global scratch area (never straddling);
+//   * literal runs of >= 16384 literals: rounds of four 2048-bit chunks, three of them decoded by the helper waves from
+//     a bit that need not start a literal -- prefix codes re-synchronise, and the decoding wave walks the true chain into
+//     each chunk only until it meets the helper's; a chunk that does not fall in is not used;
 //   * LZ77 copies, dictionary words and stored metablocks are moved by all 64 lanes (16 bytes per lane and step where
 //     source and destination are far enough apart), overlapping copies as pattern fills.
 // What bounds it is the instruction issue rate of one wave (about one instruction per 8 clocks): see DESIGN.md.
@@ -221,6 +226,25 @@ struct BitReader {
     uint32_t dw = (uint32_t)(abs >> 5);
     next_dw = dw;
     issued_half = dw >> 6;
+    rebase();
+    buf = 0; cnt = 0;
+    pull();
+    uint32_t r = (uint32_t)(abs & 31);
+    buf >>= r; cnt -= r;
+  }
+  // request the pieces a reader will need after a jump to about dword `dw` (the reader is not used until seek_ahead)
+  __device__ __forceinline__ void request_ahead(uint32_t dw) {
+    const uint32_t a = dw >> 6;
+    dma_half(a); dma_half(a + 1u); dma_half(a + 2u);
+    issued_half = a + 3u;
+  }
+  // seek to a position whose pieces request_ahead(dw) has asked for, if it did; a plain seek otherwise
+  __device__ __forceinline__ void seek_ahead(uint64_t bit_pos) {
+    uint64_t abs = bit_pos + skip_bits();
+    uint32_t dw = (uint32_t)(abs >> 5);
+    const uint32_t a = dw >> 6;
+    next_dw = dw;
+    if (!(a + 3u >= issued_half && a + 2u <= issued_half)) issued_half = a;  // pieces a, a + 1 are not both there
     rebase();
     buf = 0; cnt = 0;
     pull();
@@ -1115,6 +1139,14 @@ enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, L
 #define LEAN_ST(k, v) lds_st32(LDS_LEAN + 4u * (uint32_t)(k), (uint32_t)(v))
 
 // Rounds of a long literal run (see the helper waves above); state through LDS_LEAN like the lean function's.
+#ifdef BROTLI_AMD_PROFILE_SPEC
+__device__ unsigned long long g_spec_prof[8];
+#define SPEC_PROF(k) do { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0) g_spec_prof[k] += _t - sp_t; sp_t = _t; } while (0)
+#define SPEC_COUNT(k, v) do { if (blockIdx.x == 0 && lane == 0) g_spec_prof[k] += (v); } while (0)
+#else
+#define SPEC_PROF(k) do { } while (0)
+#define SPEC_COUNT(k, v) do { } while (0)
+#endif
 __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   const uint32_t lane = lane_id();
   tree_addr = rfl(tree_addr);
@@ -1127,6 +1159,9 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   uint32_t i = LEAN_LD(L_LITS_LEFT);
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
         while (i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw && hc_ld(HC_KIND) != 3u) {
+#ifdef BROTLI_AMD_PROFILE_SPEC
+          uint64_t sp_t = __builtin_amdgcn_s_memtime();
+#endif
           const uint64_t run_pos = br.pos();
           const uint64_t abs0 = run_pos + BitReader::skip_bits();
           const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
@@ -1134,7 +1169,9 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
           hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1);
           lds_release();
           hc_st(HC_SEQ, seq);
+          br.request_ahead(dw0 + SPEC_WINDOWS * 8u);  // where the round will normally end: there by the time it does
           spec_chunk(0, dw0, sh, tree_addr, out + P, 0);  // the first chunk: its first bit does start a literal
+          SPEC_PROF(0);
           uint64_t Pc = P + hc_ld(HC_N);
           uint32_t e = hc_ld(HC_EXIT);
           uint32_t bits_done = SPEC_WINDOWS * 64u + e;
@@ -1145,8 +1182,11 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
             if (lost) break;
           }
           lds_acquire();
+          SPEC_PROF(1);
           gu8* const spec = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_SPEC_LO) | ((uint64_t)LEAN_LD(L_SPEC_HI) << 32));
-          for (uint32_t w = 1; w < 4 && !lost; w++) {
+          uint32_t cp_src[3] = {0u, 0u, 0u}, cp_dst[3] = {0u, 0u, 0u}, cp_n[3] = {0u, 0u, 0u};
+          _Pragma("unroll") for (uint32_t w = 1; w < 4; w++) {
+            if (lost) break;
             // walk the true chain into chunk w until it steps on a start the helper marked too
             bool synced = false;
             uint32_t skip = 0;
@@ -1171,24 +1211,42 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
               if (!synced) { e = woff - 64u; bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + e; }
             }
             if (!synced) break;  // no common start within two windows: the round ends here, the run goes on from there
-            // the helper's literals from the common start on are the stream's: into place
-            const uint32_t nw = hc_ld(HC_N + w), valid = nw - skip;
-            gu8* src = spec + (w - 1u) * 2048u + skip;
-            gu8* dst = out + Pc;
-            const uint32_t n16 = valid >> 4;
-            for (uint32_t c = lane; c < n16; c += 64) {
-              u32x4 t = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-              *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t;
-            }
-            if (lane < (valid & 15u)) dst[(n16 << 4) + lane] = src[(n16 << 4) + lane];
+            // the helper's literals from the common start on are the stream's; they are moved into place below
+            const uint32_t valid = hc_ld(HC_N + w) - skip;
+            cp_src[w - 1u] = (w - 1u) * 2048u + skip; cp_dst[w - 1u] = (uint32_t)(Pc - P); cp_n[w - 1u] = valid;
             Pc += valid;
             e = hc_ld(HC_EXIT + w);
             bits_done = (w + 1u) * SPEC_WINDOWS * 64u + e;
           }
+          SPEC_PROF(2);
+          {  // all loads of the (up to three) moves first, then the stores: one memory round trip, not three
+            u32x4 t[3][2] = {};
+            _Pragma("unroll") for (uint32_t k = 0; k < 3u; k++)
+              _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
+                const uint32_t c = lane + 64u * h;
+                if (c < (cp_n[k] >> 4)) t[k][h] = *reinterpret_cast<gu32x4*>(spec + cp_src[k] + (uint64_t)c * 16);
+              }
+            uint32_t tail[3] = {0u, 0u, 0u};
+            _Pragma("unroll") for (uint32_t k = 0; k < 3u; k++) {
+              const uint32_t n16 = cp_n[k] >> 4;
+              if (lane < (cp_n[k] & 15u)) tail[k] = spec[cp_src[k] + (n16 << 4) + lane];
+            }
+            _Pragma("unroll") for (uint32_t k = 0; k < 3u; k++) {
+              gu8* dst = out + P + cp_dst[k];
+              const uint32_t n16 = cp_n[k] >> 4;
+              _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
+                const uint32_t c = lane + 64u * h;
+                if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[k][h];
+              }
+              if (lane < (cp_n[k] & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail[k];
+            }
+          }
+          SPEC_PROF(3);
           if (lost) hc_st(HC_KIND, 3);  // helpers unusable from now on
           const uint32_t got = (uint32_t)(Pc - P);
           P = Pc; i -= got;
-          br.seek(run_pos + bits_done);
+          br.seek_ahead(run_pos + bits_done);
+          SPEC_PROF(4); SPEC_COUNT(5, 1); SPEC_COUNT(6, got); SPEC_COUNT(7, bits_done);
         }
   lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
   if (lane == 0) {
@@ -2284,7 +2342,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 
 }  // namespace
 
-// One wave per stream; persistent blocks pull stream indices from `queue`.
+// One decoding wave (+ three helper waves) per stream; persistent blocks pull stream indices from `queue`.
 extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
@@ -2402,6 +2460,11 @@ extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(co
 #endif
     }
   }
+#ifdef BROTLI_AMD_PROFILE_SPEC
+  if (blockIdx.x == 0 && lane_id() == 0)
+    printf("spec rounds %llu lits %llu bits %llu ticks: chunk0 %llu wait %llu resolve %llu move %llu seek %llu\n", g_spec_prof[5], g_spec_prof[6], g_spec_prof[7],
+           g_spec_prof[0], g_spec_prof[1], g_spec_prof[2], g_spec_prof[3], g_spec_prof[4]);
+#endif
   // no more streams: the helper waves may go
   hc_st(HC_KIND, 2);
   lds_release();
