@@ -26,7 +26,7 @@
 
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
-                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream);
+                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves);
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void);
 extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictionary.bin, 122784 bytes
 
@@ -116,7 +116,7 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
   if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
-                                       b->d_dict, stream), "brotli_amd_decode_kernel launch")) return -1;
+                                       b->d_dict, stream, b->grid <= 4u * b->cus), "brotli_amd_decode_kernel launch")) return -1;
   if (!hip_ok(hipEventRecord(b->ev1, stream), "hipEventRecord")) return -1;
   b->last_stream = stream;
   b->launched = true;
@@ -175,7 +175,7 @@ int retry_with_large_arena(BrotliAmdBatch* b) {
   if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
   if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
   if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, b->max_arena,
-                                       b->d_dict, stream), "brotli_amd_decode_kernel launch (large arena)")) return -1;
+                                       b->d_dict, stream, 1), "brotli_amd_decode_kernel launch (large arena)")) return -1;
   if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
   for (uint32_t j = 0; j < m; j++) {

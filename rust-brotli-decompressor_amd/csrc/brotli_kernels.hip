@@ -1139,6 +1139,12 @@ enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, L
 #define LEAN_ST(k, v) lds_st32(LDS_LEAN + 4u * (uint32_t)(k), (uint32_t)(v))
 
 // Rounds of a long literal run (see the helper waves above); state through LDS_LEAN like the lean function's.
+#ifdef BROTLI_AMD_PROFILE_LEAN
+__device__ unsigned long long g_lean_prof[8];
+#define LEAN_PROF(k) do { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0) lp_acc[k] += _t - lp_t; lp_t = _t; } while (0)
+#else
+#define LEAN_PROF(k) do { } while (0)
+#endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
 __device__ unsigned long long g_spec_prof[8];
 #define SPEC_PROF(k) do { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0) g_spec_prof[k] += _t - sp_t; sp_t = _t; } while (0)
@@ -1301,7 +1307,11 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
   br.need32();
   uint32_t next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
 
+#ifdef BROTLI_AMD_PROFILE_LEAN
+  uint64_t lp_acc[5] = {0, 0, 0, 0, 0}; uint64_t lp_t = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
+    LEAN_PROF(3);
     if (bl1 == 0 || br.next_dw >= safe_dw) { stage = LS_BEGIN; break; }  // block switch due, or close to the end of the input
     uint32_t cmd;
     {  // read_symbol() with the root lookup already under way (cnt >= 32 here)
@@ -1326,6 +1336,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
     bl1--;
     ncmd++;
     lits_left = (uint32_t)insert_len;
+    LEAN_PROF(0);
     if (insert_len != 0) {
       if ((uint32_t)insert_len > quota || (uint32_t)insert_len > bl0) { stage = LS_AFTER_HEAD; break; }
       mlen -= insert_len;
@@ -1403,6 +1414,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
       if (i != 0) { stage = LS_LITERALS_REST; break; }
       if (quota == 0) { stage = LS_LITERALS_AT_LIMIT; break; }
     }
+    LEAN_PROF(1);
     // ---- distance (ReadDistanceInternal, decode.rs:2066-2131; see process_commands) ----
     if (distance_code >= 0) {
       distance_context = 1;
@@ -1443,6 +1455,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
     }
     br.need32();
     next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+    LEAN_PROF(2);
     // ---- copy: an LZ77 reference (not the dictionary) inside the quota that does not overlap itself ----
     {
       const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
@@ -1493,6 +1506,9 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
   }
   if (!CTX_NEVER && !ctx_regs && ctx_pend) { p1 = rdlane(pend_reg, pend_n - 1u); p2 = rdlane(pend_reg, pend_n - 2u); ctx_regs = true; }
   LEAN_FLUSH();
+#ifdef BROTLI_AMD_PROFILE_LEAN
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 4; k++) g_lean_prof[k] += lp_acc[k]; g_lean_prof[4] += ncmd; }
+#endif
 #undef LEAN_FLUSH
   lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
   if (lane == 0) {
@@ -2460,6 +2476,11 @@ extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(co
 #endif
     }
   }
+#ifdef BROTLI_AMD_PROFILE_LEAN
+  if (blockIdx.x == 0 && lane_id() == 0)
+    printf("lean cmds %llu ticks per cmd: head %llu literals %llu distance %llu copy %llu\n", g_lean_prof[4], g_lean_prof[0] / g_lean_prof[4],
+           g_lean_prof[1] / g_lean_prof[4], g_lean_prof[2] / g_lean_prof[4], g_lean_prof[3] / g_lean_prof[4]);
+#endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
   if (blockIdx.x == 0 && lane_id() == 0)
     printf("spec rounds %llu lits %llu bits %llu ticks: chunk0 %llu wait %llu resolve %llu move %llu seek %llu\n", g_spec_prof[5], g_spec_prof[6], g_spec_prof[7],
@@ -2473,13 +2494,15 @@ extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(co
 
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
-                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream) {
+                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves) {
   if (n_streams == 0) return hipSuccess;
   size_t smem = (size_t)LDS_FIXED + lds_arena_bytes;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
   static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
-  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(no_helpers ? 64 : 256), smem, stream, descs, status, n_streams, queue, scratch,
+  // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four
+  // four-wave blocks): such batches gain more from streams in flight than from helper waves in long literal runs.
+  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(no_helpers || !helper_waves ? 64 : 256), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
   return hipGetLastError();
 }

@@ -332,3 +332,28 @@ def test_helper_rounds_with_a_code_that_never_resynchronises(pkg):
     for r, out, raw, d in zip(results, outs, raws, datas):
         assert (r.result, r.error_code, r.decoded_size, r.consumed) == (1, 1, len(raw), len(d))
         assert out == raw
+
+
+def test_batches_larger_than_the_resident_grid(pkg):
+    """More streams than four blocks per CU: the host launches one-wave blocks (no helper waves, up to eight blocks per
+    CU with a smaller table arena) and streams whose tables need the large arena come back in the second pass.  Same
+    results as ever, including a stream with literal runs long enough for helper rounds (decoded without them here)."""
+    import numpy as np
+    import libbrotli_ref as ref
+    m = [e for e in _manifest() if not e.get("must_fail") and e.get("size", 1 << 30) <= 300000][:24]
+    datas = [_data(e["name"]) for e in m]
+    want = [(e["size"], e["sha256"]) for e in m]
+    if ref.encoder_available():
+        rng = np.random.Generator(np.random.PCG64(7))
+        raw = rng.choice(256, size=200000, p=(np.arange(1, 257) ** -0.3) / np.sum(np.arange(1, 257) ** -0.3)).astype(np.uint8).tobytes()
+        datas.append(ref.encode(raw, 5, 22))
+        want.append((len(raw), hashlib.sha256(raw).hexdigest()))
+    n = 2304  # nine blocks' worth per CU on a 256-CU device
+    idx = [i % len(datas) for i in range(n)]
+    batch = pkg.Batch(n)
+    results, outs = batch.decode_host([datas[i] for i in idx], [want[i][0] for i in idx], pkg.FLAG_LARGE_WINDOW)
+    batch.close()
+    for k, i in enumerate(idx):
+        r = results[k]
+        assert (r.result, r.decoded_size, r.consumed) == (1, want[i][0], len(datas[i])), (k, i)
+        assert hashlib.sha256(outs[k]).hexdigest() == want[i][1], (k, i)
