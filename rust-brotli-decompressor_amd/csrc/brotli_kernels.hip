@@ -955,53 +955,125 @@ __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_
 #define SPEC_STORE(mask, rank, val, ptr) asm volatile("s_mov_b64 exec, %0\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, -1" \
                                                       :: "s"(mask), "v"(rank), "v"(val), "s"(ptr) : "memory")
 
+// The same walk two symbols per step: Mv = code length where the symbol after this offset's still starts inside the
+// window (else 0), Jv = that length plus the next symbol's (else the length alone).
+#define SPEC_WALK2(Mv, Jv, entry, starts, woff) do { uint32_t t1_, t2_; \
+    asm volatile("s_mov_b64 %0, 0\n\ts_add_u32 %1, %6, 0xffffffc0\n" \
+                 "1:\n\tv_readlane_b32 %2, %4, %1\n\tv_readlane_b32 %3, %5, %1\n\ts_bitset1_b64 %0, %1\n\ts_add_u32 %2, %2, %1\n\t" \
+                 "s_bitset1_b64 %0, %2\n\ts_add_u32 %1, %1, %3\n\ts_cbranch_scc0 1b\n\t" \
+                 "s_add_u32 %1, %1, 64\n" \
+                 : "=&s"(starts), "=&s"(woff), "=&s"(t1_), "=&s"(t2_) : "v"(Mv), "v"(Jv), "s"(entry) : "scc"); } while (0)
+__device__ __forceinline__ uint32_t bperm(uint32_t byte_addr, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)byte_addr, (int)v); }
+
+// LDS operations of the chunk decoder are issued by hand and waited for by hand (SPEC_WAIT names the registers they
+// fill), so that a result can be asked for in one iteration of the loop and used in the next.
+#define SPEC_BPERM(dst, addr, data, OFF) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:" #OFF : "=v"(dst) : "v"(addr), "v"(data))
+#define SPEC_RD16(dst, addr) asm volatile("ds_read_u16 %0, %1" : "=v"(dst) : "v"(addr))
+#define SPEC_WAIT5(a, b, c, d, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
+#define SPEC_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+// address of the entry that decides the symbol at an offset: second-level where the root entry says so, else the root
+// entry once more (x = the 32 bits at the offset, r = its root entry)
+__device__ __forceinline__ uint32_t spec_entry_addr(uint32_t tree, uint32_t x, uint32_t r) {
+  const uint32_t Lr = r & 15u;
+  const bool sec = Lr > ROOT_BITS;
+  const uint32_t idx = (sec ? r >> 4 : 0u) + __builtin_amdgcn_ubfe(x, sec ? ROOT_BITS : 0u, sec ? Lr - ROOT_BITS : ROOT_BITS);
+  return tree + (idx << 1);
+}
+
 // One chunk: SPEC_WINDOWS windows from stream dword dw0 (+ sh bits), chain entered at bit `entry` of the first window.
 // Literals go to symout[0..n), per-window start masks / running counts to the LDS areas of wave slot w.
+// The loop is a software pipeline over windows, every LDS result is used one iteration after its request: while window
+// j is walked, the code lengths of j + 1 are on their way through ds_bpermute (every offset learns the length of the
+// symbol after its own, so the walk takes two symbols per step), the deciding table entries of j + 2 and the root
+// entries of j + 3 are being read and the stream bits of j + 4 gathered.  Two copies of the loop body hand the
+// registers to each other (A -> B -> A), so nothing is moved at the back edge.
 __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, uint32_t tree, gu8* symout, uint32_t entry) {
   const uint32_t lane = lane_id();
-  const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
   w = rfl(w); dw0 = rfl(dw0); sh = rfl(sh); tree = rfl(tree); entry = rfl(entry);
   symout = rfl_ptr(symout);
   gcu32* const base = BitReader::base();
   const uint32_t ndw = BitReader::n_dw(), tmask = BitReader::tail_mask();
-  uint32_t hc0, hc1;  // dwords [dw0, dw0 + 64) and [dw0 + 64, dw0 + 128) of the stream, one per lane
+  // sv[l] / sv1[l]: the 32 bits of the stream from bit 32 * l + sh of dword dw0 / dw0 + 64 on
+  uint32_t sv, sv1;
   {
     uint32_t i0 = dw0 + lane, i1 = dw0 + 64u + lane, v0 = 0, v1 = 0;
     if (i0 < ndw) v0 = base[i0];
     if (i1 < ndw) v1 = base[i1];
     if (i0 == ndw - 1u) v0 &= tmask;
     if (i1 == ndw - 1u) v1 &= tmask;
-    hc0 = v0; hc1 = v1;
+    const uint32_t nxt = ((lane + 1u) & 63u) << 2;
+    uint32_t n0 = bperm(nxt, v0), n1 = bperm(nxt, v1);
+    const uint32_t first1 = rdlane(v1, 0);
+    n0 = lane == 63u ? first1 : n0;               // (dword 128 of the chunk is never looked at)
+    sv = __builtin_amdgcn_alignbit(n0, v0, sh); sv1 = __builtin_amdgcn_alignbit(n1, v1, sh);
   }
-  uint32_t cnt = 0, e = entry;
-  for (uint32_t j = 0; j < SPEC_WINDOWS; j++) {
-    const uint32_t q = 2u * j;
-    const uint32_t a0 = rdlane(hc0, q), a1 = rdlane(hc0, q + 1u);
-    const uint32_t a2 = q + 2u < 64u ? rdlane(hc0, q + 2u) : rdlane(hc1, q + 2u - 64u);
-    const uint32_t a3 = q + 3u < 64u ? rdlane(hc0, q + 3u) : rdlane(hc1, q + 3u - 64u);
-    const uint64_t p01 = (uint64_t)a0 | ((uint64_t)a1 << 32), p12 = (uint64_t)a1 | ((uint64_t)a2 << 32), p23 = (uint64_t)a2 | ((uint64_t)a3 << 32);
-    const uint32_t w0 = (uint32_t)(p01 >> sh), w1 = (uint32_t)(p12 >> sh), w2 = (uint32_t)(p23 >> sh);
-    const uint32_t x = (__builtin_amdgcn_alignbit(w1, w0, lane) & lomask) | (__builtin_amdgcn_alignbit(w2, w1, lane) & ~lomask);
-    uint32_t en = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(&g_smem[tree + ((x & 0xFFu) << 1)]);
-    uint32_t L = en & 15u;
-    if (L > ROOT_BITS) {
-      uint32_t idx = (en >> 4) + ((x >> ROOT_BITS) & ((1u << (L - ROOT_BITS)) - 1u));
-      en = *reinterpret_cast<__attribute__((address_space(3))) const uint16_t*>(&g_smem[tree + (idx << 1)]);
-      L = ROOT_BITS + (en & 15u);
+  // a lane's view of window k: dwords 2k + (lane >> 5) and the one after, shifted by lane & 31
+  uint32_t va = (lane >> 5) << 2;
+  uint32_t g0A, g1A, x2A, r2A, Lr1A, e1A, L0A, sym0A, nl0A;
+  uint32_t g0B, g1B, x2B, r2B, Lr1B, e1B, L0B, sym0B, nl0B;
+  {  // fill the pipeline: windows 0 .. 3
+    uint32_t ga0, ga1, gb0, gb1, gc0, gc1;
+    SPEC_BPERM(ga0, va, sv, 0); SPEC_BPERM(ga1, va, sv, 4); SPEC_BPERM(gb0, va, sv, 8); SPEC_BPERM(gb1, va, sv, 12);
+    SPEC_WAIT4(ga0, ga1, gb0, gb1);
+    SPEC_BPERM(gc0, va, sv, 16); SPEC_BPERM(gc1, va, sv, 20); SPEC_BPERM(g0A, va, sv, 24); SPEC_BPERM(g1A, va, sv, 28);
+    const uint32_t x0 = __builtin_amdgcn_alignbit(ga1, ga0, lane), x1 = __builtin_amdgcn_alignbit(gb1, gb0, lane);
+    uint32_t r0, r1, e0;
+    SPEC_RD16(r0, tree + ((x0 & 0xFFu) << 1)); SPEC_RD16(r1, tree + ((x1 & 0xFFu) << 1));
+    SPEC_WAIT4(gc0, gc1, r0, r1);
+    asm volatile("" : "+v"(g0A), "+v"(g1A));
+    x2A = __builtin_amdgcn_alignbit(gc1, gc0, lane);
+    SPEC_RD16(r2A, tree + ((x2A & 0xFFu) << 1));
+    SPEC_RD16(e0, spec_entry_addr(tree, x0, r0)); SPEC_RD16(e1A, spec_entry_addr(tree, x1, r1));
+    Lr1A = r1 & 15u;
+    SPEC_WAIT4(r2A, e0, e1A, Lr1A);
+    const uint32_t Lr0 = r0 & 15u;
+    L0A = Lr0 > ROOT_BITS ? ROOT_BITS + (e0 & 15u) : Lr0; sym0A = e0 >> 4;
+    const uint32_t L1 = Lr1A > ROOT_BITS ? ROOT_BITS + (e1A & 15u) : Lr1A, sym1 = e1A >> 4;
+    // code length and symbol of every offset of the first two windows: what the decoding wave walks into the chunk with
+    lds_st8(LDS_HFIRST + w * 256u + lane, L0A); lds_st8(LDS_HFIRST + w * 256u + 64u + lane, sym0A);
+    lds_st8(LDS_HFIRST + w * 256u + 128u + lane, L1); lds_st8(LDS_HFIRST + w * 256u + 192u + lane, sym1);
+    const uint32_t na = (lane + L0A) << 2;
+    SPEC_BPERM(nl0A, na, L0A, 0);
+    SPEC_WAIT4(nl0A, g0A, g1A, L0A);
+    va += 24u;
+  }
+  uint32_t cnt = 0, e = entry, mlo = 0, mhi = 0, mcum = 0, j = 0;
+#define SPEC_BODY(I, O) do { \
+    va += 8u; SPEC_BPERM(g0##O, va, sv, 0); SPEC_BPERM(g1##O, va, sv, 4);                      /* window j + 4: stream bits */ \
+    x2##O = __builtin_amdgcn_alignbit(g1##I, g0##I, lane);                                     /* window j + 3: root entries */ \
+    { const uint32_t ra_ = tree + ((x2##O & 0xFFu) << 1); SPEC_RD16(r2##O, ra_); } \
+    { const uint32_t ea_ = spec_entry_addr(tree, x2##I, r2##I); Lr1##O = r2##I & 15u; SPEC_RD16(e1##O, ea_); }   /* j + 2: deciding entries */ \
+    L0##O = Lr1##I > ROOT_BITS ? ROOT_BITS + (e1##I & 15u) : Lr1##I; sym0##O = e1##I >> 4;     /* j + 1: lengths; ask for the next symbol's */ \
+    { const uint32_t na_ = (lane + L0##O) << 2; SPEC_BPERM(nl0##O, na_, L0##O, 0); } \
+    const bool in_ = lane + L0##I < 64u;                                                       /* window j: walk and store */ \
+    const uint32_t Mv_ = in_ ? L0##I : 0u, Jv_ = L0##I + (in_ ? nl0##I : 0u); \
+    uint64_t starts_; uint32_t woff_; \
+    SPEC_WALK2(Mv_, Jv_, e, starts_, woff_); \
+    const uint32_t rank_ = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts_, 0u)); \
+    gu8* so_ = symout + cnt; \
+    SPEC_STORE(starts_, rank_, sym0##I, so_); \
+    /* lane j keeps window j's start mask and the literals before it (m0 is free in this function) */ \
+    asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0" \
+                 : "+v"(mlo), "+v"(mhi), "+v"(mcum) : "s"((uint32_t)starts_), "s"((uint32_t)(starts_ >> 32)), "s"(cnt), "s"(j)); \
+    cnt += (uint32_t)__popcll(starts_); \
+    e = woff_ - 64u; j++; \
+    SPEC_WAIT5(g0##O, g1##O, r2##O, e1##O, nl0##O); \
+  } while (0)
+  for (uint32_t half = 0; half < SPEC_WINDOWS / 16u; half++) {
+    _Pragma("nounroll") for (uint32_t jj = 0; jj < 8u; jj++) {
+      SPEC_BODY(A, B);
+      SPEC_BODY(B, A);
     }
-    const uint32_t sym = en >> 4;
-    if (j < 2u) { lds_st8(LDS_HFIRST + w * 256u + j * 128u + lane, L); lds_st8(LDS_HFIRST + w * 256u + j * 128u + 64u + lane, sym); }
-    uint64_t starts; uint32_t woff;
-    SPEC_WALK(L, e, starts, woff);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u));
-    gu8* so = symout + cnt;
-    SPEC_STORE(starts, rank, sym, so);
-    if (lane == 0) {
-      *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_HMASK + w * 256u + j * 8u]) = starts;
-      lds_st32(LDS_HCUM + w * 128u + j * 4u, cnt);
-    }
-    cnt += (uint32_t)__popcll(starts);
-    e = woff - 64u;
+    // the next sixteen windows: dwords 32 .. 95 of what is loaded
+    const uint32_t far = ((lane + 32u) & 63u) << 2;
+    const uint32_t t0 = bperm(far, sv), t1 = bperm(far, sv1);
+    sv = lane < 32u ? t0 : t1;
+    va -= 128u;
+  }
+#undef SPEC_BODY
+  if (lane < SPEC_WINDOWS) {
+    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_HMASK + w * 256u + lane * 8u]) = (uint64_t)mlo | ((uint64_t)mhi << 32);
+    lds_st32(LDS_HCUM + w * 128u + lane * 4u, mcum);
   }
   hc_st(HC_N + w, cnt);
   hc_st(HC_EXIT + w, e);

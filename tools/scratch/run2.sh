@@ -1,1 +1,1 @@
-timeout 300 python tools/prof_workload.py long_backref 256 2>&1 | grep -v "^ticks\|^per command\|^fast\|amdgpu.ids" | tail
+timeout 300 python tools/prof_workload.py high_entropy 64 2>&1 | grep "spec rounds" | head -1
