@@ -938,7 +938,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   12-15 bit offset into the next chunk at which the chain of chunk 0-3 ends
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_DONE = 5, HC_N = 8, HC_EXIT = 12 };
 constexpr uint32_t SPEC_WINDOWS = 32;          // windows of 64 bits per chunk
-constexpr uint32_t SPEC_ROUND_MIN = 16384;     // literals a run must still have for a round (a round holds at most 8192)
+constexpr uint32_t SPEC_ROUND_MIN = 768;       // literals a run must still have for a round to pay
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
 __device__ __forceinline__ uint32_t hc_ld(uint32_t w) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w])); }
 __device__ __forceinline__ void hc_st(uint32_t w, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w]) = v; }
@@ -1091,7 +1091,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1..3 */, gu8* scra
     seq = j;
     lds_acquire();
     if (hc_ld(HC_KIND) != 1u) return;
-    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), scratch_sym + (me - 1u) * 2048u, 0u);
+    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), scratch_sym + me * 2048u, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the literals are in memory before the round is reported done
     lds_release();
     hc_st(HC_DONE + me - 1u, seq);
@@ -1225,6 +1225,23 @@ __device__ unsigned long long g_spec_prof[8];
 #define SPEC_PROF(k) do { } while (0)
 #define SPEC_COUNT(k, v) do { } while (0)
 #endif
+// position of the n-th (0-based) set bit of a mask that has more than n
+__device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t n) {
+  const uint32_t lane = lane_id();
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  return (uint32_t)__builtin_ctzll(__ballot(((m >> lane) & 1ull) != 0 && rank == n));
+}
+// bit offset inside chunk w at which the t-th literal of its chain starts (t < the chunk's literal count)
+__device__ __noinline__ uint32_t spec_locate(uint32_t w, uint32_t t) {
+  const uint32_t lane = lane_id();
+  w = rfl(w); t = rfl(t);
+  const uint32_t cum = lane < SPEC_WINDOWS ? lds_ld32(LDS_HCUM + w * 128u + lane * 4u) : 0xFFFFFFFFu;
+  const uint32_t k = (uint32_t)__popcll(__ballot(cum <= t)) - 1u;  // the window the literal starts in
+  const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_HMASK + w * 256u + k * 8u]);
+  const uint64_t m = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
+  return k * 64u + nth_set_bit(m, t - rdlane(cum, k));
+}
+
 __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   const uint32_t lane = lane_id();
   tree_addr = rfl(tree_addr);
@@ -1233,99 +1250,128 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
   br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
   gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
+  gu8* const spec = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_SPEC_LO) | ((uint64_t)LEAN_LD(L_SPEC_HI) << 32));
   uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
   uint32_t i = LEAN_LD(L_LITS_LEFT);
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
-        while (i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw && hc_ld(HC_KIND) != 3u) {
+  while (i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw && hc_ld(HC_KIND) != 3u) {
 #ifdef BROTLI_AMD_PROFILE_SPEC
-          uint64_t sp_t = __builtin_amdgcn_s_memtime();
+    uint64_t sp_t = __builtin_amdgcn_s_memtime();
 #endif
-          const uint64_t run_pos = br.pos();
-          const uint64_t abs0 = run_pos + BitReader::skip_bits();
-          const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
-          const uint32_t seq = hc_ld(HC_SEQ) + 1u;
-          hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1);
-          lds_release();
-          hc_st(HC_SEQ, seq);
-          br.request_ahead(dw0 + SPEC_WINDOWS * 8u);  // where the round will normally end: there by the time it does
-          spec_chunk(0, dw0, sh, tree_addr, out + P, 0);  // the first chunk: its first bit does start a literal
-          SPEC_PROF(0);
-          uint64_t Pc = P + hc_ld(HC_N);
-          uint32_t e = hc_ld(HC_EXIT);
-          uint32_t bits_done = SPEC_WINDOWS * 64u + e;
-          bool lost = false;
-          for (uint32_t w = 1; w < 4; w++) {  // (bounded: helpers that never answer must not hang the GPU)
-            uint32_t polls = 0;
-            while (hc_ld(HC_DONE + w - 1u) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
-            if (lost) break;
-          }
-          lds_acquire();
-          SPEC_PROF(1);
-          gu8* const spec = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_SPEC_LO) | ((uint64_t)LEAN_LD(L_SPEC_HI) << 32));
-          uint32_t cp_src[3] = {0u, 0u, 0u}, cp_dst[3] = {0u, 0u, 0u}, cp_n[3] = {0u, 0u, 0u};
-          _Pragma("unroll") for (uint32_t w = 1; w < 4; w++) {
-            if (lost) break;
-            // walk the true chain into chunk w until it steps on a start the helper marked too
-            bool synced = false;
-            uint32_t skip = 0;
-            for (uint32_t j = 0; j < 2u && !synced; j++) {
-              const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_HMASK + w * 256u + j * 8u]);
-              const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
-              const uint32_t Lv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + lane), sv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + 64u + lane);
-              uint64_t tstarts; uint32_t woff;
-              SPEC_WALK(Lv, e, tstarts, woff);
-              const uint64_t common = tstarts & smask;
-              uint64_t mine = tstarts;  // literals of this window that only the true chain has
-              if (common) {
-                const uint32_t p = (uint32_t)__builtin_ctzll(common);
-                mine = tstarts & ((1ull << p) - 1ull);
-                skip = rfl(lds_ld32(LDS_HCUM + w * 128u + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
-                synced = true;
-              }
-              const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-              gu8* wq = out + Pc;
-              SPEC_STORE(mine, rank, sv, wq);
-              Pc += (uint32_t)__popcll(mine);
-              if (!synced) { e = woff - 64u; bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + e; }
-            }
-            if (!synced) break;  // no common start within two windows: the round ends here, the run goes on from there
-            // the helper's literals from the common start on are the stream's; they are moved into place below
-            const uint32_t valid = hc_ld(HC_N + w) - skip;
-            cp_src[w - 1u] = (w - 1u) * 2048u + skip; cp_dst[w - 1u] = (uint32_t)(Pc - P); cp_n[w - 1u] = valid;
-            Pc += valid;
-            e = hc_ld(HC_EXIT + w);
-            bits_done = (w + 1u) * SPEC_WINDOWS * 64u + e;
-          }
-          SPEC_PROF(2);
-          {  // all loads of the (up to three) moves first, then the stores: one memory round trip, not three
-            u32x4 t[3][2] = {};
-            _Pragma("unroll") for (uint32_t k = 0; k < 3u; k++)
-              _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
-                const uint32_t c = lane + 64u * h;
-                if (c < (cp_n[k] >> 4)) t[k][h] = *reinterpret_cast<gu32x4*>(spec + cp_src[k] + (uint64_t)c * 16);
-              }
-            uint32_t tail[3] = {0u, 0u, 0u};
-            _Pragma("unroll") for (uint32_t k = 0; k < 3u; k++) {
-              const uint32_t n16 = cp_n[k] >> 4;
-              if (lane < (cp_n[k] & 15u)) tail[k] = spec[cp_src[k] + (n16 << 4) + lane];
-            }
-            _Pragma("unroll") for (uint32_t k = 0; k < 3u; k++) {
-              gu8* dst = out + P + cp_dst[k];
-              const uint32_t n16 = cp_n[k] >> 4;
-              _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
-                const uint32_t c = lane + 64u * h;
-                if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[k][h];
-              }
-              if (lane < (cp_n[k] & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail[k];
-            }
-          }
-          SPEC_PROF(3);
-          if (lost) hc_st(HC_KIND, 3);  // helpers unusable from now on
-          const uint32_t got = (uint32_t)(Pc - P);
-          P = Pc; i -= got;
-          br.seek_ahead(run_pos + bits_done);
-          SPEC_PROF(4); SPEC_COUNT(5, 1); SPEC_COUNT(6, got); SPEC_COUNT(7, bits_done);
+    // A round decodes up to 4 * 2048 literals (+ a few).  Where the run has fewer left, the round is *capped*: nothing
+    // goes to the output directly (chunk 0 uses scratch slot 0 like the helpers), and the round ends at the run's last
+    // literal, whose bit position the start masks give.
+    const uint32_t cap = i;
+    const bool capped = i < SPEC_WINDOWS * 64u * 4u + 64u;
+    const uint64_t run_pos = br.pos();
+    const uint64_t abs0 = run_pos + BitReader::skip_bits();
+    const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
+    const uint32_t seq = hc_ld(HC_SEQ) + 1u;
+    hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1);
+    lds_release();
+    hc_st(HC_SEQ, seq);
+    br.request_ahead(dw0 + SPEC_WINDOWS * 8u);  // where the round will normally end: there by the time it does
+    spec_chunk(0, dw0, sh, tree_addr, capped ? spec : out + P, 0);  // the first chunk: its first bit does start a literal
+    SPEC_PROF(0);
+    uint32_t cp_src[4] = {0u, 0u, 0u, 0u}, cp_dst[4] = {0u, 0u, 0u, 0u}, cp_n[4] = {0u, 0u, 0u, 0u};
+    uint32_t acc = hc_ld(HC_N);  // literals of the round so far
+    uint32_t e = hc_ld(HC_EXIT);
+    uint32_t bits_done = SPEC_WINDOWS * 64u + e;
+    bool full = false;           // the run's last literal has been reached
+    if (capped) {
+      if (acc >= cap) { bits_done = acc == cap ? bits_done : spec_locate(0, cap); acc = cap; full = true; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0's literals are in the scratch slot
+      cp_n[0] = acc;
+    }
+    bool lost = false;
+    for (uint32_t w = 1; w < 4; w++) {  // (bounded: helpers that never answer must not hang the GPU)
+      uint32_t polls = 0;
+      while (hc_ld(HC_DONE + w - 1u) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
+      if (lost) break;
+    }
+    lds_acquire();
+    SPEC_PROF(1);
+    _Pragma("unroll") for (uint32_t w = 1; w < 4; w++) {
+      if (lost || full) break;
+      // walk the true chain into chunk w until it steps on a start the helper marked too
+      bool synced = false;
+      uint32_t skip = 0;
+      for (uint32_t j = 0; j < 2u && !synced && !full; j++) {
+        const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_HMASK + w * 256u + j * 8u]);
+        const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
+        const uint32_t Lv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + lane), sv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + 64u + lane);
+        uint64_t tstarts; uint32_t woff;
+        SPEC_WALK(Lv, e, tstarts, woff);
+        const uint64_t common = tstarts & smask;
+        uint64_t mine = tstarts;  // literals of this window that only the true chain has
+        if (common) {
+          const uint32_t p = (uint32_t)__builtin_ctzll(common);
+          mine = tstarts & ((1ull << p) - 1ull);
+          skip = rfl(lds_ld32(LDS_HCUM + w * 128u + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
+          synced = true;
         }
+        uint32_t nm = (uint32_t)__popcll(mine);
+        if (capped && acc + nm >= cap) {  // the run ends among them
+          if (acc + nm > cap || !synced) {
+            // (ends exactly with the window's last own literal and no common start: the position after it is what
+            // the walk left the window at, unless the chain goes on inside this window -- then it is the next start)
+            const uint32_t n = cap - acc;
+            if (n < nm) { const uint32_t pos = nth_set_bit(mine, n); mine &= (1ull << pos) - 1ull; bits_done = (w * SPEC_WINDOWS + j) * 64u + pos; }
+            else bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + (woff - 64u);
+            nm = n; full = true; synced = false;
+          } else {
+            // ends exactly in front of the common start
+            bits_done = (w * SPEC_WINDOWS + j) * 64u + (uint32_t)__builtin_ctzll(common);
+            full = true; synced = false;
+          }
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        gu8* wq = out + P + acc;
+        SPEC_STORE(mine, rank, sv, wq);
+        acc += nm;
+        if (!synced && !full) { e = woff - 64u; bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + e; }
+      }
+      if (!synced) break;  // no common start within two windows (or the run is complete): the round ends here
+      // the helper's literals from the common start on are the stream's; they are moved into place below
+      uint32_t valid = hc_ld(HC_N + w) - skip;
+      e = hc_ld(HC_EXIT + w);
+      bits_done = (w + 1u) * SPEC_WINDOWS * 64u + e;
+      if (capped && acc + valid >= cap) {
+        if (acc + valid > cap) { valid = cap - acc; bits_done = w * SPEC_WINDOWS * 64u + spec_locate(w, skip + valid); }
+        full = true;
+      }
+      cp_src[w] = w * 2048u + skip; cp_dst[w] = acc; cp_n[w] = valid;
+      acc += valid;
+    }
+    SPEC_PROF(2);
+    {  // all loads of the (up to four) moves first, then the stores: one memory round trip
+      u32x4 t[4][2] = {};
+      _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++)
+        _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
+          const uint32_t c = lane + 64u * h;
+          if (c < (cp_n[k] >> 4)) t[k][h] = *reinterpret_cast<gu32x4*>(spec + cp_src[k] + (uint64_t)c * 16);
+        }
+      uint32_t tail[4] = {0u, 0u, 0u, 0u};
+      _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t n16 = cp_n[k] >> 4;
+        if (lane < (cp_n[k] & 15u)) tail[k] = spec[cp_src[k] + (n16 << 4) + lane];
+      }
+      _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++) {
+        gu8* dst = out + P + cp_dst[k];
+        const uint32_t n16 = cp_n[k] >> 4;
+        _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
+          const uint32_t c = lane + 64u * h;
+          if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[k][h];
+        }
+        if (lane < (cp_n[k] & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail[k];
+      }
+    }
+    SPEC_PROF(3);
+    if (lost) hc_st(HC_KIND, 3);  // helpers unusable from now on
+    P += acc; i -= acc;
+    br.seek_ahead(run_pos + bits_done);
+    SPEC_PROF(4); SPEC_COUNT(5, 1); SPEC_COUNT(6, acc); SPEC_COUNT(7, bits_done);
+  }
   lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
   if (lane == 0) {
     LEAN_ST(L_CHUNK_BASE, br.chunk_base);

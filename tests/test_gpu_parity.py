@@ -357,3 +357,36 @@ def test_batches_larger_than_the_resident_grid(pkg):
         r = results[k]
         assert (r.result, r.decoded_size, r.consumed) == (1, want[i][0], len(datas[i])), (k, i)
         assert hashlib.sha256(outs[k]).hexdigest() == want[i][1], (k, i)
+
+
+def test_literal_runs_of_many_lengths(pkg):
+    """Literal runs from a few hundred to tens of thousands of bytes, at entropies from under two bits to nearly eight
+    per literal, separated by copies: rounds of the helper waves that end in the middle of a chunk because the run does
+    (the last literal's bit position comes from the recorded start masks), runs too short for a round, runs that end
+    exactly at a window or chunk boundary by chance.  Also decoded into buffers that end inside a run."""
+    import numpy as np
+    import libbrotli_ref as ref
+    if not ref.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    rng = np.random.Generator(np.random.PCG64(2024))
+    datas, raws = [], []
+    for skew, nsym in ((0.2, 256), (1.0, 256), (2.0, 64), (3.0, 8), (0.0, 200)):
+        p = np.arange(1, nsym + 1, dtype=np.float64) ** -skew
+        p /= p.sum()
+        perm = rng.permutation(256)[:nsym]
+        parts, filler = [], rng.integers(0, 256, size=4096, dtype=np.uint8).tobytes()
+        parts.append(filler)
+        for run in (700, 767, 768, 769, 1100, 2047, 2048, 2049, 3000, 4095, 5000, 8191, 8256, 9000, 12000, 16383, 16385, 20000, 33000):
+            run += int(rng.integers(0, 3))
+            parts.append(perm[rng.choice(nsym, size=run, p=p)].astype(np.uint8).tobytes())
+            parts.append(filler[: int(rng.integers(16, 600))])  # a copy from the start of the stream
+        raw = b"".join(parts)
+        c = ref.encode(raw, 5, 22)
+        info, out = oracle.decode(c, len(raw), 1)
+        assert info.result == 1 and out == raw
+        datas.append(c); raws.append(raw)
+    all_d, all_caps = [], []
+    for c, raw in zip(datas, raws):
+        for cap in (len(raw), len(raw) - 1, len(raw) // 2, len(raw) // 3, 4096 + 700 + 300, 40000, 100001):
+            all_d.append(c); all_caps.append(cap)
+    _check_against_oracle(pkg, all_d, all_caps, 1, "literal runs")
