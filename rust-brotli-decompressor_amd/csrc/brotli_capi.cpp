@@ -28,6 +28,7 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
                                                uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves);
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void);
+extern "C" uint32_t brotli_amd_lds_helper_bytes(void);
 extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictionary.bin, 122784 bytes
 
 namespace {
@@ -91,7 +92,7 @@ struct BrotliAmdBatch {
   uint32_t cur_arena = 0, cus = 0, lds_fixed = 0;
   size_t lds_per_cu = 0;
   // second pass for streams whose tables did not fit the LDS arena of the first (BROTLI_AMD_FLAG_NO_SPILL)
-  uint32_t max_arena = 0, retry_grid_max = 0, last_retry_count = 0;
+  uint32_t max_arena = 0, retry_grid_max = 0, last_retry_count = 0, lds_helper = 0;
   BrotliAmdStreamDesc* d_retry_descs = nullptr;
   BrotliAmdStreamStatus* d_retry_status = nullptr;
   BrotliAmdStreamDesc* h_retry_descs = nullptr;    // pinned
@@ -132,8 +133,9 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   if (b->auto_arena && b->small_arena_pays && n > b->grid_max && b->max_arena > b->lds_arena) {
     const uint32_t per_cu = (uint32_t)std::min<size_t>(8, ((size_t)n + b->cus - 1) / b->cus);       // blocks per CU wanted
     const uint32_t per_block = (uint32_t)(b->lds_per_cu / per_cu) & ~255u;
-    if (per_block > b->lds_fixed + 8192u && per_block - b->lds_fixed < b->lds_arena) {
-      b->cur_arena = (per_block - b->lds_fixed) & ~15u;
+    const uint32_t carve = b->lds_fixed + (per_cu <= 4u ? b->lds_helper : 0u);  // (more than four blocks per CU: one-wave blocks)
+    if (per_block > carve + 8192u && per_block - carve < b->lds_arena) {
+      b->cur_arena = (per_block - carve) & ~15u;
       grid_max = b->cus * per_cu;
     }
   }
@@ -200,17 +202,18 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   b->max_streams = max_streams;
   hipDeviceProp_t prop;
   if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) { delete b; return nullptr; }
-  uint32_t fixed = brotli_amd_lds_fixed_bytes();
-  uint32_t per_block = lds_arena_bytes ? lds_arena_bytes + fixed : kDefaultLdsPerBlock;
+  // LDS of a block = fixed carve + table arena (+ what the helper waves leave for each other, in blocks that have them)
+  const uint32_t fixed = brotli_amd_lds_fixed_bytes(), helper = brotli_amd_lds_helper_bytes();
+  uint32_t per_block = lds_arena_bytes ? lds_arena_bytes + fixed + helper : kDefaultLdsPerBlock;
   size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
   if (per_block > prop.sharedMemPerBlock && prop.sharedMemPerBlock) per_block = (uint32_t)prop.sharedMemPerBlock;
-  b->lds_arena = (per_block - fixed) & ~15u;
+  b->lds_arena = (per_block - fixed - helper) & ~15u;
   b->cur_arena = b->lds_arena;
   b->auto_arena = lds_arena_bytes == 0;
-  b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_per_cu = lds_cu;
+  b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_helper = helper; b->lds_per_cu = lds_cu;
   {  // the arena of the second pass: the largest block the device allows (at most 64 KiB: two such blocks per CU at least)
     uint32_t big = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
-    b->max_arena = big > fixed ? (big - fixed) & ~15u : 0;
+    b->max_arena = big > fixed + helper ? (big - fixed - helper) & ~15u : 0;
     b->retry_grid_max = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max<size_t>(1, lds_cu / big);
   }
   uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cu / per_block));

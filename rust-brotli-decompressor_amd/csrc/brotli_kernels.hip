@@ -88,11 +88,20 @@ constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit 
 constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
 constexpr uint32_t LDS_LEAN = LDS_HOT + 96;                 // 192: state handed between process_commands and lean_commands
 constexpr uint32_t LDS_LEANWIN = LDS_LEAN + 192;            // 256: the reader's register window, handed over with the state
-constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 64: mailbox between the decoding wave and its three helper waves
-constexpr uint32_t LDS_HMASK = LDS_HCTL + 64;               // 4 x 256: per wave and window of its chunk, which bit offsets start a literal
-constexpr uint32_t LDS_HCUM = LDS_HMASK + 1024;             // 4 x 128: per wave and window, literals in the chunk's windows before it
-constexpr uint32_t LDS_HFIRST = LDS_HCUM + 512;             // 4 x 256: code lengths and symbols of all offsets of a chunk's first two windows
-constexpr uint32_t LDS_FIXED = LDS_HFIRST + 1024;           // = 8704, 16-byte aligned
+constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 80: mailbox between the decoding wave and its three helper waves
+constexpr uint32_t LDS_FIXED = LDS_HCTL + 80;               // = 6224, 16-byte aligned
+// Blocks launched with helper waves have, behind the table arena, what the waves of a round leave for each other
+// (offsets from the runtime base in mailbox word HC_BASE; one slot per wave of the block):
+constexpr uint32_t SPEC_WINDOWS = 32;                        // windows of 64 bits per chunk
+constexpr uint32_t SPEC_FIRST = 4;                           // windows at the start of a chunk the decoding wave may walk itself
+constexpr uint32_t HL_MASK = 0;                              // 4 x SPEC_WINDOWS x 8: per window of the chunk, which bit offsets start a literal
+constexpr uint32_t HL_MASK_SLOT = SPEC_WINDOWS * 8;
+constexpr uint32_t HL_CUM = HL_MASK + 4 * HL_MASK_SLOT;      // 4 x SPEC_WINDOWS x 4: literals in the chunk's windows before this one
+constexpr uint32_t HL_CUM_SLOT = SPEC_WINDOWS * 4;
+constexpr uint32_t HL_FIRST = HL_CUM + 4 * HL_CUM_SLOT;      // 4 x SPEC_FIRST x 128: code length and symbol at every offset of the chunk's first windows
+constexpr uint32_t HL_FIRST_SLOT = SPEC_FIRST * 128;
+constexpr uint32_t HELPER_LDS = HL_FIRST + 4 * HL_FIRST_SLOT;
+static_assert(4u * SPEC_WINDOWS * 64u <= BROTLI_AMD_SPEC_SCRATCH, "one scratch slot of a chunk's literals per wave");
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -936,9 +945,9 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   HCTL words: 0 round number   1 kind (1 = round, 2 = exit)   2 first dword of the round   3 bit offset in it
 //   4 LDS address of the literal tree   5-7 round finished by helper 1-3   8-11 literals in chunk 0-3
 //   12-15 bit offset into the next chunk at which the chain of chunk 0-3 ends
-enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_DONE = 5, HC_N = 8, HC_EXIT = 12 };
-constexpr uint32_t SPEC_WINDOWS = 32;          // windows of 64 bits per chunk
+enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_DONE = 5, HC_N = 8, HC_EXIT = 12, HC_BASE = 16 };
 constexpr uint32_t SPEC_ROUND_MIN = 768;       // literals a run must still have for a round to pay
+constexpr uint32_t SPEC_INPUT_DWORDS = 4u * SPEC_WINDOWS * 2u + 74u;  // input a round may look at, from the reader's next dword on
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
 __device__ __forceinline__ uint32_t hc_ld(uint32_t w) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w])); }
 __device__ __forceinline__ void hc_st(uint32_t w, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w]) = v; }
@@ -991,22 +1000,35 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
   const uint32_t lane = lane_id();
   w = rfl(w); dw0 = rfl(dw0); sh = rfl(sh); tree = rfl(tree); entry = rfl(entry);
   symout = rfl_ptr(symout);
+  const uint32_t hb = hc_ld(HC_BASE);
+  const uint32_t hfirst = hb + HL_FIRST + w * HL_FIRST_SLOT;
   gcu32* const base = BitReader::base();
   const uint32_t ndw = BitReader::n_dw(), tmask = BitReader::tail_mask();
-  // sv[l] / sv1[l]: the 32 bits of the stream from bit 32 * l + sh of dword dw0 / dw0 + 64 on
-  uint32_t sv, sv1;
+  // sa[l], sb[l], sc[l]: the 32 bits of the stream from bit 32 * l + sh of dword dw0, dw0 + 64, dw0 + 128 on
+  uint32_t sa, sb, sc = 0;
   {
-    uint32_t i0 = dw0 + lane, i1 = dw0 + 64u + lane, v0 = 0, v1 = 0;
+    constexpr bool three = SPEC_WINDOWS > 32u;
+    uint32_t i0 = dw0 + lane, i1 = dw0 + 64u + lane, i2 = dw0 + 128u + lane, v0 = 0, v1 = 0, v2 = 0;
     if (i0 < ndw) v0 = base[i0];
     if (i1 < ndw) v1 = base[i1];
+    if (three && i2 < ndw) v2 = base[i2];
     if (i0 == ndw - 1u) v0 &= tmask;
     if (i1 == ndw - 1u) v1 &= tmask;
+    if (three && i2 == ndw - 1u) v2 &= tmask;
     const uint32_t nxt = ((lane + 1u) & 63u) << 2;
     uint32_t n0 = bperm(nxt, v0), n1 = bperm(nxt, v1);
     const uint32_t first1 = rdlane(v1, 0);
-    n0 = lane == 63u ? first1 : n0;               // (dword 128 of the chunk is never looked at)
-    sv = __builtin_amdgcn_alignbit(n0, v0, sh); sv1 = __builtin_amdgcn_alignbit(n1, v1, sh);
+    n0 = lane == 63u ? first1 : n0;
+    sa = __builtin_amdgcn_alignbit(n0, v0, sh);
+    if (three) {
+      uint32_t n2 = bperm(nxt, v2);
+      const uint32_t first2 = rdlane(v2, 0);
+      n1 = lane == 63u ? first2 : n1;
+      sc = __builtin_amdgcn_alignbit(n2, v2, sh);  // (its last dword is never looked at)
+    }
+    sb = __builtin_amdgcn_alignbit(n1, v1, sh);     // (two vectors: its last dword is never looked at)
   }
+  uint32_t sv = sa;  // the 64 dwords the current sixteen windows (and the four the pipeline is ahead) come from
   // a lane's view of window k: dwords 2k + (lane >> 5) and the one after, shifted by lane & 31
   uint32_t va = (lane >> 5) << 2;
   uint32_t g0A, g1A, x2A, r2A, Lr1A, e1A, L0A, sym0A, nl0A;
@@ -1028,10 +1050,8 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
     SPEC_WAIT4(r2A, e0, e1A, Lr1A);
     const uint32_t Lr0 = r0 & 15u;
     L0A = Lr0 > ROOT_BITS ? ROOT_BITS + (e0 & 15u) : Lr0; sym0A = e0 >> 4;
-    const uint32_t L1 = Lr1A > ROOT_BITS ? ROOT_BITS + (e1A & 15u) : Lr1A, sym1 = e1A >> 4;
-    // code length and symbol of every offset of the first two windows: what the decoding wave walks into the chunk with
-    lds_st8(LDS_HFIRST + w * 256u + lane, L0A); lds_st8(LDS_HFIRST + w * 256u + 64u + lane, sym0A);
-    lds_st8(LDS_HFIRST + w * 256u + 128u + lane, L1); lds_st8(LDS_HFIRST + w * 256u + 192u + lane, sym1);
+    // code length and symbol of every offset of the first windows: what the decoding wave walks into the chunk with
+    lds_st8(hfirst + lane, L0A); lds_st8(hfirst + 64u + lane, sym0A);
     const uint32_t na = (lane + L0A) << 2;
     SPEC_BPERM(nl0A, na, L0A, 0);
     SPEC_WAIT4(nl0A, g0A, g1A, L0A);
@@ -1045,6 +1065,7 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
     { const uint32_t ea_ = spec_entry_addr(tree, x2##I, r2##I); Lr1##O = r2##I & 15u; SPEC_RD16(e1##O, ea_); }   /* j + 2: deciding entries */ \
     L0##O = Lr1##I > ROOT_BITS ? ROOT_BITS + (e1##I & 15u) : Lr1##I; sym0##O = e1##I >> 4;     /* j + 1: lengths; ask for the next symbol's */ \
     { const uint32_t na_ = (lane + L0##O) << 2; SPEC_BPERM(nl0##O, na_, L0##O, 0); } \
+    if (j + 1u < SPEC_FIRST) { lds_st8(hfirst + (j + 1u) * 128u + lane, L0##O); lds_st8(hfirst + (j + 1u) * 128u + 64u + lane, sym0##O); } \
     const bool in_ = lane + L0##I < 64u;                                                       /* window j: walk and store */ \
     const uint32_t Mv_ = in_ ? L0##I : 0u, Jv_ = L0##I + (in_ ? nl0##I : 0u); \
     uint64_t starts_; uint32_t woff_; \
@@ -1059,21 +1080,25 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
     e = woff_ - 64u; j++; \
     SPEC_WAIT5(g0##O, g1##O, r2##O, e1##O, nl0##O); \
   } while (0)
-  for (uint32_t half = 0; half < SPEC_WINDOWS / 16u; half++) {
+  _Pragma("nounroll") for (uint32_t q = 0; q < SPEC_WINDOWS / 16u; q++) {
     _Pragma("nounroll") for (uint32_t jj = 0; jj < 8u; jj++) {
       SPEC_BODY(A, B);
       SPEC_BODY(B, A);
     }
-    // the next sixteen windows: dwords 32 .. 95 of what is loaded
-    const uint32_t far = ((lane + 32u) & 63u) << 2;
-    const uint32_t t0 = bperm(far, sv), t1 = bperm(far, sv1);
-    sv = lane < 32u ? t0 : t1;
+    // the next sixteen windows: 32 dwords further on
+    if ((q & 1u) == 0u) {
+      const uint32_t far = ((lane + 32u) & 63u) << 2;
+      const uint32_t t0 = bperm(far, sa), t1 = bperm(far, sb);
+      sv = lane < 32u ? t0 : t1;
+    } else {
+      sa = sb; sb = sc; sv = sa;
+    }
     va -= 128u;
   }
 #undef SPEC_BODY
   if (lane < SPEC_WINDOWS) {
-    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[LDS_HMASK + w * 256u + lane * 8u]) = (uint64_t)mlo | ((uint64_t)mhi << 32);
-    lds_st32(LDS_HCUM + w * 128u + lane * 4u, mcum);
+    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[hb + HL_MASK + w * HL_MASK_SLOT + lane * 8u]) = (uint64_t)mlo | ((uint64_t)mhi << 32);
+    lds_st32(hb + HL_CUM + w * HL_CUM_SLOT + lane * 4u, mcum);
   }
   hc_st(HC_N + w, cnt);
   hc_st(HC_EXIT + w, e);
@@ -1091,7 +1116,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1..3 */, gu8* scra
     seq = j;
     lds_acquire();
     if (hc_ld(HC_KIND) != 1u) return;
-    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), scratch_sym + me * 2048u, 0u);
+    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), scratch_sym + me * (SPEC_WINDOWS * 64u), 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the literals are in memory before the round is reported done
     lds_release();
     hc_st(HC_DONE + me - 1u, seq);
@@ -1235,9 +1260,10 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t n) {
 __device__ __noinline__ uint32_t spec_locate(uint32_t w, uint32_t t) {
   const uint32_t lane = lane_id();
   w = rfl(w); t = rfl(t);
-  const uint32_t cum = lane < SPEC_WINDOWS ? lds_ld32(LDS_HCUM + w * 128u + lane * 4u) : 0xFFFFFFFFu;
+  const uint32_t hb = hc_ld(HC_BASE);
+  const uint32_t cum = lane < SPEC_WINDOWS ? lds_ld32(hb + HL_CUM + w * HL_CUM_SLOT + lane * 4u) : 0xFFFFFFFFu;
   const uint32_t k = (uint32_t)__popcll(__ballot(cum <= t)) - 1u;  // the window the literal starts in
-  const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_HMASK + w * 256u + k * 8u]);
+  const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[hb + HL_MASK + w * HL_MASK_SLOT + k * 8u]);
   const uint64_t m = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
   return k * 64u + nth_set_bit(m, t - rdlane(cum, k));
 }
@@ -1254,7 +1280,8 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
   uint32_t i = LEAN_LD(L_LITS_LEFT);
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
-  while (i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw && hc_ld(HC_KIND) != 3u) {
+  const uint32_t hb = hc_ld(HC_BASE);
+  while (i >= SPEC_ROUND_MIN && br.next_dw + SPEC_INPUT_DWORDS < safe_dw && hc_ld(HC_KIND) != 3u) {
 #ifdef BROTLI_AMD_PROFILE_SPEC
     uint64_t sp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1296,10 +1323,10 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
       // walk the true chain into chunk w until it steps on a start the helper marked too
       bool synced = false;
       uint32_t skip = 0;
-      for (uint32_t j = 0; j < 2u && !synced && !full; j++) {
-        const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[LDS_HMASK + w * 256u + j * 8u]);
+      for (uint32_t j = 0; j < SPEC_FIRST && !synced && !full; j++) {
+        const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[hb + HL_MASK + w * HL_MASK_SLOT + j * 8u]);
         const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
-        const uint32_t Lv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + lane), sv = lds_ld8(LDS_HFIRST + w * 256u + j * 128u + 64u + lane);
+        const uint32_t Lv = lds_ld8(hb + HL_FIRST + w * HL_FIRST_SLOT + j * 128u + lane), sv = lds_ld8(hb + HL_FIRST + w * HL_FIRST_SLOT + j * 128u + 64u + lane);
         uint64_t tstarts; uint32_t woff;
         SPEC_WALK(Lv, e, tstarts, woff);
         const uint64_t common = tstarts & smask;
@@ -1307,7 +1334,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
         if (common) {
           const uint32_t p = (uint32_t)__builtin_ctzll(common);
           mine = tstarts & ((1ull << p) - 1ull);
-          skip = rfl(lds_ld32(LDS_HCUM + w * 128u + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
+          skip = rfl(lds_ld32(hb + HL_CUM + w * HL_CUM_SLOT + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
           synced = true;
         }
         uint32_t nm = (uint32_t)__popcll(mine);
@@ -1340,14 +1367,15 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
         if (acc + valid > cap) { valid = cap - acc; bits_done = w * SPEC_WINDOWS * 64u + spec_locate(w, skip + valid); }
         full = true;
       }
-      cp_src[w] = w * 2048u + skip; cp_dst[w] = acc; cp_n[w] = valid;
+      cp_src[w] = w * (SPEC_WINDOWS * 64u) + skip; cp_dst[w] = acc; cp_n[w] = valid;
       acc += valid;
     }
     SPEC_PROF(2);
     {  // all loads of the (up to four) moves first, then the stores: one memory round trip
-      u32x4 t[4][2] = {};
+      constexpr uint32_t H = SPEC_WINDOWS / 16u;  // 1 KiB steps per slot
+      u32x4 t[4][H] = {};
       _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++)
-        _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
+        _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
           const uint32_t c = lane + 64u * h;
           if (c < (cp_n[k] >> 4)) t[k][h] = *reinterpret_cast<gu32x4*>(spec + cp_src[k] + (uint64_t)c * 16);
         }
@@ -1359,7 +1387,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
       _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++) {
         gu8* dst = out + P + cp_dst[k];
         const uint32_t n16 = cp_n[k] >> 4;
-        _Pragma("unroll") for (uint32_t h = 0; h < 2u; h++) {
+        _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
           const uint32_t c = lane + 64u * h;
           if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[k][h];
         }
@@ -1486,7 +1514,7 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
           i--;
         }
       }
-      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + 330u < safe_dw) {
+      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + SPEC_INPUT_DWORDS < safe_dw) {
         // ---- long run: rounds of four chunks, three of them decoded speculatively by the helper waves (spec_rounds) ----
         LEAN_FLUSH();
         lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
@@ -2484,7 +2512,8 @@ extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(co
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
   // waves 1-3 are helpers (see helper_wave); their mailbox is cleared before the four part ways
-  if (threadIdx.x < 16u && (uint32_t)(uintptr_t)g_dynamic_lds == 0u) lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && blockDim.x < 256u ? 3u : 0u);  // (launched without helper waves: no rounds)
+  if (threadIdx.x < 20u && (uint32_t)(uintptr_t)g_dynamic_lds == 0u)
+    lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && blockDim.x < 256u ? 3u : threadIdx.x == HC_BASE ? LDS_FIXED + lds_arena_bytes : 0u);  // (launched without helper waves: no rounds)
   __syncthreads();
   if (rfl(threadIdx.x >> 6) != 0u) {
     if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u)
@@ -2614,15 +2643,17 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
                                                uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves) {
   if (n_streams == 0) return hipSuccess;
-  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes;
+  static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
+  const bool helpers = helper_waves && !no_helpers;
+  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + (helpers ? HELPER_LDS : 0u);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
-  static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
   // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four
   // four-wave blocks): such batches gain more from streams in flight than from helper waves in long literal runs.
-  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(no_helpers || !helper_waves ? 64 : 256), smem, stream, descs, status, n_streams, queue, scratch,
+  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(helpers ? 256 : 64), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
   return hipGetLastError();
 }
 
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void) { return LDS_FIXED; }
+extern "C" uint32_t brotli_amd_lds_helper_bytes(void) { return HELPER_LDS; }
