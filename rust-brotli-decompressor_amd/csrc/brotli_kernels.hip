@@ -1231,7 +1231,7 @@ enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI,
        L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_CHUNK_BASE, L_SPEC_LO, L_SPEC_HI, L_COUNT };
 static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
 enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
-       LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7 };
+       LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7, LS_LITERAL_ROUNDS = 8 };
 #define LEAN_LD(k) rfl(lds_ld32(LDS_LEAN + 4u * (uint32_t)(k)))
 #define LEAN_ST(k, v) lds_st32(LDS_LEAN + 4u * (uint32_t)(k), (uint32_t)(v))
 
@@ -1400,6 +1400,10 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
     br.seek_ahead(run_pos + bits_done);
     SPEC_PROF(4); SPEC_COUNT(5, 1); SPEC_COUNT(6, acc); SPEC_COUNT(7, bits_done);
   }
+  {  // the literals of the rounds come off the block length and the quota (the metablock length already has the run)
+    const uint32_t got = LEAN_LD(L_LITS_LEFT) - i, bl0 = LEAN_LD(L_BL0), quota = LEAN_LD(L_QUOTA);
+    if (lane == 0) { LEAN_ST(L_BL0, bl0 - got); LEAN_ST(L_QUOTA, quota - got); }
+  }
   lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
   if (lane == 0) {
     LEAN_ST(L_CHUNK_BASE, br.chunk_base);
@@ -1514,24 +1518,10 @@ __device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_t
           i--;
         }
       }
-      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + SPEC_INPUT_DWORDS < safe_dw) {
-        // ---- long run: rounds of four chunks, three of them decoded speculatively by the helper waves (spec_rounds) ----
-        LEAN_FLUSH();
-        lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
-        if (lane == 0) {
-          LEAN_ST(L_CHUNK_BASE, br.chunk_base);
-          LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
-          LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32));
-          LEAN_ST(L_LITS_LEFT, i);
-        }
-        lds_sync();
-        spec_rounds(tree_addr);
-        br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
-        br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
-        br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
-        P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
-        const uint32_t left = LEAN_LD(L_LITS_LEFT), got = i - left;
-        i = left; bl0 -= got; quota -= got;
+      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + SPEC_INPUT_DWORDS < safe_dw && hc_ld(HC_KIND) != 3u) {
+        // ---- long run: the caller runs rounds of four chunks, three of them decoded speculatively by the helper waves
+        // (spec_rounds; not called from here: a call in this function costs the loop its SGPRs) ----
+        stage = LS_LITERAL_ROUNDS; break;
       }
       const uint32_t run_rest = i;  // what the batches below still have to decode
       gu8* wp = out + P;
@@ -1843,7 +1833,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         }
       }
       lds_sync();
-      const uint32_t stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+      uint32_t stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
       br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
@@ -1862,6 +1852,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #endif
       insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
       distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
+      if (CTX_NEVER && stage == LS_LITERAL_ROUNDS) {
+        spec_rounds(LDS_FIXED + lit_tree);
+        br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+        br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
+        br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
+        P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+        quota = LEAN_LD(L_QUOTA); bl0 = LEAN_LD(L_BL0); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
+        // what is left of the run (fewer than a round pays for, or close to the end of the input) is decoded below;
+        // a run that is complete goes on like one the lean loop completed
+        stage = lits_left != 0 ? LS_LITERALS_REST : quota == 0 ? LS_LITERALS_AT_LIMIT : LS_DISTANCE;
+      }
       if (stage == LS_AFTER_HEAD) goto after_head;
       if (stage == LS_LITERALS_REST) goto general_literals_rest;
       if (stage == LS_LITERALS_AT_LIMIT) {  // exactly at a limit: end of the metablock, flush point, or full output buffer
