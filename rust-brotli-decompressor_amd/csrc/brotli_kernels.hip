@@ -1415,7 +1415,19 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 }
 
 template <bool CTX_NEVER>
-__device__ __noinline__ uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
+// Placement of the lean loop, in 4-byte steps from a 256-byte boundary, per instance (context-free / context-modelled):
+// the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
+// 20.1 GB/s over the eight placements).  Measured on MI355X with tools/scratch-style sweeps; re-measure after edits.
+#ifndef BROTLI_AMD_LEAN_PAD_NEVER
+#define BROTLI_AMD_LEAN_PAD_NEVER 6
+#endif
+#ifndef BROTLI_AMD_LEAN_PAD_CTX
+#define BROTLI_AMD_LEAN_PAD_CTX 2
+#endif
+__device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
+  // (the function starts on a 256-byte boundary so that the placement of its loops relative to instruction-fetch
+  // lines does not change with the code in front of it)
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(CTX_NEVER ? BROTLI_AMD_LEAN_PAD_NEVER : BROTLI_AMD_LEAN_PAD_CTX));
   const uint32_t lane = lane_id();
   const Arena a = {nullptr, 0xFFFFFFFFu, 0u};  // every table of the metablock is in LDS: the arena fields are not looked at
   BitReader br;
