@@ -92,7 +92,7 @@ constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 80: mailbox betwe
 constexpr uint32_t LDS_FIXED = LDS_HCTL + 80;               // = 6224, 16-byte aligned
 // Blocks launched with helper waves have, behind the table arena, what the waves of a round leave for each other
 // (offsets from the runtime base in mailbox word HC_BASE; one slot per wave of the block):
-constexpr uint32_t SPEC_WINDOWS = 32;                        // windows of 64 bits per chunk
+constexpr uint32_t SPEC_WINDOWS = 64;                        // windows of 64 bits per chunk
 constexpr uint32_t SPEC_FIRST = 4;                           // windows at the start of a chunk the decoding wave may walk itself
 constexpr uint32_t HL_MASK = 0;                              // 4 x SPEC_WINDOWS x 8: per window of the chunk, which bit offsets start a literal
 constexpr uint32_t HL_MASK_SLOT = SPEC_WINDOWS * 8;
