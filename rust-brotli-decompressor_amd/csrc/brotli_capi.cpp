@@ -26,9 +26,9 @@
 
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
-                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves);
+                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int waves_per_block);
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void);
-extern "C" uint32_t brotli_amd_lds_helper_bytes(void);
+extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves);
 extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictionary.bin, 122784 bytes
 
 namespace {
@@ -92,7 +92,7 @@ struct BrotliAmdBatch {
   uint32_t cur_arena = 0, cus = 0, lds_fixed = 0;
   size_t lds_per_cu = 0;
   // second pass for streams whose tables did not fit the LDS arena of the first (BROTLI_AMD_FLAG_NO_SPILL)
-  uint32_t max_arena = 0, retry_grid_max = 0, last_retry_count = 0, lds_helper = 0;
+  uint32_t max_arena = 0, retry_grid_max = 0, last_retry_count = 0, lds_helper = 0, lds_helper8 = 0, waves = 4, block_max = 0;
   BrotliAmdStreamDesc* d_retry_descs = nullptr;
   BrotliAmdStreamStatus* d_retry_status = nullptr;
   BrotliAmdStreamDesc* h_retry_descs = nullptr;    // pinned
@@ -117,7 +117,7 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
   if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
-                                       b->d_dict, stream, b->grid <= 4u * b->cus), "brotli_amd_decode_kernel launch")) return -1;
+                                       b->d_dict, stream, (int)b->waves), "brotli_amd_decode_kernel launch")) return -1;
   if (!hip_ok(hipEventRecord(b->ev1, stream), "hipEventRecord")) return -1;
   b->last_stream = stream;
   b->launched = true;
@@ -139,11 +139,20 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
       grid_max = b->cus * per_cu;
     }
   }
+  b->n = n;
+  b->grid = std::min(n, grid_max);
+  // Waves per block: one decoding wave plus helpers for long literal runs.  A CU's registers hold sixteen waves of this
+  // kernel: eight-wave blocks where at most two blocks per CU are wanted, four-wave blocks up to four, one-wave blocks
+  // beyond (streams in flight are worth more than helpers there).
+  b->waves = b->grid > 4u * b->cus ? 1u : 4u;
+  if (b->grid <= 2u * b->cus) {
+    const uint32_t room = (uint32_t)std::min<size_t>(b->block_max, b->lds_per_cu / 2);
+    if (b->auto_arena && room > b->lds_fixed + b->lds_helper8 + b->lds_arena) { b->cur_arena = (room - b->lds_fixed - b->lds_helper8) & ~15u; b->waves = 8; }
+    else if (b->lds_fixed + b->lds_helper8 + b->cur_arena <= room) b->waves = 8;
+  }
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
-  b->n = n;
-  b->grid = std::min(n, grid_max);
   if (!ensure_scratch(b, b->grid)) return -1;
   if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
   return launch(b, stream);
@@ -177,7 +186,7 @@ int retry_with_large_arena(BrotliAmdBatch* b) {
   if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
   if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
   if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, b->max_arena,
-                                       b->d_dict, stream, 1), "brotli_amd_decode_kernel launch (large arena)")) return -1;
+                                       b->d_dict, stream, 4), "brotli_amd_decode_kernel launch (large arena)")) return -1;
   if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
   for (uint32_t j = 0; j < m; j++) {
@@ -203,14 +212,15 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   hipDeviceProp_t prop;
   if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) { delete b; return nullptr; }
   // LDS of a block = fixed carve + table arena (+ what the helper waves leave for each other, in blocks that have them)
-  const uint32_t fixed = brotli_amd_lds_fixed_bytes(), helper = brotli_amd_lds_helper_bytes();
+  const uint32_t fixed = brotli_amd_lds_fixed_bytes(), helper = brotli_amd_lds_helper_bytes(4);
   uint32_t per_block = lds_arena_bytes ? lds_arena_bytes + fixed + helper : kDefaultLdsPerBlock;
   size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
   if (per_block > prop.sharedMemPerBlock && prop.sharedMemPerBlock) per_block = (uint32_t)prop.sharedMemPerBlock;
   b->lds_arena = (per_block - fixed - helper) & ~15u;
   b->cur_arena = b->lds_arena;
   b->auto_arena = lds_arena_bytes == 0;
-  b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_helper = helper; b->lds_per_cu = lds_cu;
+  b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_helper = helper; b->lds_helper8 = brotli_amd_lds_helper_bytes(8); b->lds_per_cu = lds_cu;
+  b->block_max = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
   {  // the arena of the second pass: the largest block the device allows (at most 64 KiB: two such blocks per CU at least)
     uint32_t big = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
     b->max_arena = big > fixed + helper ? (big - fixed - helper) & ~15u : 0;

@@ -88,20 +88,21 @@ constexpr uint32_t LDS_BR = LDS_INWIN + 1024;               // 32: what the bit 
 constexpr uint32_t LDS_HOT = LDS_BR + 32;                   // 96: what the command loop needs only at block switches (process_commands)
 constexpr uint32_t LDS_LEAN = LDS_HOT + 96;                 // 192: state handed between process_commands and lean_commands
 constexpr uint32_t LDS_LEANWIN = LDS_LEAN + 192;            // 256: the reader's register window, handed over with the state
-constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 80: mailbox between the decoding wave and its three helper waves
+constexpr uint32_t LDS_HCTL = LDS_LEANWIN + 256;            // 80: mailbox between the decoding wave and its helper waves (round-wide words)
 constexpr uint32_t LDS_FIXED = LDS_HCTL + 80;               // = 6224, 16-byte aligned
-// Blocks launched with helper waves have, behind the table arena, what the waves of a round leave for each other
-// (offsets from the runtime base in mailbox word HC_BASE; one slot per wave of the block):
+// Blocks launched with helper waves have, behind the table arena, one slot per wave of the block with what the waves
+// of a round leave for each other (slot w at mailbox word HC_BASE + w * HL_SLOT):
 constexpr uint32_t SPEC_WINDOWS = 64;                        // windows of 64 bits per chunk
 constexpr uint32_t SPEC_FIRST = 4;                           // windows at the start of a chunk the decoding wave may walk itself
-constexpr uint32_t HL_MASK = 0;                              // 4 x SPEC_WINDOWS x 8: per window of the chunk, which bit offsets start a literal
-constexpr uint32_t HL_MASK_SLOT = SPEC_WINDOWS * 8;
-constexpr uint32_t HL_CUM = HL_MASK + 4 * HL_MASK_SLOT;      // 4 x SPEC_WINDOWS x 4: literals in the chunk's windows before this one
-constexpr uint32_t HL_CUM_SLOT = SPEC_WINDOWS * 4;
-constexpr uint32_t HL_FIRST = HL_CUM + 4 * HL_CUM_SLOT;      // 4 x SPEC_FIRST x 128: code length and symbol at every offset of the chunk's first windows
-constexpr uint32_t HL_FIRST_SLOT = SPEC_FIRST * 128;
-constexpr uint32_t HELPER_LDS = HL_FIRST + 4 * HL_FIRST_SLOT;
-static_assert(4u * SPEC_WINDOWS * 64u <= BROTLI_AMD_SPEC_SCRATCH, "one scratch slot of a chunk's literals per wave");
+constexpr uint32_t SPEC_MAX_WAVES = 8;                       // waves per block at most (one decoding, seven helpers)
+constexpr uint32_t HL_CTL = 0;                               // 64: the wave's mailbox words (HW_*)
+constexpr uint32_t HL_MASK = HL_CTL + 64;                    // SPEC_WINDOWS x 8: per window of the chunk, which bit offsets start a literal
+constexpr uint32_t HL_CUM = HL_MASK + SPEC_WINDOWS * 8;      // SPEC_WINDOWS x 4: literals in the chunk's windows before this one
+constexpr uint32_t HL_FIRST = HL_CUM + SPEC_WINDOWS * 4;     // SPEC_FIRST x 128: code length and symbol at every offset of the chunk's first windows
+constexpr uint32_t HL_SLOT = HL_FIRST + SPEC_FIRST * 128;    // = 1344
+constexpr uint32_t SPEC_SLOT_BYTES = SPEC_WINDOWS * 64u;     // a chunk's literals at most (scratch slot of a wave, in HBM)
+static_assert(SPEC_MAX_WAVES * SPEC_SLOT_BYTES <= BROTLI_AMD_SPEC_SCRATCH, "one scratch slot of a chunk's literals per wave");
+static_assert(HL_SLOT % 16 == 0, "slots keep the 8-byte alignment of their masks");
 static_assert(LDS_FIXED % 16 == 0, "arena base must stay 16-byte aligned");
 
 // All LDS traffic goes through this file-scope array so that every access is a DS instruction (address space 3)
@@ -942,15 +943,22 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 // into place once their position is known; for a chunk's first two windows it also leaves code length and symbol of
 // every bit offset, which is all the decoding wave needs to walk there.  No chunk that fails to fall in within two
 // windows is used: the round ends in front of it.
-//   HCTL words: 0 round number   1 kind (1 = round, 2 = exit)   2 first dword of the round   3 bit offset in it
-//   4 LDS address of the literal tree   5-7 round finished by helper 1-3   8-11 literals in chunk 0-3
-//   12-15 bit offset into the next chunk at which the chain of chunk 0-3 ends
-enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_DONE = 5, HC_N = 8, HC_EXIT = 12, HC_BASE = 16 };
+//   HCTL words (round-wide): round number, kind (1 = round, 2 = exit, 3 = no rounds in this launch), first dword of
+//   the round and bit offset in it, LDS address of the literal tree, base of the per-wave slots, waves in the block,
+//   address of the stream's output.  Per wave (HW_*, in its slot): round decoded, literals in the chunk, bit offset
+//   into the next chunk at which its chain ends; then, posted by the decoding wave once the chunk's place is known:
+//   move wanted for round, first literal of the chunk to move, where to (offset from the output), how many; and the
+//   helper's answer, round moved.
+enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8 };
+enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8 };
 constexpr uint32_t SPEC_ROUND_MIN = 768;       // literals a run must still have for a round to pay
-constexpr uint32_t SPEC_INPUT_DWORDS = 4u * SPEC_WINDOWS * 2u + 74u;  // input a round may look at, from the reader's next dword on
+// input a round of nw chunks may look at, from the reader's next dword on
+__device__ __forceinline__ uint32_t spec_input_dwords(uint32_t nw) { return nw * SPEC_WINDOWS * 2u + 74u; }
 typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
 __device__ __forceinline__ uint32_t hc_ld(uint32_t w) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w])); }
 __device__ __forceinline__ void hc_st(uint32_t w, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * w]) = v; }
+__device__ __forceinline__ uint32_t hw_ld(uint32_t slot, uint32_t k) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[slot + HL_CTL + 4u * k])); }
+__device__ __forceinline__ void hw_st(uint32_t slot, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[slot + HL_CTL + 4u * k]) = v; }
 __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
@@ -1000,8 +1008,8 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
   const uint32_t lane = lane_id();
   w = rfl(w); dw0 = rfl(dw0); sh = rfl(sh); tree = rfl(tree); entry = rfl(entry);
   symout = rfl_ptr(symout);
-  const uint32_t hb = hc_ld(HC_BASE);
-  const uint32_t hfirst = hb + HL_FIRST + w * HL_FIRST_SLOT;
+  const uint32_t slot = hc_ld(HC_BASE) + w * HL_SLOT;
+  const uint32_t hfirst = slot + HL_FIRST;
   gcu32* const base = BitReader::base();
   const uint32_t ndw = BitReader::n_dw(), tmask = BitReader::tail_mask();
   // sa[l], sb[l], sc[l]: the 32 bits of the stream from bit 32 * l + sh of dword dw0, dw0 + 64, dw0 + 128 on
@@ -1097,14 +1105,17 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
   }
 #undef SPEC_BODY
   if (lane < SPEC_WINDOWS) {
-    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[hb + HL_MASK + w * HL_MASK_SLOT + lane * 8u]) = (uint64_t)mlo | ((uint64_t)mhi << 32);
-    lds_st32(hb + HL_CUM + w * HL_CUM_SLOT + lane * 4u, mcum);
+    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[slot + HL_MASK + lane * 8u]) = (uint64_t)mlo | ((uint64_t)mhi << 32);
+    lds_st32(slot + HL_CUM + lane * 4u, mcum);
   }
-  hc_st(HC_N + w, cnt);
-  hc_st(HC_EXIT + w, e);
+  hw_st(slot, HW_N, cnt);
+  hw_st(slot, HW_EXIT, e);
 }
 
-__device__ __noinline__ void helper_wave(const uint32_t me /* 1..3 */, gu8* scratch_sym) {
+__device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */, gu8* scratch_sym) {
+  const uint32_t lane = lane_id();
+  const uint32_t slot = hc_ld(HC_BASE) + me * HL_SLOT;
+  gu8* const mine = scratch_sym + me * SPEC_SLOT_BYTES;
   uint32_t seq = 0;
   for (;;) {
     uint32_t j;
@@ -1116,10 +1127,40 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1..3 */, gu8* scra
     seq = j;
     lds_acquire();
     if (hc_ld(HC_KIND) != 1u) return;
-    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), scratch_sym + me * (SPEC_WINDOWS * 64u), 0u);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the literals are in memory before the round is reported done
+    spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
     lds_release();
-    hc_st(HC_DONE + me - 1u, seq);
+    hw_st(slot, HW_DONE, seq);
+    // the decoding wave says which of the chunk's literals are the stream's and where they go (none: n = 0)
+    bool go = true;
+    while (hw_ld(slot, HW_MVGO) != seq) {
+      if (hc_ld(HC_SEQ) != seq) { go = false; break; }  // the round was given up (or the kernel is about to end)
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!go) continue;
+    lds_acquire();
+    const uint32_t n = hw_ld(slot, HW_MVN);
+    if (n != 0) {
+      gu8* const src = mine + hw_ld(slot, HW_MVSRC);
+      gu8* const dst = (gu8*)(uintptr_t)(((uint64_t)hc_ld(HC_OUT_LO) | ((uint64_t)hc_ld(HC_OUT_HI) << 32)) +
+                                        ((uint64_t)hw_ld(slot, HW_MVDST_LO) | ((uint64_t)hw_ld(slot, HW_MVDST_HI) << 32)));
+      constexpr uint32_t H = SPEC_SLOT_BYTES / 1024u;
+      const uint32_t n16 = n >> 4;
+      u32x4 t[H] = {};
+      _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
+        const uint32_t c = lane + 64u * h;
+        if (c < n16) t[h] = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+      }
+      uint32_t tail = 0;
+      if (lane < (n & 15u)) tail = src[(n16 << 4) + lane];
+      _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
+        const uint32_t c = lane + 64u * h;
+        if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[h];
+      }
+      if (lane < (n & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the move is reported done
+    }
+    lds_release();
+    hw_st(slot, HW_MVDONE, seq);
   }
 }
 
@@ -1260,10 +1301,10 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint64_t m, uint32_t n) {
 __device__ __noinline__ uint32_t spec_locate(uint32_t w, uint32_t t) {
   const uint32_t lane = lane_id();
   w = rfl(w); t = rfl(t);
-  const uint32_t hb = hc_ld(HC_BASE);
-  const uint32_t cum = lane < SPEC_WINDOWS ? lds_ld32(hb + HL_CUM + w * HL_CUM_SLOT + lane * 4u) : 0xFFFFFFFFu;
+  const uint32_t slot = hc_ld(HC_BASE) + w * HL_SLOT;
+  const uint32_t cum = lane < SPEC_WINDOWS ? lds_ld32(slot + HL_CUM + lane * 4u) : 0xFFFFFFFFu;
   const uint32_t k = (uint32_t)__popcll(__ballot(cum <= t)) - 1u;  // the window the literal starts in
-  const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[hb + HL_MASK + w * HL_MASK_SLOT + k * 8u]);
+  const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[slot + HL_MASK + k * 8u]);
   const uint64_t m = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
   return k * 64u + nth_set_bit(m, t - rdlane(cum, k));
 }
@@ -1280,119 +1321,129 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
   uint32_t i = LEAN_LD(L_LITS_LEFT);
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
-  const uint32_t hb = hc_ld(HC_BASE);
-  while (i >= SPEC_ROUND_MIN && br.next_dw + SPEC_INPUT_DWORDS < safe_dw && hc_ld(HC_KIND) != 3u) {
+  const uint32_t hb = hc_ld(HC_BASE), nw = hc_ld(HC_NW);
+  hc_st(HC_OUT_LO, (uint32_t)(uintptr_t)out); hc_st(HC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
+  uint32_t seq = hc_ld(HC_SEQ);
+  uint32_t moving = 0, mv_seq = 0;  // helpers whose move (of round mv_seq) has not been seen finished
+  while (i >= SPEC_ROUND_MIN && br.next_dw + spec_input_dwords(nw) < safe_dw && hc_ld(HC_KIND) != 3u) {
 #ifdef BROTLI_AMD_PROFILE_SPEC
     uint64_t sp_t = __builtin_amdgcn_s_memtime();
 #endif
-    // A round decodes up to 4 * 2048 literals (+ a few).  Where the run has fewer left, the round is *capped*: nothing
-    // goes to the output directly (chunk 0 uses scratch slot 0 like the helpers), and the round ends at the run's last
-    // literal, whose bit position the start masks give.
+    // A round decodes up to nw * SPEC_SLOT_BYTES literals (+ a few).  Where the run has fewer left, the round is
+    // *capped*: nothing goes to the output directly (chunk 0 uses scratch slot 0 like the helpers), and the round ends
+    // at the run's last literal, whose bit position the start masks give.
     const uint32_t cap = i;
-    const bool capped = i < SPEC_WINDOWS * 64u * 4u + 64u;
+    const bool capped = i < nw * SPEC_SLOT_BYTES + 64u;
     const uint64_t run_pos = br.pos();
     const uint64_t abs0 = run_pos + BitReader::skip_bits();
     const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
-    const uint32_t seq = hc_ld(HC_SEQ) + 1u;
+    seq++;
     hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1);
     lds_release();
     hc_st(HC_SEQ, seq);
-    br.request_ahead(dw0 + SPEC_WINDOWS * 8u);  // where the round will normally end: there by the time it does
+    br.request_ahead(dw0 + nw * SPEC_WINDOWS * 2u);  // where the round will normally end: there by the time it does
     spec_chunk(0, dw0, sh, tree_addr, capped ? spec : out + P, 0);  // the first chunk: its first bit does start a literal
     SPEC_PROF(0);
-    uint32_t cp_src[4] = {0u, 0u, 0u, 0u}, cp_dst[4] = {0u, 0u, 0u, 0u}, cp_n[4] = {0u, 0u, 0u, 0u};
-    uint32_t acc = hc_ld(HC_N);  // literals of the round so far
-    uint32_t e = hc_ld(HC_EXIT);
+    uint32_t acc = hw_ld(hb, HW_N);  // literals of the round so far
+    uint32_t e = hw_ld(hb, HW_EXIT);
     uint32_t bits_done = SPEC_WINDOWS * 64u + e;
+    uint32_t own = 0;            // literals of chunk 0 to move out of scratch slot 0 (capped rounds)
     bool full = false;           // the run's last literal has been reached
     if (capped) {
       if (acc >= cap) { bits_done = acc == cap ? bits_done : spec_locate(0, cap); acc = cap; full = true; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk 0's literals are in the scratch slot
-      cp_n[0] = acc;
+      own = acc;
     }
     bool lost = false;
-    for (uint32_t w = 1; w < 4; w++) {  // (bounded: helpers that never answer must not hang the GPU)
+    for (uint32_t w = 1; w < nw; w++) {  // (bounded: helpers that never answer must not hang the GPU)
       uint32_t polls = 0;
-      while (hc_ld(HC_DONE + w - 1u) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
+      while (hw_ld(hb + w * HL_SLOT, HW_DONE) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
       if (lost) break;
     }
     lds_acquire();
     SPEC_PROF(1);
-    _Pragma("unroll") for (uint32_t w = 1; w < 4; w++) {
-      if (lost || full) break;
-      // walk the true chain into chunk w until it steps on a start the helper marked too
-      bool synced = false;
-      uint32_t skip = 0;
-      for (uint32_t j = 0; j < SPEC_FIRST && !synced && !full; j++) {
-        const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[hb + HL_MASK + w * HL_MASK_SLOT + j * 8u]);
-        const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
-        const uint32_t Lv = lds_ld8(hb + HL_FIRST + w * HL_FIRST_SLOT + j * 128u + lane), sv = lds_ld8(hb + HL_FIRST + w * HL_FIRST_SLOT + j * 128u + 64u + lane);
-        uint64_t tstarts; uint32_t woff;
-        SPEC_WALK(Lv, e, tstarts, woff);
-        const uint64_t common = tstarts & smask;
-        uint64_t mine = tstarts;  // literals of this window that only the true chain has
-        if (common) {
-          const uint32_t p = (uint32_t)__builtin_ctzll(common);
-          mine = tstarts & ((1ull << p) - 1ull);
-          skip = rfl(lds_ld32(hb + HL_CUM + w * HL_CUM_SLOT + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
-          synced = true;
-        }
-        uint32_t nm = (uint32_t)__popcll(mine);
-        if (capped && acc + nm >= cap) {  // the run ends among them
-          if (acc + nm > cap || !synced) {
-            // (ends exactly with the window's last own literal and no common start: the position after it is what
-            // the walk left the window at, unless the chain goes on inside this window -- then it is the next start)
-            const uint32_t n = cap - acc;
-            if (n < nm) { const uint32_t pos = nth_set_bit(mine, n); mine &= (1ull << pos) - 1ull; bits_done = (w * SPEC_WINDOWS + j) * 64u + pos; }
-            else bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + (woff - 64u);
-            nm = n; full = true; synced = false;
-          } else {
-            // ends exactly in front of the common start
-            bits_done = (w * SPEC_WINDOWS + j) * 64u + (uint32_t)__builtin_ctzll(common);
-            full = true; synced = false;
+    if (!lost) { moving = 0; mv_seq = seq; }  // (every helper has finished the move of the round before: it decoded this round's chunk after it)
+    bool open = !lost && !full;  // chunks are still being taken
+    for (uint32_t w = 1; w < nw; w++) {
+      const uint32_t slot = hb + w * HL_SLOT;
+      uint32_t mv_src = 0, mv_n = 0, mv_dst = acc;
+      if (open) {
+        // walk the true chain into chunk w until it steps on a start the helper marked too
+        bool synced = false;
+        uint32_t skip = 0;
+        for (uint32_t j = 0; j < SPEC_FIRST && !synced && !full; j++) {
+          const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[slot + HL_MASK + j * 8u]);
+          const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
+          const uint32_t Lv = lds_ld8(slot + HL_FIRST + j * 128u + lane), sv = lds_ld8(slot + HL_FIRST + j * 128u + 64u + lane);
+          uint64_t tstarts; uint32_t woff;
+          SPEC_WALK(Lv, e, tstarts, woff);
+          const uint64_t common = tstarts & smask;
+          uint64_t mine = tstarts;  // literals of this window that only the true chain has
+          if (common) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(common);
+            mine = tstarts & ((1ull << p) - 1ull);
+            skip = rfl(lds_ld32(slot + HL_CUM + j * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
+            synced = true;
           }
+          uint32_t nm = (uint32_t)__popcll(mine);
+          if (capped && acc + nm >= cap) {  // the run ends among them
+            if (acc + nm > cap || !synced) {
+              // (ends exactly with the window's last own literal and no common start: the position after it is what
+              // the walk left the window at, unless the chain goes on inside this window -- then it is the next start)
+              const uint32_t n = cap - acc;
+              if (n < nm) { const uint32_t pos = nth_set_bit(mine, n); mine &= (1ull << pos) - 1ull; bits_done = (w * SPEC_WINDOWS + j) * 64u + pos; }
+              else bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + (woff - 64u);
+              nm = n; full = true; synced = false;
+            } else {
+              // ends exactly in front of the common start
+              bits_done = (w * SPEC_WINDOWS + j) * 64u + (uint32_t)__builtin_ctzll(common);
+              full = true; synced = false;
+            }
+          }
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+          gu8* wq = out + P + acc;
+          SPEC_STORE(mine, rank, sv, wq);
+          acc += nm;
+          if (!synced && !full) { e = woff - 64u; bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + e; }
         }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-        gu8* wq = out + P + acc;
-        SPEC_STORE(mine, rank, sv, wq);
-        acc += nm;
-        if (!synced && !full) { e = woff - 64u; bits_done = (w * SPEC_WINDOWS + j + 1u) * 64u + e; }
+        if (!synced) open = false;  // no common start within the first windows (or the run is complete): the round ends here
+        else {
+          // the helper's literals from the common start on are the stream's: it moves them into place itself
+          uint32_t valid = hw_ld(slot, HW_N) - skip;
+          e = hw_ld(slot, HW_EXIT);
+          bits_done = (w + 1u) * SPEC_WINDOWS * 64u + e;
+          if (capped && acc + valid >= cap) {
+            if (acc + valid > cap) { valid = cap - acc; bits_done = w * SPEC_WINDOWS * 64u + spec_locate(w, skip + valid); }
+            full = true; open = false;
+          }
+          mv_src = skip; mv_dst = acc; mv_n = valid;
+          acc += valid;
+        }
       }
-      if (!synced) break;  // no common start within two windows (or the run is complete): the round ends here
-      // the helper's literals from the common start on are the stream's; they are moved into place below
-      uint32_t valid = hc_ld(HC_N + w) - skip;
-      e = hc_ld(HC_EXIT + w);
-      bits_done = (w + 1u) * SPEC_WINDOWS * 64u + e;
-      if (capped && acc + valid >= cap) {
-        if (acc + valid > cap) { valid = cap - acc; bits_done = w * SPEC_WINDOWS * 64u + spec_locate(w, skip + valid); }
-        full = true;
+      if (!lost) {
+        const uint64_t d = P + mv_dst;
+        hw_st(slot, HW_MVSRC, mv_src); hw_st(slot, HW_MVDST_LO, (uint32_t)d); hw_st(slot, HW_MVDST_HI, (uint32_t)(d >> 32)); hw_st(slot, HW_MVN, mv_n);
+        lds_release();
+        hw_st(slot, HW_MVGO, seq);
+        if (mv_n) moving |= 1u << w;
       }
-      cp_src[w] = w * (SPEC_WINDOWS * 64u) + skip; cp_dst[w] = acc; cp_n[w] = valid;
-      acc += valid;
     }
     SPEC_PROF(2);
-    {  // all loads of the (up to four) moves first, then the stores: one memory round trip
-      constexpr uint32_t H = SPEC_WINDOWS / 16u;  // 1 KiB steps per slot
-      u32x4 t[4][H] = {};
-      _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++)
-        _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
-          const uint32_t c = lane + 64u * h;
-          if (c < (cp_n[k] >> 4)) t[k][h] = *reinterpret_cast<gu32x4*>(spec + cp_src[k] + (uint64_t)c * 16);
-        }
-      uint32_t tail[4] = {0u, 0u, 0u, 0u};
-      _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++) {
-        const uint32_t n16 = cp_n[k] >> 4;
-        if (lane < (cp_n[k] & 15u)) tail[k] = spec[cp_src[k] + (n16 << 4) + lane];
+    if (own) {  // chunk 0 of a capped round: out of scratch slot 0
+      constexpr uint32_t H = SPEC_SLOT_BYTES / 1024u;
+      const uint32_t n16 = own >> 4;
+      u32x4 t[H] = {};
+      _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
+        const uint32_t c = lane + 64u * h;
+        if (c < n16) t[h] = *reinterpret_cast<gu32x4*>(spec + (uint64_t)c * 16);
       }
-      _Pragma("unroll") for (uint32_t k = 0; k < 4u; k++) {
-        gu8* dst = out + P + cp_dst[k];
-        const uint32_t n16 = cp_n[k] >> 4;
-        _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
-          const uint32_t c = lane + 64u * h;
-          if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[k][h];
-        }
-        if (lane < (cp_n[k] & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail[k];
+      uint32_t tail = 0;
+      if (lane < (own & 15u)) tail = spec[(n16 << 4) + lane];
+      gu8* dst = out + P;
+      _Pragma("unroll") for (uint32_t h = 0; h < H; h++) {
+        const uint32_t c = lane + 64u * h;
+        if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[h];
       }
+      if (lane < (own & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail;
     }
     SPEC_PROF(3);
     if (lost) hc_st(HC_KIND, 3);  // helpers unusable from now on
@@ -1400,6 +1451,23 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
     br.seek_ahead(run_pos + bits_done);
     SPEC_PROF(4); SPEC_COUNT(5, 1); SPEC_COUNT(6, acc); SPEC_COUNT(7, bits_done);
   }
+  // what the helpers are still moving into place is part of the output before anything after the run reads it
+  for (uint32_t w = 1; w < nw; w++) {
+    if (!((moving >> w) & 1u)) continue;
+    uint32_t polls = 0;
+    while (hw_ld(hb + w * HL_SLOT, HW_MVDONE) != mv_seq) {
+      if (++polls > (1u << 20)) {  // (never seen; the launch must not hang and the output must not be wrong)
+        hc_st(HC_KIND, 3);
+        const uint32_t slot = hb + w * HL_SLOT, n = hw_ld(slot, HW_MVN);
+        gu8* src = spec + w * SPEC_SLOT_BYTES + hw_ld(slot, HW_MVSRC);
+        gu8* dst = out + ((uint64_t)hw_ld(slot, HW_MVDST_LO) | ((uint64_t)hw_ld(slot, HW_MVDST_HI) << 32));
+        for (uint32_t c = lane; c < n; c += 64) dst[c] = src[c];
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  lds_acquire();
   {  // the literals of the rounds come off the block length and the quota (the metablock length already has the run)
     const uint32_t got = LEAN_LD(L_LITS_LEFT) - i, bl0 = LEAN_LD(L_BL0), quota = LEAN_LD(L_QUOTA);
     if (lane == 0) { LEAN_ST(L_BL0, bl0 - got); LEAN_ST(L_QUOTA, quota - got); }
@@ -1530,7 +1598,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
           i--;
         }
       }
-      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + SPEC_INPUT_DWORDS < safe_dw && hc_ld(HC_KIND) != 3u) {
+      if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + spec_input_dwords(SPEC_MAX_WAVES) < safe_dw && hc_ld(HC_KIND) != 3u) {
         // ---- long run: the caller runs rounds of four chunks, three of them decoded speculatively by the helper waves
         // (spec_rounds; not called from here: a call in this function costs the loop its SGPRs) ----
         stage = LS_LITERAL_ROUNDS; break;
@@ -2518,15 +2586,19 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 }  // namespace
 
 // One decoding wave (+ three helper waves) per stream; persistent blocks pull stream indices from `queue`.
-extern "C" __global__ __launch_bounds__(256, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
+extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
   // waves 1-3 are helpers (see helper_wave); their mailbox is cleared before the four part ways
-  if (threadIdx.x < 20u && (uint32_t)(uintptr_t)g_dynamic_lds == 0u)
-    lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && blockDim.x < 256u ? 3u : threadIdx.x == HC_BASE ? LDS_FIXED + lds_arena_bytes : 0u);  // (launched without helper waves: no rounds)
+  if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
+    const uint32_t nw = blockDim.x >> 6;
+    if (threadIdx.x < 20u)
+      lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && nw < 2u ? 3u : threadIdx.x == HC_BASE ? LDS_FIXED + lds_arena_bytes : threadIdx.x == HC_NW ? nw : 0u);
+    if (nw >= 2u && threadIdx.x < nw * 16u) lds_st32(LDS_FIXED + lds_arena_bytes + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
+  }  // (launched without helper waves: no rounds)
   __syncthreads();
   if (rfl(threadIdx.x >> 6) != 0u) {
     if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u)
@@ -2657,16 +2729,16 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
                                                uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves) {
   if (n_streams == 0) return hipSuccess;
   static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
-  const bool helpers = helper_waves && !no_helpers;
-  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + (helpers ? HELPER_LDS : 0u);
+  const uint32_t waves = no_helpers || helper_waves < 2 ? 1u : (uint32_t)helper_waves > SPEC_MAX_WAVES ? SPEC_MAX_WAVES : (uint32_t)helper_waves;
+  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + (waves > 1u ? waves * HL_SLOT : 0u);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
   // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four
   // four-wave blocks): such batches gain more from streams in flight than from helper waves in long literal runs.
-  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(helpers ? 256 : 64), smem, stream, descs, status, n_streams, queue, scratch,
+  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(64u * waves), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
   return hipGetLastError();
 }
 
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void) { return LDS_FIXED; }
-extern "C" uint32_t brotli_amd_lds_helper_bytes(void) { return HELPER_LDS; }
+extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves) { return waves > 1u ? waves * HL_SLOT : 0u; }
