@@ -13,7 +13,7 @@
 //   src/decode.rs:152-372, 516-1465, 2921-3288  stream/metablock headers       -> decode_stream() (must run on device:
 //                             a metablock's compressed extent is only known after decoding it)
 //
-// Execution model: ONE DECODING WAVEFRONT PER STREAM (wave 0 of a 256-thread block), fully fused; waves 1-3 of the block
+// Execution model: ONE DECODING WAVEFRONT PER STREAM (wave 0 of a block of one, four or eight waves), fully fused; the other waves of the block
 // are helpers that decode chunks of long literal runs speculatively (spec_rounds / spec_chunk / helper_wave) and
 // sleep otherwise.  The entropy decode of a Brotli stream is a serial
 // dependent chain, so all 64 lanes of the wave execute it uniformly (values live in SGPRs; table entries come back
@@ -27,7 +27,7 @@
 //     of the current literal block type) live one entry per lane in VGPRs and are indexed with v_readlane;
 //   * Huffman tables are built lane-parallel (ballot counting sort + parallel replicate) into an LDS arena;
 //     objects that do not fit the LDS arena spill to a per-block global scratch area (never straddling);
-//   * literal runs of >= 16384 literals: rounds of four 2048-bit chunks, three of them decoded by the helper waves from
+//   * literal runs of >= 768 literals: rounds of one 4096-bit chunk per wave, all but the first decoded by the helper waves from
 //     a bit that need not start a literal -- prefix codes re-synchronise, and the decoding wave walks the true chain into
 //     each chunk only until it meets the helper's; a chunk that does not fall in is not used;
 //   * LZ77 copies, dictionary words and stored metablocks are moved by all 64 lanes (16 bytes per lane and step where
@@ -932,17 +932,17 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 #endif
 
 // ===================================== helper waves: speculative literal runs =====================================
-// A block is four waves: wave 0 decodes its stream, waves 1-3 wait for work in an LDS mailbox.  The work: a long run
-// of literals with one prefix code (high-entropy data: tens of thousands of literals between two copies).  A round
-// is 4 chunks of 2048 stream bits; the decoding wave takes the first, whose first bit is known to start a literal,
-// each helper decodes one of the others *as if* a literal started at its first bit.  It usually does not -- but
-// prefix codes re-synchronise: after a few symbols the helper's chain of literal starts falls in with the true one.
-// The decoding wave then walks the true chain from where the chunk before ended only until it steps on a start the
-// helper has marked too; from there on the helper's literals are the stream's.  Per window a helper records the
-// start mask and the running literal count (LDS), its literals go to a scratch area in global memory and are moved
-// into place once their position is known; for a chunk's first two windows it also leaves code length and symbol of
-// every bit offset, which is all the decoding wave needs to walk there.  No chunk that fails to fall in within two
-// windows is used: the round ends in front of it.
+// A block is up to eight waves: wave 0 decodes its stream, the others wait for work in an LDS mailbox.  The work: a
+// run of literals with one prefix code (high-entropy data: tens of thousands of literals between two copies).  A round
+// is one chunk of SPEC_WINDOWS * 64 stream bits per wave; the decoding wave takes the first, whose first bit is known to
+// start a literal, each helper decodes one of the others *as if* a literal started at its first bit.  It usually does
+// not -- but prefix codes re-synchronise: after a few symbols the helper's chain of literal starts falls in with the
+// true one.  The decoding wave then walks the true chain from where the chunk before ended only until it steps on a
+// start the helper has marked too; from there on the helper's literals are the stream's.  Per window a helper records
+// the start mask and the running literal count (LDS), its literals go to a scratch slot in global memory and it moves
+// them into place itself once the decoding wave has told it which and where; for a chunk's first SPEC_FIRST windows it
+// also leaves code length and symbol of every bit offset, which is all the decoding wave needs to walk there.  No chunk
+// that fails to fall in within those windows is used: the round ends in front of it.
 //   HCTL words (round-wide): round number, kind (1 = round, 2 = exit, 3 = no rounds in this launch), first dword of
 //   the round and bit offset in it, LDS address of the literal tree, base of the per-wave slots, waves in the block,
 //   address of the stream's output.  Per wave (HW_*, in its slot): round decoded, literals in the chunk, bit offset
@@ -1599,7 +1599,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
         }
       }
       if (CTX_NEVER && i >= SPEC_ROUND_MIN && br.next_dw + spec_input_dwords(SPEC_MAX_WAVES) < safe_dw && hc_ld(HC_KIND) != 3u) {
-        // ---- long run: the caller runs rounds of four chunks, three of them decoded speculatively by the helper waves
+        // ---- long run: the caller runs rounds of one chunk per wave, all but the first decoded speculatively by the helper waves
         // (spec_rounds; not called from here: a call in this function costs the loop its SGPRs) ----
         stage = LS_LITERAL_ROUNDS; break;
       }
@@ -2585,14 +2585,14 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 
 }  // namespace
 
-// One decoding wave (+ three helper waves) per stream; persistent blocks pull stream indices from `queue`.
+// One decoding wave (+ up to seven helper waves) per stream; persistent blocks pull stream indices from `queue`.
 extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
-  // waves 1-3 are helpers (see helper_wave); their mailbox is cleared before the four part ways
+  // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
     const uint32_t nw = blockDim.x >> 6;
     if (threadIdx.x < 20u)
