@@ -334,10 +334,12 @@ def test_helper_rounds_with_a_code_that_never_resynchronises(pkg):
         assert out == raw
 
 
-def test_batches_larger_than_the_resident_grid(pkg):
-    """More streams than four blocks per CU: the host launches one-wave blocks (no helper waves, up to eight blocks per
-    CU with a smaller table arena) and streams whose tables need the large arena come back in the second pass.  Same
-    results as ever, including a stream with literal runs long enough for helper rounds (decoded without them here)."""
+@pytest.mark.parametrize("n", [2304, 700])
+def test_batches_larger_than_the_resident_grid(pkg, n):
+    """The host picks the block shape by batch size: eight waves (seven helpers) up to two blocks per CU, four waves up
+    to four blocks per CU (700 streams on a 256-CU device), one-wave blocks beyond (2304 streams: no helper waves, up to
+    eight blocks per CU with a smaller table arena; streams whose tables need the large arena come back in the second
+    pass).  Same results in every shape, including a stream with literal runs long enough for helper rounds."""
     import numpy as np
     import libbrotli_ref as ref
     m = [e for e in _manifest() if not e.get("must_fail") and e.get("size", 1 << 30) <= 300000][:24]
@@ -348,7 +350,6 @@ def test_batches_larger_than_the_resident_grid(pkg):
         raw = rng.choice(256, size=200000, p=(np.arange(1, 257) ** -0.3) / np.sum(np.arange(1, 257) ** -0.3)).astype(np.uint8).tobytes()
         datas.append(ref.encode(raw, 5, 22))
         want.append((len(raw), hashlib.sha256(raw).hexdigest()))
-    n = 2304  # nine blocks' worth per CU on a 256-CU device
     idx = [i % len(datas) for i in range(n)]
     batch = pkg.Batch(n)
     results, outs = batch.decode_host([datas[i] for i in idx], [want[i][0] for i in idx], pkg.FLAG_LARGE_WINDOW)
@@ -390,3 +391,15 @@ def test_literal_runs_of_many_lengths(pkg):
         for cap in (len(raw), len(raw) - 1, len(raw) // 2, len(raw) // 3, 4096 + 700 + 300, 40000, 100001):
             all_d.append(c); all_caps.append(cap)
     _check_against_oracle(pkg, all_d, all_caps, 1, "literal runs")
+    # the same through four-wave blocks (a batch of more than two and at most four blocks per CU)
+    reps = 600 // len(all_d) + 1
+    batch = pkg.Batch(len(all_d))
+    r1, o1 = batch.decode_host(all_d, all_caps, 1)
+    batch.close()
+    batch = pkg.Batch(len(all_d) * reps)
+    r4, o4 = batch.decode_host(all_d * reps, all_caps * reps, 1)
+    batch.close()
+    for k in range(len(all_d) * reps):
+        a, b = r1[k % len(all_d)], r4[k]
+        assert (a.result, a.error_code, a.decoded_size, a.consumed) == (b.result, b.error_code, b.decoded_size, b.consumed), k
+        assert o1[k % len(all_d)] == o4[k], k
