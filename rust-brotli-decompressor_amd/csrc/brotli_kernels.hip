@@ -1482,6 +1482,30 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   lds_sync();
 }
 
+// The pending copy of the lean loop lives in registers the compiler does not know about: v[120:123] (16 bytes per lane)
+// and v124 (one byte per lane), named in inline asm only.  As C++ variables they were shuffled through other registers
+// at the loop's back edge, and every such move waited for the load that had just been issued (or, before the next
+// load, for the acknowledgement of the stores); loaded here, nothing waits until the bytes are stored.
+#define PEND_REGS "v120", "v121", "v122", "v123", "v124"
+__device__ __forceinline__ uint64_t lanes_below(uint32_t n) { return n >= 64u ? ~0ull : (1ull << n) - 1ull; }
+__device__ __forceinline__ void pend_load16(gu8* src, uint32_t n16, uint32_t lane16) {
+  asm volatile("s_mov_b64 exec, %0\n\tglobal_load_dwordx4 v[120:123], %1, %2\n\ts_mov_b64 exec, -1" :: "s"(lanes_below(n16)), "v"(lane16), "s"(src) : "memory", PEND_REGS);
+}
+__device__ __forceinline__ void pend_load8(gu8* src, uint32_t n, uint32_t off) {  // byte src[off] of lanes below n
+  asm volatile("s_mov_b64 exec, %0\n\tglobal_load_ubyte v124, %1, %2\n\ts_mov_b64 exec, -1" :: "s"(lanes_below(n)), "v"(off), "s"(src) : "memory", PEND_REGS);
+}
+__device__ __forceinline__ void pend_store16(gu8* dst, uint32_t n16, uint32_t lane16) {
+  asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx4 %1, v[120:123], %2\n\ts_mov_b64 exec, -1" :: "s"(lanes_below(n16)), "v"(lane16), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void pend_store8(gu8* dst, uint32_t n, uint32_t lane) {
+  asm volatile("s_mov_b64 exec, %0\n\tglobal_store_byte %1, v124, %2\n\ts_mov_b64 exec, -1" :: "s"(lanes_below(n)), "v"(lane), "s"(dst) : "memory");
+}
+__device__ __forceinline__ uint32_t pend_byte(uint32_t k) {  // the byte lane k holds
+  uint32_t r;
+  asm volatile("s_waitcnt vmcnt(0)\n\tv_readlane_b32 %0, v124, %1" : "=s"(r) : "s"(k) : "memory");
+  return r;
+}
+
 template <bool CTX_NEVER>
 // Placement of the lean loop, in 4-byte steps from a 256-byte boundary, per instance (context-free / context-modelled):
 // the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
@@ -1517,16 +1541,18 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
   const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
   const uint32_t tree_addr = LDS_FIXED + lit_tree;
   // copy whose bytes are in registers but not stored yet (16 bytes per lane + a byte tail)
-  u32x4 pendv = {0, 0, 0, 0}; uint32_t pendv_n16 = 0, pend_reg = 0, pend_n = 0; uint64_t pend_pos = 0;
+  uint32_t pendv_n16 = 0, pend_n = 0; uint64_t pend_pos = 0;  // (the bytes: see PEND_REGS)
+  const uint32_t lane16 = lane << 4;
   // context-modelled metablocks: literals collected one per lane (stored 64 at a time or before the next copy), the
   // two bytes before P in p1/p2 when ctx_regs, else in the pending short copy (ctx_pend) or in memory
   uint32_t lit_reg = 0, lit_n = 0; uint64_t lit_pos = P;
   uint32_t p1 = CTX_NEVER ? 0u : LEAN_LD(L_P1), p2 = CTX_NEVER ? 0u : LEAN_LD(L_P2);
   bool ctx_regs = CTX_NEVER ? true : LEAN_LD(L_CTX_REGS) != 0u, ctx_pend = false;
   const uint32_t trivial = CTX_NEVER ? 1u : LEAN_LD(L_TRIVIAL), ctx_lut = CTX_NEVER ? 0u : LEAN_LD(L_CTX_LUT);
-#define LEAN_FLUSH() do { if (!CTX_NEVER && lit_n) { if (lane < lit_n) out[lit_pos + lane] = (uint8_t)lit_reg; lit_n = 0; } \
-                          if (pendv_n16) { if (lane < pendv_n16) *reinterpret_cast<gu32x4*>(out + pend_pos + (uint64_t)lane * 16) = pendv; } \
-                          if (pend_n) { if (lane < pend_n) out[pend_pos + ((uint64_t)pendv_n16 << 4) + lane] = (uint8_t)pend_reg; } \
+#define LEAN_FLUSH() do { if (pendv_n16 | pend_n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* the pending bytes have arrived */ \
+                          if (pendv_n16) pend_store16(out + pend_pos, pendv_n16, lane16); \
+                          if (pend_n) pend_store8(out + pend_pos + ((uint64_t)pendv_n16 << 4), pend_n, lane); \
+                          if (!CTX_NEVER && lit_n) { if (lane < lit_n) out[lit_pos + lane] = (uint8_t)lit_reg; lit_n = 0; } \
                           pendv_n16 = 0; pend_n = 0; } while (0)
   uint32_t stage = LS_BEGIN;
   int32_t insert_len = 0, copy_len = 0, distance_code = 0;
@@ -1575,7 +1601,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
         // ---- context-modelled: one at a time, the tree depends on the two bytes before ----
         if (!ctx_regs) {
           if (ctx_pend) {  // they are the tail of the short copy still in pend_reg (copy lengths start at 2)
-            p1 = rdlane(pend_reg, pend_n - 1u); p2 = rdlane(pend_reg, pend_n - 2u);
+            p1 = pend_byte(pend_n - 1u); p2 = pend_byte(pend_n - 2u);
           } else {
             LEAN_FLUSH();
             p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u;
@@ -1684,9 +1710,8 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
         mlen -= copy_len;
         LEAN_FLUSH();
         gu8* src = out + P - dist;
-        uint32_t b = 0;
-        if (lane < n) b = src[dist >= n ? lane : lane % dist];
-        pend_reg = b; pend_n = n; pend_pos = P;
+        pend_load8(src, n, dist >= n ? lane : lane % dist);
+        pend_n = n; pend_pos = P;
         ctx_regs = false; ctx_pend = true;
         P += n;
         quota -= n;
@@ -1696,7 +1721,14 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
       if (dist < n) { stage = LS_POST_DISTANCE; break; }
       if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
       mlen -= copy_len;
+#ifdef BROTLI_AMD_PROFILE_LEAN
+      { uint64_t t0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); uint64_t t1_ = __builtin_amdgcn_s_memtime();
+        LEAN_FLUSH();
+        uint64_t t2_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); uint64_t t3_ = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == 0) { g_lean_prof[5] += t1_ - t0_; g_lean_prof[6] += t3_ - t2_; } }
+#else
       LEAN_FLUSH();
+#endif
       if (!CTX_NEVER) { ctx_regs = false; ctx_pend = false; }
       gu8* src = out + P - dist;
       uint32_t n16 = n >> 4, rem = n & 15u;
@@ -1710,17 +1742,15 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
         src += (uint64_t)whole * 16; P += (uint64_t)whole * 16; quota -= whole * 16; n16 -= whole;
       }
       // the load is issued now, the store when the next command gets here (its source may be what this one writes)
-      u32x4 v = {0, 0, 0, 0};
-      if (lane < n16) v = *reinterpret_cast<gu32x4*>(src + (uint64_t)lane * 16);
-      uint32_t b = 0;
-      if (lane < rem) b = src[(n16 << 4) + lane];
-      pendv = v; pendv_n16 = n16; pend_reg = b; pend_n = rem; pend_pos = P;
+      if (n16) pend_load16(src, n16, lane16);
+      if (rem) pend_load8(src, rem, (n16 << 4) + lane);
+      pendv_n16 = n16; pend_n = rem; pend_pos = P;
       P += (n16 << 4) + rem;
       quota -= (n16 << 4) + rem;
       if (quota == 0) { stage = LS_COMMAND_DONE; break; }
     }
   }
-  if (!CTX_NEVER && !ctx_regs && ctx_pend) { p1 = rdlane(pend_reg, pend_n - 1u); p2 = rdlane(pend_reg, pend_n - 2u); ctx_regs = true; }
+  if (!CTX_NEVER && !ctx_regs && ctx_pend) { p1 = pend_byte(pend_n - 1u); p2 = pend_byte(pend_n - 2u); ctx_regs = true; }
   LEAN_FLUSH();
 #ifdef BROTLI_AMD_PROFILE_LEAN
   if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 4; k++) g_lean_prof[k] += lp_acc[k]; g_lean_prof[4] += ncmd; }
@@ -2710,7 +2740,8 @@ extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(co
   }
 #ifdef BROTLI_AMD_PROFILE_LEAN
   if (blockIdx.x == 0 && lane_id() == 0)
-    printf("lean cmds %llu ticks per cmd: head %llu literals %llu distance %llu copy %llu\n", g_lean_prof[4], g_lean_prof[0] / g_lean_prof[4],
+    printf("lean cmds %llu wait before flush %llu after flush stores %llu (ticks per cmd); ticks per cmd: head %llu literals %llu distance %llu copy %llu\n", g_lean_prof[4],
+           g_lean_prof[5] / g_lean_prof[4], g_lean_prof[6] / g_lean_prof[4], g_lean_prof[0] / g_lean_prof[4],
            g_lean_prof[1] / g_lean_prof[4], g_lean_prof[2] / g_lean_prof[4], g_lean_prof[3] / g_lean_prof[4]);
 #endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
