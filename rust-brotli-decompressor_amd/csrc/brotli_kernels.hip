@@ -1511,10 +1511,10 @@ template <bool CTX_NEVER>
 // the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
 // 20.1 GB/s over the eight placements).  Measured on MI355X with tools/scratch-style sweeps; re-measure after edits.
 #ifndef BROTLI_AMD_LEAN_PAD_NEVER
-#define BROTLI_AMD_LEAN_PAD_NEVER 6
+#define BROTLI_AMD_LEAN_PAD_NEVER 2
 #endif
 #ifndef BROTLI_AMD_LEAN_PAD_CTX
-#define BROTLI_AMD_LEAN_PAD_CTX 2
+#define BROTLI_AMD_LEAN_PAD_CTX 1
 #endif
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   // (the function starts on a 256-byte boundary so that the placement of its loops relative to instruction-fetch
