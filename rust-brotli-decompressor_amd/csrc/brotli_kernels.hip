@@ -949,8 +949,13 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   into the next chunk at which its chain ends; then, posted by the decoding wave once the chunk's place is known:
 //   move wanted for round, first literal of the chunk to move, where to (offset from the output), how many; and the
 //   helper's answer, round moved.
-enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8 };
-enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8 };
+enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10 };
+enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
+       // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
+       // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
+       // the common start, windows walked, offset at which the walk left the last of them; and, from the decoding wave
+       // with the move: whether those literals are the stream's
+       HW_RES = 9, HW_RSYNC = 10, HW_RNM = 11, HW_RSKIP = 12, HW_RWIN = 13, HW_REXIT = 14, HW_MVOWN = 15 };
 constexpr uint32_t SPEC_ROUND_MIN = 768;       // literals a run must still have for a round to pay
 // input a round of nw chunks may look at, from the reader's next dword on
 __device__ __forceinline__ uint32_t spec_input_dwords(uint32_t nw) { return nw * SPEC_WINDOWS * 2u + 74u; }
@@ -1130,8 +1135,45 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
     lds_release();
     hw_st(slot, HW_DONE, seq);
-    // the decoding wave says which of the chunk's literals are the stream's and where they go (none: n = 0)
+    // Where does the chain of the chunk before meet this chunk's?  If that chunk's own chain is the stream's (the
+    // decoding wave checks that, chunk by chunk), its exit offset is where the stream's chain enters this chunk: every
+    // helper walks it into its own first windows at the same time.  (Capped rounds: the decoding wave does it all.)
+    uint64_t own_mask[SPEC_FIRST] = {}; uint32_t own_sym[SPEC_FIRST] = {}, own_cnt[SPEC_FIRST] = {}, own_win = 0;
+    const bool self = hc_ld(HC_CAPPED) == 0u;
     bool go = true;
+    if (self) {
+      while (hw_ld(slot - HL_SLOT, HW_DONE) != seq) {
+        if (hc_ld(HC_SEQ) != seq) { go = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!go) continue;
+      lds_acquire();
+      uint32_t e = hw_ld(slot - HL_SLOT, HW_EXIT), nm = 0, skip = 0;
+      bool synced = false;
+      _Pragma("unroll") for (uint32_t k = 0; k < SPEC_FIRST; k++) {
+        if (synced) continue;
+        const uint64_t sm = *reinterpret_cast<__attribute__((address_space(3))) const uint64_t*>(&g_smem[slot + HL_MASK + k * 8u]);
+        const uint64_t smask = ((uint64_t)rfl((uint32_t)(sm >> 32)) << 32) | rfl((uint32_t)sm);
+        const uint32_t Lv = lds_ld8(slot + HL_FIRST + k * 128u + lane);
+        own_sym[k] = lds_ld8(slot + HL_FIRST + k * 128u + 64u + lane);
+        uint64_t tstarts; uint32_t woff;
+        SPEC_WALK(Lv, e, tstarts, woff);
+        const uint64_t common = tstarts & smask;
+        uint64_t m = tstarts;
+        if (common) {
+          const uint32_t p = (uint32_t)__builtin_ctzll(common);
+          m = tstarts & ((1ull << p) - 1ull);
+          skip = rfl(lds_ld32(slot + HL_CUM + k * 4u)) + (uint32_t)__popcll(smask & ((1ull << p) - 1ull));
+          synced = true;
+        }
+        own_mask[k] = m; own_cnt[k] = nm; nm += (uint32_t)__popcll(m);
+        e = woff - 64u; own_win = k + 1u;
+      }
+      hw_st(slot, HW_RSYNC, synced ? 1u : 0u); hw_st(slot, HW_RNM, nm); hw_st(slot, HW_RSKIP, skip); hw_st(slot, HW_RWIN, own_win); hw_st(slot, HW_REXIT, e);
+      lds_release();
+      hw_st(slot, HW_RES, seq);
+    }
+    // the decoding wave says which of the chunk's literals are the stream's and where they go (none: n = 0)
     while (hw_ld(slot, HW_MVGO) != seq) {
       if (hc_ld(HC_SEQ) != seq) { go = false; break; }  // the round was given up (or the kernel is about to end)
       __builtin_amdgcn_s_sleep(2);
@@ -1139,10 +1181,22 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     if (!go) continue;
     lds_acquire();
     const uint32_t n = hw_ld(slot, HW_MVN);
+    if (self && hw_ld(slot, HW_MVOWN) != 0u) {  // the literals of the walk above are the stream's: in front of the chunk's own
+      gu8* const d0 = (gu8*)(uintptr_t)(((uint64_t)hc_ld(HC_OUT_LO) | ((uint64_t)hc_ld(HC_OUT_HI) << 32)) +
+                                       ((uint64_t)hw_ld(slot, HW_MVDST_LO) | ((uint64_t)hw_ld(slot, HW_MVDST_HI) << 32)));
+      _Pragma("unroll") for (uint32_t k = 0; k < SPEC_FIRST; k++) {
+        if (k >= own_win) continue;
+        const uint64_t m = own_mask[k];
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        gu8* wq = d0 + own_cnt[k];
+        SPEC_STORE(m, rank, own_sym[k], wq);
+      }
+    }
     if (n != 0) {
       gu8* const src = mine + hw_ld(slot, HW_MVSRC);
       gu8* const dst = (gu8*)(uintptr_t)(((uint64_t)hc_ld(HC_OUT_LO) | ((uint64_t)hc_ld(HC_OUT_HI) << 32)) +
-                                        ((uint64_t)hw_ld(slot, HW_MVDST_LO) | ((uint64_t)hw_ld(slot, HW_MVDST_HI) << 32)));
+                                        ((uint64_t)hw_ld(slot, HW_MVDST_LO) | ((uint64_t)hw_ld(slot, HW_MVDST_HI) << 32))) +
+                        (self ? hw_ld(slot, HW_RNM) : 0u);
       constexpr uint32_t H = SPEC_SLOT_BYTES / 1024u;
       const uint32_t n16 = n >> 4;
       u32x4 t[H] = {};
@@ -1157,8 +1211,8 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
         if (c < n16) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t[h];
       }
       if (lane < (n & 15u)) dst[(n16 << 4) + lane] = (uint8_t)tail;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the move is reported done
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the move is reported done
     lds_release();
     hw_st(slot, HW_MVDONE, seq);
   }
@@ -1338,11 +1392,13 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
     const uint64_t abs0 = run_pos + BitReader::skip_bits();
     const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
     seq++;
-    hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1);
+    hc_st(HC_DW0, dw0); hc_st(HC_SHIFT, sh); hc_st(HC_TREE, tree_addr); hc_st(HC_KIND, 1); hc_st(HC_CAPPED, capped ? 1u : 0u);
     lds_release();
     hc_st(HC_SEQ, seq);
     br.request_ahead(dw0 + nw * SPEC_WINDOWS * 2u);  // where the round will normally end: there by the time it does
     spec_chunk(0, dw0, sh, tree_addr, capped ? spec : out + P, 0);  // the first chunk: its first bit does start a literal
+    lds_release();
+    hw_st(hb, HW_DONE, seq);     // (helper 1 takes this chunk's exit offset from here)
     SPEC_PROF(0);
     uint32_t acc = hw_ld(hb, HW_N);  // literals of the round so far
     uint32_t e = hw_ld(hb, HW_EXIT);
@@ -1359,14 +1415,33 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
       while (hw_ld(hb + w * HL_SLOT, HW_DONE) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
       if (lost) break;
     }
+    if (!capped && !lost)
+      for (uint32_t w = 1; w < nw; w++) {  // every helper's account of how the chain enters its chunk
+        uint32_t polls = 0;
+        while (hw_ld(hb + w * HL_SLOT, HW_RES) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
+        if (lost) break;
+      }
     lds_acquire();
     SPEC_PROF(1);
     if (!lost) { moving = 0; mv_seq = seq; }  // (every helper has finished the move of the round before: it decoded this round's chunk after it)
     bool open = !lost && !full;  // chunks are still being taken
     for (uint32_t w = 1; w < nw; w++) {
       const uint32_t slot = hb + w * HL_SLOT;
-      uint32_t mv_src = 0, mv_n = 0, mv_dst = acc;
-      if (open) {
+      uint32_t mv_src = 0, mv_n = 0, mv_dst = acc, mv_own = 0;
+      if (open && !capped) {
+        // the helper has walked the chain of the chunk before into its own; that chain is the stream's (every chunk up
+        // to here fell in), so the helper's account stands: add it up
+        const uint32_t nm = hw_ld(slot, HW_RNM);
+        mv_own = 1; mv_dst = acc; acc += nm;
+        if (hw_ld(slot, HW_RSYNC) != 0u) {
+          const uint32_t skip = hw_ld(slot, HW_RSKIP), valid = hw_ld(slot, HW_N) - skip;
+          mv_src = skip; mv_n = valid; acc += valid;
+          bits_done = (w + 1u) * SPEC_WINDOWS * 64u + hw_ld(slot, HW_EXIT);
+        } else {  // no common start within the first windows: the round ends behind the windows walked
+          bits_done = (w * SPEC_WINDOWS + hw_ld(slot, HW_RWIN)) * 64u + hw_ld(slot, HW_REXIT);
+          open = false;
+        }
+      } else if (open) {
         // walk the true chain into chunk w until it steps on a start the helper marked too
         bool synced = false;
         uint32_t skip = 0;
@@ -1422,9 +1497,10 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
       if (!lost) {
         const uint64_t d = P + mv_dst;
         hw_st(slot, HW_MVSRC, mv_src); hw_st(slot, HW_MVDST_LO, (uint32_t)d); hw_st(slot, HW_MVDST_HI, (uint32_t)(d >> 32)); hw_st(slot, HW_MVN, mv_n);
+        hw_st(slot, HW_MVOWN, mv_own);
         lds_release();
         hw_st(slot, HW_MVGO, seq);
-        if (mv_n) moving |= 1u << w;
+        if (mv_n | mv_own) moving |= 1u << w;
       }
     }
     SPEC_PROF(2);
@@ -1456,12 +1532,8 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
     if (!((moving >> w) & 1u)) continue;
     uint32_t polls = 0;
     while (hw_ld(hb + w * HL_SLOT, HW_MVDONE) != mv_seq) {
-      if (++polls > (1u << 20)) {  // (never seen; the launch must not hang and the output must not be wrong)
-        hc_st(HC_KIND, 3);
-        const uint32_t slot = hb + w * HL_SLOT, n = hw_ld(slot, HW_MVN);
-        gu8* src = spec + w * SPEC_SLOT_BYTES + hw_ld(slot, HW_MVSRC);
-        gu8* dst = out + ((uint64_t)hw_ld(slot, HW_MVDST_LO) | ((uint64_t)hw_ld(slot, HW_MVDST_HI) << 32));
-        for (uint32_t c = lane; c < n; c += 64) dst[c] = src[c];
+      if (++polls > (1u << 22)) {  // (never seen; the launch must not hang and the output must not be silently wrong:
+        hc_st(HC_KIND, 3); hc_st(HC_FAILED, 1);  // the caller reports the stream as failed)
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -1964,6 +2036,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
       if (CTX_NEVER && stage == LS_LITERAL_ROUNDS) {
         spec_rounds(LDS_FIXED + lit_tree);
+        if (hc_ld(HC_FAILED) != 0u) STOP(E_UNREACHABLE);  // a helper wave did not finish moving its literals (never seen)
         br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
         br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
         br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
