@@ -1410,38 +1410,47 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
       own = acc;
     }
     bool lost = false;
-    for (uint32_t w = 1; w < nw; w++) {  // (bounded: helpers that never answer must not hang the GPU)
+    {  // lane w looks at helper w's words: round decoded and, in uncapped rounds, its account of how the chain enters its
+       // chunk (bounded: helpers that never answer must not hang the GPU)
+      const bool helper_lane = lane >= 1u && lane < nw;
+      lds_vu32* const flag = reinterpret_cast<lds_vu32*>(&g_smem[hb + (helper_lane ? lane : 0u) * HL_SLOT + HL_CTL + 4u * (capped ? HW_DONE : HW_RES)]);
       uint32_t polls = 0;
-      while (hw_ld(hb + w * HL_SLOT, HW_DONE) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
-      if (lost) break;
+      while (__ballot(helper_lane && *flag != seq) != 0ull) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
     }
-    if (!capped && !lost)
-      for (uint32_t w = 1; w < nw; w++) {  // every helper's account of how the chain enters its chunk
-        uint32_t polls = 0;
-        while (hw_ld(hb + w * HL_SLOT, HW_RES) != seq) { if (++polls > (1u << 20)) { lost = true; break; } __builtin_amdgcn_s_sleep(1); }
-        if (lost) break;
-      }
     lds_acquire();
     SPEC_PROF(1);
     if (!lost) { moving = 0; mv_seq = seq; }  // (every helper has finished the move of the round before: it decoded this round's chunk after it)
     bool open = !lost && !full;  // chunks are still being taken
+    if (!capped && open) {
+      // Every helper has walked the chain of the chunk before into its own chunk.  Up to the first chunk that did not
+      // fall in, that chain was the stream's, so the accounts stand: lane w adds up helper w's and posts its move.
+      const bool helper_lane = lane >= 1u && lane < nw;
+      const uint32_t slot = hb + (helper_lane ? lane : 0u) * HL_SLOT + HL_CTL;
+      const uint32_t rnm = lds_ld32(slot + 4u * HW_RNM), rsync = lds_ld32(slot + 4u * HW_RSYNC), rskip = lds_ld32(slot + 4u * HW_RSKIP);
+      const uint32_t cn = lds_ld32(slot + 4u * HW_N), cexit = lds_ld32(slot + 4u * HW_EXIT), rwin = lds_ld32(slot + 4u * HW_RWIN), rexit = lds_ld32(slot + 4u * HW_REXIT);
+      const uint64_t unsynced = __ballot(helper_lane && rsync == 0u);
+      const uint32_t u = unsynced ? (uint32_t)__builtin_ctzll(unsynced) : nw;  // first chunk that did not fall in
+      const uint32_t valid = lane < u ? cn - rskip : 0u;
+      const uint32_t contrib = lane == 0u ? acc : helper_lane && lane <= u ? rnm + valid : 0u;
+      uint32_t before = 0, total = 0;  // exclusive prefix sum over lanes 0 .. nw - 1
+      for (uint32_t k = 0; k < nw; k++) { before = lane == k ? total : before; total += rdlane(contrib, k); }
+      acc = total;
+      bits_done = u >= nw ? nw * SPEC_WINDOWS * 64u + rdlane(cexit, nw - 1u) : (u * SPEC_WINDOWS + rdlane(rwin, u)) * 64u + rdlane(rexit, u);
+      if (helper_lane) {
+        const uint64_t d = P + before;
+        lds_st32(slot + 4u * HW_MVSRC, rskip); lds_st32(slot + 4u * HW_MVDST_LO, (uint32_t)d); lds_st32(slot + 4u * HW_MVDST_HI, (uint32_t)(d >> 32));
+        lds_st32(slot + 4u * HW_MVN, valid); lds_st32(slot + 4u * HW_MVOWN, lane <= u ? 1u : 0u);
+      }
+      lds_release();
+      if (helper_lane) *reinterpret_cast<lds_vu32*>(&g_smem[slot + 4u * HW_MVGO]) = seq;
+      moving = (uint32_t)__ballot(helper_lane && lane <= u);
+      open = false;
+    }
     for (uint32_t w = 1; w < nw; w++) {
+      if (!capped) break;
       const uint32_t slot = hb + w * HL_SLOT;
       uint32_t mv_src = 0, mv_n = 0, mv_dst = acc, mv_own = 0;
-      if (open && !capped) {
-        // the helper has walked the chain of the chunk before into its own; that chain is the stream's (every chunk up
-        // to here fell in), so the helper's account stands: add it up
-        const uint32_t nm = hw_ld(slot, HW_RNM);
-        mv_own = 1; mv_dst = acc; acc += nm;
-        if (hw_ld(slot, HW_RSYNC) != 0u) {
-          const uint32_t skip = hw_ld(slot, HW_RSKIP), valid = hw_ld(slot, HW_N) - skip;
-          mv_src = skip; mv_n = valid; acc += valid;
-          bits_done = (w + 1u) * SPEC_WINDOWS * 64u + hw_ld(slot, HW_EXIT);
-        } else {  // no common start within the first windows: the round ends behind the windows walked
-          bits_done = (w * SPEC_WINDOWS + hw_ld(slot, HW_RWIN)) * 64u + hw_ld(slot, HW_REXIT);
-          open = false;
-        }
-      } else if (open) {
+      if (open) {
         // walk the true chain into chunk w until it steps on a start the helper marked too
         bool synced = false;
         uint32_t skip = 0;
