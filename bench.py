@@ -45,8 +45,10 @@ def load_pkg():
 def build_workload(name, rank):
     """-> (label, unique streams [(compressed, raw_size, sha256)], copies per unique stream)"""
     import workloads as w
-    if name == "alice29x1024" or not w.encoder_available():
-        return "1024 x alice29.txt.compressed (reference fixture, wbits 22)", w.fixture_streams("alice29.txt.compressed"), 1024
+    m = re.fullmatch(r"alice29x(\d+)", name)
+    if m or not w.encoder_available():
+        n = int(m.group(1)) if m else 1024
+        return "%d x alice29.txt.compressed (reference fixture, wbits 22)" % n, w.fixture_streams("alice29.txt.compressed"), n
     n_unique = int(os.environ.get("BROTLI_BENCH_UNIQUE", "32"))
     m = re.fullmatch(r"(longbackref|highentropy)_(\d+)x(\d+)(KiB|MiB)", name)
     if m and name not in ("longbackref_256x4MiB", "highentropy_256x4MiB"):

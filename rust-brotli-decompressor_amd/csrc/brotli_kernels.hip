@@ -1592,10 +1592,10 @@ template <bool CTX_NEVER>
 // the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
 // 20.1 GB/s over the eight placements).  Measured on MI355X with tools/scratch-style sweeps; re-measure after edits.
 #ifndef BROTLI_AMD_LEAN_PAD_NEVER
-#define BROTLI_AMD_LEAN_PAD_NEVER 2
+#define BROTLI_AMD_LEAN_PAD_NEVER 1
 #endif
 #ifndef BROTLI_AMD_LEAN_PAD_CTX
-#define BROTLI_AMD_LEAN_PAD_CTX 1
+#define BROTLI_AMD_LEAN_PAD_CTX 4
 #endif
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   // (the function starts on a 256-byte boundary so that the placement of its loops relative to instruction-fetch
@@ -1618,6 +1618,14 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
   const uint32_t dt0 = LEAN_LD(L_DT0), dt1 = LEAN_LD(L_DT1), dt2 = LEAN_LD(L_DT2), dt3 = LEAN_LD(L_DT3);
   const int32_t max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
   const uint32_t postfix_bits = LEAN_LD(L_POSTFIX), num_direct = LEAN_LD(L_NUM_DIRECT);
+  // NPOSTFIX = NDIRECT = 0 (what encoders use by default): distance codes 16 .. 63 map to (extra bits, first distance)
+  // through a table held one entry per lane instead of the arithmetic of decode.rs:2099-2128
+  const bool dlut_ok = postfix_bits == 0u && num_direct == 16u;
+  uint32_t dlut;
+  {
+    const uint32_t dv = (lane - 16u) & 63u, nb = (dv >> 1) + 1u;
+    dlut = nb | ((((2u + (dv & 1u)) << nb) - 3u) << 5);  // distance = ((2 + (dv & 1)) << nb) - 4 + bits + 1
+  }
   const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
   const uint32_t lomask = lane < 32 ? 0xFFFFFFFFu : 0u;
   const uint32_t tree_addr = LDS_FIXED + lit_tree;
@@ -1760,6 +1768,9 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
           else { v -= mag; if (v <= 0) v = 0x7fffffff; }
           distance_code = v;
         }
+      } else if (dlut_ok && code < 64u) {
+        const uint32_t de = rdlane(dlut, code);
+        distance_code = (int32_t)((de >> 5) + br.read(de & 31u));
       } else {
         int32_t distval = (int32_t)code - (int32_t)num_direct;
         int32_t dc = (int32_t)code;
