@@ -1124,10 +1124,12 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
   uint32_t seq = 0;
   for (;;) {
     uint32_t j;
-    for (;;) {  // idle until the decoding wave posts a round (it always posts `exit` at the end)
+    for (uint32_t idle = 0;; idle++) {  // idle until the decoding wave posts a round (it always posts `exit` at the end)
       j = hc_ld(HC_SEQ);
       if (j != seq) break;
-      __builtin_amdgcn_s_sleep(16);
+      // right after a round the next one is due any moment; otherwise look every 8 K clocks only (a stream without
+      // long literal runs never posts one, and seven waves polling at full rate are a billion instructions per launch)
+      if (idle < 256u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(127);
     }
     seq = j;
     lds_acquire();
