@@ -1597,7 +1597,7 @@ template <bool CTX_NEVER>
 #define BROTLI_AMD_LEAN_PAD_NEVER 1
 #endif
 #ifndef BROTLI_AMD_LEAN_PAD_CTX
-#define BROTLI_AMD_LEAN_PAD_CTX 4
+#define BROTLI_AMD_LEAN_PAD_CTX 7
 #endif
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   // (the function starts on a 256-byte boundary so that the placement of its loops relative to instruction-fetch
@@ -1797,22 +1797,10 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
       const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
       const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
       if (distance_code > max_distance || distance_code <= 0 || n > quota) { stage = LS_POST_DISTANCE; break; }
-      if (!CTX_NEVER && n <= 64u) {
-        // short copy where literal context matters: one byte per lane (pattern when it overlaps itself), so that the
-        // next literal can take the two bytes before it straight from the register
-        if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
-        mlen -= copy_len;
-        LEAN_FLUSH();
-        gu8* src = out + P - dist;
-        pend_load8(src, n, dist >= n ? lane : lane % dist);
-        pend_n = n; pend_pos = P;
-        ctx_regs = false; ctx_pend = true;
-        P += n;
-        quota -= n;
-        if (quota == 0) { stage = LS_COMMAND_DONE; break; }
-        continue;
-      }
-      if (dist < n) { stage = LS_POST_DISTANCE; break; }
+      // (one path through here for every kind of copy: two that each updated P and the quota and went back to the top
+      // of the loop made the compiler shuffle a dozen scalars at the back edge)
+      const bool tiny = !CTX_NEVER && n <= 64u;  // short copy where literal context matters: one byte per lane
+      if (!tiny && dist < n) { stage = LS_POST_DISTANCE; break; }
       if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
       mlen -= copy_len;
 #ifdef BROTLI_AMD_PROFILE_LEAN
@@ -1823,21 +1811,29 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
 #else
       LEAN_FLUSH();
 #endif
-      if (!CTX_NEVER) { ctx_regs = false; ctx_pend = false; }
       gu8* src = out + P - dist;
-      uint32_t n16 = n >> 4, rem = n & 15u;
-      if (n > 1024u) {  // long: all but the last (partial) KiB right away, 16 bytes per lane and step
-        gu8* dst = out + P;
-        const uint32_t whole = (n16 - 1u) & ~63u;  // 16-byte pieces in whole steps, at least one piece is left for below
-        for (uint32_t c = lane; c < whole; c += 64) {
-          u32x4 t = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-          *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t;
+      uint32_t n16 = 0, rem = n;
+      if (tiny) {
+        // (pattern when it overlaps itself) so that the next literal can take the two bytes before it straight from
+        // the register
+        pend_load8(src, n, dist >= n ? lane : lane % dist);
+        ctx_regs = false; ctx_pend = true;
+      } else {
+        if (!CTX_NEVER) { ctx_regs = false; ctx_pend = false; }
+        n16 = n >> 4; rem = n & 15u;
+        if (n > 1024u) {  // long: all but the last (partial) KiB right away, 16 bytes per lane and step
+          gu8* dst = out + P;
+          const uint32_t whole = (n16 - 1u) & ~63u;  // 16-byte pieces in whole steps, at least one piece is left for below
+          for (uint32_t c = lane; c < whole; c += 64) {
+            u32x4 t = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+            *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = t;
+          }
+          src += (uint64_t)whole * 16; P += (uint64_t)whole * 16; quota -= whole * 16; n16 -= whole;
         }
-        src += (uint64_t)whole * 16; P += (uint64_t)whole * 16; quota -= whole * 16; n16 -= whole;
+        // the load is issued now, the store when the next command gets here (its source may be what this one writes)
+        if (n16) pend_load16(src, n16, lane16);
+        if (rem) pend_load8(src, rem, (n16 << 4) + lane);
       }
-      // the load is issued now, the store when the next command gets here (its source may be what this one writes)
-      if (n16) pend_load16(src, n16, lane16);
-      if (rem) pend_load8(src, rem, (n16 << 4) + lane);
       pendv_n16 = n16; pend_n = rem; pend_pos = P;
       P += (n16 << 4) + rem;
       quota -= (n16 << 4) + rem;
