@@ -2163,6 +2163,42 @@ general_literals_rest:
       if (prof_fast_syms == 0) prof_fast_syms = 0x100000u | (LDS_ONLY ? 1u : 0u) | (trivial ? 2u : 0u) | (mlen >= 0 ? 4u : 0u) | (i >= 8 ? 8u : 0u) | (bl0 >= 8 ? 16u : 0u) | (out_cap - P >= 8 ? 32u : 0u);
 #endif
       PROF_LIT(prof_lit, prof_t);
+rounds_again:
+      // A long run that the lean loop could not take whole (it crosses a flush point of the ring buffer, the end of a
+      // literal block or of the output buffer): rounds of the helper waves for the part in front of that limit, the
+      // checked loops below for what is left of that part, and again behind the limit.
+      if (CTX_NEVER && LDS_ONLY && trivial && mlen >= 0 && i >= (int32_t)SPEC_ROUND_MIN && !lit_zero &&
+          br.next_dw + spec_input_dwords(SPEC_MAX_WAVES) < safe_dw && hc_ld(HC_KIND) != 3u) {
+        uint64_t lim = out_cap - P;
+        const uint64_t rb_ = next_boundary > P ? next_boundary - P : 0;
+        if (rb_ < lim) lim = rb_;
+        uint32_t part = (uint32_t)i < bl0 ? (uint32_t)i : bl0;
+        if (lim < (uint64_t)part) part = (uint32_t)lim;
+        if (part >= SPEC_ROUND_MIN) {
+          FLUSH_LITERALS();
+          FLUSH_PENDING();
+          lds_sync();
+          lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
+          if (lane == 0) {
+            LEAN_ST(L_CHUNK_BASE, br.chunk_base);
+            LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+            LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32));
+            LEAN_ST(L_LITS_LEFT, part); LEAN_ST(L_BL0, bl0); LEAN_ST(L_QUOTA, part);
+          }
+          lds_sync();
+          spec_rounds(LDS_FIXED + lit_tree);
+          if (hc_ld(HC_FAILED) != 0u) STOP(E_UNREACHABLE);
+          br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+          br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
+          br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
+          P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+          const uint32_t got = part - LEAN_LD(L_LITS_LEFT);
+          i -= (int32_t)got; bl0 -= got;
+          ctx_src = CTX_MEMORY;
+          if (P >= next_boundary) RING_CROSS();
+          if (got != 0 && part == got) goto rounds_again;  // the part is done: behind the limit there may be another
+        }
+      }
       if (LDS_ONLY && trivial && mlen >= 0) {
         while (i >= 8 && bl0 >= 8) {
           uint64_t room = out_cap - P;
@@ -2218,7 +2254,7 @@ general_literals_rest:
 #ifdef BROTLI_AMD_PROFILE
           prof_fast_batches++; prof_fast_syms += n;
 #endif
-          if (P >= next_boundary) RING_CROSS();
+          if (P >= next_boundary) { RING_CROSS(); if (i >= (int32_t)SPEC_ROUND_MIN) goto rounds_again; }
         }
       }
       PROF_LIT(prof_dist, prof_t);
@@ -2229,6 +2265,7 @@ general_literals_rest:
           BLOCK_SWITCH(0, bl0, r);
           if (r == BS_NEEDS_INPUT) STOP(mlen < 0 ? E_BLOCK_LENGTH_1 : E_NEEDS_MORE_INPUT);
           if (r == BS_SWITCHED) prepare_literal();
+          if (i >= (int32_t)SPEC_ROUND_MIN) goto rounds_again;
         }
         uint32_t tree = lit_tree;
         if (!CTX_NEVER && !trivial) {
@@ -2250,7 +2287,7 @@ general_literals_rest:
         if (bl0 == 0) STOP(E_WINDOW_BITS);  // decode.rs:2434-2439
         bl0--;
         i--;
-        if (P >= next_boundary) RING_CROSS();
+        if (P >= next_boundary) { RING_CROSS(); if (i >= (int32_t)SPEC_ROUND_MIN) goto rounds_again; }
       }
       PROF_LIT(prof_copy, prof_t);
       if (mlen <= 0) STOP(E_SUCCESS);  // METABLOCK_DONE, copy part ignored (decode.rs:2552-2556)

@@ -8,7 +8,7 @@ from conftest import load_pkg
 pkg = load_pkg()
 kind = sys.argv[1] if len(sys.argv) > 1 else "long_backref"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-(c, sz, sha), = w.make_streams(kind, 1, 4 << 20, 1000)
+(c, sz, sha), = w.make_streams(kind, 1, (int(sys.argv[3]) if len(sys.argv) > 3 else 4) << 20, 1000)
 src = torch.frombuffer(bytearray(c), dtype=torch.uint8).cuda()
 si, so = (len(c) + 255) // 256 * 256, (sz + 255) // 256 * 256
 inp = torch.zeros(n * si, dtype=torch.uint8, device="cuda"); out = torch.zeros(n * so, dtype=torch.uint8, device="cuda")

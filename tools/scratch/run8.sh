@@ -1,4 +1,2 @@
-export BROTLI_BENCH_UNIQUE=1
-for wl in longbackref_1x64MiB highentropy_1x64MiB; do
-  timeout 600 python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl', d['value'], d['roofline']['kernel_ms'], d['config']['workload'])"
-done
+BROTLI_AMD_LIB=$PWD/tools/scratch/lib_prof.so timeout 300 python tools/prof_workload.py high_entropy 8 4 2>&1 | grep "kernel ms\|ticks total\|per command"
+BROTLI_AMD_LIB=$PWD/tools/scratch/lib_prof.so timeout 300 python tools/prof_workload.py high_entropy 8 16 2>&1 | grep "kernel ms\|ticks total\|per command"
