@@ -1381,15 +1381,24 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   hc_st(HC_OUT_LO, (uint32_t)(uintptr_t)out); hc_st(HC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
   uint32_t seq = hc_ld(HC_SEQ);
   uint32_t moving = 0, mv_seq = 0;  // helpers whose move (of round mv_seq) has not been seen finished
+  // no round holds more literals than its bits divided by the shortest code length of the tree (root entries tell)
+  uint32_t round_max;
+  {
+    uint32_t m = 9u;
+    for (uint32_t k = 0; k < 4u; k++) { const uint32_t L = lds_ld16(tree_addr + ((lane + 64u * k) << 1)) & 15u; m = L < m ? L : m; }
+    uint32_t minlen = 9u;
+    for (uint32_t k = 1; k < 9u; k++) if (__ballot(m == k) != 0ull) { minlen = k; break; }
+    round_max = nw * SPEC_WINDOWS * 64u / minlen + 64u;
+  }
   while (i >= SPEC_ROUND_MIN && br.next_dw + spec_input_dwords(nw) < safe_dw && hc_ld(HC_KIND) != 3u) {
 #ifdef BROTLI_AMD_PROFILE_SPEC
     uint64_t sp_t = __builtin_amdgcn_s_memtime();
 #endif
-    // A round decodes up to nw * SPEC_SLOT_BYTES literals (+ a few).  Where the run has fewer left, the round is
+    // A round decodes up to round_max literals.  Where the run has fewer left, the round is
     // *capped*: nothing goes to the output directly (chunk 0 uses scratch slot 0 like the helpers), and the round ends
     // at the run's last literal, whose bit position the start masks give.
     const uint32_t cap = i;
-    const bool capped = i < nw * SPEC_SLOT_BYTES + 64u;
+    const bool capped = i < round_max;
     const uint64_t run_pos = br.pos();
     const uint64_t abs0 = run_pos + BitReader::skip_bits();
     const uint32_t dw0 = (uint32_t)(abs0 >> 5), sh = (uint32_t)abs0 & 31u;
