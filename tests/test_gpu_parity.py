@@ -403,3 +403,27 @@ def test_literal_runs_of_many_lengths(pkg):
         a, b = r1[k % len(all_d)], r4[k]
         assert (a.result, a.error_code, a.decoded_size, a.consumed) == (b.result, b.error_code, b.decoded_size, b.consumed), k
         assert o1[k % len(all_d)] == o4[k], k
+
+
+def test_long_literal_runs_across_ring_flush_points(pkg):
+    """Literal runs much longer than the ring buffer (windows of 1 KiB to 256 KiB, runs of 10^5 literals): the reference
+    flushes its ring every window's worth of output, which bounds how far a command may go without a check; the lean
+    loop does not take such a run, the checked path decodes it part by part between flush points -- with helper rounds
+    where a part is long enough -- and the delivered sizes at every output limit must still be the reference's."""
+    import numpy as np
+    import libbrotli_ref as ref
+    if not ref.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    rng = np.random.Generator(np.random.PCG64(4242))
+    p = np.arange(1, 257, dtype=np.float64) ** -0.5
+    p /= p.sum()
+    perm = rng.permutation(256)
+    raw = perm[rng.choice(256, size=700000, p=p)].astype(np.uint8).tobytes()
+    raw = raw + raw[1000:3000] + raw[:50]
+    datas, caps = [], []
+    for lgwin in (10, 12, 16, 18, 22):
+        for q in (1, 5):
+            c = ref.encode(raw, q, lgwin)
+            for cap in (len(raw), len(raw) - 1, 300000, 65536, 65537, 4097, 262144 + 5):
+                datas.append(c); caps.append(cap)
+    _check_against_oracle(pkg, datas, caps, 1, "ring flush points")
