@@ -45,6 +45,9 @@ def load_pkg():
 def build_workload(name, rank):
     """-> (label, unique streams [(compressed, raw_size, sha256)], copies per unique stream)"""
     import workloads as w
+    m = re.fullmatch(r"fixture:([\w.]+)x(\d+)", name)  # any of the reference's fixtures, n copies (cliff hunting)
+    if m:
+        return "%s x %s (reference fixture)" % (m.group(2), m.group(1)), w.fixture_streams(m.group(1)), int(m.group(2))
     m = re.fullmatch(r"alice29x(\d+)", name)
     if m or not w.encoder_available():
         n = int(m.group(1)) if m else 1024

@@ -1,3 +1,3 @@
-BROTLI_AMD_LIB=$PWD/tools/scratch/lib_proflean.so timeout 300 python tools/prof_workload.py long_backref 8 4 2>&1 | grep "kernel ms\|lean cmds" | head -2
-BROTLI_AMD_LIB=$PWD/tools/scratch/lib_proflean.so timeout 300 python tools/prof_workload.py long_backref 8 16 2>&1 | grep "kernel ms\|lean cmds" | head -2
-BROTLI_AMD_LIB=$PWD/tools/scratch/lib_prof.so timeout 300 python tools/prof_workload.py long_backref 8 16 2>&1 | grep "kernel ms\|ticks total\|per command\|lean exits" | head -8
+for f in reducetostream.map.compressed metablock_reset.compressed plrabn12.txt.compressed plrabn12.txt.bro lcet10.txt.compressed random_then_unicode.compressed mapsdatazrh.compressed zeros.compressed quickfox_repeated.compressed compressed_repeated.compressed alice29.txt.bro asyoulik.txt.compressed; do
+  timeout 300 python bench.py --workload "fixture:${f}x1024" --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$f', d['value'], d['roofline']['kernel_ms'], d['config'].get('second_pass_streams'))" 2>&1 | tail -1
+done
