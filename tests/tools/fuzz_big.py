@@ -1,7 +1,7 @@
 """GPU vs oracle on the bench workloads' 4 MiB streams: valid streams with tight output buffers, damaged streams with
 roomy ones (long literal runs, copies > 1 KiB, quota and ring-buffer limits of the lean loop)."""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 from conftest import load_pkg
 import oracle_lib as oracle, workloads as w

@@ -1,6 +1,6 @@
-"""Differential fuzzing GPU vs oracle beyond what the test suite runs: python tools/fuzz_campaign.py <first_seed> <n_seeds> [per_seed]"""
+"""Differential fuzzing GPU vs oracle beyond what the test suite runs: python tests/tools/fuzz_campaign.py <first_seed> <n_seeds> [per_seed]"""
 import json, os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 from conftest import load_pkg
 import oracle_lib as oracle, param_corpus

@@ -1,6 +1,6 @@
 """Decode one fixture on the GPU and report the first output byte that differs from the oracle's."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import load_pkg
