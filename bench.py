@@ -166,8 +166,16 @@ def main():
             raise SystemExit("rank %d: stream %d is not bit-exact" % (rank, i))
     del host
 
+    def step():
+        # the whole job: where streams had to come back for a pass with a larger table arena, that is the first pass
+        # and the passes after it (submit + wait); otherwise the one kernel, launched again on the same descriptors
+        if second_pass:
+            batch.decode_device(in_ptrs, sizes, out_ptrs, caps, pkg.FLAG_LARGE_WINDOW, stream)
+            batch.wait()
+        else:
+            batch.relaunch(stream)
     for _ in range(args.warmup):
-        batch.relaunch(stream)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -175,9 +183,11 @@ def main():
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.relaunch(stream)
+        ts = time.perf_counter()
+        step()
         # HIP events recorded around the launch on the launch stream; reading them waits for this step only
-        kernel_ms.append(batch.last_kernel_ms())
+        # (several passes: wall time of the step, the events only bracket the first)
+        kernel_ms.append(batch.last_kernel_ms() if not second_pass else (time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -34,6 +34,10 @@ extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictiona
 namespace {
 
 constexpr size_t kDictSize = 122784;
+// One-wave blocks per CU at most (a CU's registers hold sixteen waves of the kernel) and the smallest table arena worth a
+// first pass; what does not fit a pass's arena comes back in the next (retry_with_larger_arenas).
+static const size_t kMaxBlocksPerCu = getenv("BROTLI_AMD_MAX_BLOCKS_PER_CU") ? (size_t)atoi(getenv("BROTLI_AMD_MAX_BLOCKS_PER_CU")) : 14;
+static const uint32_t kMinSmallArena = getenv("BROTLI_AMD_MIN_SMALL_ARENA") ? (uint32_t)atoi(getenv("BROTLI_AMD_MIN_SMALL_ARENA")) : 4096u;
 constexpr uint64_t kScratchPerBlock = (2u << 20) + BROTLI_AMD_SPEC_SCRATCH;  // worst-case table arena of one metablock + helper scratch
 constexpr uint32_t kDefaultLdsPerBlock = 36 * 1024;
 
@@ -88,7 +92,9 @@ struct BrotliAmdBatch {
   bool launched = false;
   // first-pass arena of this launch: the configured one, or a smaller one when the batch has more streams than the
   // device can hold blocks of the configured size (more waves in flight; what does not fit goes to the second pass)
-  bool auto_arena = false, small_arena_pays = true;
+  bool auto_arena = false;
+  uint32_t per_cu_cap = 0;  // blocks per CU a first pass may ask for (lowered when most of a batch had to come back)
+  uint32_t cur_per_cu = 0;  // blocks per CU the first pass of this launch was shaped for
   uint32_t cur_arena = 0, cus = 0, lds_fixed = 0;
   size_t lds_per_cu = 0;
   // second pass for streams whose tables did not fit the LDS arena of the first (BROTLI_AMD_FLAG_NO_SPILL)
@@ -124,20 +130,23 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   return 0;
 }
 
+// Table arena of one-wave blocks packed per_cu to a CU (0: too small to be worth a pass).
+uint32_t small_arena(const BrotliAmdBatch* b, uint32_t per_cu) {
+  const uint32_t per_block = (uint32_t)(b->lds_per_cu / per_cu) & ~255u;
+  return per_block > b->lds_fixed + kMinSmallArena ? (per_block - b->lds_fixed) & ~15u : 0u;
+}
+
 int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n) filled
   if (n == 0) { b->n = 0; b->launched = false; return 0; }
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   // arena of this launch (see cur_arena)
   b->cur_arena = b->lds_arena;
   uint32_t grid_max = b->grid_max;
-  if (b->auto_arena && b->small_arena_pays && n > b->grid_max && b->max_arena > b->lds_arena) {
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(8, ((size_t)n + b->cus - 1) / b->cus);       // blocks per CU wanted
-    const uint32_t per_block = (uint32_t)(b->lds_per_cu / per_cu) & ~255u;
-    const uint32_t carve = b->lds_fixed + (per_cu <= 4u ? b->lds_helper : 0u);  // (more than four blocks per CU: one-wave blocks)
-    if (per_block > carve + 8192u && per_block - carve < b->lds_arena) {
-      b->cur_arena = (per_block - carve) & ~15u;
-      grid_max = b->cus * per_cu;
-    }
+  b->cur_per_cu = 0;
+  if (b->auto_arena && n > b->grid_max && b->max_arena > b->lds_arena) {
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(b->per_cu_cap, ((size_t)n + b->cus - 1) / b->cus);  // blocks per CU wanted
+    const uint32_t arena = per_cu > 4u ? small_arena(b, per_cu) : 0u;
+    if (arena != 0 && arena < b->lds_arena) { b->cur_arena = arena; grid_max = b->cus * per_cu; b->cur_per_cu = per_cu; }
   }
   b->n = n;
   b->grid = std::min(n, grid_max);
@@ -159,42 +168,57 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
 }
 
 // Streams that came back with BROTLI_AMD_RESULT_RETRY_ARENA continue, from the metablock boundary they stopped at, in
-// a launch whose blocks have the largest LDS arena the device allows (fewer blocks per CU; spilling is allowed there).
-int retry_with_large_arena(BrotliAmdBatch* b) {
-  std::vector<uint32_t> idx;
-  for (uint32_t i = 0; i < b->n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_RETRY_ARENA) idx.push_back(i);
-  b->last_retry_count = (uint32_t)idx.size();
-  if (idx.empty()) return 0;
-  if (!b->d_retry_descs) {
-    bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
-    ok = ok && hip_ok(hipMalloc(&b->d_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipMalloc(retry status)");
-    ok = ok && hip_ok(hipHostMalloc(&b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipHostMalloc(retry descs)");
-    ok = ok && hip_ok(hipHostMalloc(&b->h_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipHostMalloc(retry status)");
-    if (!ok) return -1;
-  }
-  const uint32_t m = (uint32_t)idx.size();
-  if (b->cur_arena < b->lds_arena && m > b->n / 4) b->small_arena_pays = false;  // this kind of stream needs the full arena
-  for (uint32_t j = 0; j < m; j++) {
-    BrotliAmdStreamDesc d = b->h_descs[idx[j]];
-    d.flags = (d.flags & ~BROTLI_AMD_FLAG_NO_SPILL) | BROTLI_AMD_FLAG_RESUME;
-    d.resume = b->h_status[idx[j]].resume;
-    b->h_retry_descs[j] = d;
-  }
-  const uint32_t grid = std::min(m, b->retry_grid_max);
-  hipStream_t stream = b->last_stream;
-  if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
-  if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
-  if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
-  if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, b->max_arena,
-                                       b->d_dict, stream, 4), "brotli_amd_decode_kernel launch (large arena)")) return -1;
-  if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
-  if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
-  for (uint32_t j = 0; j < m; j++) {
-    BrotliAmdStreamStatus& first = b->h_status[idx[j]];
-    BrotliAmdStreamStatus second = b->h_retry_status[j];
-    second.num_metablocks += first.num_metablocks;
-    second.num_commands += first.num_commands;
-    first = second;
+// a launch whose blocks have a larger LDS arena (fewer blocks per CU): a first pass packed more than eight blocks to a
+// CU is followed by one with eight, then by the configured arena, then by the largest block the device allows, where
+// spilling to global memory is allowed; each pass takes only what the one before could not hold.
+int retry_with_larger_arenas(BrotliAmdBatch* b) {
+  b->last_retry_count = 0;
+  uint32_t level = b->cur_per_cu;  // 0: the first pass had the configured arena already
+  for (int pass = 0; pass < 4; pass++) {
+    std::vector<uint32_t> idx;
+    for (uint32_t i = 0; i < b->n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_RETRY_ARENA) idx.push_back(i);
+    if (idx.empty()) return 0;
+    const uint32_t m = (uint32_t)idx.size();
+    if (pass == 0) {
+      b->last_retry_count = m;
+      // most of the batch did not fit: later batches of this object start one level up
+      if (level > 4u && m > b->n / 4) b->per_cu_cap = level > 8u ? 8u : 4u;
+    }
+    if (!b->d_retry_descs) {
+      bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
+      ok = ok && hip_ok(hipMalloc(&b->d_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipMalloc(retry status)");
+      ok = ok && hip_ok(hipHostMalloc(&b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipHostMalloc(retry descs)");
+      ok = ok && hip_ok(hipHostMalloc(&b->h_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipHostMalloc(retry status)");
+      if (!ok) return -1;
+    }
+    // shape of this pass
+    uint32_t arena, grid_max; int waves; bool last;
+    if (level > 8u && small_arena(b, 8) > b->cur_arena) { level = 8; arena = small_arena(b, 8); grid_max = b->cus * 8u; waves = 1; last = false; }
+    else if (level > 4u && b->lds_arena > b->cur_arena) { level = 4; arena = b->lds_arena; grid_max = b->grid_max; waves = 4; last = false; }
+    else { level = 2; arena = b->max_arena; grid_max = b->retry_grid_max; waves = 4; last = true; }
+    for (uint32_t j = 0; j < m; j++) {
+      BrotliAmdStreamDesc d = b->h_descs[idx[j]];
+      d.flags = (last ? d.flags & ~BROTLI_AMD_FLAG_NO_SPILL : d.flags) | BROTLI_AMD_FLAG_RESUME;
+      d.resume = b->h_status[idx[j]].resume;
+      b->h_retry_descs[j] = d;
+    }
+    const uint32_t grid = std::min(m, grid_max);
+    hipStream_t stream = b->last_stream;
+    if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
+    if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
+    if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
+    if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, arena,
+                                         b->d_dict, stream, waves), "brotli_amd_decode_kernel launch (larger arena)")) return -1;
+    if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
+    if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
+    for (uint32_t j = 0; j < m; j++) {
+      BrotliAmdStreamStatus& first = b->h_status[idx[j]];
+      BrotliAmdStreamStatus next = b->h_retry_status[j];
+      next.num_metablocks += first.num_metablocks;
+      next.num_commands += first.num_commands;
+      first = next;
+    }
+    if (last) return 0;
   }
   return 0;
 }
@@ -219,6 +243,7 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   b->lds_arena = (per_block - fixed - helper) & ~15u;
   b->cur_arena = b->lds_arena;
   b->auto_arena = lds_arena_bytes == 0;
+  b->per_cu_cap = (uint32_t)kMaxBlocksPerCu;
   b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_helper = helper; b->lds_helper8 = brotli_amd_lds_helper_bytes(8); b->lds_per_cu = lds_cu;
   b->block_max = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
   {  // the arena of the second pass: the largest block the device allows (at most 64 KiB: two such blocks per CU at least)
@@ -226,7 +251,7 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
     b->max_arena = big > fixed + helper ? (big - fixed - helper) & ~15u : 0;
     b->retry_grid_max = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max<size_t>(1, lds_cu / big);
   }
-  uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cu / per_block));
+  uint32_t blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(kMaxBlocksPerCu, lds_cu / per_block));
   b->grid_max = grid_blocks ? grid_blocks : (uint32_t)prop.multiProcessorCount * blocks_per_cu;
   b->d_dict = device_dictionary(dev);
   bool ok = b->d_dict != nullptr;
@@ -287,7 +312,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   if (!hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * b->n, hipMemcpyDeviceToHost, b->last_stream), "hipMemcpyAsync(status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize")) return -1;
-  if (retry_with_large_arena(b) != 0) return -1;
+  if (retry_with_larger_arenas(b) != 0) return -1;
   if (results) {
     for (uint32_t i = 0; i < b->n; i++) {
       const BrotliAmdStreamStatus& s = b->h_status[i];
