@@ -37,7 +37,7 @@ constexpr size_t kDictSize = 122784;
 // One-wave blocks per CU at most (a CU's registers hold sixteen waves of the kernel) and the smallest table arena worth a
 // first pass; what does not fit a pass's arena comes back in the next (retry_with_larger_arenas).
 static const size_t kMaxBlocksPerCu = getenv("BROTLI_AMD_MAX_BLOCKS_PER_CU") ? (size_t)atoi(getenv("BROTLI_AMD_MAX_BLOCKS_PER_CU")) : 14;
-static const uint32_t kMinSmallArena = getenv("BROTLI_AMD_MIN_SMALL_ARENA") ? (uint32_t)atoi(getenv("BROTLI_AMD_MIN_SMALL_ARENA")) : 4096u;
+static const uint32_t kMinSmallArena = getenv("BROTLI_AMD_MIN_SMALL_ARENA") ? (uint32_t)atoi(getenv("BROTLI_AMD_MIN_SMALL_ARENA")) : 3584u;  // (16 blocks per CU: 4016 bytes)
 constexpr uint64_t kScratchPerBlock = (2u << 20) + BROTLI_AMD_SPEC_SCRATCH;  // worst-case table arena of one metablock + helper scratch
 constexpr uint32_t kDefaultLdsPerBlock = 36 * 1024;
 
@@ -181,8 +181,8 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
     const uint32_t m = (uint32_t)idx.size();
     if (pass == 0) {
       b->last_retry_count = m;
-      // most of the batch did not fit: later batches of this object start one level up
-      if (level > 4u && m > b->n / 4) b->per_cu_cap = level > 8u ? 8u : 4u;
+      // a good part of the batch did not fit: later batches of this object are packed less densely
+      if (level > 4u && m > b->n / 16) b->per_cu_cap = level > 8u ? std::max(8u, level - 2u) : 4u;
     }
     if (!b->d_retry_descs) {
       bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
