@@ -86,6 +86,8 @@ struct BrotliAmdBatch {
   uint64_t scratch_blocks = 0;
   BrotliAmdStreamDesc* h_descs = nullptr;    // pinned
   BrotliAmdStreamStatus* h_status = nullptr;  // pinned
+  uint32_t* h_order = nullptr;                 // pinned: queue header + the order in which blocks take the streams
+  bool ordered = false;
   const uint8_t* d_dict = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t last_stream = nullptr;
@@ -120,7 +122,9 @@ bool ensure_scratch(BrotliAmdBatch* b, uint32_t grid) {
 }
 
 int launch(BrotliAmdBatch* b, hipStream_t stream) {
-  if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
+  // queue header (pull counter, order flag) and, for batches of more streams than blocks, the order
+  b->h_order[0] = 0; b->h_order[1] = b->ordered ? 1u : 0u;
+  if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
   if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
                                        b->d_dict, stream, (int)b->waves), "brotli_amd_decode_kernel launch")) return -1;
@@ -163,6 +167,15 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
   if (!ensure_scratch(b, b->grid)) return -1;
+  // more streams than blocks: the blocks take them longest first (compressed size as the measure), so that no block starts
+  // a long stream when the others are done
+  static const bool no_order = getenv("BROTLI_AMD_NO_ORDER") != nullptr;  // (experiments)
+  b->ordered = n > b->grid && !no_order;
+  if (b->ordered) {
+    uint32_t* order = b->h_order + 16;
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order, order + n, [b](uint32_t x, uint32_t y) { return b->h_descs[x].in_size > b->h_descs[y].in_size; });
+  }
   if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
   return launch(b, stream);
 }
@@ -206,7 +219,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
     hipStream_t stream = b->last_stream;
     if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
     if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
-    if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t), stream), "hipMemsetAsync(queue)")) return -1;
+    if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t) * 16, stream), "hipMemsetAsync(queue)")) return -1;
     if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, arena,
                                          b->d_dict, stream, waves), "brotli_amd_decode_kernel launch (larger arena)")) return -1;
     if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
@@ -257,9 +270,10 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   bool ok = b->d_dict != nullptr;
   ok = ok && hip_ok(hipMalloc(&b->d_descs, sizeof(BrotliAmdStreamDesc) * max_streams), "hipMalloc(descs)");
   ok = ok && hip_ok(hipMalloc(&b->d_status, sizeof(BrotliAmdStreamStatus) * max_streams), "hipMalloc(status)");
-  ok = ok && hip_ok(hipMalloc(&b->d_queue, 64), "hipMalloc(queue)");
+  ok = ok && hip_ok(hipMalloc(&b->d_queue, sizeof(uint32_t) * (16 + (size_t)max_streams)), "hipMalloc(queue)");
   ok = ok && hip_ok(hipHostMalloc(&b->h_descs, sizeof(BrotliAmdStreamDesc) * max_streams), "hipHostMalloc(descs)");
   ok = ok && hip_ok(hipHostMalloc(&b->h_status, sizeof(BrotliAmdStreamStatus) * max_streams), "hipHostMalloc(status)");
+  ok = ok && hip_ok(hipHostMalloc(&b->h_order, sizeof(uint32_t) * (16 + (size_t)max_streams)), "hipHostMalloc(order)");
   ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
   if (!ok) { BrotliAmdBatchDestroy(b); return nullptr; }
   return b;
@@ -282,6 +296,7 @@ extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (b->d_stage_out) (void)hipFree(b->d_stage_out);
   if (b->h_descs) (void)hipHostFree(b->h_descs);
   if (b->h_status) (void)hipHostFree(b->h_status);
+  if (b->h_order) (void)hipHostFree(b->h_order);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   delete b;

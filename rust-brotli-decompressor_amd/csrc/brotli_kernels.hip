@@ -300,7 +300,7 @@ struct BitReader {
     lo = buf | (e << cnt);         // 32 <= cnt <= 63
     hi = e >> (64 - cnt);
   }
-  __device__ __forceinline__ void advance(uint32_t n) {  // n <= 96
+  __device__ __forceinline__ void advance(uint32_t n) {  // (a short way: the window follows piece by piece)
     if (n <= cnt) { drop(n); return; }
     n -= cnt; buf = 0; cnt = 0;
     next_dw += n >> 5; n &= 31;
@@ -2680,7 +2680,9 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         uint64_t byte = br.pos() >> 3, isz = br.total_bits() >> 3;
         uint64_t avail = isz > byte ? isz - byte : 0;
         if ((uint64_t)(uint32_t)s.mlen > avail) { br.seek(isz * 8 + 8); return E_NEEDS_MORE_INPUT; }
-        br.seek((byte + (uint32_t)s.mlen) * 8);
+        // (a short skip stays in the reader's window: a seek fetches the input anew, 12 K clocks per metadata block)
+        if ((uint32_t)s.mlen <= 128u) { if (s.mlen != 0) br.advance((uint32_t)s.mlen * 8u); }
+        else br.seek((byte + (uint32_t)s.mlen) * 8);
         s.mlen = 0;
       } else if (s.mlen != 0 && s.rb_size == 0) {
         allocate_ring(s, br);
@@ -2801,6 +2803,9 @@ extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(co
     if (lane == 0) idx = atomicAdd(queue, 1u);
     idx = rfl(idx);
     if (idx >= n_streams) break;
+    // (the host may give an order in which to take the streams -- longest first, so that the last blocks to finish do not
+    // start a long stream when the others are done: queue[1] != 0, stream of the k-th pull in queue[16 + k])
+    if (queue[1] != 0u) idx = rfl(queue[16u + idx]);
     const BrotliAmdStreamDesc d = descs[idx];
     BrotliAmdStreamStatus* st = status + idx;
 
