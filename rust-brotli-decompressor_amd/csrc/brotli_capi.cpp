@@ -187,15 +187,18 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
 int retry_with_larger_arenas(BrotliAmdBatch* b) {
   b->last_retry_count = 0;
   uint32_t level = b->cur_per_cu;  // 0: the first pass had the configured arena already
+  bool many_came_back = false;
   for (int pass = 0; pass < 4; pass++) {
     std::vector<uint32_t> idx;
     for (uint32_t i = 0; i < b->n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_RETRY_ARENA) idx.push_back(i);
-    if (idx.empty()) return 0;
     const uint32_t m = (uint32_t)idx.size();
+    // a good part of the batch did not fit the first pass: later batches of this object start with the shape that
+    // did hold (nearly) all of it
+    if (many_came_back && m <= b->n / 16) { b->per_cu_cap = std::max(4u, level); many_came_back = false; }
+    if (idx.empty()) return 0;
     if (pass == 0) {
       b->last_retry_count = m;
-      // a good part of the batch did not fit: later batches of this object are packed less densely
-      if (level > 4u && m > b->n / 16) b->per_cu_cap = level > 8u ? std::max(8u, level - 2u) : 4u;
+      many_came_back = level > 4u && m > b->n / 16;
     }
     if (!b->d_retry_descs) {
       bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
@@ -231,7 +234,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
       next.num_commands += first.num_commands;
       first = next;
     }
-    if (last) return 0;
+    if (last) { if (many_came_back) b->per_cu_cap = 4; return 0; }
   }
   return 0;
 }
