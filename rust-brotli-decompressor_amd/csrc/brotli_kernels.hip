@@ -1579,7 +1579,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 // at the loop's back edge, and every such move waited for the load that had just been issued (or, before the next
 // load, for the acknowledgement of the stores); loaded here, nothing waits until the bytes are stored.
 #define PEND_REGS "v120", "v121", "v122", "v123", "v124"
-__device__ __forceinline__ uint64_t lanes_below(uint32_t n) { return n >= 64u ? ~0ull : (1ull << n) - 1ull; }
+__device__ __forceinline__ uint64_t lanes_below(uint32_t n) { return ~0ull >> (64u - n); }  // 1 <= n <= 64
 __device__ __forceinline__ void pend_load16(gu8* src, uint32_t n16, uint32_t lane16) {
   asm volatile("s_mov_b64 exec, %0\n\tglobal_load_dwordx4 v[120:123], %1, %2\n\ts_mov_b64 exec, -1" :: "s"(lanes_below(n16)), "v"(lane16), "s"(src) : "memory", PEND_REGS);
 }
@@ -1603,10 +1603,10 @@ template <bool CTX_NEVER>
 // the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
 // 20.1 GB/s over the eight placements).  Measured on MI355X with tools/scratch-style sweeps; re-measure after edits.
 #ifndef BROTLI_AMD_LEAN_PAD_NEVER
-#define BROTLI_AMD_LEAN_PAD_NEVER 1
+#define BROTLI_AMD_LEAN_PAD_NEVER 5
 #endif
 #ifndef BROTLI_AMD_LEAN_PAD_CTX
-#define BROTLI_AMD_LEAN_PAD_CTX 7
+#define BROTLI_AMD_LEAN_PAD_CTX 5
 #endif
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   // (the function starts on a 256-byte boundary so that the placement of its loops relative to instruction-fetch
