@@ -1601,7 +1601,7 @@ __device__ __forceinline__ uint32_t pend_byte(uint32_t k) {  // the byte lane k 
 template <bool CTX_NEVER>
 // Placement of the lean loop, in 4-byte steps from a 256-byte boundary, per instance (context-free / context-modelled):
 // the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
-// 20.1 GB/s over the eight placements).  Measured on MI355X with tools/scratch-style sweeps; re-measure after edits.
+// 20.1 GB/s over the eight placements).  Measured on MI355X with tools/tune_lean_placement.sh; to be measured again after every edit of this function.
 #ifndef BROTLI_AMD_LEAN_PAD_NEVER
 #define BROTLI_AMD_LEAN_PAD_NEVER 5
 #endif
