@@ -1273,10 +1273,9 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
   "v_cndmask_b32 %[v3], 64, %[v3], vcc\n\t" \
   "s_mov_b64 s[92:93], 0\n\t" \
   "s_mov_b32 %[off], 0xffffffc0\n\t" \
-  "s_cmp_lt_u32 %[i], 8\n\t" \
-  "s_cbranch_scc1 4f\n\t" \
-  /* eight literals or more to go: two per step (ds_bpermute hands every offset the length of the symbol after its own; */ \
-  /* v4 = length where that symbol still starts in the window, else 0; v1 = both lengths, else the one) */ \
+  /* two symbols per step: ds_bpermute hands every offset the length of the symbol after its own; v4 = length where */ \
+  /* that symbol still starts in the window, else 0; v1 = both lengths, else the one.  (Measured against one per step */ \
+  /* for runs below a threshold: two per step is faster from three literals on, which is every batch.) */ \
   "v_add_u32 %[v4], %[v3], %[lane]\n\t" \
   "v_lshlrev_b32 %[v1], 2, %[v4]\n\t" \
   "ds_bpermute_b32 %[v1], %[v1], %[v3]\n\t" \
@@ -1294,13 +1293,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
   "s_add_u32 %[t1], %[t1], %[off]\n\t" \
   "s_bitset1_b64 s[92:93], %[t1]\n\t" \
   "s_add_u32 %[off], %[off], %[t0]\n\t" \
-  "s_cbranch_scc0 9b\n\t" \
-  "s_branch 10f\n" \
-  "4:\n\t" \
-  "v_readlane_b32 %[t1], %[v3], %[off]\n\t" \
-  "s_bitset1_b64 s[92:93], %[off]\n\t" \
-  "s_add_u32 %[off], %[off], %[t1]\n\t" \
-  "s_cbranch_scc0 4b\n" \
+  "s_cbranch_scc0 9b\n" \
   "10:\n\t" \
   "s_add_u32 %[off], %[off], 64\n\t" \
   "s_bcnt1_i32_b64 %[n], s[92:93]\n\t" \
@@ -1627,7 +1620,7 @@ template <bool CTX_NEVER>
 // the loops of a lone wave are sensitive to where they lie relative to the 32-byte instruction-fetch lines (C3: 18.9 to
 // 20.1 GB/s over the eight placements).  Measured on MI355X with tools/tune_lean_placement.sh; to be measured again after every edit of this function.
 #ifndef BROTLI_AMD_LEAN_PAD_NEVER
-#define BROTLI_AMD_LEAN_PAD_NEVER 6
+#define BROTLI_AMD_LEAN_PAD_NEVER 3
 #endif
 #ifndef BROTLI_AMD_LEAN_PAD_CTX
 #define BROTLI_AMD_LEAN_PAD_CTX 5
