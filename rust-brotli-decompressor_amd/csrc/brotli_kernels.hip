@@ -1623,7 +1623,7 @@ template <bool CTX_NEVER>
 #define BROTLI_AMD_LEAN_PAD_NEVER 3
 #endif
 #ifndef BROTLI_AMD_LEAN_PAD_CTX
-#define BROTLI_AMD_LEAN_PAD_CTX 5
+#define BROTLI_AMD_LEAN_PAD_CTX 3
 #endif
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   // (the function starts on a 256-byte boundary so that the placement of its loops relative to instruction-fetch
@@ -1666,6 +1666,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
   uint32_t p1 = CTX_NEVER ? 0u : LEAN_LD(L_P1), p2 = CTX_NEVER ? 0u : LEAN_LD(L_P2);
   bool ctx_regs = CTX_NEVER ? true : LEAN_LD(L_CTX_REGS) != 0u, ctx_pend = false;
   const uint32_t trivial = CTX_NEVER ? 1u : LEAN_LD(L_TRIVIAL), ctx_lut = CTX_NEVER ? 0u : LEAN_LD(L_CTX_LUT);
+  const uint32_t lut0v = CTX_NEVER ? 0u : lds_ld32(ctx_lut + 4u * lane), lut1v = CTX_NEVER ? 0u : lds_ld32(ctx_lut + 256u + 4u * lane);
 #define LEAN_FLUSH() do { if (pendv_n16 | pend_n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* the pending bytes have arrived */ \
                           if (pendv_n16) pend_store16(out + pend_pos, pendv_n16, lane16); \
                           if (pend_n) pend_store8(out + pend_pos + ((uint64_t)pendv_n16 << 4), pend_n, lane); \
@@ -1730,7 +1731,9 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
         while (i > 0 && br.next_dw < safe_dw) {
           uint32_t tree = lit_tree;
           if (!trivial) {
-            uint32_t context = rfl(lds_ld8(ctx_lut + p1) | lds_ld8(ctx_lut + 256 + p2));
+            // (the two 256-entry lookup tables of the block type's context mode, four entries per lane: two v_readlane
+            // instead of an LDS round trip per literal)
+            const uint32_t context = ((rdlane(lut0v, p1 >> 2) >> ((p1 & 3u) << 3)) | (rdlane(lut1v, p2 >> 2) >> ((p2 & 3u) << 3))) & 0xFFu;
             tree = rdlane(ctx_tree_v, context);
           }
           uint32_t lit = read_symbol<true>(br, a, tree);
