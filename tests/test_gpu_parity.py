@@ -427,3 +427,31 @@ def test_long_literal_runs_across_ring_flush_points(pkg):
             for cap in (len(raw), len(raw) - 1, 300000, 65536, 65537, 4097, 262144 + 5):
                 datas.append(c); caps.append(cap)
     _check_against_oracle(pkg, datas, caps, 1, "ring flush points")
+
+
+@pytest.mark.parametrize("seed", [101, 102])
+def test_literal_heavy_streams_of_random_makeup(pkg, seed):
+    """Segments of literals whose distribution changes inside a stream (the encoder answers with several literal block
+    types and trees, so block switches fall inside long runs), copies in between, qualities 1-9, windows 16-24, tight
+    and roomy buffers: the helper rounds next to block switches (tests/tools/fuzz_rounds.py runs this at length)."""
+    import numpy as np
+    import libbrotli_ref as ref
+    if not ref.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    datas, caps = [], []
+    for _ in range(20):
+        parts = []
+        for _ in range(int(rng.integers(2, 9))):
+            nsym = int(rng.choice([2, 5, 17, 64, 200, 256]))
+            p = np.arange(1, nsym + 1, dtype=np.float64) ** -float(rng.choice([0.0, 0.3, 1.0, 2.5]))
+            p /= p.sum()
+            perm = rng.permutation(256)[:nsym]
+            parts.append(perm[rng.choice(nsym, size=int(rng.choice([300, 800, 3000, 20000, 70000, 150000])), p=p)].astype(np.uint8).tobytes())
+            if rng.random() < 0.7:
+                parts.append(parts[int(rng.integers(0, len(parts)))][: int(rng.integers(4, 2000))])
+        raw = b"".join(parts)
+        c = ref.encode(raw, int(rng.choice([1, 3, 5, 6, 9])), int(rng.choice([16, 18, 20, 22, 24])))
+        for cap in (len(raw), int(rng.integers(1, len(raw))), len(raw) + 100):
+            datas.append(c); caps.append(cap)
+    _check_against_oracle(pkg, datas, caps, 1, "random make-up")
