@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -42,6 +43,10 @@ constexpr uint64_t kScratchPerBlock = (2u << 20) + BROTLI_AMD_SPEC_SCRATCH;  // 
 constexpr uint32_t kDefaultLdsPerBlock = 36 * 1024;
 
 thread_local std::string g_last_error;
+// Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
+// BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
+std::atomic<bool> g_scan_blocks_ok{getenv("BROTLI_AMD_NO_SCAN") == nullptr};
+constexpr uint32_t kScanArena = 40960;  // table arena of such a block (with the engine's rings: about 108 KiB of LDS)
 
 bool hip_ok(hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
@@ -126,8 +131,16 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   b->h_order[0] = 0; b->h_order[1] = b->ordered ? 1u : 0u;
   if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
-  if (!hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
-                                       b->d_dict, stream, (int)b->waves), "brotli_amd_decode_kernel launch")) return -1;
+  hipError_t le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
+                                           b->d_dict, stream, (int)b->waves);
+  if (le != hipSuccess && b->waves == 16u) {
+    // the device does not give one block the LDS the command engine wants: blocks of eight waves from now on
+    (void)hipGetLastError();
+    g_scan_blocks_ok = false;
+    b->waves = 8;
+    le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena, b->d_dict, stream, 8);
+  }
+  if (!hip_ok(le, "brotli_amd_decode_kernel launch")) return -1;
   if (!hip_ok(hipEventRecord(b->ev1, stream), "hipEventRecord")) return -1;
   b->last_stream = stream;
   b->launched = true;
@@ -162,6 +175,11 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     const uint32_t room = (uint32_t)std::min<size_t>(b->block_max, b->lds_per_cu / 2);
     if (b->auto_arena && room > b->lds_fixed + b->lds_helper8 + b->lds_arena) { b->cur_arena = (room - b->lds_fixed - b->lds_helper8) & ~15u; b->waves = 8; }
     else if (b->lds_fixed + b->lds_helper8 + b->cur_arena <= room) b->waves = 8;
+  }
+  if (g_scan_blocks_ok.load() && b->grid <= b->cus) {
+    const uint32_t h16 = brotli_amd_lds_helper_bytes(16);
+    const uint32_t arena = b->auto_arena ? kScanArena : b->cur_arena;
+    if ((size_t)b->lds_fixed + h16 + arena <= b->lds_per_cu) { b->cur_arena = arena; b->waves = 16; }
   }
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)

@@ -949,7 +949,9 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   into the next chunk at which its chain ends; then, posted by the decoding wave once the chunk's place is known:
 //   move wanted for round, first literal of the chunk to move, where to (offset from the output), how many; and the
 //   helper's answer, round moved.
-enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10 };
+enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
+       HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */ };
+enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
        // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
@@ -1117,6 +1119,8 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
   hw_st(slot, HW_EXIT, e);
 }
 
+__device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
+
 __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */, gu8* scratch_sym) {
   const uint32_t lane = lane_id();
   const uint32_t slot = hc_ld(HC_BASE) + me * HL_SLOT;
@@ -1133,7 +1137,10 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     }
     seq = j;
     lds_acquire();
-    if (hc_ld(HC_KIND) != 1u) return;
+    const uint32_t kind = hc_ld(HC_KIND);
+    if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
+    if (kind != HK_ROUND) return;
+    if (rfl(me) >= hc_ld(HC_NW)) continue;                // (rounds are for the first eight waves of a block)
     spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
     lds_release();
     hw_st(slot, HW_DONE, seq);
@@ -1591,6 +1598,8 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
   lds_sync();
 }
 
+#include "brotli_scan_engine.h"
+
 // The pending copy of the lean loop lives in registers the compiler does not know about: v[120:123] (16 bytes per lane)
 // and v124 (one byte per lane), named in inline asm only.  As C++ variables they were shuffled through other registers
 // at the loop's back edge, and every such move waited for the load that had just been issued (or, before the next
@@ -1899,7 +1908,7 @@ struct HotArgs {
   Arena ar;
   gu8* out; gcu8* dict;
   uint64_t out_cap, P, next_boundary, rb_size;
-  uint32_t window_bits;
+  uint32_t window_bits, large_window;
   int32_t mlen, max_backward;
   int32_t d0, d1, d2, d3;
   uint32_t bl0, bl1, bl2;
@@ -2035,8 +2044,61 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32));
   }
 
+  // ---- the command engine (brotli_scan_engine.h): blocks of sixteen waves, metablocks whose literals never depend on
+  // context, no large window.  It takes commands until one needs the checked code below (or the input runs short) and
+  // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
+  const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
+  uint32_t scan_wait = 0, scan_fails = 0;
+  bool force_checked = false;  // the command the engine stopped at goes through the checked stages
+
   for (;;) {
-    if (LDS_ONLY && bl1 != 0 && quota != 0 && !(CTX_NEVER && lit_zero) && br.next_dw < safe_dw) {
+    if (LDS_ONLY && CTX_NEVER) {
+     if (scan_block && scan_wait == 0u && bl1 != 0 && quota >= SC_MIN_QUOTA && !lit_zero && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS) {
+      const uint64_t abs_bit = br.pos() + BitReader::skip_bits();
+      const uint64_t origin = abs_bit & ~63ull;
+      const uint64_t avail = BitReader::total_bits() + BitReader::skip_bits() - origin;
+      if (avail >= 2u * SC_N + SC_AHEAD + 64u && (origin >> 5) < 0xFFFFFFFFull) {
+        FLUSH_LITERALS();
+        FLUSH_PENDING();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the other waves read the output as copy sources
+        const uint32_t sb = hc_ld(HC_SCAN_BASE);
+        lds_sync();
+        if (lane == 0) {
+          LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
+          LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
+          LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3);
+        }
+        sc_ctl_st(sb, SCC_BASE_DW, (uint32_t)(origin >> 5)); sc_ctl_st(sb, SCC_IN_LIMIT, avail > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)avail);
+        sc_ctl_st(sb, SCC_ENTRY, (uint32_t)(abs_bit - origin));
+        sc_ctl_st(sb, SCC_LIT_TREE, LDS_FIXED + lit_tree); sc_ctl_st(sb, SCC_CMD_TREE, LDS_FIXED + cmd_tree);
+        sc_ctl_st(sb, SCC_DT0, LDS_FIXED + dt0); sc_ctl_st(sb, SCC_DT0 + 1, LDS_FIXED + dt1); sc_ctl_st(sb, SCC_DT0 + 2, LDS_FIXED + dt2); sc_ctl_st(sb, SCC_DT0 + 3, LDS_FIXED + dt3);
+        sc_ctl_st(sb, SCC_POSTFIX, postfix_bits); sc_ctl_st(sb, SCC_NUM_DIRECT, num_direct);
+        sc_ctl_st(sb, SCC_OUT_LO, (uint32_t)(uintptr_t)out); sc_ctl_st(sb, SCC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
+        hc_st(HC_KIND, HK_SCAN);
+        lds_release();
+        hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
+        const uint32_t took = rfl(scan_engine(0));
+        const uint32_t form = LEAN_LD(L_SC_POS_HI);
+        const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
+        if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
+        br.seek(pos);
+        P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+        quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
+        bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
+        d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
+        num_commands += took;
+        lit_pos = P;
+        if (took < 64u) { scan_fails = scan_fails < 12u ? scan_fails + 1u : 12u; scan_wait = 1u << scan_fails; } else scan_fails = 0;
+        insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
+        distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
+        lds_sync();
+        if (form == SCX_LITERALS_REST) { if (lits_left != 0) goto general_literals_rest; goto general_distance; }
+        if (form == SCX_POST_DISTANCE) goto general_post_distance;
+        force_checked = true;
+      }
+     } else if (scan_wait != 0u) scan_wait--;
+    }
+    if (LDS_ONLY && bl1 != 0 && quota != 0 && !(CTX_NEVER && lit_zero) && br.next_dw < safe_dw && !force_checked) {
       // ---- the lean loop takes over until a stage needs the checked code below ----
       if (!CTX_NEVER && ctx_src == CTX_PEND) {  // the context bytes leave the pending copy before it is stored
         uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
@@ -2107,6 +2169,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (stage == LS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
     }
     // ---- COMMAND_BEGIN ----
+    force_checked = false;
     if (bl1 == 0) {
       int r;
       BLOCK_SWITCH(1, bl1, r);
@@ -2549,7 +2612,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
   HotArgs h;
   h.br = s.br; h.ar = s.ar; h.out = s.out; h.dict = s.dict;
   h.out_cap = s.out_cap; h.P = s.P; h.next_boundary = s.next_boundary; h.rb_size = s.rb_size;
-  h.window_bits = s.window_bits; h.mlen = s.mlen; h.max_backward = s.max_backward;
+  h.window_bits = s.window_bits; h.large_window = s.large_window; h.mlen = s.mlen; h.max_backward = s.max_backward;
   h.d0 = s.dist_rb0; h.d1 = s.dist_rb1; h.d2 = s.dist_rb2; h.d3 = s.dist_rb3;
   h.bl0 = s.bl0; h.bl1 = s.bl1; h.bl2 = s.bl2;
   h.postfix_bits = s.postfix_bits; h.num_direct = s.num_direct;
@@ -2775,7 +2838,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 }  // namespace
 
 // One decoding wave (+ up to seven helper waves) per stream; persistent blocks pull stream indices from `queue`.
-extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
+extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
@@ -2783,10 +2846,12 @@ extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(co
   const uint32_t lane = lane_id();
   // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
-    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t nw = blockDim.x >> 6, nr = nw < SPEC_MAX_WAVES ? nw : SPEC_MAX_WAVES;  // waves in the block, waves that take part in rounds
     if (threadIdx.x < 20u)
-      lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && nw < 2u ? 3u : threadIdx.x == HC_BASE ? LDS_FIXED + lds_arena_bytes : threadIdx.x == HC_NW ? nw : 0u);
-    if (nw >= 2u && threadIdx.x < nw * 16u) lds_st32(LDS_FIXED + lds_arena_bytes + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
+      lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && nw < 2u ? (uint32_t)HK_NO_ROUNDS : threadIdx.x == HC_BASE ? LDS_FIXED + lds_arena_bytes :
+                                            threadIdx.x == HC_NW ? nr : threadIdx.x == HC_NW_ALL ? nw :
+                                            threadIdx.x == HC_SCAN_BASE && nw == SC_WAVES ? LDS_FIXED + lds_arena_bytes + nr * HL_SLOT : 0u);
+    if (nw >= 2u && threadIdx.x < nr * 16u) lds_st32(LDS_FIXED + lds_arena_bytes + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
   }  // (launched without helper waves: no rounds)
   __syncthreads();
   if (rfl(threadIdx.x >> 6) != 0u) {
@@ -2911,19 +2976,27 @@ extern "C" __global__ __launch_bounds__(512, 4) void brotli_amd_decode_kernel(co
     printf("spec rounds %llu lits %llu bits %llu ticks: chunk0 %llu wait %llu resolve %llu move %llu seek %llu\n", g_spec_prof[5], g_spec_prof[6], g_spec_prof[7],
            g_spec_prof[0], g_spec_prof[1], g_spec_prof[2], g_spec_prof[3], g_spec_prof[4]);
 #endif
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
+    printf("scan engine: %llu invocations, %llu commands, %llu batches, %llu entries; ticks: input %llu S/J1 %llu J2-32 %llu REC %llu walk %llu resolve %llu execute %llu\n",
+           g_scan_prof[17], g_scan_prof[16], g_scan_prof[13], g_scan_prof[12], g_scan_prof[0], g_scan_prof[1], g_scan_prof[2], g_scan_prof[3], g_scan_prof[4],
+           g_scan_prof[5], g_scan_prof[6]);
+#endif
   // no more streams: the helper waves may go
   hc_st(HC_KIND, 2);
   lds_release();
   hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
 }
 
+extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves);
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
                                                uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves) {
   if (n_streams == 0) return hipSuccess;
   static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
-  const uint32_t waves = no_helpers || helper_waves < 2 ? 1u : (uint32_t)helper_waves > SPEC_MAX_WAVES ? SPEC_MAX_WAVES : (uint32_t)helper_waves;
-  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + (waves > 1u ? waves * HL_SLOT : 0u);
+  // (sixteen waves: a block with the command engine; otherwise at most eight)
+  const uint32_t waves = no_helpers || helper_waves < 2 ? 1u : (uint32_t)helper_waves >= SC_WAVES ? SC_WAVES : (uint32_t)helper_waves > SPEC_MAX_WAVES ? SPEC_MAX_WAVES : (uint32_t)helper_waves;
+  size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + brotli_amd_lds_helper_bytes(waves);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
   // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four
@@ -2934,4 +3007,7 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
 }
 
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void) { return LDS_FIXED; }
-extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves) { return waves > 1u ? waves * HL_SLOT : 0u; }
+extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves) {
+  if (waves >= SC_WAVES) return SPEC_MAX_WAVES * HL_SLOT + SC_BYTES;
+  return waves > 1u ? waves * HL_SLOT : 0u;
+}
