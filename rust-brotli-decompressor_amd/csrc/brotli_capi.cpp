@@ -178,8 +178,9 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   }
   if (g_scan_blocks_ok.load() && b->grid <= b->cus) {
     const uint32_t h16 = brotli_amd_lds_helper_bytes(16);
-    const uint32_t arena = b->auto_arena ? kScanArena : b->cur_arena;
-    if ((size_t)b->lds_fixed + h16 + arena <= b->lds_per_cu) { b->cur_arena = arena; b->waves = 16; }
+    const size_t room = b->lds_per_cu > (size_t)b->lds_fixed + h16 ? b->lds_per_cu - b->lds_fixed - h16 : 0;
+    const uint32_t arena = b->auto_arena ? (uint32_t)std::min<size_t>(kScanArena, room & ~(size_t)15) : b->cur_arena;
+    if (arena <= room && (!b->auto_arena || arena >= 16384u)) { b->cur_arena = arena; b->waves = 16; }
   }
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)

@@ -2048,16 +2048,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // context, no large window.  It takes commands until one needs the checked code below (or the input runs short) and
   // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
   const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
-  uint32_t scan_wait = 0, scan_fails = 0;
-  bool force_checked = false;  // the command the engine stopped at goes through the checked stages
+  uint32_t scan_fails = 0;
+  uint32_t force_checked = 0;  // commands that go through the checked stages before the engine (or the lean loop) is tried again:
+                               // the command the engine stopped at, more of them after invocations that got nowhere
 
   for (;;) {
     if (LDS_ONLY && CTX_NEVER) {
-     if (scan_block && scan_wait == 0u && bl1 != 0 && quota >= SC_MIN_QUOTA && !lit_zero && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS) {
+     if (scan_block && force_checked == 0u && bl1 != 0 && quota >= SC_MIN_QUOTA && !lit_zero && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS) {
       const uint64_t abs_bit = br.pos() + BitReader::skip_bits();
       const uint64_t origin = abs_bit & ~63ull;
       const uint64_t avail = BitReader::total_bits() + BitReader::skip_bits() - origin;
-      if (avail >= 2u * SC_N + SC_AHEAD + 64u && (origin >> 5) < 0xFFFFFFFFull) {
+      if (avail >= 8u * SC_N && (origin >> 5) < 0xFFFFFFFFull) {
         FLUSH_LITERALS();
         FLUSH_PENDING();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the other waves read the output as copy sources
@@ -2088,17 +2089,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
         num_commands += took;
         lit_pos = P;
-        if (took < 64u) { scan_fails = scan_fails < 12u ? scan_fails + 1u : 12u; scan_wait = 1u << scan_fails; } else scan_fails = 0;
+        force_checked = 1u;
+        if (took < 64u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
         insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
         distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
         lds_sync();
         if (form == SCX_LITERALS_REST) { if (lits_left != 0) goto general_literals_rest; goto general_distance; }
         if (form == SCX_POST_DISTANCE) goto general_post_distance;
-        force_checked = true;
       }
-     } else if (scan_wait != 0u) scan_wait--;
+     }
     }
-    if (LDS_ONLY && bl1 != 0 && quota != 0 && !(CTX_NEVER && lit_zero) && br.next_dw < safe_dw && !force_checked) {
+    if (LDS_ONLY && bl1 != 0 && quota != 0 && !(CTX_NEVER && lit_zero) && br.next_dw < safe_dw && force_checked == 0u) {
       // ---- the lean loop takes over until a stage needs the checked code below ----
       if (!CTX_NEVER && ctx_src == CTX_PEND) {  // the context bytes leave the pending copy before it is stored
         uint32_t q1 = rdlane(pend_reg, ctx_len - 1);
@@ -2169,7 +2170,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (stage == LS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
     }
     // ---- COMMAND_BEGIN ----
-    force_checked = false;
+    if (force_checked != 0u) force_checked--;
     if (bl1 == 0) {
       int r;
       BLOCK_SWITCH(1, bl1, r);
@@ -2844,6 +2845,9 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
                                                                            const uint8_t* __restrict__ dict) {
   const uint32_t lane = lane_id();
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  const uint64_t scan_prof_t0 = __builtin_amdgcn_s_memtime();
+#endif
   // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
     const uint32_t nw = blockDim.x >> 6, nr = nw < SPEC_MAX_WAVES ? nw : SPEC_MAX_WAVES;  // waves in the block, waves that take part in rounds
@@ -2978,9 +2982,14 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 #endif
 #ifdef BROTLI_AMD_PROFILE_SCAN
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
-    printf("scan engine: %llu invocations, %llu commands, %llu batches, %llu entries; ticks: input %llu S/J1 %llu J2-32 %llu REC %llu walk %llu resolve %llu execute %llu\n",
-           g_scan_prof[17], g_scan_prof[16], g_scan_prof[13], g_scan_prof[12], g_scan_prof[0], g_scan_prof[1], g_scan_prof[2], g_scan_prof[3], g_scan_prof[4],
-           g_scan_prof[5], g_scan_prof[6]);
+    printf("scan engine: %llu invocations, %llu commands, %llu batches, %llu entries; wave 0 ticks: execute %llu S/J1 %llu J2-32 %llu own copies %llu walk %llu resolve %llu wait for REC %llu D2/D4 %llu\n",
+           g_scan_prof[17], g_scan_prof[16], g_scan_prof[13], g_scan_prof[12], g_scan_prof[6], g_scan_prof[1], g_scan_prof[2], g_scan_prof[8], g_scan_prof[4],
+           g_scan_prof[5], g_scan_prof[3], g_scan_prof[7]);
+  if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
+    printf("kernel ticks of block 0: %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0));
+  if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
+    printf("scan engine exits: input ends %llu, counts/limits %llu, distance %llu, by-hand precheck %llu, long run %llu; invocations that took < 64 commands %llu\n",
+           g_scan_prof[18], g_scan_prof[19], g_scan_prof[20], g_scan_prof[21], g_scan_prof[22], g_scan_prof[23]);
 #endif
   // no more streams: the helper waves may go
   hc_st(HC_KIND, 2);

@@ -15,14 +15,18 @@
 //     REC       the command that would start at this bit: command symbol + extra bits (decode.rs:2134-2189), its
 //               insert_len literals skipped through J*, its distance symbol + extra bits (decode.rs:2066-2131),
 //               packed with the bit distance to the next command
+//     D2 / D4   bits from this bit to the second / fourth command after the one that would start here
 //   pass 2:
-//     walk      wave 0 follows REC from the stream's real position: one LDS round trip per command, 64 commands a batch
+//     walk      wave 0 follows the stream's real chain through D4 / REC: one LDS round trip per four commands; the lanes
+//               behind such an anchor find their own command (64 entries a batch, up to SC_GROUP batches a tick)
 //     resolve   wave 0, lane = command: output offsets (prefix sums), block counts, the distance ring
 //               (decode.rs:2017-2049) and every limit the reference checks; the first command that needs anything
 //               unusual (dictionary word, overlapping copy, block switch, end of the metablock / output / ring segment)
 //               ends the engine's part in front of it and the checked command loop takes over for that command
-//     execute   all waves: literals out of S through J*, then the LZ77 copies (decode.rs:2641-2680); copies whose source
-//               lies in the batch's own output are done last, in order, by wave 0
+//     execute   all waves: literals out of S through J*, and the LZ77 copies (decode.rs:2641-2680) whose source lies in
+//               front of the group; copies that read the group's own output are done afterwards, in order, by wave 0
+//   The passes overlap: while the other fifteen waves build REC for step s, wave 0 walks and resolves the region of
+//   step s - 1 (REC, D2 and D4 are double-buffered), and what it posts is executed by everyone at the start of step s + 1.
 //
 // Everything lives in LDS rings indexed by stream bit position (mod SC_R); what a phase reads is always behind the
 // frontier of the phase that produces it (the lags below).  Results never depend on the speculation: a REC entry is
@@ -30,16 +34,26 @@
 #pragma once
 
 constexpr uint32_t SC_WAVES = 16;                 // waves of a block that runs the engine
-constexpr uint32_t SC_R = 4096;                   // ring size in stream bits
+#ifndef BROTLI_AMD_SCAN_R
+#define BROTLI_AMD_SCAN_R 8192
+#endif
+constexpr uint32_t SC_R = BROTLI_AMD_SCAN_R;      // ring size in stream bits
 constexpr uint32_t SC_M = SC_R - 1;
-constexpr uint32_t SC_N = 2048;                   // bits a step advances by
-constexpr uint32_t SC_IN_DW = SC_R / 32;          // input ring in dwords (+ 2 mirrored at the end)
-// frontier lags (bits): J(2n)[b] reads Jn at up to b + 15 n; REC[b] reads J* up to b + 63 + 63 * 15 and the input 96 bits on
-constexpr uint32_t SC_LAG_REC = 1088, SC_LAG_32 = 256, SC_LAG_16 = 128, SC_LAG_8 = 64, SC_LAG_4 = 64, SC_LAG_2 = 64, SC_LAG_IN = 64;
-constexpr uint32_t SC_AHEAD = SC_LAG_REC + SC_LAG_32 + SC_LAG_16 + SC_LAG_8 + SC_LAG_4 + SC_LAG_2 + SC_LAG_IN;  // input frontier - REC frontier
-static_assert(SC_N + SC_AHEAD <= SC_R, "ring too small for one step plus the lags");
+constexpr uint32_t SC_N = SC_R / 4;               // bits a step advances by
+constexpr uint32_t SC_N2 = 2 * SC_N;              // REC / D2 / D4 hold two steps (the one being built, the one being walked)
+constexpr uint32_t SC_IN_DW = 2 * SC_R / 32;      // input ring in dwords (+ 2 mirrored at the end): it runs one step ahead of the tables
+constexpr uint32_t SC_GROUP = 4;                  // batches wave 0 may post per tick
+// frontier lags (bits): J2/J4[b] read J1 up to b + 45, J8/J16[b] read J4 up to b + 180, J32[b] reads J16 up to b + 240;
+// REC[b] reads J* up to b + 63 + 63 * 15 and the input 96 bits on
+constexpr uint32_t SC_LAG_REC = 1088, SC_LAG_32 = 256, SC_LAG_16 = 192, SC_LAG_4 = 64, SC_LAG_IN = 64;
+constexpr uint32_t SC_AHEAD = SC_LAG_REC + SC_LAG_32 + SC_LAG_16 + SC_LAG_4 + SC_LAG_IN;  // input frontier - REC frontier
+// what is executed at the start of step s + 1 was walked in step s out of the region of step s - 1, while S / J1 of step
+// s + 1 are being written: three steps and the lags must fit the ring
+static_assert(3 * SC_N + SC_AHEAD <= SC_R, "ring too small");
+static_assert(4 * SC_N + SC_AHEAD + 64 <= SC_IN_DW * 32, "input ring too small");
 constexpr uint32_t SC_LONG_EXIT = 8192;           // literal runs from here on go back to the rounds of the helper waves
 constexpr uint32_t SC_MIN_QUOTA = 2048;           // output bytes that must be possible for the engine to start
+constexpr uint32_t SC_MIN_INPUT = 2 * SC_N + SC_AHEAD + 64;  // stream bits that must be left for the engine to start
 
 // LDS layout, offsets from the engine's base
 constexpr uint32_t SC_CTL = 0;                    // 128: control words
@@ -51,14 +65,19 @@ constexpr uint32_t SC_J4 = SC_J2 + SC_R;
 constexpr uint32_t SC_J8 = SC_J4 + SC_R;
 constexpr uint32_t SC_J16 = SC_J8 + SC_R;
 constexpr uint32_t SC_J32 = SC_J16 + SC_R;        // u16
-constexpr uint32_t SC_REC = SC_J32 + 2 * SC_R;    // 8 bytes per bit of the current step
-constexpr uint32_t SC_XL = SC_REC + 8 * SC_N;     // 64 x 16: the batch being executed
-constexpr uint32_t SC_BYTES = SC_XL + 64 * 16;
+constexpr uint32_t SC_REC = SC_J32 + 2 * SC_R;    // 8 bytes per bit of two steps
+constexpr uint32_t SC_D2 = SC_REC + 8 * SC_N2;    // u16 per bit: bits to the command after next (0: not known)
+constexpr uint32_t SC_D4 = SC_D2 + 2 * SC_N2;     // u16: bits to the fourth command from here
+constexpr uint32_t SC_XL = SC_D4 + 2 * SC_N2;     // SC_GROUP x 64 x 16: the group being executed
+constexpr uint32_t SC_BYTES = SC_XL + SC_GROUP * 1024;
 static_assert(SC_S % 16 == 0 && SC_REC % 16 == 0 && SC_XL % 16 == 0, "alignment");
 
-enum { SCC_CMD = 0, SCC_K = 1, SCC_P_LO = 2, SCC_P_HI = 3, SCC_BASE_DW = 4, SCC_IN_LIMIT = 5, SCC_LIT_TREE = 6, SCC_CMD_TREE = 7,
-       SCC_DT0 = 8, SCC_POSTFIX = 12, SCC_NUM_DIRECT = 13, SCC_OUT_LO = 14, SCC_OUT_HI = 15, SCC_ENTRY = 16 };
-enum { SCC_CMD_EXEC = 1, SCC_CMD_STEP = 2, SCC_CMD_EXIT = 3 };
+// control words: the invocation's parameters (written by the decoding wave before the others join), then what wave 0
+// posts per tick: a group of up to SC_GROUP batches (entries in SC_XL, per batch its entry count and output position) and
+// two flags -- the walk stopped short of its limit because the group was full; the engine's part ends with this group
+enum { SCC_BASE_DW = 4, SCC_IN_LIMIT = 5, SCC_LIT_TREE = 6, SCC_CMD_TREE = 7, SCC_DT0 = 8, SCC_POSTFIX = 12, SCC_NUM_DIRECT = 13,
+       SCC_OUT_LO = 14, SCC_OUT_HI = 15, SCC_ENTRY = 16, SCC_NG = 17, SCC_FLAGS = 18, SCC_GK = 19 /* + batch */, SCC_GP = 23 /* + 2 * batch */ };
+enum { SCF_BEHIND = 1, SCF_LEAVE = 2 };
 enum { SCK_NONE = 0, SCK_EXPLICIT = 1, SCK_SHORT = 2, SCK_IMPLICIT = 3 };
 
 __device__ __forceinline__ uint32_t sc_ctl_ld(uint32_t sb, uint32_t k) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[sb + SC_CTL + 4u * k])); }
@@ -193,108 +212,265 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
     bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
     d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
     max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
+    sc_ctl_st(sb, SCC_NG, 0u); sc_ctl_st(sb, SCC_FLAGS, 0u);
   }
   // a literal run being walked by hand (commands REC does not hold): literals still to skip, then the distance and the copy
   bool in_run = false; uint32_t run_p = 0, run_rem = 0, run_copy = 0, run_implicit = 0, run_dctx = 0;
   uint32_t exit_form = SCX_BEGIN, exit_copy = 0, exit_dctx = 0; int32_t exit_dcode = 0;
+  uint32_t exit_why = 0;  // (profiling) 0 input ends, 1 block counts / output limits, 2 distance, 3 a command to walk by hand that does not fit, 4 long literal run
+  (void)exit_why;
 
   // frontiers (bits from the origin): below them the ring holds valid entries
-  uint32_t f_in = 0, f_1 = 0, f_2 = 0, f_4 = 0, f_8 = 0, f_16 = 0, f_32 = 0, f_rec = 0;
-
-  for (;;) {
-    // ================= pass 1: one step =================
-    const uint32_t e_rec = f_rec + SC_N;
-    const uint32_t t_32 = e_rec + SC_LAG_REC, t_16 = t_32 + SC_LAG_32, t_8 = t_16 + SC_LAG_16, t_4 = t_8 + SC_LAG_8, t_2 = t_4 + SC_LAG_4,
-                   t_1 = t_2 + SC_LAG_2, t_in = t_1 + SC_LAG_IN;
-    if (t_in > in_limit) {  // the input ends before another step's worth: every wave sees that, wave 0 hands the stream back where it is
-      break;
-    }
-    // input: dwords [f_in / 32, t_in / 32) into the ring (first two ring slots mirrored behind its end)
-    for (uint32_t i = (f_in >> 5) + threadIdx.x; i < (t_in >> 5); i += 64u * SC_WAVES) {
+  uint32_t f_1 = 0, f_4 = 0, f_16 = 0, f_32 = 0, f_rec = 0;
+  const uint32_t limit_dw = (in_limit + 31u) >> 5;  // dwords of the input that may be read
+  // input of the first step (later steps find theirs in the ring: it is fetched one step ahead)
+  if (SC_N + SC_AHEAD <= in_limit)
+    for (uint32_t i = threadIdx.x; i < ((SC_N + SC_AHEAD) >> 5); i += 64u * SC_WAVES) {
       const uint32_t v = in_dw[i];
-      const uint32_t slot = i & (SC_IN_DW - 1u);
-      lds_st32(sb + SC_IN + (slot << 2), v);
-      if (slot < 2u) lds_st32(sb + SC_IN + ((SC_IN_DW + slot) << 2), v);
+      lds_st32(sb + SC_IN + (i << 2), v);
+      if (i < 2u) lds_st32(sb + SC_IN + ((SC_IN_DW + i) << 2), v);
     }
-    f_in = t_in;
-    __syncthreads();
-    SCAN_PROF(0);
-    // S / J1
-    for (uint32_t w = (f_1 >> 6) + me; w < (t_1 >> 6); w += SC_WAVES) {
-      const uint32_t p = (w << 6) + lane;
-      uint32_t sym, L;
-      sc_lookup(lit_tree, sc_bits32(sb, p), sym, L);
-      lds_st8(sb + SC_S + (p & SC_M), sym);
-      lds_st8(sb + SC_J1 + (p & SC_M), L);
-    }
-    f_1 = t_1;
-    __syncthreads();
-    SCAN_PROF(1);
-#define SC_LEVEL(FROM, TO, f_to, t_to) \
-    for (uint32_t w = ((f_to) >> 6) + me; w < ((t_to) >> 6); w += SC_WAVES) { \
-      const uint32_t p = (w << 6) + lane; \
-      const uint32_t a = lds_ld8(sb + FROM + (p & SC_M)); \
-      const uint32_t c = lds_ld8(sb + FROM + ((p + a) & SC_M)); \
-      lds_st8(sb + TO + (p & SC_M), a + c); \
-    } \
-    f_to = (t_to); \
-    __syncthreads();
-    SC_LEVEL(SC_J1, SC_J2, f_2, t_2)
-    SC_LEVEL(SC_J2, SC_J4, f_4, t_4)
-    SC_LEVEL(SC_J4, SC_J8, f_8, t_8)
-    SC_LEVEL(SC_J8, SC_J16, f_16, t_16)
-#undef SC_LEVEL
-    for (uint32_t w = (f_32 >> 6) + me; w < (t_32 >> 6); w += SC_WAVES) {
-      const uint32_t p = (w << 6) + lane;
-      const uint32_t a = lds_ld8(sb + SC_J16 + (p & SC_M));
-      const uint32_t c = lds_ld8(sb + SC_J16 + ((p + a) & SC_M));
-      lds_st16(sb + SC_J32 + ((p & SC_M) << 1), a + c);
-    }
-    f_32 = t_32;
-    __syncthreads();
-    SCAN_PROF(2);
-    // REC: the command that would start at every bit of [f_rec, e_rec)
-    for (uint32_t w = (f_rec >> 6) + me; w < (e_rec >> 6); w += SC_WAVES) {
-      const uint32_t p = (w << 6) + lane;
-      uint32_t lo, hi;
-      sc_bits64(sb, p, lo, hi);
-      const ScHead h = sc_head(lo, hi, cmd_tree, lut_vgpr);
-      bool ok = h.insert < 64u && h.copy < 8192u;
-      uint32_t q = sc_skip(sb, p + h.bits, h.insert & 63u);
-      uint32_t kind = SCK_IMPLICIT, val = 0;
-      if (!h.implicit) {
-        uint32_t dlo, dhi;
-        sc_bits64(sb, q, dlo, dhi);
-        const uint32_t dtree = h.dctx == 0u ? dt0 : h.dctx == 1u ? dt1 : h.dctx == 2u ? dt2 : dt3;
-        const ScDist d = sc_dist(dlo, dhi, dtree, postfix_bits, num_direct);
-        kind = d.kind; val = d.val; q += d.bits;
-        ok = ok && val < (1u << 26);
-      }
-      const uint32_t delta = q - p;
-      ok = ok && delta != 0u && delta < 2048u;
-      const uint32_t rlo = delta | (h.bits << 11) | (h.insert << 17) | ((h.copy & 0x1FFu) << 23);
-      const uint32_t rhi = (h.copy >> 9) | (kind << 4) | (val << 6);
-      const uint32_t ra = sb + SC_REC + ((p & (SC_N - 1u)) << 3);
-      lds_st32(ra, ok ? rlo : 0u);
-      lds_st32(ra + 4u, ok ? rhi : 0u);
-    }
-    f_rec = e_rec;
-    __syncthreads();
-    SCAN_PROF(3);
+  __syncthreads();
 
-    // ================= pass 2: batches of up to 64 commands =================
-    // Per batch: wave 0 walks and resolves, then posts the batch (SCC_K entries in SC_XL, output position, and what
-    // comes after it: another batch, the next step, or the end of the engine's part); barrier; every wave executes.
-    bool leave = false;
-    for (;;) {
-      uint32_t v_ins = 0, v_copy = 0, v_dist = 0, v_off = 0, v_dep = 0, kp = 0;  // (wave 0) the batch, lane = entry
-      if (me == 0) {
+  // A tick is either a STEP (the tables advance by SC_N bits; meanwhile wave 0 walks the region completed in the step
+  // before), a SYNC tick (no tables: wave 0 catches up with everything that is complete) or the FINAL one (the last
+  // group is executed).  Every tick starts by executing the group posted in the tick before.
+  enum { M_STEP = 0, M_SYNC = 1, M_FINAL = 2 };
+  uint32_t mode = (SC_N + SC_AHEAD <= in_limit) ? (uint32_t)M_STEP : (uint32_t)M_FINAL;
+  for (;;) {
+    // ================= part 1 (all waves): the posted group =================
+    {
+      const uint32_t ng = sc_ctl_ld(sb, SCC_NG);
+      for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t k_exec = sc_ctl_ld(sb, SCC_GK + g);
+        gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g) | ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g + 1u) << 32));
+        const uint32_t xb = sb + SC_XL + g * 1024u;
+        // Wave w takes entries w, w + 16, ...: the loads of their copies first (copies whose source lies in front of the
+        // group), then their literals (lane i the i-th literal of the entry: out of S through J*, the entries' chains side
+        // by side), then the copies' stores.
+        uint32_t hold[4] = {0, 0, 0, 0}, x0[4], cn[4], off[4], q[4];
+        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) {
+          const uint32_t k = me + t * SC_WAVES;
+          const uint32_t xa = xb + ((k < k_exec ? k : 0u) << 4);
+          x0[t] = rfl(lds_ld32(xa)); cn[t] = rfl(lds_ld32(xa + 4u)); off[t] = rfl(lds_ld32(xa + 12u));
+          const uint32_t dist = rfl(lds_ld32(xa + 8u));
+          if (k >= k_exec) { x0[t] = 0u; cn[t] = 0u; }
+          if (cn[t] == 0u || (x0[t] >> 31) != 0u) { cn[t] = 0u; continue; }
+          gu8* const dst = o + off[t] + ((x0[t] >> 16) & 63u); gu8* const src = dst - dist;
+          if (cn[t] <= 64u) { if (lane < cn[t]) hold[t] = src[lane]; }
+          else {
+            const uint32_t n16 = cn[t] >> 4;
+            for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+            const uint32_t tail = n16 << 4;
+            if (tail + lane < cn[t]) dst[tail + lane] = src[tail + lane];
+            cn[t] = 0u;
+          }
+        }
+        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) q[t] = x0[t] & SC_M;
+#define SC_XHOP(BIT, EXPR) _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) if ((lane & BIT) && lane < ((x0[t] >> 16) & 63u)) q[t] += EXPR;
+        SC_XHOP(1u, lds_ld8(sb + SC_J1 + (q[t] & SC_M)))
+        SC_XHOP(2u, lds_ld8(sb + SC_J2 + (q[t] & SC_M)))
+        SC_XHOP(4u, lds_ld8(sb + SC_J4 + (q[t] & SC_M)))
+        SC_XHOP(8u, lds_ld8(sb + SC_J8 + (q[t] & SC_M)))
+        SC_XHOP(16u, lds_ld8(sb + SC_J16 + (q[t] & SC_M)))
+        SC_XHOP(32u, lds_ld16(sb + SC_J32 + ((q[t] & SC_M) << 1)))
+#undef SC_XHOP
+        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++)
+          if (lane < ((x0[t] >> 16) & 63u)) o[off[t] + lane] = (uint8_t)lds_ld8(sb + SC_S + (q[t] & SC_M));
+        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++)
+          if (cn[t] != 0u && lane < cn[t]) o[off[t] + ((x0[t] >> 16) & 63u) + lane] = (uint8_t)hold[t];
+      }
+    }
+    SCAN_PROF(6);
+    uint32_t walk_limit = f_rec;  // REC is complete below this
+    uint32_t pre_v = 0, pre_i = 0; bool pre_ok = false;
+    if (mode == M_STEP) {
+      // ================= pass 1: one step =================
+      const uint32_t e_rec = f_rec + SC_N;
+      const uint32_t t_32 = e_rec + SC_LAG_REC, t_16 = t_32 + SC_LAG_32, t_4 = t_16 + SC_LAG_16, t_1 = t_4 + SC_LAG_4, t_in = t_1 + SC_LAG_IN;
+      // the next step's input: requested now, put into the ring at the end of this step's tables
+      pre_i = (t_in >> 5) + threadIdx.x;
+      pre_ok = threadIdx.x < (SC_N >> 5) && pre_i < limit_dw;
+      if (pre_ok) pre_v = in_dw[pre_i];
+      // S / J1: the literal that would start at every bit, and its length -- two windows per wave and pass
+      for (uint32_t w0 = (f_1 >> 6) + me; w0 < (t_1 >> 6); w0 += 2u * SC_WAVES) {
+        uint32_t p[2], x[2], e[2], L[2];
+        p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (t_1 >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
+        _Pragma("unroll") for (int u = 0; u < 2; u++) x[u] = sc_bits32(sb, p[u]);
+        _Pragma("unroll") for (int u = 0; u < 2; u++) e[u] = lds_ld16(lit_tree + ((x[u] & 0xFFu) << 1));
+        _Pragma("unroll") for (int u = 0; u < 2; u++) L[u] = e[u] & 15u;
+        if (__ballot(L[0] > ROOT_BITS || L[1] > ROOT_BITS) != 0ull) {
+          uint32_t e2[2];
+          _Pragma("unroll") for (int u = 0; u < 2; u++) {
+            const bool sec = L[u] > ROOT_BITS;
+            const uint32_t idx = sec ? (e[u] >> 4) + __builtin_amdgcn_ubfe(x[u], ROOT_BITS, L[u] - ROOT_BITS) : (x[u] & 0xFFu);
+            e2[u] = lds_ld16(lit_tree + (idx << 1));
+          }
+          _Pragma("unroll") for (int u = 0; u < 2; u++) if (L[u] > ROOT_BITS) { e[u] = e2[u]; L[u] = ROOT_BITS + (e2[u] & 15u); }
+        }
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { lds_st8(sb + SC_S + (p[u] & SC_M), e[u] >> 4); lds_st8(sb + SC_J1 + (p[u] & SC_M), L[u]); }
+      }
+      f_1 = t_1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the group's stores: in memory before anyone reads them as copy sources)
+      __syncthreads();
+      SCAN_PROF(1);
+      // binary lifting, two levels per pass: TO2[p] = position after two FROM-hops, TO4[p] after four
+#define SC_LEVELS(FROM, TO2, TO4, f_to, t_to) \
+      for (uint32_t w0 = ((f_to) >> 6) + me; w0 < ((t_to) >> 6); w0 += 2u * SC_WAVES) { \
+        uint32_t p[2], a1[2], a2[2], a3[2], a4[2]; \
+        p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < ((t_to) >> 6) ? w0 + SC_WAVES : w0) << 6) + lane; \
+        _Pragma("unroll") for (int u = 0; u < 2; u++) a1[u] = lds_ld8(sb + FROM + (p[u] & SC_M)); \
+        _Pragma("unroll") for (int u = 0; u < 2; u++) a2[u] = a1[u] + lds_ld8(sb + FROM + ((p[u] + a1[u]) & SC_M)); \
+        _Pragma("unroll") for (int u = 0; u < 2; u++) a3[u] = a2[u] + lds_ld8(sb + FROM + ((p[u] + a2[u]) & SC_M)); \
+        _Pragma("unroll") for (int u = 0; u < 2; u++) a4[u] = a3[u] + lds_ld8(sb + FROM + ((p[u] + a3[u]) & SC_M)); \
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { lds_st8(sb + TO2 + (p[u] & SC_M), a2[u]); lds_st8(sb + TO4 + (p[u] & SC_M), a4[u]); } \
+      } \
+      f_to = (t_to); \
+      __syncthreads();
+      SC_LEVELS(SC_J1, SC_J2, SC_J4, f_4, t_4)
+      SC_LEVELS(SC_J4, SC_J8, SC_J16, f_16, t_16)
+#undef SC_LEVELS
+      for (uint32_t w0 = (f_32 >> 6) + me; w0 < (t_32 >> 6); w0 += 2u * SC_WAVES) {
+        uint32_t p[2], a[2], c[2];
+        p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (t_32 >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
+        _Pragma("unroll") for (int u = 0; u < 2; u++) a[u] = lds_ld8(sb + SC_J16 + (p[u] & SC_M));
+        _Pragma("unroll") for (int u = 0; u < 2; u++) c[u] = lds_ld8(sb + SC_J16 + ((p[u] + a[u]) & SC_M));
+        _Pragma("unroll") for (int u = 0; u < 2; u++) lds_st16(sb + SC_J32 + ((p[u] & SC_M) << 1), a[u] + c[u]);
+      }
+      f_32 = t_32;
+      __syncthreads();
+      SCAN_PROF(2);
+      if (me != 0) {
+        // REC: the command that would start at every bit of [f_rec, e_rec) -- fifteen waves, two windows per wave and pass,
+        // stage by stage (wave 0 is walking the step before meanwhile)
+        for (uint32_t w0 = (f_rec >> 6) + (me - 1u); w0 < (e_rec >> 6); w0 += 2u * (SC_WAVES - 1u)) {
+          uint32_t p[2], lo[2], hi[2], q[2], kind[2], val[2];
+          ScHead h[2];
+          bool ok[2];
+          p[0] = (w0 << 6) + lane; p[1] = ((w0 + (SC_WAVES - 1u) < (e_rec >> 6) ? w0 + (SC_WAVES - 1u) : w0) << 6) + lane;
+          _Pragma("unroll") for (int u = 0; u < 2; u++) sc_bits64(sb, p[u], lo[u], hi[u]);
+          {  // heads (sc_head, the two lookups side by side)
+            uint32_t e[2], L[2];
+            _Pragma("unroll") for (int u = 0; u < 2; u++) e[u] = lds_ld16(cmd_tree + ((lo[u] & 0xFFu) << 1));
+            _Pragma("unroll") for (int u = 0; u < 2; u++) L[u] = e[u] & 15u;
+            if (__ballot(L[0] > ROOT_BITS || L[1] > ROOT_BITS) != 0ull) {
+              uint32_t e2[2];
+              _Pragma("unroll") for (int u = 0; u < 2; u++) {
+                const bool sec = L[u] > ROOT_BITS;
+                const uint32_t idx = sec ? (e[u] >> 4) + __builtin_amdgcn_ubfe(lo[u], ROOT_BITS, L[u] - ROOT_BITS) : (lo[u] & 0xFFu);
+                e2[u] = lds_ld16(cmd_tree + (idx << 1));
+              }
+              _Pragma("unroll") for (int u = 0; u < 2; u++) if (L[u] > ROOT_BITS) { e[u] = e2[u]; L[u] = ROOT_BITS + (e2[u] & 15u); }
+            }
+            uint32_t ie[2], ce[2], cc[2];
+            _Pragma("unroll") for (int u = 0; u < 2; u++) {
+              const uint32_t cmd = e[u] >> 4, cell = cmd >> 6;
+              const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
+              cc[u] = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+              ie[u] = bperm(ins_code << 2, lut_vgpr); ce[u] = bperm((32u + cc[u]) << 2, lut_vgpr);
+              h[u].implicit = cmd < 128u ? 1u : 0u;
+            }
+            _Pragma("unroll") for (int u = 0; u < 2; u++) {
+              uint64_t w = (((uint64_t)hi[u] << 32) | lo[u]) >> L[u];
+              const uint32_t ib = ie[u] >> 16, cb = ce[u] >> 16;
+              h[u].insert = (ie[u] & 0xFFFFu) + ((uint32_t)w & ((1u << ib) - 1u));
+              w >>= ib;
+              h[u].copy = (ce[u] & 0xFFFFu) + ((uint32_t)w & ((1u << cb) - 1u));
+              h[u].bits = L[u] + ib + cb;
+              h[u].dctx = cc[u] > 2u ? 3u : cc[u];
+              ok[u] = h[u].insert < 64u && h[u].copy < 8192u;
+              q[u] = p[u] + h[u].bits;
+            }
+          }
+          // the literals are skipped (sc_skip, level by level for both)
+#define SC_HOP(BIT, EXPR) _Pragma("unroll") for (int u = 0; u < 2; u++) if (h[u].insert & BIT) q[u] += EXPR;
+          SC_HOP(1u, lds_ld8(sb + SC_J1 + (q[u] & SC_M)))
+          SC_HOP(2u, lds_ld8(sb + SC_J2 + (q[u] & SC_M)))
+          SC_HOP(4u, lds_ld8(sb + SC_J4 + (q[u] & SC_M)))
+          SC_HOP(8u, lds_ld8(sb + SC_J8 + (q[u] & SC_M)))
+          SC_HOP(16u, lds_ld8(sb + SC_J16 + (q[u] & SC_M)))
+          SC_HOP(32u, lds_ld16(sb + SC_J32 + ((q[u] & SC_M) << 1)))
+#undef SC_HOP
+          {  // distances
+            uint32_t dlo[2], dhi[2];
+            _Pragma("unroll") for (int u = 0; u < 2; u++) sc_bits64(sb, q[u], dlo[u], dhi[u]);
+            ScDist d[2];
+            _Pragma("unroll") for (int u = 0; u < 2; u++) {
+              const uint32_t dtree = h[u].dctx == 0u ? dt0 : h[u].dctx == 1u ? dt1 : h[u].dctx == 2u ? dt2 : dt3;
+              d[u] = sc_dist(dlo[u], dhi[u], dtree, postfix_bits, num_direct);
+            }
+            _Pragma("unroll") for (int u = 0; u < 2; u++) {
+              kind[u] = h[u].implicit ? (uint32_t)SCK_IMPLICIT : d[u].kind; val[u] = h[u].implicit ? 0u : d[u].val;
+              if (!h[u].implicit) { q[u] += d[u].bits; ok[u] = ok[u] && val[u] < (1u << 26); }
+            }
+          }
+          _Pragma("unroll") for (int u = 0; u < 2; u++) {
+            const uint32_t delta = q[u] - p[u];
+            const bool good = ok[u] && delta != 0u && delta < 2048u;
+            const uint32_t rlo = delta | (h[u].bits << 11) | (h[u].insert << 17) | ((h[u].copy & 0x1FFu) << 23);
+            const uint32_t rhi = (h[u].copy >> 9) | (kind[u] << 4) | (val[u] << 6);
+            const uint32_t ra = sb + SC_REC + ((p[u] & (SC_N2 - 1u)) << 3);
+            lds_st32(ra, good ? rlo : 0u);
+            lds_st32(ra + 4u, good ? rhi : 0u);
+          }
+        }
+      }
+      // (f_rec moves when the step's D2 / D4 are done, below)
+    }
+
+    // ================= part 2 (wave 0): walk, resolve, post =================
+    if (me == 0) {
+      // copies of the executed group that read the group's own output: one after the other (a wave's stores are visible
+      // to its later loads); in STEP ticks the barrier behind S / J1 has put the others' stores in front of this, in
+      // SYNC and FINAL ticks the barrier below does
+      if (mode != M_STEP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+      {
+        const uint32_t ng = sc_ctl_ld(sb, SCC_NG);
+        for (uint32_t g = 0; g < ng; g++) {
+          const uint32_t k_exec = sc_ctl_ld(sb, SCC_GK + g);
+          gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g) | ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g + 1u) << 32));
+          const uint32_t xa = sb + SC_XL + g * 1024u + (lane << 4);
+          const uint32_t x0 = lds_ld32(xa), xn = lds_ld32(xa + 4u), xd = lds_ld32(xa + 8u), xo = lds_ld32(xa + 12u);
+          uint64_t dm = __ballot(lane < k_exec && (x0 >> 31) != 0u);
+          while (dm) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(dm);
+            dm &= dm - 1ull;
+            const uint32_t n = rdlane(xn, k), dist = rdlane(xd, k), dpos = rdlane(xo, k) + ((rdlane(x0, k) >> 16) & 63u);
+            gu8* const dst = o + dpos; gu8* const src = dst - dist;
+            if (dist < n) {
+              // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
+              if (dist >= 64u) { for (uint32_t c = lane; c < n + lane; c += 64u) if (c < n) dst[c] = src[c]; }  // a step reads what earlier steps wrote
+              else {
+                uint32_t mm = lane % dist; const uint32_t step = 64u % dist;
+                for (uint32_t c = 0; c < n; c += 64u) { if (c + lane < n) dst[c + lane] = src[mm]; mm += step; if (mm >= dist) mm -= dist; }
+              }
+            } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
+            else {
+              const uint32_t n16 = n >> 4;
+              for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+              const uint32_t tail = n16 << 4;
+              if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+            }
+          }
+        }
+      }
+      SCAN_PROF(8);
+      uint32_t ng = 0, flags = 0;
+      const uint64_t p_group = P;  // copies that read at or behind this are the ones wave 0 does itself, next tick
+      bool stop = mode == M_FINAL, step_done = mode == M_FINAL;
+      while (!stop && !step_done && ng < SC_GROUP) {
+        // ---- walk: up to 64 entries.  The walk writes an entry's first lane only ("anchor"): the command's position (rC; a
+        // run of four commands whose total length D4 knows takes four lanes, the three behind the anchor are found
+        // afterwards, by their own lanes), or, for the pieces of a command walked by hand, the piece itself (rA, rB, rC
+        // with bit 31 set).
         uint32_t rA = 0, rB = 0, rC = 0, K = 0;
-        bool stop = false, step_done = false;
+        uint64_t anchors = 0;
         uint32_t man_lane = 64u, man_end = 0;  // lane of the copy of a command walked by hand, and the bit after its distance
 #define SC_APPEND(a_, b_, c_) do { const uint32_t a__ = (a_), b__ = (b_), c__ = (c_); \
           asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0" \
-                       : "+v"(rA), "+v"(rB), "+v"(rC) : "s"(a__), "s"(b__), "s"(c__), "s"(K) : "m0"); K++; } while (0)
+                       : "+v"(rA), "+v"(rB), "+v"(rC) : "s"(a__), "s"(b__), "s"(c__), "s"(K) : "m0"); anchors |= 1ull << K; K++; } while (0)
+#define SC_ANCHOR(c_, n_) do { const uint32_t c__ = (c_); \
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(rC) : "s"(c__), "s"(K) : "m0"); anchors |= 1ull << K; K += (n_); } while (0)
         for (;;) {
           if (in_run) {
             // literals of a command walked by hand: pieces of up to 32, one lane each; then its distance and copy
@@ -319,23 +495,42 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             SC_APPEND(run_copy, (kind << 30) | (val & 0x3FFFFFFFu), 0xC0000000u);
             b = man_end; in_run = false;
           }
+          // four commands per LDS round trip where D4 knows the way
+          while (K <= 60u && b < walk_limit) {
+            const uint32_t d4 = rfl(lds_ld16(sb + SC_D4 + ((b & (SC_N2 - 1u)) << 1)));
+            if (d4 == 0u) break;
+            SC_ANCHOR(b, 4u);
+            b += d4;
+          }
           if (K >= 64u) break;
-          if (b >= f_rec) { step_done = true; break; }
-          const uint32_t ra = sb + SC_REC + ((b & (SC_N - 1u)) << 3);
-          const uint32_t rlo = rfl(lds_ld32(ra)), rhi = rfl(lds_ld32(ra + 4u));
-          const uint32_t delta = rlo & 0x7FFu;
-          if (delta != 0u) { SC_APPEND(rlo, rhi, b); b += delta; continue; }
+          if (b >= walk_limit) { step_done = true; break; }
+          const uint32_t delta = rfl(lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3))) & 0x7FFu;
+          if (delta != 0u) { SC_ANCHOR(b, 1u); b += delta; continue; }
           // not in REC: a command to walk by hand.  The batch so far goes first, so that the counts below are exact.
           if (K != 0u) break;
           uint32_t lo, hi;
           sc_bits64(sb, b, lo, hi);
           const ScHead h = sc_head(lo, hi, cmd_tree, lut_vgpr);
           const uint32_t hins = rfl(h.insert), hcopy = rfl(h.copy), hbits = rfl(h.bits), himp = rfl(h.implicit), hctx = rfl(h.dctx);
-          if (hbits == 0u || hins >= SC_LONG_EXIT || bl1 == 0u || hins > bl0 || (uint64_t)hins + hcopy >= (uint64_t)quota || (!himp && bl2 == 0u)) { stop = true; break; }
+          if (hbits == 0u || hins >= SC_LONG_EXIT || bl1 == 0u || hins > bl0 || (uint64_t)hins + hcopy >= (uint64_t)quota || (!himp && bl2 == 0u)) { stop = true; exit_why = hins >= SC_LONG_EXIT ? 4u : 3u; break; }
           in_run = true; run_p = b + hbits; run_rem = hins; run_copy = hcopy; run_implicit = himp; run_dctx = hctx;
         }
 #undef SC_APPEND
+#undef SC_ANCHOR
         SCAN_PROF(4);
+        // ---- the lanes behind an anchor find their command: one or two hops from the anchor's position, then its REC ----
+        {
+          const uint64_t am = anchors & (~0ull >> (63u - lane));       // anchors at or below this lane
+          const uint32_t al = am ? sc_msb64(am) : 0u, j = lane - al;
+          const uint32_t ac = bperm(al << 2, rC);
+          if (lane < K && (ac >> 31) == 0u) {
+            uint32_t pos = ac;
+            if (j & 2u) pos += lds_ld16(sb + SC_D2 + ((pos & (SC_N2 - 1u)) << 1));
+            if (j & 1u) pos += lds_ld32(sb + SC_REC + ((pos & (SC_N2 - 1u)) << 3)) & 0x7FFu;
+            const uint32_t ra = sb + SC_REC + ((pos & (SC_N2 - 1u)) << 3);
+            rA = lds_ld32(ra); rB = lds_ld32(ra + 4u); rC = pos;
+          }
+        }
         // ---- resolve: lane k = entry k of the batch ----
         const bool active = lane < K;
         const bool manual = (rC >> 31) != 0u;
@@ -383,13 +578,14 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
           const uint64_t pk = P + out_excl + ins;
           const int32_t maxd = pk < (uint64_t)(uint32_t)max_backward ? (int32_t)pk : max_backward;
-          ok = ok && dist > 0 && dist <= maxd && (uint32_t)dist >= copy;
+          ok = ok && dist > 0 && dist <= maxd;
         }
         const uint64_t stopmask = __ballot(active && !ok);
-        kp = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
+        const uint32_t kp = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
         uint32_t extra_cmd = 0, extra_dst = 0;
         if (kp < K) {
           stop = true;
+          exit_why = rdlane((lit_incl <= bl0 && cmd_incl <= bl1 && dst_incl <= bl2 && s2 < quota) ? 2u : 1u, kp);
           if (kp == man_lane) {
             // the copy of a command walked by hand: its literals are out, its distance is read -- the checked loop
             // goes on behind the distance (decode.rs:2583, postReadDistance)
@@ -424,95 +620,74 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           else if (got == 3u) { d0 = nv[0]; d1 = nv[1]; d2 = nv[2]; d3 = o0; }
           else if (got == 4u) { d0 = nv[0]; d1 = nv[1]; d2 = nv[2]; d3 = nv[3]; }
         }
-        // the batch for the executing waves
-        const uint32_t dep = (copy != 0u && out_excl + ins + copy > (uint32_t)dist) ? 1u : 0u;  // source reaches into this batch's output
-        if (lane < kp) {
-          const uint32_t xa = sb + SC_XL + (lane << 4);
-          lds_st32(xa, litidx | (ins << 16) | (dep << 31)); lds_st32(xa + 4u, copy); lds_st32(xa + 8u, (uint32_t)dist); lds_st32(xa + 12u, out_excl);
+        if (kp != 0u) {
+          // the batch for the executing waves; a copy whose source reaches into the group's own output is wave 0's (bit 31)
+          const uint64_t src_end = (P - p_group) + out_excl + ins + copy;
+          const uint32_t dep = (copy != 0u && src_end > (uint64_t)(uint32_t)dist) ? 1u : 0u;
+          if (lane < kp) {
+            const uint32_t xa = sb + SC_XL + ng * 1024u + (lane << 4);
+            lds_st32(xa, litidx | (ins << 16) | (dep << 31)); lds_st32(xa + 4u, copy); lds_st32(xa + 8u, (uint32_t)dist); lds_st32(xa + 12u, out_excl);
+          }
+          sc_ctl_st(sb, SCC_GK + ng, kp); sc_ctl_st(sb, SCC_GP + 2u * ng, (uint32_t)P); sc_ctl_st(sb, SCC_GP + 2u * ng + 1u, (uint32_t)(P >> 32));
+          ng++;
         }
-        v_ins = ins; v_copy = copy; v_dist = (uint32_t)dist; v_off = out_excl; v_dep = dep;
-        sc_ctl_st(sb, SCC_K, kp); sc_ctl_st(sb, SCC_P_LO, (uint32_t)P); sc_ctl_st(sb, SCC_P_HI, (uint32_t)(P >> 32));
-        sc_ctl_st(sb, SCC_CMD, stop ? SCC_CMD_EXIT : step_done ? SCC_CMD_STEP : SCC_CMD_EXEC);
         // state after the batch
         P += out_tot; bl0 -= lit_tot; bl1 -= cmd_tot; bl2 -= dst_tot; quota -= out_tot; mlen -= (int32_t)out_tot; ncmd += cmd_tot;
         SCAN_PROF(5);
         SCAN_COUNT(12, kp); SCAN_COUNT(13, 1);
       }
-      __syncthreads();  // ---- the batch is posted ----
-      const uint32_t k_exec = sc_ctl_ld(sb, SCC_K), next = sc_ctl_ld(sb, SCC_CMD);
-      if (k_exec != 0u) {
-        gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, SCC_P_LO) | ((uint64_t)sc_ctl_ld(sb, SCC_P_HI) << 32));
-        // literals: wave w takes entries w, w + 16, ...; lane i the i-th literal of the entry
-        for (uint32_t k = me; k < k_exec; k += SC_WAVES) {
-          const uint32_t xa = sb + SC_XL + (k << 4);
-          const uint32_t x0 = rfl(lds_ld32(xa)), off = rfl(lds_ld32(xa + 12u));
-          const uint32_t n = (x0 >> 16) & 63u;
-          if (lane < n) {
-            const uint32_t q = sc_skip(sb, x0 & SC_M, lane);
-            o[off + lane] = (uint8_t)lds_ld8(sb + SC_S + (q & SC_M));
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // copies whose source lies in front of the batch: the loads of a wave's entries first, then the stores
-        {
-          uint32_t hold[4] = {0, 0, 0, 0};
-          _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) {
-            const uint32_t k = me + t * SC_WAVES;
-            if (k >= k_exec) continue;
-            const uint32_t xa = sb + SC_XL + (k << 4);
-            const uint32_t x0 = rfl(lds_ld32(xa)), n = rfl(lds_ld32(xa + 4u)), dist = rfl(lds_ld32(xa + 8u)), off = rfl(lds_ld32(xa + 12u));
-            if (n == 0u || (x0 >> 31) != 0u) continue;
-            gu8* const dst = o + off + ((x0 >> 16) & 63u); gu8* const src = dst - dist;
-            if (n <= 64u) { if (lane < n) hold[t] = src[lane]; }
-            else {
-              const uint32_t n16 = n >> 4;
-              for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-              const uint32_t tail = n16 << 4;
-              if (tail + lane < n) dst[tail + lane] = src[tail + lane];
-            }
-          }
-          _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) {
-            const uint32_t k = me + t * SC_WAVES;
-            if (k >= k_exec) continue;
-            const uint32_t xa = sb + SC_XL + (k << 4);
-            const uint32_t x0 = rfl(lds_ld32(xa)), n = rfl(lds_ld32(xa + 4u)), off = rfl(lds_ld32(xa + 12u));
-            if (n == 0u || (x0 >> 31) != 0u || n > 64u) continue;
-            if (lane < n) o[off + ((x0 >> 16) & 63u) + lane] = (uint8_t)hold[t];
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (me == 0) {
-          // copies that read what this batch wrote: one after the other (a wave's stores are visible to its later loads)
-          uint64_t dm = __ballot(lane < kp && v_dep != 0u);
-          while (dm) {
-            const uint32_t k = (uint32_t)__builtin_ctzll(dm);
-            dm &= dm - 1ull;
-            const uint32_t n = rdlane(v_copy, k), dist = rdlane(v_dist, k), dpos = rdlane(v_off, k) + rdlane(v_ins, k);
-            gu8* const dst = o + dpos; gu8* const src = dst - dist;
-            if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
-            else {
-              const uint32_t n16 = n >> 4;
-              for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-              const uint32_t tail = n16 << 4;
-              if (tail + lane < n) dst[tail + lane] = src[tail + lane];
-            }
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          SCAN_PROF(6);
+      if (stop) flags |= SCF_LEAVE;
+      else if (!step_done) flags |= SCF_BEHIND;  // the group is full: the walk goes on in a tick of its own
+      if (mode == M_FINAL) flags = SCF_LEAVE;
+      sc_ctl_st(sb, SCC_NG, ng); sc_ctl_st(sb, SCC_FLAGS, flags);
+    } else if (mode != M_STEP) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // (the group's stores, in front of wave 0's own copies)
+    }
+    if (mode == M_STEP && pre_ok) {
+      // the next step's input goes into its ring slots (nothing reads them before the next step)
+      const uint32_t slot = pre_i & (SC_IN_DW - 1u);
+      lds_st32(sb + SC_IN + (slot << 2), pre_v);
+      if (slot < 2u) lds_st32(sb + SC_IN + ((SC_IN_DW + slot) << 2), pre_v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ---- REC of the step is complete; the group is posted ----
+    SCAN_PROF(3);
+    if (mode == M_STEP) {
+      // D2 / D4: bits from every bit of the step to the second and the fourth command after the one that would start there
+      // (0 where one of them is not in REC or lies beyond the step)
+      const uint32_t e_rec = f_rec + SC_N;
+      for (uint32_t w0 = (f_rec >> 6) + me; w0 < (e_rec >> 6); w0 += 2u * SC_WAVES) {
+        uint32_t p[2], d1[2], d2[2], d3[2], d4[2];
+        p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (e_rec >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
+#define SC_DLT(pos) (lds_ld32(sb + SC_REC + (((pos) & (SC_N2 - 1u)) << 3)) & 0x7FFu)
+        _Pragma("unroll") for (int u = 0; u < 2; u++) d1[u] = SC_DLT(p[u]);
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d1[u] != 0u && p[u] + d1[u] < e_rec) ? SC_DLT(p[u] + d1[u]) : 0u; d2[u] = t ? d1[u] + t : 0u; }
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d2[u] != 0u && p[u] + d2[u] < e_rec) ? SC_DLT(p[u] + d2[u]) : 0u; d3[u] = t ? d2[u] + t : 0u; }
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d3[u] != 0u && p[u] + d3[u] < e_rec) ? SC_DLT(p[u] + d3[u]) : 0u; d4[u] = t ? d3[u] + t : 0u; }
+#undef SC_DLT
+        _Pragma("unroll") for (int u = 0; u < 2; u++) {
+          lds_st16(sb + SC_D2 + ((p[u] & (SC_N2 - 1u)) << 1), d2[u]);
+          lds_st16(sb + SC_D4 + ((p[u] & (SC_N2 - 1u)) << 1), d4[u]);
         }
       }
-      if (next == SCC_CMD_EXEC) continue;  // another batch of this step
-      leave = next == SCC_CMD_EXIT;
-      break;
+      f_rec = e_rec;
+      __syncthreads();
+      SCAN_PROF(7);
     }
-    if (leave) break;
+    // ---- what comes next (every wave decides the same from the posted flags) ----
+    if (mode == M_FINAL) break;
+    const uint32_t flags = sc_ctl_ld(sb, SCC_FLAGS);
+    const bool can_step = f_rec + SC_N + SC_AHEAD <= in_limit;
+    if (flags & SCF_LEAVE) mode = M_FINAL;
+    else if (flags & SCF_BEHIND) mode = M_SYNC;
+    else if (walk_limit < f_rec) mode = can_step ? (uint32_t)M_STEP : (uint32_t)M_SYNC;  // a complete region that has not been walked yet
+    else mode = can_step ? (uint32_t)M_STEP : (uint32_t)M_FINAL;
   }
   __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
   if (me != 0) return 0;
 #ifdef BROTLI_AMD_PROFILE_SCAN
-  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 16; k++) g_scan_prof[k] += sp_acc[k]; g_scan_prof[16] += ncmd; g_scan_prof[17] += 1; }
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 16; k++) g_scan_prof[k] += sp_acc[k]; g_scan_prof[16] += ncmd; g_scan_prof[17] += 1; g_scan_prof[18 + (exit_why < 5u ? exit_why : 0u)] += 1; if (ncmd < 64u) g_scan_prof[23] += 1; }
 #endif
   // ---- hand the stream back (LDS_LEAN, as lean_commands does) ----
   uint32_t pos = b, lits_left = 0, insert_len = 0, copy_len = exit_copy; int32_t dcode = exit_dcode; uint32_t dctx = exit_dctx;
