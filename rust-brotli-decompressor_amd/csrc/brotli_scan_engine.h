@@ -39,25 +39,25 @@ constexpr uint32_t SC_WAVES = 16;                 // waves of a block that runs 
 #endif
 constexpr uint32_t SC_R = BROTLI_AMD_SCAN_R;      // ring size in stream bits
 constexpr uint32_t SC_M = SC_R - 1;
-constexpr uint32_t SC_N = SC_R / 4;               // bits a step advances by
-constexpr uint32_t SC_N2 = 2 * SC_N;              // REC / D2 / D4 hold two steps (the one being built, the one being walked)
+constexpr uint32_t SC_N = SC_R / 4 - 128;         // bits a step advances by: 30 windows of 64 (two per wave for the fifteen waves that build REC)
+constexpr uint32_t SC_N2 = SC_R / 2;              // REC / D2 / D4 rings: two steps (the one being built, the one being walked), a power of two
 constexpr uint32_t SC_IN_DW = 2 * SC_R / 32;      // input ring in dwords (+ 2 mirrored at the end): it runs one step ahead of the tables
-constexpr uint32_t SC_GROUP = 4;                  // batches wave 0 may post per tick
+constexpr uint32_t SC_GROUP = 2;                  // batches wave 0 may post per tick
 // frontier lags (bits): J2/J4[b] read J1 up to b + 45, J8/J16[b] read J4 up to b + 180, J32[b] reads J16 up to b + 240;
 // REC[b] reads J* up to b + 63 + 63 * 15 and the input 96 bits on
 constexpr uint32_t SC_LAG_REC = 1088, SC_LAG_32 = 256, SC_LAG_16 = 192, SC_LAG_4 = 64, SC_LAG_IN = 64;
 constexpr uint32_t SC_AHEAD = SC_LAG_REC + SC_LAG_32 + SC_LAG_16 + SC_LAG_4 + SC_LAG_IN;  // input frontier - REC frontier
 // what is executed at the start of step s + 1 was walked in step s out of the region of step s - 1, while S / J1 of step
 // s + 1 are being written: three steps and the lags must fit the ring
-static_assert(3 * SC_N + SC_AHEAD <= SC_R, "ring too small");
+static_assert(3 * SC_N + SC_AHEAD <= SC_R && 2 * SC_N <= SC_N2 && SC_N % 64 == 0, "ring too small");
 static_assert(4 * SC_N + SC_AHEAD + 64 <= SC_IN_DW * 32, "input ring too small");
 constexpr uint32_t SC_LONG_EXIT = 8192;           // literal runs from here on go back to the rounds of the helper waves
 constexpr uint32_t SC_MIN_QUOTA = 2048;           // output bytes that must be possible for the engine to start
 constexpr uint32_t SC_MIN_INPUT = 2 * SC_N + SC_AHEAD + 64;  // stream bits that must be left for the engine to start
 
 // LDS layout, offsets from the engine's base
-constexpr uint32_t SC_CTL = 0;                    // 128: control words
-constexpr uint32_t SC_IN = 128;                   // input ring: SC_IN_DW + 2 dwords
+constexpr uint32_t SC_CTL = 0;                    // 256: control words
+constexpr uint32_t SC_IN = 256;                   // input ring: SC_IN_DW + 2 dwords
 constexpr uint32_t SC_S = SC_IN + (SC_IN_DW + 2) * 4 + 8;   // literal at every bit
 constexpr uint32_t SC_J1 = SC_S + SC_R;           // code length at every bit
 constexpr uint32_t SC_J2 = SC_J1 + SC_R;
@@ -68,15 +68,17 @@ constexpr uint32_t SC_J32 = SC_J16 + SC_R;        // u16
 constexpr uint32_t SC_REC = SC_J32 + 2 * SC_R;    // 8 bytes per bit of two steps
 constexpr uint32_t SC_D2 = SC_REC + 8 * SC_N2;    // u16 per bit: bits to the command after next (0: not known)
 constexpr uint32_t SC_D4 = SC_D2 + 2 * SC_N2;     // u16: bits to the fourth command from here
-constexpr uint32_t SC_XL = SC_D4 + 2 * SC_N2;     // SC_GROUP x 64 x 16: the group being executed
-constexpr uint32_t SC_BYTES = SC_XL + SC_GROUP * 1024;
+constexpr uint32_t SC_XL = SC_D4 + 2 * SC_N2;     // 2 x SC_GROUP x 64 x 16: the group being executed and the one being posted
+constexpr uint32_t SC_BYTES = SC_XL + 2 * SC_GROUP * 1024;
 static_assert(SC_S % 16 == 0 && SC_REC % 16 == 0 && SC_XL % 16 == 0, "alignment");
 
 // control words: the invocation's parameters (written by the decoding wave before the others join), then what wave 0
 // posts per tick: a group of up to SC_GROUP batches (entries in SC_XL, per batch its entry count and output position) and
 // two flags -- the walk stopped short of its limit because the group was full; the engine's part ends with this group
 enum { SCC_BASE_DW = 4, SCC_IN_LIMIT = 5, SCC_LIT_TREE = 6, SCC_CMD_TREE = 7, SCC_DT0 = 8, SCC_POSTFIX = 12, SCC_NUM_DIRECT = 13,
-       SCC_OUT_LO = 14, SCC_OUT_HI = 15, SCC_ENTRY = 16, SCC_NG = 17, SCC_FLAGS = 18, SCC_GK = 19 /* + batch */, SCC_GP = 23 /* + 2 * batch */ };
+       SCC_OUT_LO = 14, SCC_OUT_HI = 15, SCC_ENTRY = 16, SCC_FLAGS = 18,
+       // the two group buffers (posted in even / odd ticks): words from SCC_GRP + 16 * parity
+       SCC_GRP = 32, SCG_NG = 0, SCG_ANYDEP = 1, SCG_K = 2 /* + batch */, SCG_P = 6 /* + 2 * batch */ };
 enum { SCF_BEHIND = 1, SCF_LEAVE = 2 };
 enum { SCK_NONE = 0, SCK_EXPLICIT = 1, SCK_SHORT = 2, SCK_IMPLICIT = 3 };
 
@@ -212,7 +214,8 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
     bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
     d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
     max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
-    sc_ctl_st(sb, SCC_NG, 0u); sc_ctl_st(sb, SCC_FLAGS, 0u);
+    sc_ctl_st(sb, SCC_FLAGS, 0u);
+    sc_ctl_st(sb, SCC_GRP + SCG_NG, 0u); sc_ctl_st(sb, SCC_GRP + SCG_ANYDEP, 0u); sc_ctl_st(sb, SCC_GRP + 16u + SCG_NG, 0u); sc_ctl_st(sb, SCC_GRP + 16u + SCG_ANYDEP, 0u);
   }
   // a literal run being walked by hand (commands REC does not hold): literals still to skip, then the distance and the copy
   bool in_run = false; uint32_t run_p = 0, run_rem = 0, run_copy = 0, run_implicit = 0, run_dctx = 0;
@@ -221,7 +224,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
   (void)exit_why;
 
   // frontiers (bits from the origin): below them the ring holds valid entries
-  uint32_t f_1 = 0, f_4 = 0, f_16 = 0, f_32 = 0, f_rec = 0;
+  uint32_t f_1 = 0, f_4 = 0, f_16 = 0, f_32 = 0, f_rec = 0, f_d = 0;
   const uint32_t limit_dw = (in_limit + 31u) >> 5;  // dwords of the input that may be read
   // input of the first step (later steps find theirs in the ring: it is fetched one step ahead)
   if (SC_N + SC_AHEAD <= in_limit)
@@ -237,52 +240,83 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
   // group is executed).  Every tick starts by executing the group posted in the tick before.
   enum { M_STEP = 0, M_SYNC = 1, M_FINAL = 2 };
   uint32_t mode = (SC_N + SC_AHEAD <= in_limit) ? (uint32_t)M_STEP : (uint32_t)M_FINAL;
-  for (;;) {
+  uint32_t par = 0;  // the group buffer this tick posts into (the other one holds what the tick before posted)
+  for (;; par ^= 1u) {
+    const uint32_t gx = SCC_GRP + 16u * (par ^ 1u), xl_exec = sb + SC_XL + (par ^ 1u) * (SC_GROUP * 1024u);  // the group to execute
+    const uint32_t gp = SCC_GRP + 16u * par, xl_post = sb + SC_XL + par * (SC_GROUP * 1024u);                // the group to post
     // ================= part 1 (all waves): the posted group =================
     {
-      const uint32_t ng = sc_ctl_ld(sb, SCC_NG);
+      const uint32_t ng = sc_ctl_ld(sb, gx + SCG_NG);
       for (uint32_t g = 0; g < ng; g++) {
-        const uint32_t k_exec = sc_ctl_ld(sb, SCC_GK + g);
-        gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g) | ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g + 1u) << 32));
-        const uint32_t xb = sb + SC_XL + g * 1024u;
+        const uint32_t k_exec = sc_ctl_ld(sb, gx + SCG_K + g);
+        gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, gx + SCG_P + 2u * g) | ((uint64_t)sc_ctl_ld(sb, gx + SCG_P + 2u * g + 1u) << 32));
+        const uint32_t xb = xl_exec + g * 1024u;
         // Wave w takes entries w, w + 16, ...: the loads of their copies first (copies whose source lies in front of the
         // group), then their literals (lane i the i-th literal of the entry: out of S through J*, the entries' chains side
-        // by side), then the copies' stores.
-        uint32_t hold[4] = {0, 0, 0, 0}, x0[4], cn[4], off[4], q[4];
-        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) {
-          const uint32_t k = me + t * SC_WAVES;
-          const uint32_t xa = xb + ((k < k_exec ? k : 0u) << 4);
-          x0[t] = rfl(lds_ld32(xa)); cn[t] = rfl(lds_ld32(xa + 4u)); off[t] = rfl(lds_ld32(xa + 12u));
-          const uint32_t dist = rfl(lds_ld32(xa + 8u));
-          if (k >= k_exec) { x0[t] = 0u; cn[t] = 0u; }
-          if (cn[t] == 0u || (x0[t] >> 31) != 0u) { cn[t] = 0u; continue; }
-          gu8* const dst = o + off[t] + ((x0[t] >> 16) & 63u); gu8* const src = dst - dist;
-          if (cn[t] <= 64u) { if (lane < cn[t]) hold[t] = src[lane]; }
-          else {
-            const uint32_t n16 = cn[t] >> 4;
-            for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-            const uint32_t tail = n16 << 4;
-            if (tail + lane < cn[t]) dst[tail + lane] = src[tail + lane];
-            cn[t] = 0u;
-          }
-        }
-        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) q[t] = x0[t] & SC_M;
-#define SC_XHOP(BIT, EXPR) _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) if ((lane & BIT) && lane < ((x0[t] >> 16) & 63u)) q[t] += EXPR;
-        SC_XHOP(1u, lds_ld8(sb + SC_J1 + (q[t] & SC_M)))
-        SC_XHOP(2u, lds_ld8(sb + SC_J2 + (q[t] & SC_M)))
-        SC_XHOP(4u, lds_ld8(sb + SC_J4 + (q[t] & SC_M)))
-        SC_XHOP(8u, lds_ld8(sb + SC_J8 + (q[t] & SC_M)))
-        SC_XHOP(16u, lds_ld8(sb + SC_J16 + (q[t] & SC_M)))
-        SC_XHOP(32u, lds_ld16(sb + SC_J32 + ((q[t] & SC_M) << 1)))
+        // by side), then the copies' stores.  Two entries at a time where the batch has at most 32, else four.
+#define SC_EXEC(NS) do { \
+        uint32_t hold[NS], x0[NS], cn[NS], off[NS], q[NS]; \
+        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { \
+          const uint32_t k = me + t * SC_WAVES; \
+          const uint32_t xa = xb + ((k < k_exec ? k : 0u) << 4); \
+          x0[t] = rfl(lds_ld32(xa)); cn[t] = rfl(lds_ld32(xa + 4u)); off[t] = rfl(lds_ld32(xa + 12u)); hold[t] = 0; \
+          const uint32_t dist = rfl(lds_ld32(xa + 8u)); \
+          if (k >= k_exec) { x0[t] = 0u; cn[t] = 0u; } \
+          if (cn[t] == 0u || (x0[t] >> 31) != 0u) { cn[t] = 0u; continue; } \
+          gu8* const dst = o + off[t] + ((x0[t] >> 16) & 63u); gu8* const src = dst - dist; \
+          if (cn[t] <= 64u) { if (lane < cn[t]) hold[t] = src[lane]; } \
+          else { \
+            const uint32_t n16 = cn[t] >> 4; \
+            for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16); \
+            const uint32_t tail = n16 << 4; \
+            if (tail + lane < cn[t]) dst[tail + lane] = src[tail + lane]; \
+            cn[t] = 0u; \
+          } \
+        } \
+        uint32_t nmax = 0; \
+        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { q[t] = x0[t] & SC_M; const uint32_t n_ = (x0[t] >> 16) & 63u; nmax = n_ > nmax ? n_ : nmax; } \
+        if (nmax != 0u) { \
+          SC_XHOP(NS, 1u, lds_ld8(sb + SC_J1 + (q[t] & SC_M))) \
+          if (nmax > 2u) { SC_XHOP(NS, 2u, lds_ld8(sb + SC_J2 + (q[t] & SC_M))) } \
+          if (nmax > 4u) { SC_XHOP(NS, 4u, lds_ld8(sb + SC_J4 + (q[t] & SC_M))) } \
+          if (nmax > 8u) { SC_XHOP(NS, 8u, lds_ld8(sb + SC_J8 + (q[t] & SC_M))) } \
+          if (nmax > 16u) { SC_XHOP(NS, 16u, lds_ld8(sb + SC_J16 + (q[t] & SC_M))) } \
+          if (nmax > 32u) { SC_XHOP(NS, 32u, lds_ld16(sb + SC_J32 + ((q[t] & SC_M) << 1))) } \
+          _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) \
+            if (lane < ((x0[t] >> 16) & 63u)) o[off[t] + lane] = (uint8_t)lds_ld8(sb + SC_S + (q[t] & SC_M)); \
+        } \
+        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) \
+          if (cn[t] != 0u && lane < cn[t]) o[off[t] + ((x0[t] >> 16) & 63u) + lane] = (uint8_t)hold[t]; \
+      } while (0)
+#define SC_XHOP(NS, BIT, EXPR) _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if ((lane & BIT) && lane < ((x0[t] >> 16) & 63u)) q[t] += EXPR;
+        if (k_exec <= 2u * SC_WAVES) { if (me < k_exec) SC_EXEC(2u); }
+        else SC_EXEC(4u);
 #undef SC_XHOP
-        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++)
-          if (lane < ((x0[t] >> 16) & 63u)) o[off[t] + lane] = (uint8_t)lds_ld8(sb + SC_S + (q[t] & SC_M));
-        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++)
-          if (cn[t] != 0u && lane < cn[t]) o[off[t] + ((x0[t] >> 16) & 63u) + lane] = (uint8_t)hold[t];
+#undef SC_EXEC
       }
     }
     SCAN_PROF(6);
-    uint32_t walk_limit = f_rec;  // REC is complete below this
+    if (f_d < f_rec) {
+      // D2 / D4 of the region whose REC the tick before completed: bits from every bit to the second and the fourth command
+      // after the one that would start there (0 where one of them is not in REC or lies beyond the region)
+      for (uint32_t w0 = (f_d >> 6) + me; w0 < (f_rec >> 6); w0 += 2u * SC_WAVES) {
+        uint32_t p[2], d1[2], d2[2], d3[2], d4[2];
+        p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (f_rec >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
+#define SC_DLT(pos) (lds_ld32(sb + SC_REC + (((pos) & (SC_N2 - 1u)) << 3)) & 0x7FFu)
+        _Pragma("unroll") for (int u = 0; u < 2; u++) d1[u] = SC_DLT(p[u]);
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d1[u] != 0u && p[u] + d1[u] < f_rec) ? SC_DLT(p[u] + d1[u]) : 0u; d2[u] = t ? d1[u] + t : 0u; }
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d2[u] != 0u && p[u] + d2[u] < f_rec) ? SC_DLT(p[u] + d2[u]) : 0u; d3[u] = t ? d2[u] + t : 0u; }
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d3[u] != 0u && p[u] + d3[u] < f_rec) ? SC_DLT(p[u] + d3[u]) : 0u; d4[u] = t ? d3[u] + t : 0u; }
+#undef SC_DLT
+        _Pragma("unroll") for (int u = 0; u < 2; u++) {
+          lds_st16(sb + SC_D2 + ((p[u] & (SC_N2 - 1u)) << 1), d2[u]);
+          lds_st16(sb + SC_D4 + ((p[u] & (SC_N2 - 1u)) << 1), d4[u]);
+        }
+      }
+      f_d = f_rec;
+    }
+    SCAN_PROF(7);
+    uint32_t walk_limit = f_rec;  // REC, D2 and D4 are complete below this (once the barrier in front of the walk is passed)
     uint32_t pre_v = 0, pre_i = 0; bool pre_ok = false;
     if (mode == M_STEP) {
       // ================= pass 1: one step =================
@@ -418,44 +452,44 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
       // (f_rec moves when the step's D2 / D4 are done, below)
     }
 
-    // ================= part 2 (wave 0): walk, resolve, post =================
-    if (me == 0) {
+    // ================= part 2: wave 0 walks, resolves and posts; the last wave does the executed group's own copies =================
+    // (in STEP ticks the barrier behind S / J1 has put everyone's stores of part 1 in memory; in SYNC and FINAL ticks this one does)
+    if (mode != M_STEP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    if (me == SC_WAVES - 1u && sc_ctl_ld(sb, gx + SCG_ANYDEP) != 0u) {
       // copies of the executed group that read the group's own output: one after the other (a wave's stores are visible
-      // to its later loads); in STEP ticks the barrier behind S / J1 has put the others' stores in front of this, in
-      // SYNC and FINAL ticks the barrier below does
-      if (mode != M_STEP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-      {
-        const uint32_t ng = sc_ctl_ld(sb, SCC_NG);
-        for (uint32_t g = 0; g < ng; g++) {
-          const uint32_t k_exec = sc_ctl_ld(sb, SCC_GK + g);
-          gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g) | ((uint64_t)sc_ctl_ld(sb, SCC_GP + 2u * g + 1u) << 32));
-          const uint32_t xa = sb + SC_XL + g * 1024u + (lane << 4);
-          const uint32_t x0 = lds_ld32(xa), xn = lds_ld32(xa + 4u), xd = lds_ld32(xa + 8u), xo = lds_ld32(xa + 12u);
-          uint64_t dm = __ballot(lane < k_exec && (x0 >> 31) != 0u);
-          while (dm) {
-            const uint32_t k = (uint32_t)__builtin_ctzll(dm);
-            dm &= dm - 1ull;
-            const uint32_t n = rdlane(xn, k), dist = rdlane(xd, k), dpos = rdlane(xo, k) + ((rdlane(x0, k) >> 16) & 63u);
-            gu8* const dst = o + dpos; gu8* const src = dst - dist;
-            if (dist < n) {
-              // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
-              if (dist >= 64u) { for (uint32_t c = lane; c < n + lane; c += 64u) if (c < n) dst[c] = src[c]; }  // a step reads what earlier steps wrote
-              else {
-                uint32_t mm = lane % dist; const uint32_t step = 64u % dist;
-                for (uint32_t c = 0; c < n; c += 64u) { if (c + lane < n) dst[c + lane] = src[mm]; mm += step; if (mm >= dist) mm -= dist; }
-              }
-            } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
+      // to its later loads)
+      const uint32_t ng = sc_ctl_ld(sb, gx + SCG_NG);
+      for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t k_exec = sc_ctl_ld(sb, gx + SCG_K + g);
+        gu8* const o = out + ((uint64_t)sc_ctl_ld(sb, gx + SCG_P + 2u * g) | ((uint64_t)sc_ctl_ld(sb, gx + SCG_P + 2u * g + 1u) << 32));
+        const uint32_t xa = xl_exec + g * 1024u + (lane << 4);
+        const uint32_t x0 = lds_ld32(xa), xn = lds_ld32(xa + 4u), xd = lds_ld32(xa + 8u), xo = lds_ld32(xa + 12u);
+        uint64_t dm = __ballot(lane < k_exec && (x0 >> 31) != 0u);
+        while (dm) {
+          const uint32_t k = (uint32_t)__builtin_ctzll(dm);
+          dm &= dm - 1ull;
+          const uint32_t n = rdlane(xn, k), dist = rdlane(xd, k), dpos = rdlane(xo, k) + ((rdlane(x0, k) >> 16) & 63u);
+          gu8* const dst = o + dpos; gu8* const src = dst - dist;
+          if (dist < n) {
+            // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
+            if (dist >= 64u) { for (uint32_t c = lane; c < n + lane; c += 64u) if (c < n) dst[c] = src[c]; }  // a step reads what earlier steps wrote
             else {
-              const uint32_t n16 = n >> 4;
-              for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
-              const uint32_t tail = n16 << 4;
-              if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+              uint32_t mm = lane % dist; const uint32_t step = 64u % dist;
+              for (uint32_t c = 0; c < n; c += 64u) { if (c + lane < n) dst[c + lane] = src[mm]; mm += step; if (mm >= dist) mm -= dist; }
             }
+          } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
+          else {
+            const uint32_t n16 = n >> 4;
+            for (uint32_t c = lane; c < n16; c += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)c * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)c * 16);
+            const uint32_t tail = n16 << 4;
+            if (tail + lane < n) dst[tail + lane] = src[tail + lane];
           }
         }
       }
+    }
+    if (me == 0) {
       SCAN_PROF(8);
-      uint32_t ng = 0, flags = 0;
+      uint32_t ng = 0, flags = 0, any_dep = 0;
       const uint64_t p_group = P;  // copies that read at or behind this are the ones wave 0 does itself, next tick
       bool stop = mode == M_FINAL, step_done = mode == M_FINAL;
       while (!stop && !step_done && ng < SC_GROUP) {
@@ -504,6 +538,10 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           }
           if (K >= 64u) break;
           if (b >= walk_limit) { step_done = true; break; }
+          if (K <= 62u) {  // two commands where D2 knows the way (the end of a region, mostly)
+            const uint32_t d2h = rfl(lds_ld16(sb + SC_D2 + ((b & (SC_N2 - 1u)) << 1)));
+            if (d2h != 0u) { SC_ANCHOR(b, 2u); b += d2h; continue; }
+          }
           const uint32_t delta = rfl(lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3))) & 0x7FFu;
           if (delta != 0u) { SC_ANCHOR(b, 1u); b += delta; continue; }
           // not in REC: a command to walk by hand.  The batch so far goes first, so that the counts below are exact.
@@ -531,15 +569,15 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             rA = lds_ld32(ra); rB = lds_ld32(ra + 4u); rC = pos;
           }
         }
-        // ---- resolve: lane k = entry k of the batch ----
+        // ---- resolve: lane k = entry k of the batch (selects, not branches: every lane does the same) ----
         const bool active = lane < K;
         const bool manual = (rC >> 31) != 0u;
-        const uint32_t ins = !active ? 0u : manual ? (rC >> 24) & 63u : (rA >> 17) & 63u;
-        const uint32_t copy = !active ? 0u : manual ? rA : (rA >> 23) | ((rB & 15u) << 9);
-        const uint32_t kind = !active ? (uint32_t)SCK_NONE : manual ? rB >> 30 : (rB >> 4) & 3u;
+        const uint32_t ins = active ? (manual ? (rC >> 24) & 63u : (rA >> 17) & 63u) : 0u;
+        const uint32_t copy = active ? (manual ? rA : (rA >> 23) | ((rB & 15u) << 9)) : 0u;
+        const uint32_t kind = active ? (manual ? rB >> 30 : (rB >> 4) & 3u) : (uint32_t)SCK_NONE;
         const uint32_t val = manual ? rB & 0x3FFFFFFFu : rB >> 6;
-        const uint32_t litidx = manual ? rC & SC_M : (rC + ((rA >> 11) & 63u)) & SC_M;
-        const uint32_t iscmd = !active ? 0u : manual ? (rC >> 30) & 1u : 1u;
+        const uint32_t litidx = (manual ? rC : rC + ((rA >> 11) & 63u)) & SC_M;
+        const uint32_t iscmd = active ? (manual ? (rC >> 30) & 1u : 1u) : 0u;
         const uint32_t isdist = (kind == SCK_EXPLICIT || kind == SCK_SHORT) ? 1u : 0u;
         const uint32_t s1 = sc_scan(ins | (iscmd << 16) | (isdist << 24));
         const uint32_t s2 = sc_scan(ins + copy);
@@ -552,33 +590,40 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         const uint32_t code = kind == SCK_SHORT ? val : 0u;
         const bool pushes = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
         const uint64_t pm = __ballot(pushes);
-        uint64_t m = pm & ((1ull << lane) - 1ull);
-        const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
-        const uint32_t npush = (uint32_t)__popcll(m);
-        const bool from_carry = npush <= back;
-        const uint32_t ci = back - npush;  // (meaningful when from_carry)
-        const int32_t carry = ci == 0u ? d0 : ci == 1u ? d1 : ci == 2u ? d2 : d3;
-        if (!from_carry) for (uint32_t t = 0; t < back; t++) m &= ~(1ull << sc_msb64(m));
-        const uint32_t src = from_carry ? 0u : sc_msb64(m);
         int32_t dist = kind == SCK_EXPLICIT ? (int32_t)val : 0;
-        uint32_t resolved = need ? 0u : 1u;
-        while (__ballot(resolved == 0u) != 0ull) {
-          const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dist);
-          const uint32_t sr = bperm(src << 2, resolved);
-          if (resolved == 0u && (from_carry || sr != 0u)) {
+        if (__ballot(need) != 0ull) {
+          const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
+          // the pushes in front of this lane, as two halves: the (back + 1)-th last of them is the source
+          const uint64_t below = pm & ((1ull << lane) - 1ull);
+          uint32_t mlo = (uint32_t)below, mhi = (uint32_t)(below >> 32);
+          const uint32_t npush = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+          const bool from_carry = npush <= back;
+          const uint32_t ci = back - npush;  // (meaningful when from_carry)
+          const int32_t carry = ci == 0u ? d0 : ci == 1u ? d1 : ci == 2u ? d2 : d3;
+          _Pragma("unroll") for (uint32_t t = 0; t < 3u; t++) {
+            const bool clr = t < back && !from_carry;
+            const uint32_t h = mhi ? 31u - (uint32_t)__clz(mhi) : 0u, l = mlo ? 31u - (uint32_t)__clz(mlo) : 0u;
+            const uint32_t nhi = mhi & ~(1u << h), nlo = mhi ? mlo : mlo & ~(1u << l);
+            mhi = clr ? nhi : mhi; mlo = clr ? nlo : mlo;
+          }
+          const uint32_t src = from_carry ? 0u : (mhi ? 63u - (uint32_t)__clz(mhi) : mlo ? 31u - (uint32_t)__clz(mlo) : 0u);
+          uint32_t resolved = need ? 0u : 1u;
+          const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
+          while (__ballot(resolved == 0u) != 0ull) {
+            const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dist);
+            const uint32_t sr = bperm(src << 2, resolved);
+            const bool can = resolved == 0u && (from_carry || sr != 0u);
             int32_t v = from_carry ? carry : sv;
-            if (code != 0u) {
-              const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
-              if (code & 1u) v += mag; else { v -= mag; if (v <= 0) v = 0x7fffffff; }
-            }
-            dist = v; resolved = 1u;
+            const int32_t vp = v + mag, vm = v - mag;
+            v = code == 0u ? v : (code & 1u) ? vp : (vm <= 0 ? 0x7fffffff : vm);
+            dist = can ? v : dist; resolved = can ? 1u : resolved;
           }
         }
-        if (kind != SCK_NONE) {
+        {
           // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
           const uint64_t pk = P + out_excl + ins;
           const int32_t maxd = pk < (uint64_t)(uint32_t)max_backward ? (int32_t)pk : max_backward;
-          ok = ok && dist > 0 && dist <= maxd;
+          ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
         }
         const uint64_t stopmask = __ballot(active && !ok);
         const uint32_t kp = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
@@ -624,11 +669,12 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           // the batch for the executing waves; a copy whose source reaches into the group's own output is wave 0's (bit 31)
           const uint64_t src_end = (P - p_group) + out_excl + ins + copy;
           const uint32_t dep = (copy != 0u && src_end > (uint64_t)(uint32_t)dist) ? 1u : 0u;
+          if (__ballot(lane < kp && dep != 0u) != 0ull) any_dep = 1u;
           if (lane < kp) {
-            const uint32_t xa = sb + SC_XL + ng * 1024u + (lane << 4);
+            const uint32_t xa = xl_post + ng * 1024u + (lane << 4);
             lds_st32(xa, litidx | (ins << 16) | (dep << 31)); lds_st32(xa + 4u, copy); lds_st32(xa + 8u, (uint32_t)dist); lds_st32(xa + 12u, out_excl);
           }
-          sc_ctl_st(sb, SCC_GK + ng, kp); sc_ctl_st(sb, SCC_GP + 2u * ng, (uint32_t)P); sc_ctl_st(sb, SCC_GP + 2u * ng + 1u, (uint32_t)(P >> 32));
+          sc_ctl_st(sb, gp + SCG_K + ng, kp); sc_ctl_st(sb, gp + SCG_P + 2u * ng, (uint32_t)P); sc_ctl_st(sb, gp + SCG_P + 2u * ng + 1u, (uint32_t)(P >> 32));
           ng++;
         }
         // state after the batch
@@ -639,10 +685,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
       if (stop) flags |= SCF_LEAVE;
       else if (!step_done) flags |= SCF_BEHIND;  // the group is full: the walk goes on in a tick of its own
       if (mode == M_FINAL) flags = SCF_LEAVE;
-      sc_ctl_st(sb, SCC_NG, ng); sc_ctl_st(sb, SCC_FLAGS, flags);
-    } else if (mode != M_STEP) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // (the group's stores, in front of wave 0's own copies)
+      sc_ctl_st(sb, gp + SCG_NG, ng); sc_ctl_st(sb, SCC_FLAGS, flags); sc_ctl_st(sb, gp + SCG_ANYDEP, any_dep);
     }
     if (mode == M_STEP && pre_ok) {
       // the next step's input goes into its ring slots (nothing reads them before the next step)
@@ -653,28 +696,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // ---- REC of the step is complete; the group is posted ----
     SCAN_PROF(3);
-    if (mode == M_STEP) {
-      // D2 / D4: bits from every bit of the step to the second and the fourth command after the one that would start there
-      // (0 where one of them is not in REC or lies beyond the step)
-      const uint32_t e_rec = f_rec + SC_N;
-      for (uint32_t w0 = (f_rec >> 6) + me; w0 < (e_rec >> 6); w0 += 2u * SC_WAVES) {
-        uint32_t p[2], d1[2], d2[2], d3[2], d4[2];
-        p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (e_rec >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
-#define SC_DLT(pos) (lds_ld32(sb + SC_REC + (((pos) & (SC_N2 - 1u)) << 3)) & 0x7FFu)
-        _Pragma("unroll") for (int u = 0; u < 2; u++) d1[u] = SC_DLT(p[u]);
-        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d1[u] != 0u && p[u] + d1[u] < e_rec) ? SC_DLT(p[u] + d1[u]) : 0u; d2[u] = t ? d1[u] + t : 0u; }
-        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d2[u] != 0u && p[u] + d2[u] < e_rec) ? SC_DLT(p[u] + d2[u]) : 0u; d3[u] = t ? d2[u] + t : 0u; }
-        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d3[u] != 0u && p[u] + d3[u] < e_rec) ? SC_DLT(p[u] + d3[u]) : 0u; d4[u] = t ? d3[u] + t : 0u; }
-#undef SC_DLT
-        _Pragma("unroll") for (int u = 0; u < 2; u++) {
-          lds_st16(sb + SC_D2 + ((p[u] & (SC_N2 - 1u)) << 1), d2[u]);
-          lds_st16(sb + SC_D4 + ((p[u] & (SC_N2 - 1u)) << 1), d4[u]);
-        }
-      }
-      f_rec = e_rec;
-      __syncthreads();
-      SCAN_PROF(7);
-    }
+    if (mode == M_STEP) f_rec += SC_N;
     // ---- what comes next (every wave decides the same from the posted flags) ----
     if (mode == M_FINAL) break;
     const uint32_t flags = sc_ctl_ld(sb, SCC_FLAGS);
