@@ -4,19 +4,27 @@
 One "step" = one pass of the decode kernel over one batch of compressed streams that already sit in HBM
 (outputs stay in HBM).  Default workload = the configuration the metric is quoted on: a 1 GiB batch of
 wbits-22 (4 MiB window) streams, 256 x 4 MiB, synthetic long-back-reference data (SURVEY.md section 8d, C3 as
-256 independent streams).  N > 1: one process per GPU (torchrun), every rank decodes its own 1 GiB batch --
-streams are independent, so the path shards with no data-path collective ("weak" scaling); RCCL carries only
-the workload descriptor (broadcast) and the per-rank status words (all_gather).
+256 independent streams), 256 distinct streams.
 
-Prints ONE JSON line on rank 0 (contract in the task description), with two extra objects:
-  roofline     -- HBM roofline of the decode kernel: algorithmic bytes (compressed read + decompressed written)
-                  per launch / mean kernel time from HIP events on the launch stream, against 8 TB/s
-  cpu_baseline -- the CPU oracle ("port": the reference itself is Rust and cannot be built here) on a bounded
-                  sample of the same workload, all host cores
+N > 1: one process per GPU (torchrun).  The job is N x 256 streams ("weak" scaling: 1 GiB per GPU).  Rank 0 owns
+the descriptor table (one row per stream: compressed size, output capacity, weight), broadcasts it (RCCL), every
+rank takes its part by the deterministic longest-processing-time rule of rust-brotli-decompressor_amd/sharding.py
+-- the code the 2-rank gloo test covers -- generates the streams of its part locally (they are a function of the
+stream index: payload never crosses xGMI), decodes them on its GPU, and the per-stream status words are gathered.
+
+Prints ONE JSON line on rank 0 (contract in the task description), with these extra objects:
+  roofline       -- HBM roofline of the decode kernel: algorithmic bytes (compressed read + decompressed written)
+                    per launch / mean kernel time from HIP events on the launch stream, against 8 TB/s
+  cpu_baseline   -- the CPU oracle ("port": the reference itself is Rust and cannot be built here) on a bounded
+                    sample of the same workload: all host threads, one thread, and -- when libbrotlidec.so.1 can
+                    be loaded -- Google's C decoder on one thread as a proxy for the reference (a port of it)
+  extra_configs  -- (N = 1 only) the other configurations of BASELINE.json, each timed the same way with its own
+                    roofline: C2 1024 x alice29, C4 256 x 4 MiB high-entropy literals, C3 as ONE many-metablock stream
 """
 import argparse
 import ctypes
 import hashlib
+import importlib.util
 import json
 import os
 import re
@@ -30,20 +38,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def load_pkg():
-    import importlib.util
-    name = "rust_brotli_decompressor_amd"
+def _load(name, path):
     if name in sys.modules:
         return sys.modules[name]
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py"))
+    spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
     return mod
 
 
-def build_workload(name, rank):
-    """-> (label, unique streams [(compressed, raw_size, sha256)], copies per unique stream)"""
+def load_pkg():
+    return _load("rust_brotli_decompressor_amd", os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py"))
+
+
+def load_sharding():
+    return _load("brotli_amd_sharding", os.path.join(ROOT, "rust-brotli-decompressor_amd", "sharding.py"))
+
+
+def build_workload(name, n_unique=None):
+    """-> (label, unique streams [(compressed, raw_size, sha256)], streams per GPU).  Stream i of a job is unique[i % len(unique)]."""
     import workloads as w
     m = re.fullmatch(r"fixture:([\w.]+)x(\d+)", name)  # any of the reference's fixtures, n copies (cliff hunting)
     if m:
@@ -52,24 +66,115 @@ def build_workload(name, rank):
     if m or not w.encoder_available():
         n = int(m.group(1)) if m else 1024
         return "%d x alice29.txt.compressed (reference fixture, wbits 22)" % n, w.fixture_streams("alice29.txt.compressed"), n
-    n_unique = int(os.environ.get("BROTLI_BENCH_UNIQUE", "32"))
     m = re.fullmatch(r"(longbackref|highentropy)_(\d+)x(\d+)(KiB|MiB)", name)
-    if m and name not in ("longbackref_256x4MiB", "highentropy_256x4MiB"):
-        # occupancy sweeps: the same total volume cut into more, smaller streams (still wbits 22)
-        kind, n, size = m.group(1), int(m.group(2)), int(m.group(3)) << (10 if m.group(4) == "KiB" else 20)
-        u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", n_unique, size, 3000 + 4096 * rank)
-        return "%d x %d KiB streams, wbits 22, brotli -q5, %s (%d distinct streams)" % (n, size >> 10, kind, n_unique), u, max(1, n // n_unique)
-    if name == "longbackref_256x4MiB":
-        u = w.make_streams("long_backref", n_unique, 4 << 20, 1000 + 4096 * rank)
-        return "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, long back-references (%d distinct streams)" % n_unique, u, 256 // n_unique
-    if name == "highentropy_256x4MiB":
-        u = w.make_streams("high_entropy", n_unique, 4 << 20, 2000 + 4096 * rank)
-        return "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, high-entropy literals (%d distinct streams)" % n_unique, u, 256 // n_unique
-    raise SystemExit("unknown workload " + name)
+    if not m:
+        raise SystemExit("unknown workload " + name)
+    kind, n, size = m.group(1), int(m.group(2)), int(m.group(3)) << (10 if m.group(4) == "KiB" else 20)
+    nu = min(n, n_unique if n_unique else int(os.environ.get("BROTLI_BENCH_UNIQUE", "256")))
+    seed0 = {"longbackref": 1000, "highentropy": 2000}[kind] if (n, size) == (256, 4 << 20) else 3000
+    u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", nu, size, seed0)
+    what = "long back-references" if kind == "longbackref" else "high-entropy literals"
+    if (n, size) == (256, 4 << 20):
+        label = "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, %s (%d distinct streams)" % (what, nu)
+    else:
+        label = "%d x %d KiB streams, wbits 22, brotli -q5, %s (%d distinct streams)" % (n, size >> 10, what, nu)
+    return label, u, n
 
 
-def cpu_baseline(unique, budget_s=12.0):
-    """CPU oracle on a bounded sample of the same streams, one stream per thread, all cores."""
+class DeviceJob:
+    """A list of streams resident in HBM (own compressed copy and own output buffer each) and the batch object that decodes it."""
+
+    def __init__(self, pkg, torch, dev, unique, indices):
+        self.pkg, self.torch, self.unique, self.indices = pkg, torch, unique, list(indices)
+        n = len(self.indices)
+        self.in_stride = max((len(c) + 255) // 256 * 256 for c, _, _ in unique)
+        self.out_stride = max((sz + 255) // 256 * 256 for _, sz, _ in unique)
+        self.d_in = torch.zeros(max(1, n) * self.in_stride, dtype=torch.uint8, device=dev)
+        self.d_out = torch.zeros(max(1, n) * self.out_stride, dtype=torch.uint8, device=dev)
+        staged = {}
+        self.sizes, self.caps = [], []
+        for j, i in enumerate(self.indices):
+            u = i % len(unique)
+            c, sz, _ = unique[u]
+            if u not in staged:
+                staged[u] = torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev)
+            self.d_in[j * self.in_stride: j * self.in_stride + len(c)] = staged[u]
+            self.sizes.append(len(c))
+            self.caps.append(sz)
+        self.in_ptrs = [self.d_in.data_ptr() + j * self.in_stride for j in range(n)]
+        self.out_ptrs = [self.d_out.data_ptr() + j * self.out_stride for j in range(n)]
+        torch.cuda.synchronize()
+        self.batch = pkg.Batch(max(1, n), lds_arena_bytes=int(os.environ.get("BROTLI_BENCH_LDS_ARENA", "0")))
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.comp_total = sum(self.sizes)
+        self.raw_total = sum(self.caps)
+
+    def decode_and_check(self):
+        """First decode + bit-exact check against the regenerated raw data (SHA-256 per stream) -> status rows"""
+        if not self.indices:
+            self.second_pass = 0
+            return []
+        self.batch.decode_device(self.in_ptrs, self.sizes, self.out_ptrs, self.caps, self.pkg.FLAG_LARGE_WINDOW, self.stream)
+        res = self.batch.wait()
+        # The timed region re-runs the (first-pass) kernel only: it is the whole job as long as no stream needed the
+        # second, large-arena launch (reported so that it cannot go unnoticed; then the whole submit + wait is timed).
+        self.second_pass = self.batch.last_second_pass_count()
+        bad = [j for j, r in enumerate(res) if r.result != 1 or r.decoded_size != self.caps[j]]
+        if bad:
+            raise SystemExit("decode failed: stream %d result %d error %d" % (self.indices[bad[0]], res[bad[0]].result, res[bad[0]].error_code))
+        host = self.d_out.cpu().numpy()
+        for j, i in enumerate(self.indices):
+            _, sz, sha = self.unique[i % len(self.unique)]
+            if hashlib.sha256(host[j * self.out_stride: j * self.out_stride + sz].tobytes()).hexdigest() != sha:
+                raise SystemExit("stream %d is not bit-exact" % i)
+        return [[r.result, r.error_code, r.decoded_size, r.consumed] for r in res]
+
+    def step(self):
+        if not self.indices:
+            return 0.0
+        if self.second_pass:
+            ts = time.perf_counter()
+            self.batch.decode_device(self.in_ptrs, self.sizes, self.out_ptrs, self.caps, self.pkg.FLAG_LARGE_WINDOW, self.stream)
+            self.batch.wait()
+            return (time.perf_counter() - ts) * 1e3
+        self.batch.relaunch(self.stream)
+        # HIP events recorded around the launch on the launch stream; reading them waits for this step only
+        return self.batch.last_kernel_ms()
+
+    def close(self):
+        self.batch.close()
+
+
+def roofline(comp, raw, kernel_ms, traffic=None):
+    achieved = (comp + raw) / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "kernel": "brotli_amd_decode_kernel", "kernel_ms": round(kernel_ms, 3),
+            "decompressed_frac": round(raw / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None):
+    """One configuration on this GPU, bit-exact checked -> extra_configs entry"""
+    label, unique, n = build_workload(name, n_unique)
+    job = DeviceJob(pkg, torch, dev, unique, range(n))
+    job.decode_and_check()
+    for _ in range(warmup):
+        job.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms = [job.step() for _ in range(steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    out = {"workload": label, "streams": n, "decompressed_bytes": job.raw_total, "compressed_bytes": job.comp_total,
+           "value": round(job.raw_total * steps / elapsed / 1e6, 1), "unit": "MB/s", "steps": steps,
+           "second_pass_streams": job.second_pass, "roofline": roofline(job.comp_total, job.raw_total, sum(ms) / len(ms))}
+    job.close()
+    return out
+
+
+def cpu_baseline(unique, budget_s=10.0):
+    """CPU legs on a bounded sample of the same streams: the oracle on all host threads (one stream per thread), on one
+    thread, and Google's libbrotlidec on one thread when it can be loaded."""
     import oracle_lib as oracle
     L = oracle.lib()
     cores = os.cpu_count() or 1
@@ -93,9 +198,38 @@ def cpu_baseline(unique, budget_s=12.0):
         best = dt if best is None else min(best, dt)
         reps += 1
     assert all(i.result == 1 for i in infos)
-    return {"value": round(total / best / 1e6, 1), "unit": "MB/s decompressed", "cores": cores, "kind": "port",
-            "sample": "%d streams of the workload (%.0f MiB), best of %d passes, one stream per thread; the Rust reference "
-                      "cannot be built in this image, this is the repo's C restatement (oracle/)" % (n, total / 2**20, reps)}
+    # one thread: a few streams, one after the other
+    k1 = min(n, 4)
+    best1, t_start = None, time.time()
+    for _ in range(5):
+        t = time.time()
+        L.brotli_oracle_decode_batch(k1, a_in, a_is, a_out, a_oc, 1, 1, infos)
+        dt = time.time() - t
+        best1 = dt if best1 is None else min(best1, dt)
+        if time.time() - t_start > 4.0:
+            break
+    total1 = sum(sz for _, sz, _ in sample[:k1])
+    out = {"value": round(total / best / 1e6, 1), "unit": "MB/s decompressed", "cores": cores, "kind": "port",
+           "value_1thread": round(total1 / best1 / 1e6, 1),
+           "sample": "%d streams of the workload (%.0f MiB), best of %d passes, one stream per thread; 1 thread: %d streams, best of 5; "
+                     "the Rust reference cannot be built in this image, this is the repo's C restatement (oracle/)" % (n, total / 2**20, reps, k1)}
+    try:
+        import libbrotli_ref as ref
+        if ref.available():
+            bestp = None
+            for _ in range(3):
+                t = time.time()
+                for c, sz, _ in sample[:k1]:
+                    r = ref.decode(c, sz + 64)
+                    assert r[0] == 1
+                dt = time.time() - t
+                bestp = dt if bestp is None else min(bestp, dt)
+            out["libbrotlidec_proxy"] = {"value_1thread": round(total1 / bestp / 1e6, 1), "unit": "MB/s decompressed",
+                                         "note": "Google libbrotlidec 1.0.9 through ctypes, one thread, %d streams, best of 3: a proxy for the "
+                                                 "reference (a port of it); the reference itself was not run" % k1}
+    except Exception as e:  # noqa: BLE001 -- the proxy is optional
+        out["libbrotlidec_proxy"] = {"error": str(e)[:100]}
+    return out
 
 
 def main():
@@ -104,11 +238,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("BROTLI_BENCH_WORKLOAD", "longbackref_256x4MiB"),
-                    help="longbackref_256x4MiB (default, the metric's configuration), highentropy_256x4MiB, alice29x1024, or "
-                         "<longbackref|highentropy>_<streams>x<size><KiB|MiB> for occupancy sweeps")
+                    help="longbackref_256x4MiB (default, the metric's configuration), highentropy_256x4MiB, alice29x1024, "
+                         "fixture:<name>x<n>, or <longbackref|highentropy>_<streams>x<size><KiB|MiB> for occupancy sweeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (C2, C4, C3 as one stream)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -118,121 +254,95 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")  # RCCL over xGMI
     pkg = load_pkg()
+    sharding = load_sharding()
 
-    # rank 0 decides the workload and broadcasts its descriptor (the only thing that crosses xGMI before the run)
+    # rank 0 decides the workload and broadcasts its name; the streams are a function of (workload, stream index)
     desc = [args.workload]
     if world > 1:
         dist.broadcast_object_list(desc, src=0)
-    label, unique, copies = build_workload(desc[0], rank)
-    n = len(unique) * copies
-    comp_total = sum(len(c) for c, _, _ in unique) * copies
-    raw_total = sum(sz for _, sz, _ in unique) * copies
+    label, unique, per_gpu = build_workload(desc[0])
+    n_total = per_gpu * world
+    # descriptor table of the whole job on rank 0 -> every rank (RCCL broadcast); LPT partition; this rank's part
+    table = np.array([[len(unique[i % len(unique)][0]), unique[i % len(unique)][1], unique[i % len(unique)][1]] for i in range(n_total)],
+                     dtype=np.int64).reshape(-1, sharding.DESC_COLS)
+    table = sharding.broadcast_descriptors(table if rank == 0 else None, 0, dev if world > 1 else "cpu")
+    mine = sharding.lpt_partition(table[:, 2], world)[rank]
 
-    # inputs resident in HBM: every stream gets its own compressed copy and its own output buffer
-    dev = torch.device("cuda", local_rank)
-    in_stride = max((len(c) + 255) // 256 * 256 for c, _, _ in unique)
-    out_stride = max((sz + 255) // 256 * 256 for _, sz, _ in unique)
-    d_in = torch.zeros(n * in_stride, dtype=torch.uint8, device=dev)
-    d_out = torch.zeros(n * out_stride, dtype=torch.uint8, device=dev)
-    sizes, caps = [], []
-    for i in range(n):
-        c, sz, _ = unique[i % len(unique)]
-        d_in[i * in_stride: i * in_stride + len(c)] = torch.frombuffer(bytearray(c), dtype=torch.uint8).to(dev)
-        sizes.append(len(c))
-        caps.append(sz)
-    in_ptrs = [d_in.data_ptr() + i * in_stride for i in range(n)]
-    out_ptrs = [d_out.data_ptr() + i * out_stride for i in range(n)]
-    torch.cuda.synchronize()
+    job = DeviceJob(pkg, torch, dev, unique, mine)
+    status_rows = job.decode_and_check()
 
-    batch = pkg.Batch(n, lds_arena_bytes=int(os.environ.get("BROTLI_BENCH_LDS_ARENA", "0")))
-    stream = torch.cuda.current_stream().cuda_stream
-    batch.decode_device(in_ptrs, sizes, out_ptrs, caps, pkg.FLAG_LARGE_WINDOW, stream)
-    res = batch.wait()
-    # The timed region below re-runs the (first-pass) kernel only: it is the whole job as long as no stream needed the
-    # second, large-arena launch (none does in the workloads of BASELINE.json; reported so that it cannot go unnoticed).
-    second_pass = batch.last_second_pass_count()
-    # bit-exact check of this rank's batch against the regenerated raw data (SHA-256 per stream)
-    bad = [i for i, r in enumerate(res) if r.result != 1 or r.decoded_size != caps[i]]
-    if bad:
-        raise SystemExit("decode failed on rank %d: stream %d result %d error %d" % (rank, bad[0], res[bad[0]].result, res[bad[0]].error_code))
-    host = d_out.cpu().numpy()
-    for i in range(n):
-        _, sz, sha = unique[i % len(unique)]
-        if hashlib.sha256(host[i * out_stride: i * out_stride + sz].tobytes()).hexdigest() != sha:
-            raise SystemExit("rank %d: stream %d is not bit-exact" % (rank, i))
-    del host
-
-    def step():
-        # the whole job: where streams had to come back for a pass with a larger table arena, that is the first pass
-        # and the passes after it (submit + wait); otherwise the one kernel, launched again on the same descriptors
-        if second_pass:
-            batch.decode_device(in_ptrs, sizes, out_ptrs, caps, pkg.FLAG_LARGE_WINDOW, stream)
-            batch.wait()
-        else:
-            batch.relaunch(stream)
     for _ in range(args.warmup):
-        step()
+        job.step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        step()
-        # HIP events recorded around the launch on the launch stream; reading them waits for this step only
-        # (several passes: wall time of the step, the events only bracket the first)
-        kernel_ms.append(batch.last_kernel_ms() if not second_pass else (time.perf_counter() - ts) * 1e3)
+    kernel_ms = [job.step() for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    # per-stream status words back to every rank (the gather of sharding.py), the step time as the maximum over ranks
+    status = sharding.gather_status(np.array(status_rows, dtype=np.int64).reshape(-1, sharding.STATUS_COLS), mine, n_total, dev if world > 1 else "cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    st = torch.tensor([float(raw_total), float(comp_total), float(sum(kernel_ms) / len(kernel_ms))], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(st) for _ in range(world)]
-        dist.all_gather(gathered, st)  # per-rank status words
-    else:
-        gathered = [st]
     if rank == 0:
+        assert int((status[:, 0] == 1).sum()) == n_total, "a stream of the job did not decode"
         elapsed_max = float(t.item())
-        total_raw = sum(float(g[0].item()) for g in gathered)
+        total_raw = float(status[:, 2].sum())
         value = total_raw * args.steps / elapsed_max / 1e6
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = (comp_total + raw_total) / (mean_kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes of the committed profile (same command, separate rocprofv3 runs)
         traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_r01.json")))
-            if pmc["workload"] == desc[0]:
-                traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        for prof in ("pmc_r02.json", "pmc_r01.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                if pmc["workload"] == desc[0]:
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": "decompressed MB/s (bit-exact vs reference fixtures; HIP decode kernel, inputs resident in HBM)",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": label, "streams_per_gpu": n, "decompressed_bytes_per_gpu": raw_total,
-                       "compressed_bytes_per_gpu": comp_total, "parallelism": "independent streams sharded over %d GPU(s)" % world,
-                       "second_pass_streams": second_pass},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "brotli_amd_decode_kernel", "kernel_ms": round(mean_kernel_ms, 3),
-                         "decompressed_frac": round(raw_total / (mean_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "config": {"workload": label, "streams_per_gpu": per_gpu, "streams_total": n_total, "decompressed_bytes_per_gpu": job.raw_total,
+                       "compressed_bytes_per_gpu": job.comp_total,
+                       "parallelism": "independent streams, LPT partition over %d GPU(s) (sharding.py), no data-path collective" % world,
+                       "second_pass_streams": job.second_pass},
+            "roofline": roofline(job.comp_total, job.raw_total, mean_kernel_ms, traffic),
         }
-        if not args.no_cpu_baseline and world == 1:  # (a host-side baseline: rank 0 at N = 1 only)
+    job.close()
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:  # (a host-side baseline: rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(unique)
+        if not args.no_extra and desc[0] == "longbackref_256x4MiB":
+            import workloads as w
+            extra = []
+            legs = [("alice29x1024", 10, None)]
+            if w.encoder_available():
+                legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1)]
+            for name, steps, nu in legs:
+                try:
+                    e = time_single_gpu(pkg, torch, dev, name, steps, 1, nu)
+                    if name == "longbackref_1x64MiB":
+                        e["workload"] = "C3 as ONE stream: 64 MiB, wbits 22, brotli -q5, many metablocks, long back-references (a single stream does not shard: one block of the GPU decodes it)"
+                    extra.append(e)
+                except SystemExit as ex:  # a failing leg must not hide the headline
+                    extra.append({"workload": name, "error": str(ex)})
+            out["extra_configs"] = extra
+    if rank == 0:
         print(json.dumps(out))
-    batch.close()
     if world > 1:
         dist.destroy_process_group()
 

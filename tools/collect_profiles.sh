@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-extra"
 run() {  # name, rocprofv3 options...
   local name=$1; shift
   rm -rf "/tmp/rp_$name"

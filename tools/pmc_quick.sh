@@ -10,7 +10,7 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pq_$i
-  timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pq_$i -o pq -- python $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pq_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pq_$i -o pq -- python $REPO/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /tmp/pq_$i.log 2>&1
   DB=$(find /tmp/pq_$i -name '*.db' | head -1)
   python - "$DB" <<'PY'
 import sqlite3, sys

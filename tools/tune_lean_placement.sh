@@ -19,7 +19,7 @@ if [ "${1:-}" = build ]; then
 else
   for pad in 0 1 2 3 4 5 6 7; do
     for wl in longbackref_256x4MiB alice29x1024; do
-      BROTLI_AMD_LIB=$REPO/tools/scratch/lib_pad$pad.so timeout 300 python "$REPO/bench.py" --workload $wl --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 |
+      BROTLI_AMD_LIB=$REPO/tools/scratch/lib_pad$pad.so timeout 300 python "$REPO/bench.py" --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | tail -1 |
         python -c "import json,sys; d=json.loads(sys.stdin.read()); print('pad $pad $wl %.1f MB/s' % d['value'])"
     done
   done
