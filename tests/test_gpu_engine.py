@@ -1,0 +1,188 @@
+"""The command engine (csrc/brotli_scan_engine.h) against the CPU oracle, through the C ABI (needs a real MI355X).
+
+The engine runs in blocks of sixteen waves -- batches of at most one stream per CU, which every batch here is -- on
+metablocks whose literals do not depend on context.  It parses a command at every bit position, follows the real chain,
+and hands every command that needs anything unusual to the checked command loop: these tests aim at the hand-overs
+(overlapping copies, literal runs of 64 .. 8191 and beyond, copies of 8 KiB and more, block switches, ring flush points
+every window, output limits, truncated and damaged input, prefix codes of maximal depth) and at sizes the fixtures
+never reach (one stream of many metablocks; bit positions beyond 2^32)."""
+import hashlib
+import os
+import random
+import sys
+
+import pytest
+
+import oracle_lib as oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc():
+    import libbrotli_ref as ref
+    if not ref.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    return ref
+
+
+def _check_against_oracle(pkg, datas, caps, flags=1, what=""):
+    batch = pkg.Batch(len(datas))
+    results, outs = batch.decode_host(datas, caps, flags)
+    batch.close()
+    bad = []
+    for i, (d, cap) in enumerate(zip(datas, caps)):
+        info, exp = oracle.decode(d, cap, flags)
+        r = results[i]
+        ok = (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp)
+        if ok and info.result == 1:
+            ok = r.consumed == info.consumed and r.num_commands == info.num_commands
+        if not ok:
+            bad.append((i, what, (r.result, r.error_code, r.decoded_size), (info.result, info.error_code, info.decoded_size), r.consumed, info.consumed, len(d), cap))
+    assert not bad, (len(bad), bad[:10])
+
+
+def _variants(rnd, c, n, damaged=6):
+    """a valid stream with exact, short and roomy output buffers, truncated and bit-flipped copies of it"""
+    datas, caps = [], []
+    for cap in (n, n - 1, n // 2, rnd.randrange(1, n), n + 1000):
+        datas.append(c); caps.append(cap)
+    for _ in range(damaged):
+        d = bytearray(c)
+        if rnd.random() < 0.4:
+            d = d[:rnd.randrange(1, len(d))]
+        else:
+            for _ in range(rnd.choice([1, 1, 2])):
+                pos = rnd.randrange(0, len(d))
+                d[pos] ^= 1 << rnd.randrange(8)
+        datas.append(bytes(d)); caps.append(n + 4096)
+    return datas, caps
+
+
+def test_one_large_stream_of_many_metablocks(pkg):
+    """BASELINE config 3 as written, at 64 MiB: ONE stream, window 22, many metablocks, long back-references; whole,
+    with a buffer one byte short, truncated, and with a flipped bit deep inside"""
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    if not w.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    raw = w.long_backref_stream(4321, 64 << 20)
+    c = w.brotli_compress(raw, 5, 22)
+    info, out = oracle.decode(c, len(raw), 1)
+    assert info.result == 1 and out == raw and info.num_metablocks > 10
+    d_cut = c[: len(c) * 3 // 5]
+    d_flip = bytearray(c); d_flip[len(c) // 2] ^= 0x10
+    _check_against_oracle(pkg, [c, c, d_cut, bytes(d_flip)], [len(raw), len(raw) - 1, len(raw), len(raw)], 1, "64 MiB stream")
+
+
+def test_bit_positions_beyond_32_bits(pkg):
+    """A stream whose compressed size exceeds 2^32 bits (544 MiB of high-entropy literals): reader positions, the engine's
+    origin and the output offset all pass 4 Gi; checked by SHA-256 and by the oracle's status words"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    if not w.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    rng = np.random.Generator(np.random.PCG64(77))
+    p = np.arange(1, 257, dtype=np.float64) ** -0.6
+    p /= p.sum()
+    perm = rng.permutation(256).astype(np.uint8)
+    parts = [perm[rng.choice(256, size=32 << 20, p=p)].tobytes() for _ in range(17)]
+    raw = b"".join(parts)
+    del parts
+    c = w.brotli_compress(raw, 5, 22)
+    assert len(c) * 8 > (1 << 32)
+    info, out = oracle.decode(c, len(raw), 1)
+    assert info.result == 1 and hashlib.sha256(out).digest() == hashlib.sha256(raw).digest()
+    del out
+    batch = pkg.Batch(1)
+    results, outs = batch.decode_host([c], [len(raw)], 1)
+    batch.close()
+    r = results[0]
+    assert (r.result, r.error_code, r.decoded_size, r.consumed) == (1, 1, len(raw), len(c))
+    assert hashlib.sha256(outs[0]).digest() == hashlib.sha256(raw).digest()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_streams_that_stress_the_engines_hand_overs(pkg, seed):
+    import numpy as np
+    ref = _enc()
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    rnd = random.Random(seed)
+
+    def zipf(n, nsym=64, s=1.0, base=32):
+        pr = np.arange(1, nsym + 1, dtype=np.float64) ** -s
+        pr /= pr.sum()
+        return (rng.choice(nsym, size=n, p=pr) + base).astype(np.uint8).tobytes()
+
+    raws = []
+    # periodic data: overlapping copies of every small distance, some interrupted by fresh symbols
+    for period in (1, 2, 3, 5, 7, 13, 63, 64, 65, 100, 300, 1100):
+        pat = zipf(period)
+        body = bytearray(pat * (200000 // period + 1))[:200000]
+        for _ in range(rnd.randrange(0, 40)):
+            body[rnd.randrange(len(body))] = rnd.randrange(32, 96)
+        raws.append(zipf(3000) + bytes(body) + zipf(500))
+    # text-like seed with short matches, then literal runs of 64 .. 9000 between copies of every size
+    for _ in range(3):
+        parts = [zipf(300000)]
+        for _ in range(120):
+            parts.append(zipf(rnd.choice([64, 65, 100, 500, 767, 768, 2000, 5000, 9000]) + rnd.randrange(3)))
+            src = b"".join(parts)
+            n = rnd.choice([4, 9, 70, 600, 8191, 8192, 8193, 20000, 100000])
+            off = rnd.randrange(0, max(1, len(src) - n))
+            parts.append(src[off:off + n])
+        raws.append(b"".join(parts))
+    # a prefix code of maximal depth for the literals (lengths 6, 9, 12, 15) with short copies in between
+    syms = rng.permutation(256)[:253].astype(np.uint8)
+    block = np.concatenate([np.repeat(syms[:60], 512), np.repeat(syms[60:89], 64), np.repeat(syms[89:93], 8), syms[93:253]])
+    deep = b"".join(rng.permutation(block).tobytes() for _ in range(6))
+    parts = []
+    for k in range(0, len(deep) - 40, 40):
+        parts.append(deep[k:k + 40])
+        if k > 4000:
+            o = rnd.randrange(0, k - 100)
+            parts.append(deep[o:o + rnd.randrange(4, 30)])
+    raws.append(b"".join(parts))
+    # the bench's own long-back-reference make-up, small
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    raws.append(w.long_backref_stream(9000 + seed, 2 << 20))
+
+    datas, caps = [], []
+    for raw in raws:
+        q = rnd.choice([2, 4, 5, 5, 6, 9])
+        lgwin = rnd.choice([16, 18, 20, 22, 22, 24])
+        c = ref.encode(raw, q, lgwin)
+        d, cp = _variants(rnd, c, len(raw), damaged=4)
+        datas += d; caps += cp
+    _check_against_oracle(pkg, datas, caps, 1, "hand-overs")
+
+
+def test_many_block_types(pkg):
+    """literal, command and distance statistics that change every few KiB: the encoder answers with many block types and
+    short blocks (block switches every few dozen commands: the engine's part ends at each of them)"""
+    import numpy as np
+    ref = _enc()
+    rng = np.random.Generator(np.random.PCG64(31337))
+    rnd = random.Random(5)
+    datas, caps = [], []
+    for _ in range(6):
+        parts = []
+        for seg in range(60):
+            nsym = int(rng.choice([4, 16, 64]))
+            base = int(rng.choice([0, 48, 97, 160]))
+            pr = np.arange(1, nsym + 1, dtype=np.float64) ** -float(rng.choice([0.5, 1.0, 2.0]))
+            pr /= pr.sum()
+            seg_raw = (rng.choice(nsym, size=int(rng.integers(2000, 20000)), p=pr) + base).astype(np.uint8).tobytes()
+            if seg % 3 == 2 and parts:  # a stretch made of copies only
+                src = b"".join(parts)
+                seg_raw = b"".join(src[o:o + n] for o, n in ((rnd.randrange(0, len(src) - 300), rnd.randrange(5, 300)) for _ in range(80)))
+            parts.append(seg_raw)
+        raw = b"".join(parts)
+        c = ref.encode(raw, rnd.choice([4, 5, 6]), 22)
+        info, out = oracle.decode(c, len(raw), 1)
+        assert info.result == 1 and out == raw
+        d, cp = _variants(rnd, c, len(raw), damaged=3)
+        datas += d; caps += cp
+    _check_against_oracle(pkg, datas, caps, 1, "block types")
