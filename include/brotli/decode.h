@@ -112,15 +112,26 @@ BROTLI_DEC_API BrotliDecoderResult BrotliDecoderDecompress(size_t encoded_size, 
 BROTLI_DEC_API BrotliDecoderReturnInfo BrotliDecoderDecompressWithReturnInfo(size_t encoded_size, const uint8_t* encoded_buffer,
                                                                              size_t decoded_size, uint8_t* decoded_buffer);
 
-/* ffi/mod.rs:179 -> decode.h:227.  The scratch arrays are validated and otherwise unused: decoder state
- * lives in device memory here. */
+/* ffi/mod.rs:179 -> decode.h:227.  The reference decodes out of the three scratch slices (src/lib.rs:374-401) and
+ * reports a request they cannot serve as ERROR_UNREACHABLE with decoded_size 0 (ffi/mod.rs:686-713).  Decoder state
+ * lives in device memory here, so nothing is stored in them, but the same requests are accounted against their sizes:
+ * 1080 HuffmanCode cells at creation (state.rs:395), 6 x 1080 more at the first compressed metablock
+ * (decode.rs:2958-2969), per metablock 1080 cells and one uint32_t per prefix code (huffman/mod.rs:61-72) and one byte
+ * per context mode / context-map entry (decode.rs:1295, 3155), and ring size + 66 bytes for the ring buffer
+ * (decode.rs:1843-1855).  Known divergence: the model is the peak of what is alive at once; slices that hold the peak
+ * but are too fragmented for the reference's first-fit allocator succeed here and fail there. */
 BROTLI_DEC_API BrotliDecoderReturnInfo BrotliDecoderDecompressPrealloc(size_t encoded_size, const uint8_t* encoded_buffer, size_t decoded_size,
                                                                        uint8_t* decoded_buffer, size_t scratch_u8_size,
                                                                        uint8_t* scratch_u8_buffer, size_t scratch_u32_size,
                                                                        uint32_t* scratch_u32_buffer, size_t scratch_hc_size,
                                                                        HuffmanCode* scratch_hc_buffer);
 
-/* ffi/mod.rs:390 -> decode.h:278.  total_out may be NULL; input is never over-consumed on SUCCESS. */
+/* ffi/mod.rs:390 -> decode.h:278.  total_out may be NULL; input is never over-consumed on SUCCESS.
+ * While output the decoder owes does not fit *available_out, a call consumes no input and returns NEEDS_MORE_OUTPUT
+ * (decode.rs:2835-2846).  Cost model of this implementation: the compressed bytes of a call are copied to the device
+ * and the stream is decoded again from the last completed metablock boundary, so a metablock delivered in k pieces is
+ * decoded up to k times (the reference resumes inside a metablock); an instance keeps about one window plus the
+ * metablock in flight on the device, not the whole stream.  The batch and one-shot entry points are the fast paths. */
 BROTLI_DEC_API BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState* state, size_t* available_in, const uint8_t** next_in,
                                                                  size_t* available_out, uint8_t** next_out, size_t* total_out);
 

@@ -70,6 +70,13 @@ const uint8_t* device_dictionary(int dev) {
   return g_dict_by_device[dev];
 }
 
+// Every entry point leaves the caller's current HIP device as it found it.
+struct DeviceGuard {
+  int saved = -1;
+  DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+  ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 bool current_device(int* dev) {
   int count = 0;
   if (!hip_ok(hipGetDeviceCount(&count), "hipGetDeviceCount")) return false;
@@ -94,7 +101,8 @@ struct BrotliAmdBatch {
   uint32_t* h_order = nullptr;                 // pinned: queue header + the order in which blocks take the streams
   bool ordered = false;
   const uint8_t* d_dict = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // around the first launch; around a launch of a later pass
+  float retry_ms = 0.0f;  // kernel time of the later passes of the last job
   hipStream_t last_stream = nullptr;
   bool launched = false;
   // first-pass arena of this launch: the configured one, or a smaller one when the batch has more streams than the
@@ -205,6 +213,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
 // spilling to global memory is allowed; each pass takes only what the one before could not hold.
 int retry_with_larger_arenas(BrotliAmdBatch* b) {
   b->last_retry_count = 0;
+  b->retry_ms = 0.0f;
   uint32_t level = b->cur_per_cu;  // 0: the first pass had the configured arena already
   bool many_came_back = false;
   for (int pass = 0; pass < 4; pass++) {
@@ -242,15 +251,20 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
     if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
     if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
     if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t) * 16, stream), "hipMemsetAsync(queue)")) return -1;
+    if (!hip_ok(hipEventRecord(b->ev2, stream), "hipEventRecord")) return -1;
     if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, arena,
                                          b->d_dict, stream, waves), "brotli_amd_decode_kernel launch (larger arena)")) return -1;
+    if (!hip_ok(hipEventRecord(b->ev3, stream), "hipEventRecord")) return -1;
     if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
     if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
+    { float ms = 0.0f; if (hipEventElapsedTime(&ms, b->ev2, b->ev3) == hipSuccess) b->retry_ms += ms; }
     for (uint32_t j = 0; j < m; j++) {
       BrotliAmdStreamStatus& first = b->h_status[idx[j]];
       BrotliAmdStreamStatus next = b->h_retry_status[j];
-      next.num_metablocks += first.num_metablocks;
+      next.num_metablocks += first.num_metablocks;  // (the metablock a pass stopped in front of is counted by the pass that decodes it)
       next.num_commands += first.num_commands;
+      next.peak_trees = std::max(next.peak_trees, first.peak_trees); next.peak_map_bytes = std::max(next.peak_map_bytes, first.peak_map_bytes);
+      next.any_compressed |= first.any_compressed;
       first = next;
     }
     if (last) { if (many_came_back) b->per_cu_cap = 4; return 0; }
@@ -261,6 +275,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
 }  // namespace
 
 extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t lds_arena_bytes, uint32_t grid_blocks) {
+  DeviceGuard guard;
   int dev = 0;
   if (!current_device(&dev)) return nullptr;
   if (max_streams == 0) max_streams = 1;
@@ -297,12 +312,16 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   ok = ok && hip_ok(hipHostMalloc(&b->h_status, sizeof(BrotliAmdStreamStatus) * max_streams), "hipHostMalloc(status)");
   ok = ok && hip_ok(hipHostMalloc(&b->h_order, sizeof(uint32_t) * (16 + (size_t)max_streams)), "hipHostMalloc(order)");
   ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
+  ok = ok && hip_ok(hipEventCreate(&b->ev2), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev3), "hipEventCreate");
+  ok = ok && hip_ok(hipMemset(b->d_status, 0, sizeof(BrotliAmdStreamStatus) * max_streams), "hipMemset(status)");
+  if (ok) std::memset(b->h_status, 0, sizeof(BrotliAmdStreamStatus) * max_streams);
   if (!ok) { BrotliAmdBatchDestroy(b); return nullptr; }
   return b;
 }
 
 extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (!b) return;
+  DeviceGuard guard;
   (void)hipSetDevice(b->device);
   if (b->launched && b->last_stream != nullptr) (void)hipStreamSynchronize(b->last_stream);
   else (void)hipDeviceSynchronize();
@@ -321,12 +340,15 @@ extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (b->h_order) (void)hipHostFree(b->h_order);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->ev2) (void)hipEventDestroy(b->ev2);
+  if (b->ev3) (void)hipEventDestroy(b->ev3);
   delete b;
 }
 
 extern "C" int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* b, uint32_t n, const void* const* d_in, const size_t* in_sizes, void* const* d_out,
                                           const size_t* out_caps, uint32_t flags, void* hip_stream) {
   if (!b || n > b->max_streams || (n && (!d_in || !in_sizes || !d_out || !out_caps))) { g_last_error = "invalid batch arguments"; return -1; }
+  DeviceGuard guard;
   for (uint32_t i = 0; i < n; i++) {
     BrotliAmdStreamDesc& d = b->h_descs[i];
     std::memset(&d, 0, sizeof d);
@@ -339,6 +361,7 @@ extern "C" int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* b, uint32_t n, const v
 
 extern "C" int BrotliAmdBatchRelaunch(BrotliAmdBatch* b, void* hip_stream) {
   if (!b || b->n == 0) { g_last_error = "nothing to relaunch"; return -1; }
+  DeviceGuard guard;
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   return launch(b, static_cast<hipStream_t>(hip_stream));
 }
@@ -346,6 +369,7 @@ extern "C" int BrotliAmdBatchRelaunch(BrotliAmdBatch* b, void* hip_stream) {
 extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
   if (!b) return -1;
   if (b->n == 0 || !b->launched) return 0;
+  DeviceGuard guard;
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   if (!hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * b->n, hipMemcpyDeviceToHost, b->last_stream), "hipMemcpyAsync(status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize")) return -1;
@@ -368,13 +392,14 @@ extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
   float ms = 0.0f;
   if (!hip_ok(hipEventSynchronize(b->ev1), "hipEventSynchronize")) return -1.0f;
   if (!hip_ok(hipEventElapsedTime(&ms, b->ev0, b->ev1), "hipEventElapsedTime")) return -1.0f;
-  return ms;
+  return ms + b->retry_ms;
 }
 
 extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uint8_t* const* in, const size_t* in_sizes, uint8_t* const* out,
                                         const size_t* out_caps, uint32_t flags, BrotliAmdResult* results) {
   if (!b || n > b->max_streams || (n && (!in || !in_sizes || !out || !out_caps))) { g_last_error = "invalid batch arguments"; return -1; }
   if (n == 0) return 0;
+  DeviceGuard guard;
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   // one input arena and one output arena, 64-byte aligned slots
   std::vector<size_t> in_off(n), out_off(n);
@@ -475,14 +500,22 @@ uint32_t peek_window_bits(const uint8_t* in, size_t n) {
   return n3 ? 8 + n3 : 17;
 }
 
+// Device resources of the one-shot entry points: one set per calling thread (the reference's one-shot calls share
+// nothing -- src/lib.rs:447-468 builds a fresh state per call -- so concurrent callers must not serialise on a lock);
+// freed when the thread ends.
 struct OneShot {
-  std::mutex mu;
   BrotliAmdBatch* batch = nullptr;
   uint8_t* d_in = nullptr; size_t in_cap = 0;
   uint8_t* d_out = nullptr; size_t out_cap = 0;
   int device = -1;
+  void release() {
+    if (batch) BrotliAmdBatchDestroy(batch);
+    if (d_in || d_out) { DeviceGuard guard; if (device >= 0) (void)hipSetDevice(device); if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); }
+    batch = nullptr; d_in = d_out = nullptr; in_cap = out_cap = 0; device = -1;
+  }
+  ~OneShot() { release(); }
 };
-OneShot g_oneshot;
+thread_local OneShot t_oneshot;
 
 void fill_error(BrotliDecoderReturnInfo* r, BrotliDecoderErrorCode code, const char* msg) {
   std::memset(r, 0, sizeof *r);
@@ -513,13 +546,13 @@ bool run_once(OneShot& o, size_t n_in, size_t cap, uint32_t flags, BrotliAmdStre
 }
 
 // reference src/lib.rs:447-468 (brotli_decode) + BrotliDecoderReturnInfo::new (lib.rs:343-370)
-BrotliDecoderReturnInfo oneshot_decode(const uint8_t* in, size_t n_in, uint8_t* out, size_t cap) {
+BrotliDecoderReturnInfo oneshot_decode(const uint8_t* in, size_t n_in, uint8_t* out, size_t cap, BrotliAmdStreamStatus* status_out = nullptr) {
   BrotliDecoderReturnInfo r;
-  std::lock_guard<std::mutex> lock(g_oneshot.mu);
-  OneShot& o = g_oneshot;
+  OneShot& o = t_oneshot;
+  DeviceGuard guard;
   int dev = 0;
   if (!current_device(&dev)) { fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP device unavailable: " + g_last_error).c_str()); return r; }
-  if (o.batch && o.device != dev) { BrotliAmdBatchDestroy(o.batch); o.batch = nullptr; if (o.d_in) (void)hipFree(o.d_in); if (o.d_out) (void)hipFree(o.d_out); o.d_in = o.d_out = nullptr; o.in_cap = o.out_cap = 0; }
+  if (o.batch && o.device != dev) o.release();  // the caller moved to another device
   if (!o.batch) { o.batch = BrotliAmdBatchCreate(1, 0, 0); o.device = dev; }
   if (!o.batch) { fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP device unavailable: " + g_last_error).c_str()); return r; }
   const uint32_t flags = BROTLI_AMD_FLAG_LARGE_WINDOW;  // lib.rs:457 -> BrotliState::new -> large_window = true
@@ -554,6 +587,7 @@ BrotliDecoderReturnInfo oneshot_decode(const uint8_t* in, size_t n_in, uint8_t* 
     fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, ("HIP runtime failure: " + g_last_error).c_str());
     return r;
   }
+  if (status_out) *status_out = st;
   std::memset(&r, 0, sizeof r);
   r.decoded_size = got;
   r.result = (BrotliDecoderResult)st.result;
@@ -602,7 +636,28 @@ extern "C" BrotliDecoderReturnInfo BrotliDecoderDecompressPrealloc(size_t encode
       !valid_slice(scratch_u8_buffer, scratch_u8_size) || !valid_slice(scratch_u32_buffer, scratch_u32_size) ||
       !valid_slice(scratch_hc_buffer, scratch_hc_size))
     return invalid_arguments();
-  return oneshot_decode(encoded_buffer, encoded_size, decoded_buffer, decoded_size);
+  // The reference decodes out of the three scratch slices (src/lib.rs:374-401: stack allocators over them) and a
+  // request they cannot serve panics, which the C ABI reports as ERROR_UNREACHABLE with decoded_size 0
+  // (src/ffi/mod.rs:686-713).  Nothing is decoded out of them here (the tables live in the GPU's LDS), but the same
+  // requests are accounted: the context-map prefix code at creation (state.rs:395), block-type and block-length trees
+  // at the first compressed metablock (decode.rs:2958-2969), per metablock its prefix codes (1080 cells and one u32
+  // each, huffman/mod.rs:61-72), its context modes and maps (decode.rs:1295, 3155), and the ring buffer
+  // (decode.rs:1843-1855).  The model is the peak of what is alive at once: a slice large enough for the peak but too
+  // fragmented for the reference's first-fit allocator succeeds here and fails there (documented in decode.h).
+  constexpr uint64_t kTable = 1080;  // BROTLI_HUFFMAN_MAX_TABLE_SIZE, huffman/mod.rs:36
+  if (scratch_hc_size < kTable) { BrotliDecoderReturnInfo r; fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, "scratch exhausted (HuffmanCode)"); return r; }
+  BrotliAmdStreamStatus st;
+  std::memset(&st, 0, sizeof st);
+  BrotliDecoderReturnInfo r = oneshot_decode(encoded_buffer, encoded_size, decoded_buffer, decoded_size, &st);
+  if (r.code == BROTLI_DECODER_ERROR_UNREACHABLE || r.code == BROTLI_DECODER_ERROR_INVALID_ARGUMENTS) return r;
+  const uint64_t need_hc = kTable + (st.any_compressed ? 6 * kTable : 0) + (uint64_t)st.peak_trees * kTable;
+  const uint64_t need_u32 = st.peak_trees;
+  const uint64_t need_u8 = (st.ring_bytes ? st.ring_bytes + 42 + 24 : 0) + st.peak_map_bytes;
+  if (need_hc > scratch_hc_size || need_u32 > scratch_u32_size || need_u8 > scratch_u8_size) {
+    fill_error(&r, BROTLI_DECODER_ERROR_UNREACHABLE, need_hc > scratch_hc_size ? "scratch exhausted (HuffmanCode)" : need_u32 > scratch_u32_size ? "scratch exhausted (u32)" : "scratch exhausted (u8)");
+    return r;
+  }
+  return r;
 }
 
 // ============================================== streaming ==============================================
@@ -614,8 +669,13 @@ struct BrotliDecoderStateStruct {
   char error_text[256]; bool has_error_text;
   BrotliAmdBatch* batch;
   int device;
-  uint8_t* d_in; size_t d_in_len, d_in_cap;
-  uint8_t* d_out; size_t d_out_cap;
+  // Device copies of the part of the stream that can still matter: compressed bytes from a little in front of the last
+  // completed metablock boundary (in_base = stream offset of d_in[0]; d_in_len = stream bytes received in all), output
+  // from one window in front of that boundary or from the first byte not yet copied off the device, whichever is lower
+  // (out_base = output offset of d_out[0]).  The kernel is handed pointers biased by the bases, so that it goes on
+  // addressing the stream and the output from their beginnings.
+  uint8_t* d_in; size_t d_in_len, d_in_cap; uint64_t in_base;
+  uint8_t* d_out; size_t d_out_cap; uint64_t out_base;
   BrotliAmdResume resume;
   uint64_t fetched;        // output bytes already copied off the device
   uint64_t total_out;      // output bytes handed to the caller (partial_pos_out)
@@ -635,12 +695,13 @@ void set_runtime_error(BrotliDecoderState* s, const char* what) {
   s->has_error_text = true;
 }
 
-bool dev_grow(uint8_t** p, size_t* cap, size_t keep, size_t need) {  // keeps the first `keep` bytes
-  if (need <= *cap && *p) return true;
-  size_t want = std::max<size_t>(std::max<size_t>(need, *cap * 2), 1 << 16);
+// (Re)allocates a device buffer of at least `need` bytes that starts with bytes [from, from + keep) of the old one.
+bool dev_rebase(uint8_t** p, size_t* cap, size_t from, size_t keep, size_t need) {
+  if (from == 0 && need <= *cap && *p) return true;
+  size_t want = std::max<size_t>(std::max<size_t>(need, from == 0 ? *cap * 2 : *cap), 1 << 16);
   uint8_t* np = nullptr;
   if (!hip_ok(hipMalloc(&np, want + 256), "hipMalloc(stream buffer)")) return false;
-  if (*p && keep && !hip_ok(hipMemcpy(np, *p, keep, hipMemcpyDeviceToDevice), "hipMemcpy(grow)")) { (void)hipFree(np); return false; }
+  if (*p && keep && !hip_ok(hipMemcpy(np, *p + from, keep, hipMemcpyDeviceToDevice), "hipMemcpy(rebase)")) { (void)hipFree(np); return false; }
   if (*p) (void)hipFree(*p);
   *p = np; *cap = want;
   return true;
@@ -653,22 +714,77 @@ size_t hand_over(BrotliDecoderState* s, uint8_t* dst, size_t room) {
   return n;
 }
 
+// What lies in front of everything a later pass can touch is dropped: input below the last completed metablock
+// boundary (with a margin: the reader fetches whole 256-byte pieces), output below both the bytes still to be copied
+// off the device and one window (the farthest a back-reference reaches) in front of that boundary.  Memory of an
+// instance stays O(window + one metablock), not O(stream).
+bool trim_buffers(BrotliDecoderState* s, bool eager = false) {
+  if (!s->have_resume || s->resume.window_bits == 0) return true;
+  const uint64_t in_keep = (s->resume.bit_pos >> 3) > 1024 ? ((s->resume.bit_pos >> 3) - 1024) & ~(uint64_t)255 : 0;
+  if (in_keep > s->in_base && in_keep - s->in_base >= std::max<uint64_t>(1 << 16, s->d_in_cap / 2)) {
+    const size_t from = (size_t)(in_keep - s->in_base), keep = (size_t)(s->d_in_len - in_keep);
+    if (!dev_rebase(&s->d_in, &s->d_in_cap, from, keep, keep)) return false;
+    s->in_base = in_keep;
+  }
+  const uint64_t window = 1ull << s->resume.window_bits;
+  uint64_t out_keep = s->resume.out_pos > window ? s->resume.out_pos - window : 0;
+  if (s->fetched < out_keep) out_keep = s->fetched;
+  out_keep &= ~(uint64_t)255;
+  if (out_keep > s->out_base && out_keep - s->out_base >= (eager ? std::max<uint64_t>(1 << 16, s->d_out_cap / 4) : std::max<uint64_t>(1 << 20, s->d_out_cap / 2))) {
+    const size_t from = (size_t)(out_keep - s->out_base);
+    const size_t keep = s->d_out_cap - from;  // (whatever the last pass wrote lies below the buffer's end)
+    if (!dev_rebase(&s->d_out, &s->d_out_cap, from, keep, s->d_out_cap)) return false;
+    s->out_base = out_keep;
+  }
+  return true;
+}
+
+// Copies what the reference would have flushed by now off the device, behind what the caller has not taken yet.
+// 0 = ok, 1 = HIP failure, 2 = allocation failure
+int fetch_output(BrotliDecoderState* s, uint64_t deliverable) {
+  if (deliverable <= s->fetched) return 0;
+  size_t n = (size_t)(deliverable - s->fetched);
+  if (s->outq_len + n > s->outq_cap) {
+    size_t ncap = std::max(s->outq_cap * 2, s->outq_len + n);
+    uint8_t* nq = static_cast<uint8_t*>(st_alloc(s, ncap));
+    if (!nq) return 2;
+    if (s->outq_len) std::memcpy(nq, s->outq, s->outq_len);
+    st_free(s, s->outq);
+    s->outq = nq; s->outq_cap = ncap;
+  }
+  if (!hip_ok(hipMemcpy(s->outq + s->outq_len, s->d_out + (s->fetched - s->out_base), n, hipMemcpyDeviceToHost), "hipMemcpy(output)")) return 1;
+  s->outq_len += n;
+  s->fetched = deliverable;
+  return 0;
+}
+
 // One decode pass over everything received so far, from the last completed metablock boundary.
-bool decode_pass(BrotliDecoderState* s, BrotliAmdStreamStatus* st) {
+// 0 = ok, 1 = HIP failure, 2 = allocation failure
+int decode_pass(BrotliDecoderState* s, BrotliAmdStreamStatus* st) {
   for (;;) {
-    if (!dev_grow(&s->d_out, &s->d_out_cap, (size_t)s->fetched, std::max<size_t>(s->d_out_cap, std::max<size_t>(1 << 16, 6 * s->d_in_len)))) return false;
+    const size_t pending_in = (size_t)(s->d_in_len - s->in_base);
+    if (!dev_rebase(&s->d_out, &s->d_out_cap, 0, s->d_out_cap, std::max<size_t>(s->d_out_cap, std::max<size_t>(1 << 16, 6 * pending_in)))) return 1;
     BrotliAmdStreamDesc& d = s->batch->h_descs[0];
     std::memset(&d, 0, sizeof d);
-    d.in = s->d_in; d.in_size = s->d_in_len; d.out = s->d_out; d.out_cap = s->d_out_cap;
+    d.in = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(s->d_in) - (uintptr_t)s->in_base); d.in_size = s->d_in_len;
+    d.out = reinterpret_cast<uint8_t*>(reinterpret_cast<uintptr_t>(s->d_out) - (uintptr_t)s->out_base); d.out_cap = s->out_base + s->d_out_cap;
     d.flags = (s->large_window ? BROTLI_AMD_FLAG_LARGE_WINDOW : 0u) | (s->canny ? 0u : BROTLI_AMD_FLAG_NO_CANNY);
     if (s->have_resume) { d.flags |= BROTLI_AMD_FLAG_RESUME; d.resume = s->resume; }
-    if (submit(s->batch, 1, nullptr) != 0) return false;
-    if (BrotliAmdBatchWait(s->batch, nullptr) != 0) return false;
+    if (submit(s->batch, 1, nullptr) != 0) return 1;
+    if (BrotliAmdBatchWait(s->batch, nullptr) != 0) return 1;
     *st = s->batch->h_status[0];
     if (st->resume.window_bits != 0) { s->resume = st->resume; s->have_resume = true; }
-    if (st->result != BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT) return true;
-    // device output buffer exhausted: everything below the resume point is final, enlarge and continue
-    if (!dev_grow(&s->d_out, &s->d_out_cap, (size_t)std::max<uint64_t>(s->fetched, s->have_resume ? s->resume.out_pos : 0), s->d_out_cap * 2)) return false;
+    // bytes the reference would have flushed by now: all of them on success / needs-more-input, the part
+    // below the last ring-buffer boundary on a fatal error (decode.rs:2835-2846, 2899-2913)
+    if (int e = fetch_output(s, st->decoded_size)) return e;
+    if (st->result != BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT) return 0;
+    // device output buffer exhausted: everything below the resume point is final.  What is dead is dropped; where that
+    // does not leave half the buffer free, the buffer doubles.
+    const uint64_t before = s->out_base;
+    if (!trim_buffers(s, true)) return 1;
+    const uint64_t live = (s->have_resume ? s->resume.out_pos : 0) > s->out_base ? (s->have_resume ? s->resume.out_pos : 0) - s->out_base : 0;
+    if (s->out_base == before || live > s->d_out_cap / 2)
+      if (!dev_rebase(&s->d_out, &s->d_out_cap, 0, s->d_out_cap, s->d_out_cap * 2)) return 1;
   }
 }
 
@@ -691,8 +807,12 @@ extern "C" BrotliDecoderState* BrotliDecoderCreateInstance(brotli_alloc_func all
 extern "C" void BrotliDecoderDestroyInstance(BrotliDecoderState* s) {
   if (!s) return;
   if (s->batch) BrotliAmdBatchDestroy(s->batch);
-  if (s->d_in) (void)hipFree(s->d_in);
-  if (s->d_out) (void)hipFree(s->d_out);
+  if (s->d_in || s->d_out) {
+    DeviceGuard guard;
+    if (s->device >= 0) (void)hipSetDevice(s->device);
+    if (s->d_in) (void)hipFree(s->d_in);
+    if (s->d_out) (void)hipFree(s->d_out);
+  }
   st_free(s, s->outq);
   brotli_free_func f = s->free_func; void* opaque = s->opaque;
   if (f) f(opaque, s); else std::free(s);
@@ -723,21 +843,33 @@ extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState*
     s->error_code = BROTLI_DECODER_ERROR_INVALID_ARGUMENTS;
     return BROTLI_DECODER_RESULT_ERROR;
   }
-  // lazily bind to the current device
-  if (!s->batch) {
-    int dev = 0;
-    if (!current_device(&dev)) { set_runtime_error(s, "HIP device unavailable"); return BROTLI_DECODER_RESULT_ERROR; }
-    s->batch = BrotliAmdBatchCreate(1, 0, 0);
-    if (!s->batch) { set_runtime_error(s, "HIP device unavailable"); return BROTLI_DECODER_RESULT_ERROR; }
-    s->device = dev;
+  // Output the decoder still owes comes first, and while it does not fit no input is consumed: a caller that sees
+  // NEEDS_MORE_OUTPUT finds its input where it left it (decode.rs:2835-2846; bit_reader/mod.rs:295-306).
+  if (s->outq_len != s->outq_off) {
+    size_t n0 = hand_over(s, *next_out, *available_out);
+    *next_out += n0; *available_out -= n0;
+    if (s->outq_len != s->outq_off) {
+      if (total_out) *total_out = (size_t)s->total_out;
+      s->error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT;
+      return BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT;
+    }
   }
-  if (!hip_ok(hipSetDevice(s->device), "hipSetDevice")) { set_runtime_error(s, "HIP runtime failure"); return BROTLI_DECODER_RESULT_ERROR; }
-
   const size_t given = *available_in;
   bool new_input = false;
   if (!s->finished && !s->pending_error && given) {
-    if (!dev_grow(&s->d_in, &s->d_in_cap, s->d_in_len, s->d_in_len + given) ||
-        !hip_ok(hipMemcpy(s->d_in + s->d_in_len, *next_in, given, hipMemcpyHostToDevice), "hipMemcpy(input)")) {
+    DeviceGuard guard;
+    // lazily bind to the current device
+    if (!s->batch) {
+      int dev = 0;
+      if (!current_device(&dev)) { set_runtime_error(s, "HIP device unavailable"); return BROTLI_DECODER_RESULT_ERROR; }
+      s->batch = BrotliAmdBatchCreate(1, 0, 0);
+      if (!s->batch) { set_runtime_error(s, "HIP device unavailable"); return BROTLI_DECODER_RESULT_ERROR; }
+      s->device = dev;
+    }
+    if (!hip_ok(hipSetDevice(s->device), "hipSetDevice")) { set_runtime_error(s, "HIP runtime failure"); return BROTLI_DECODER_RESULT_ERROR; }
+    const size_t fill = (size_t)(s->d_in_len - s->in_base);
+    if (!dev_rebase(&s->d_in, &s->d_in_cap, 0, fill, fill + given) ||
+        !hip_ok(hipMemcpy(s->d_in + fill, *next_in, given, hipMemcpyHostToDevice), "hipMemcpy(input)")) {
       set_runtime_error(s, "HIP runtime failure");
       return BROTLI_DECODER_RESULT_ERROR;
     }
@@ -745,29 +877,11 @@ extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState*
     *next_in += given; *available_in = 0;
     s->used = true;
     new_input = true;
-  }
-  if (new_input) {
     BrotliAmdStreamStatus st;
-    if (!decode_pass(s, &st)) { set_runtime_error(s, "HIP runtime failure"); return BROTLI_DECODER_RESULT_ERROR; }
-    // bytes the reference would have flushed by now: all of them on success / needs-more-input, the part
-    // below the last ring-buffer boundary on a fatal error (decode.rs:2835-2846, 2899-2913)
-    uint64_t deliverable = st.decoded_size;
-    if (deliverable > s->fetched) {
-      size_t n = (size_t)(deliverable - s->fetched);
-      if (s->outq_len + n > s->outq_cap) {
-        size_t ncap = std::max(s->outq_cap * 2, s->outq_len + n);
-        uint8_t* nq = static_cast<uint8_t*>(st_alloc(s, ncap));
-        if (!nq) { s->error_code = BROTLI_DECODER_ERROR_ALLOC_RING_BUFFER_2; return BROTLI_DECODER_RESULT_ERROR; }
-        if (s->outq_len) std::memcpy(nq, s->outq, s->outq_len);
-        st_free(s, s->outq);
-        s->outq = nq; s->outq_cap = ncap;
-      }
-      if (!hip_ok(hipMemcpy(s->outq + s->outq_len, s->d_out + s->fetched, n, hipMemcpyDeviceToHost), "hipMemcpy(output)")) {
-        set_runtime_error(s, "HIP runtime failure");
-        return BROTLI_DECODER_RESULT_ERROR;
-      }
-      s->outq_len += n;
-      s->fetched = deliverable;
+    if (int e = decode_pass(s, &st)) {
+      if (e == 2) { s->error_code = BROTLI_DECODER_ERROR_ALLOC_RING_BUFFER_2; return BROTLI_DECODER_RESULT_ERROR; }
+      set_runtime_error(s, "HIP runtime failure");
+      return BROTLI_DECODER_RESULT_ERROR;
     }
     if (st.result == BROTLI_DECODER_RESULT_SUCCESS) {
       s->finished = true;
@@ -777,8 +891,12 @@ extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState*
       *next_in -= unused; *available_in += unused;
     } else if (st.result == BROTLI_DECODER_RESULT_ERROR) {
       s->pending_error = st.error_code;
+    } else if (!trim_buffers(s)) {
+      set_runtime_error(s, "HIP runtime failure");
+      return BROTLI_DECODER_RESULT_ERROR;
     }
   }
+  (void)new_input;
   size_t n = hand_over(s, *next_out, *available_out);
   *next_out += n; *available_out -= n;
   if (total_out) *total_out = (size_t)s->total_out;
@@ -829,6 +947,11 @@ extern "C" size_t* BrotliDecoderMallocUsize(BrotliDecoderState* s, size_t size) 
   return static_cast<size_t*>(st_alloc(s, size * sizeof(size_t)));
 }
 extern "C" void BrotliDecoderFreeUsize(BrotliDecoderState* s, size_t* data, size_t) { if (s) st_free(s, data); }
+
+// Debug aid for tests/ (not part of the public headers): device bytes a streaming instance holds at the moment.
+extern "C" __attribute__((visibility("default"))) size_t brotli_amd_debug_stream_device_bytes(const BrotliDecoderState* s) {
+  return s ? s->d_in_cap + s->d_out_cap : 0;
+}
 
 // Debug/profiling aid for tools/ (not part of the public headers): raw status block of stream i after Wait.
 extern "C" __attribute__((visibility("default"))) const BrotliAmdStreamStatus* brotli_amd_debug_status(BrotliAmdBatch* b, uint32_t i) {

@@ -57,6 +57,13 @@ typedef struct BrotliAmdStreamStatus {
   uint32_t spilled_metablocks;  // metablocks whose tables did not fit the LDS part of the arena
   uint64_t num_commands;
   BrotliAmdResume resume; // last completed metablock boundary
+  // What the reference's three allocators would have been asked for (BrotliDecoderDecompressPrealloc accounts its scratch
+  // slices with these): prefix codes alive in one metablock at most (each BROTLI_HUFFMAN_MAX_TABLE_SIZE HuffmanCode cells
+  // and one u32, huffman/mod.rs:61-72), bytes of context modes and maps alive in one metablock at most (decode.rs:1295,
+  // 3155), the emulated ring buffer (decode.rs:1843-1855), and whether any compressed metablock was started (the block
+  // type and block length trees, decode.rs:2958-2969)
+  uint32_t peak_trees, peak_map_bytes, any_compressed, reserved2;
+  uint64_t ring_bytes;
 } BrotliAmdStreamStatus;
 
 #ifdef __cplusplus

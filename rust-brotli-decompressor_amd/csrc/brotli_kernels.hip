@@ -423,6 +423,7 @@ struct Stream {
   uint32_t bl_vgpr;        // per-lane: block length code LUT image
   uint32_t num_metablocks, num_spilled;
   uint64_t num_commands;
+  uint32_t peak_trees, peak_maps, any_compressed;  // what the reference's allocators would have been asked for (see BrotliAmdStreamStatus)
 #ifdef BROTLI_AMD_PROFILE
   uint64_t prof[6];
 #endif
@@ -2641,7 +2642,7 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
   } else {
-    if (rfl(s.flags) & BROTLI_AMD_FLAG_NO_SPILL) return E_RETRY_ARENA;  // nothing of this metablock has been output yet
+    if (rfl(s.flags) & BROTLI_AMD_FLAG_NO_SPILL) { s.num_metablocks--; return E_RETRY_ARENA; }  // nothing of this metablock has been output yet (the next pass counts it)
     s.num_spilled++;
     e = process_commands<false, false>(&h);
   }
@@ -2809,6 +2810,10 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
         TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
         TRY(decode_tree_group(s, num_dist_codes, max_dist_symbol, s.num_dist_trees, &s.dist_trees));
+        {  // (scratch accounting of the reference's prealloc entry point: trees and map bytes alive in this metablock)
+          const uint32_t trees = s.num_lit_trees + s.nbt1 + s.num_dist_trees, maps = s.nbt0 * 65u + s.nbt2 * 4u;
+          s.peak_trees = trees > s.peak_trees ? trees : s.peak_trees; s.peak_maps = maps > s.peak_maps ? maps : s.peak_maps; s.any_compressed = 1;
+        }
 #ifdef BROTLI_AMD_PROFILE_HDR
         s.prof[4] += __builtin_amdgcn_s_memtime() - hdr_t0;
 #endif
@@ -2910,6 +2915,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     s.flags = d.flags;
     s.lut_vgpr = lut; s.bl_vgpr = bl;
     s.num_metablocks = 0; s.num_spilled = 0; s.num_commands = 0;
+    s.peak_trees = 0; s.peak_maps = 0; s.any_compressed = 0;
     s.mlen = 0;
 #ifdef BROTLI_AMD_PROFILE
     s.prof[0] = s.prof[1] = s.prof[2] = s.prof[3] = s.prof[4] = s.prof[5] = 0;
@@ -2918,6 +2924,13 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     s.is_last = 0; s.is_uncompressed = 0; s.is_metadata = 0;
     s.br.set_input((uint64_t)d.in, d.in_size);
     const bool resume = (d.flags & BROTLI_AMD_FLAG_RESUME) && d.resume.window_bits != 0;
+    if (resume && (d.resume.out_pos > d.out_cap || d.resume.bit_pos > d.in_size * 8)) {  // a resume block that does not belong to these buffers
+      if (lane == 0) {
+        st->result = 0; st->error_code = E_UNREACHABLE; st->decoded_size = 0; st->consumed = 0; st->produced = 0;
+        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0; st->resume = d.resume;
+      }
+      continue;
+    }
     if (resume) {
       s.P = d.resume.out_pos;
       s.dist_rb0 = d.resume.dist_rb[0]; s.dist_rb1 = d.resume.dist_rb[1]; s.dist_rb2 = d.resume.dist_rb[2]; s.dist_rb3 = d.resume.dist_rb[3];
@@ -2928,6 +2941,11 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       s.br.seek(d.resume.bit_pos);
       if (lane == 0) st->resume = d.resume;
     } else {
+      if (lane == 0) {  // no metablock boundary yet (the host looks at window_bits to tell)
+        BrotliAmdResume z; z.bit_pos = 0; z.out_pos = 0; z.dist_rb[0] = z.dist_rb[1] = z.dist_rb[2] = z.dist_rb[3] = 0; z.dist_rb_idx = 0;
+        z.window_bits = 0; z.large_window = 0; z.rb_size_log2 = 0; z.is_last_done = 0; z.reserved = 0;
+        st->resume = z;
+      }
       s.P = 0;
       s.dist_rb0 = 4; s.dist_rb1 = 11; s.dist_rb2 = 15; s.dist_rb3 = 16;  // state.rs:296, most recent first
       s.dist_rb_idx = 0;
@@ -2960,6 +2978,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       st->num_metablocks = s.num_metablocks;
       st->num_commands = s.num_commands;
       st->spilled_metablocks = s.num_spilled;
+      st->peak_trees = s.peak_trees; st->peak_map_bytes = s.peak_maps; st->ring_bytes = s.rb_size; st->any_compressed = s.any_compressed;
 #ifdef BROTLI_AMD_PROFILE
       // debugging aid: cycle split of the command loop in the (otherwise unused) resume block of the status
       st->resume.bit_pos = __builtin_amdgcn_s_memtime() - prof_start;
