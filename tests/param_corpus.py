@@ -1,8 +1,12 @@
 """Synthetic streams that reach what the reference's own fixtures leave unpinned: NPOSTFIX /
 NDIRECT != 0, every literal context mode, many block types, every window size including large windows, several
-metablocks, flushes and metadata blocks.  Made with Google's libbrotlienc 1.0.9 (the image has it, here and on the
-GPU box); every stream is known to decode to its raw data with libbrotlidec, so the expected output needs no oracle.
+metablocks, flushes and metadata blocks.  Made with Google's libbrotlienc 1.0.9 where the image has it; every stream is
+known to decode to its raw data with libbrotlidec, so the expected output needs no oracle.  A smaller edition of the
+same corpus is committed under tests/golden/param_corpus/ (tools/make_param_corpus.py; SHA-256 of every raw input in
+its manifest), so that the tests that use it never skip: corpus() falls back to it on a box without the encoder.
 -> list of (label, compressed, raw)."""
+import hashlib
+import json
 import os
 
 import numpy as np
@@ -12,7 +16,7 @@ import libbrotli_ref as ref
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _raws():
+def _raws(scale=1.0):
     rng = np.random.Generator(np.random.PCG64(20260928))
     import oracle_lib as oracle
     alice = open(os.path.join(ROOT, "tests", "golden", "testdata", "alice29.txt.compressed"), "rb").read()
@@ -25,14 +29,32 @@ def _raws():
     noise = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
     runs = b"".join(bytes([int(b)]) * int(n) for b, n in zip(rng.integers(0, 256, 400), rng.integers(1, 300, 400)))
     mixed = text[:30000] + ints[:20000] + noise[:5000] + text[30000:50000] + runs[:10000] + zipf[:20000]
-    return {"text": text[:120000], "utf8": utf, "ints": ints, "floats": floats, "zipf": zipf, "noise": noise, "runs": runs, "mixed": mixed,
-            "tiny": b"abcabcabcabc", "empty": b""}
+    raws = {"text": text[:120000], "utf8": utf, "ints": ints, "floats": floats, "zipf": zipf, "noise": noise, "runs": runs, "mixed": mixed}
+    raws = {k: v[:max(64, int(len(v) * scale)) & ~3] for k, v in raws.items()}
+    raws.update({"tiny": b"abcabcabcabc", "empty": b""})
+    return raws
 
 
-def corpus(limit=None):
+COMMITTED = os.path.join(ROOT, "tests", "golden", "param_corpus")
+
+
+def committed():
+    """the committed edition: compressed streams from the repository, raw data from the checker, pinned by the manifest's SHA-256"""
+    import oracle_lib as oracle
+    out = []
+    for e in json.load(open(os.path.join(COMMITTED, "manifest.json"))):
+        comp = open(os.path.join(COMMITTED, e["file"]), "rb").read()
+        info, raw = oracle.decode(comp, e["size"] + 16, 1)
+        assert info.result == 1 and len(raw) == e["size"] and hashlib.sha256(raw).hexdigest() == e["sha256"], e["label"]
+        out.append((e["label"], comp, raw))
+    return out
+
+
+def corpus(limit=None, scale=1.0):
     if not ref.encoder_available():
-        return []
-    raws = _raws()
+        c = committed()
+        return c[:limit] if limit else c
+    raws = _raws(scale)
     out = []
 
     def add(label, raw, params, chunks=None, ops=None):

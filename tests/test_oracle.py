@@ -213,3 +213,16 @@ def test_parameterised_encoder_corpus():
         assert (info2.result == 1) == (not label.startswith("large-")), label
         seen_np = seen_np or label.startswith("np3-")
     assert seen_np
+
+
+def test_committed_parameterised_corpus():
+    """the edition of that corpus that travels with the repository (tests/golden/param_corpus, tools/make_param_corpus.py):
+    the oracle reproduces raw data with the manifest's sizes and SHA-256, so the GPU tests that use the corpus never skip"""
+    import param_corpus
+    streams = param_corpus.committed()
+    assert len(streams) >= 100
+    labels = [l for l, _, _ in streams]
+    assert any(l.startswith("np3-") for l in labels) and any(l.startswith("large-") for l in labels) and "metadata" in labels
+    for label, comp, raw in streams:
+        info, out = oracle.decode(comp, len(raw), oracle.FLAG_LARGE_WINDOW)  # exact fit
+        assert (info.result, info.decoded_size, info.consumed) == (1, len(raw), len(comp)) and out == raw, label
