@@ -226,3 +226,23 @@ def test_committed_parameterised_corpus():
     for label, comp, raw in streams:
         info, out = oracle.decode(comp, len(raw), oracle.FLAG_LARGE_WINDOW)  # exact fit
         assert (info.result, info.decoded_size, info.consumed) == (1, len(raw), len(comp)) and out == raw, label
+
+
+def test_custom_dictionary_vectors():
+    """BrotliState::new_with_custom_dictionary (src/state.rs:400-411): the reference's two known-answer tests
+    (src/test.rs:438-520, tests/golden/custom_dict_vectors.json).  The GPU path has no custom dictionaries (not part of the
+    C ABI); the restatement is pinned here so that it stays a restatement of the whole decode path."""
+    import ctypes
+    L = oracle.lib()
+    L.brotli_oracle_decode_dict.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                            ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(oracle.OracleInfo)]
+    for v in json.load(open(os.path.join(GOLD, "custom_dict_vectors.json"))):
+        comp, d, exp = bytes.fromhex(v["compressed"]), bytes.fromhex(v["dictionary"]), bytes.fromhex(v["expected"])
+        out = ctypes.create_string_buffer(len(exp) + 64)
+        info = oracle.OracleInfo()
+        L.brotli_oracle_decode_dict(comp, len(comp), out, len(out), 1, d, len(d), ctypes.byref(info))
+        assert (info.result, info.decoded_size) == (1, len(exp)), v["name"]
+        assert out.raw[:len(exp)] == exp, v["name"]
+        # without the dictionary the same bytes do not decode to the same data
+        info2, out2 = oracle.decode(comp, len(exp) + 64, 1)
+        assert info2.result != 1 or out2 != exp, v["name"]
