@@ -417,7 +417,11 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             }
           }
           // the literals are skipped (sc_skip, level by level for both)
+#ifdef BROTLI_AMD_SCAN_BRANCHLESS
+#define SC_HOP(BIT, EXPR) _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t hop_ = EXPR; q[u] += (h[u].insert & BIT) ? hop_ : 0u; }
+#else
 #define SC_HOP(BIT, EXPR) _Pragma("unroll") for (int u = 0; u < 2; u++) if (h[u].insert & BIT) q[u] += EXPR;
+#endif
           SC_HOP(1u, lds_ld8(sb + SC_J1 + (q[u] & SC_M)))
           SC_HOP(2u, lds_ld8(sb + SC_J2 + (q[u] & SC_M)))
           SC_HOP(4u, lds_ld8(sb + SC_J4 + (q[u] & SC_M)))
