@@ -186,3 +186,19 @@ def test_many_block_types(pkg):
         d, cp = _variants(rnd, c, len(raw), damaged=3)
         datas += d; caps += cp
     _check_against_oracle(pkg, datas, caps, 1, "block types")
+
+
+def test_emitter_vectors(pkg):
+    """the repository's own emitter's streams (tests/golden/emitter/): 40 / 60 / 256 literal block types, every literal
+    context mode with chosen context maps, block-type codes 0 and 1, NPOSTFIX / NDIRECT != 0, a stream of compressed,
+    metadata, stored and empty metablocks; whole, with exact, short and half buffers, truncated and damaged"""
+    import json
+    d = os.path.join(ROOT, "tests", "golden", "emitter")
+    rnd = random.Random(11)
+    datas, caps = [], []
+    for e in json.load(open(os.path.join(d, "manifest.json"))):
+        comp = open(os.path.join(d, e["file"]), "rb").read()
+        dd, cc = _variants(rnd, comp, e["size"], damaged=8)
+        datas += dd; caps += cc
+    _check_against_oracle(pkg, datas, caps, 0, "emitter vectors")
+    _check_against_oracle(pkg, datas, caps, 1, "emitter vectors, large windows allowed")

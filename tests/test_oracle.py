@@ -246,3 +246,32 @@ def test_custom_dictionary_vectors():
         # without the dictionary the same bytes do not decode to the same data
         info2, out2 = oracle.decode(comp, len(exp) + 64, 1)
         assert info2.result != 1 or out2 != exp, v["name"]
+
+
+def test_emitter_vectors():
+    """streams of the repository's own emitter (tools/brotli_emit.py, tests/golden/emitter/): 40 / 60 / 256 literal block
+    types, every context mode with chosen context maps, NPOSTFIX / NDIRECT != 0, compressed / metadata / stored / empty
+    metablocks in one stream -- what libbrotlienc cannot be steered to ("unpinned")"""
+    d = os.path.join(GOLD, "emitter")
+    man = json.load(open(os.path.join(d, "manifest.json")))
+    assert max(e["max_block_types"] for e in man) == 256 and any(e["metablocks"] >= 6 for e in man)
+    for e in man:
+        comp = open(os.path.join(d, e["file"]), "rb").read()
+        info, out = oracle.decode(comp, e["size"], 0)  # exact fit, standard windows
+        assert (info.result, info.decoded_size, info.consumed) == (1, e["size"], len(comp)), e["label"]
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e["label"]
+        assert (info.num_metablocks, info.num_commands, info.max_block_types) == (e["metablocks"], e["commands"], e["max_block_types"]), e["label"]
+        if ref.available():
+            r = ref.decode(comp, e["size"] + 16, False)
+            assert r[0] == 1 and hashlib.sha256(r[2]).hexdigest() == e["sha256"], e["label"]
+
+
+def test_emitter_is_deterministic():
+    """tools/make_emitter_vectors.py writes the committed bytes again (the emitter uses no library and no clock)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_emitter_vectors as m
+    man = {e["label"]: e for e in json.load(open(os.path.join(GOLD, "emitter", "manifest.json")))}
+    for label, comp, raw in m.vectors():
+        assert comp == open(os.path.join(GOLD, "emitter", man[label]["file"]), "rb").read(), label
+        assert hashlib.sha256(raw).hexdigest() == man[label]["sha256"], label
