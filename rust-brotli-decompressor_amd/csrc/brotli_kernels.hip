@@ -2757,10 +2757,34 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
     {
       ColdScope c(s);
       BitReader& br = c.br;
-      TRY(decode_metablock_length(br, s));
-      s.num_metablocks++;
-      if ((s.is_metadata || s.is_uncompressed) && !jump_to_byte_boundary(br)) return E_PADDING_2;  // decode.rs:2990-2994
-      if (s.is_metadata) {
+      // A run of metadata blocks (streams made of tens of thousands of them exist: empty.compressed.17 / .18 of the
+      // reference) is skipped here, block after block, without leaving the reader's registers; the resume point moves
+      // again at the next metablock that is not one.
+      const uint64_t stream_bits = br.total_bits();
+      const uint32_t reader_skip = BitReader::skip_bits();
+      for (;;) {
+        {
+          // the common shape in one look: ISLAST = 0, MNIBBLES = 3, reserved = 0, MSKIPBYTES = k, MSKIPLEN - 1 in k bytes
+          // (decode.rs:243-372); anything else, and every error, goes through the general parser below
+          uint32_t run = 0;
+          for (;;) {
+            const uint32_t pk = br.peek32();
+            const uint32_t kb = (pk >> 4) & 3u;
+            const uint32_t len = kb == 0u ? 0u : ((pk >> 6) & 0xFFu) + 1u;
+            if ((pk & 0xFu) != 6u || kb > 1u || len > 128u) break;  // (at most 14 header bits and 7 of padding: all inside pk)
+            const uint64_t p0 = (uint64_t)br.next_dw * 32 - br.cnt - reader_skip;
+            const uint32_t hdr = 6u + 8u * kb, pad = (8u - (uint32_t)((p0 + hdr) & 7u)) & 7u;
+            if (p0 + hdr + pad + 8ull * len > stream_bits || ((pk >> hdr) & mask_bits(pad)) != 0u) break;
+            if (hdr + pad + 8u * len <= 32u) br.drop(hdr + pad + 8u * len);  // (peek32 left at least 32 bits in the buffer)
+            else { br.drop(hdr + pad); br.advance(len * 8u); }
+            run++;
+          }
+          if (run != 0u) { s.num_metablocks += run; s.is_last = 0; s.is_metadata = 1; s.is_uncompressed = 0; s.mlen = 0; }
+        }
+        TRY(decode_metablock_length(br, s));
+        s.num_metablocks++;
+        if ((s.is_metadata || s.is_uncompressed) && !jump_to_byte_boundary(br)) return E_PADDING_2;  // decode.rs:2990-2994
+        if (!s.is_metadata) break;
         // skip MLEN bytes (decode.rs:3031-3045)
         uint64_t byte = br.pos() >> 3, isz = br.total_bits() >> 3;
         uint64_t avail = isz > byte ? isz - byte : 0;
@@ -2769,9 +2793,9 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         if ((uint32_t)s.mlen <= 128u) { if (s.mlen != 0) br.advance((uint32_t)s.mlen * 8u); }
         else br.seek((byte + (uint32_t)s.mlen) * 8);
         s.mlen = 0;
-      } else if (s.mlen != 0 && s.rb_size == 0) {
-        allocate_ring(s, br);
+        if (s.is_last) break;
       }
+      if (!s.is_metadata && s.mlen != 0 && s.rb_size == 0) allocate_ring(s, br);
     }
     if (!s.is_metadata && s.mlen != 0) {
       if (s.is_uncompressed) {
