@@ -18,7 +18,7 @@ extern "C" {
                                          // BROTLI_AMD_RESULT_RETRY_ARENA at the boundary before it (the host then
                                          // resumes the stream in a launch with a larger arena) instead of spilling
 #define BROTLI_AMD_RESULT_RETRY_ARENA 4  // (never reaches the caller of the C ABI)
-#define BROTLI_AMD_SPEC_SCRATCH 32768u   // bytes at the end of each block's global scratch that the helper waves use for
+#define BROTLI_AMD_SPEC_SCRATCH 65536u   // bytes at the end of each block's global scratch that the helper waves use for
                                          // speculatively decoded literals (the table arena is the part in front of it)
 
 // State at a metablock boundary: everything that survives from one metablock to the next in the

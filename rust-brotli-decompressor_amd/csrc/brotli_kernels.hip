@@ -94,7 +94,7 @@ constexpr uint32_t LDS_FIXED = LDS_HCTL + 80;               // = 6224, 16-byte a
 // of a round leave for each other (slot w at mailbox word HC_BASE + w * HL_SLOT):
 constexpr uint32_t SPEC_WINDOWS = 64;                        // windows of 64 bits per chunk
 constexpr uint32_t SPEC_FIRST = 4;                           // windows at the start of a chunk the decoding wave may walk itself
-constexpr uint32_t SPEC_MAX_WAVES = 8;                       // waves per block at most (one decoding, seven helpers)
+constexpr uint32_t SPEC_MAX_WAVES = 16;                      // waves of a round at most (one decoding, fifteen helpers: the blocks of sixteen waves)
 constexpr uint32_t HL_CTL = 0;                               // 64: the wave's mailbox words (HW_*)
 constexpr uint32_t HL_MASK = HL_CTL + 64;                    // SPEC_WINDOWS x 8: per window of the chunk, which bit offsets start a literal
 constexpr uint32_t HL_CUM = HL_MASK + SPEC_WINDOWS * 8;      // SPEC_WINDOWS x 4: literals in the chunk's windows before this one
@@ -2080,6 +2080,10 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
         const uint32_t took = rfl(scan_engine(0));
+        {  // the literal rounds' mailbox words lie in the engine's rings: back to their idle state
+          const uint32_t hb_ = hc_ld(HC_BASE);
+          for (uint32_t t = lane; t < SC_WAVES * 16u; t += 64u) lds_st32(hb_ + (t >> 4) * HL_SLOT + HL_CTL + 4u * (t & 15u), 0u);
+        }
         const uint32_t form = LEAN_LD(L_SC_POS_HI);
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
@@ -2880,11 +2884,15 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
   // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
     const uint32_t nw = blockDim.x >> 6, nr = nw < SPEC_MAX_WAVES ? nw : SPEC_MAX_WAVES;  // waves in the block, waves that take part in rounds
+    // behind the table arena: the rounds' slots -- or, in blocks of sixteen waves, the command engine's rings, and the
+    // slots lie inside them (on REC: rounds and engine never run at the same time; process_commands clears the slots'
+    // mailbox words after every invocation of the engine)
+    const uint32_t behind = LDS_FIXED + lds_arena_bytes, slots = nw == SC_WAVES ? behind + SC_REC : behind;
     if (threadIdx.x < 20u)
-      lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && nw < 2u ? (uint32_t)HK_NO_ROUNDS : threadIdx.x == HC_BASE ? LDS_FIXED + lds_arena_bytes :
+      lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && nw < 2u ? (uint32_t)HK_NO_ROUNDS : threadIdx.x == HC_BASE ? slots :
                                             threadIdx.x == HC_NW ? nr : threadIdx.x == HC_NW_ALL ? nw :
-                                            threadIdx.x == HC_SCAN_BASE && nw == SC_WAVES ? LDS_FIXED + lds_arena_bytes + nr * HL_SLOT : 0u);
-    if (nw >= 2u && threadIdx.x < nr * 16u) lds_st32(LDS_FIXED + lds_arena_bytes + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
+                                            threadIdx.x == HC_SCAN_BASE && nw == SC_WAVES ? behind : 0u);
+    if (nw >= 2u && threadIdx.x < nr * 16u) lds_st32(slots + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
   }  // (launched without helper waves: no rounds)
   __syncthreads();
   if (rfl(threadIdx.x >> 6) != 0u) {
@@ -3047,7 +3055,7 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   if (n_streams == 0) return hipSuccess;
   static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
   // (sixteen waves: a block with the command engine; otherwise at most eight)
-  const uint32_t waves = no_helpers || helper_waves < 2 ? 1u : (uint32_t)helper_waves >= SC_WAVES ? SC_WAVES : (uint32_t)helper_waves > SPEC_MAX_WAVES ? SPEC_MAX_WAVES : (uint32_t)helper_waves;
+  const uint32_t waves = no_helpers || helper_waves < 2 ? 1u : (uint32_t)helper_waves >= SC_WAVES ? SC_WAVES : (uint32_t)helper_waves > 8u ? 8u : (uint32_t)helper_waves;
   size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + brotli_amd_lds_helper_bytes(waves);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
@@ -3060,6 +3068,6 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
 
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void) { return LDS_FIXED; }
 extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves) {
-  if (waves >= SC_WAVES) return SPEC_MAX_WAVES * HL_SLOT + SC_BYTES;
+  if (waves >= SC_WAVES) return SC_BYTES;  // (the rounds' slots lie inside the engine's rings)
   return waves > 1u ? waves * HL_SLOT : 0u;
 }

@@ -71,6 +71,7 @@ constexpr uint32_t SC_D4 = SC_D2 + 2 * SC_N2;     // u16: bits to the fourth com
 constexpr uint32_t SC_XL = SC_D4 + 2 * SC_N2;     // 2 x SC_GROUP x 64 x 16: the group being executed and the one being posted
 constexpr uint32_t SC_BYTES = SC_XL + 2 * SC_GROUP * 1024;
 static_assert(SC_S % 16 == 0 && SC_REC % 16 == 0 && SC_XL % 16 == 0, "alignment");
+static_assert(SC_WAVES * HL_SLOT <= 8 * SC_N2, "the literal rounds' slots of a sixteen-wave block lie on REC");
 
 // control words: the invocation's parameters (written by the decoding wave before the others join), then what wave 0
 // posts per tick: a group of up to SC_GROUP batches (entries in SC_XL, per batch its entry count and output position) and
