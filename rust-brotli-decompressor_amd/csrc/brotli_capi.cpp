@@ -184,6 +184,8 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     if (b->auto_arena && room > b->lds_fixed + b->lds_helper8 + b->lds_arena) { b->cur_arena = (room - b->lds_fixed - b->lds_helper8) & ~15u; b->waves = 8; }
     else if (b->lds_fixed + b->lds_helper8 + b->cur_arena <= room) b->waves = 8;
   }
+  static const bool force_scan = getenv("BROTLI_AMD_FORCE_SCAN") != nullptr;  // (experiments: engine blocks whatever the batch)
+  if (force_scan && b->grid > b->cus) b->grid = b->cus;
   if (g_scan_blocks_ok.load() && b->grid <= b->cus) {
     const uint32_t h16 = brotli_amd_lds_helper_bytes(16);
     const size_t room = b->lds_per_cu > (size_t)b->lds_fixed + h16 ? b->lds_per_cu - b->lds_fixed - h16 : 0;
