@@ -46,6 +46,7 @@ thread_local std::string g_last_error;
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
 std::atomic<bool> g_scan_blocks_ok{getenv("BROTLI_AMD_NO_SCAN") == nullptr};
+constexpr uint64_t kEngineQueueMinBytes = 32768;  // mean compressed size from which a batch of cus < n <= 3 cus streams gets engine blocks
 constexpr uint32_t kScanArena = 40960;  // table arena of such a block (with the engine's rings: about 108 KiB of LDS)
 
 bool hip_ok(hipError_t e, const char* what) {
@@ -184,14 +185,26 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     if (b->auto_arena && room > b->lds_fixed + b->lds_helper8 + b->lds_arena) { b->cur_arena = (room - b->lds_fixed - b->lds_helper8) & ~15u; b->waves = 8; }
     else if (b->lds_fixed + b->lds_helper8 + b->cur_arena <= room) b->waves = 8;
   }
-  static const bool force_scan = getenv("BROTLI_AMD_FORCE_SCAN") != nullptr;  // (experiments: engine blocks whatever the batch)
-  if (force_scan && b->grid > b->cus) b->grid = b->cus;
+  // Up to three large streams per CU: sixteen-wave blocks, one per CU, take them one after the other (the command engine
+  // decodes a stream 3.5x faster than one wave does; measured on 384 / 512 x 4 MiB of the metric's data: 61 / 81 GB/s
+  // against 33 / 44 with two eight-wave blocks per CU, while 1024 streams are faster four to a CU).  Metablocks the
+  // engine cannot take go back and continue in a launch of small blocks (BROTLI_AMD_FLAG_ENGINE_ONLY).
+  static const bool no_wide = getenv("BROTLI_AMD_NO_ENGINE_QUEUE") != nullptr;  // (experiments)
+  bool engine_queue = false;
+  if (g_scan_blocks_ok.load() && !no_wide && b->auto_arena && b->grid > b->cus && n <= 3u * b->cus) {
+    uint64_t in_total = 0;
+    for (uint32_t i = 0; i < n; i++) in_total += b->h_descs[i].in_size;
+    if (in_total / n >= kEngineQueueMinBytes) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
+  }
   if (g_scan_blocks_ok.load() && b->grid <= b->cus) {
     const uint32_t h16 = brotli_amd_lds_helper_bytes(16);
     const size_t room = b->lds_per_cu > (size_t)b->lds_fixed + h16 ? b->lds_per_cu - b->lds_fixed - h16 : 0;
     const uint32_t arena = b->auto_arena ? (uint32_t)std::min<size_t>(kScanArena, room & ~(size_t)15) : b->cur_arena;
     if (arena <= room && (!b->auto_arena || arena >= 16384u)) { b->cur_arena = arena; b->waves = 16; }
   }
+  engine_queue = engine_queue && b->waves == 16u;
+  for (uint32_t i = 0; i < n; i++)
+    b->h_descs[i].flags = engine_queue ? b->h_descs[i].flags | BROTLI_AMD_FLAG_ENGINE_ONLY : b->h_descs[i].flags & ~BROTLI_AMD_FLAG_ENGINE_ONLY;
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
@@ -244,7 +257,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
     else { level = 2; arena = b->max_arena; grid_max = b->retry_grid_max; waves = 4; last = true; }
     for (uint32_t j = 0; j < m; j++) {
       BrotliAmdStreamDesc d = b->h_descs[idx[j]];
-      d.flags = (last ? d.flags & ~BROTLI_AMD_FLAG_NO_SPILL : d.flags) | BROTLI_AMD_FLAG_RESUME;
+      d.flags = ((last ? d.flags & ~BROTLI_AMD_FLAG_NO_SPILL : d.flags) & ~BROTLI_AMD_FLAG_ENGINE_ONLY) | BROTLI_AMD_FLAG_RESUME;
       d.resume = b->h_status[idx[j]].resume;
       b->h_retry_descs[j] = d;
     }

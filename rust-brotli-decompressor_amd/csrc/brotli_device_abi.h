@@ -17,6 +17,11 @@ extern "C" {
 #define BROTLI_AMD_FLAG_NO_SPILL 8u      // a metablock whose tables do not fit the LDS arena ends the decode with result
                                          // BROTLI_AMD_RESULT_RETRY_ARENA at the boundary before it (the host then
                                          // resumes the stream in a launch with a larger arena) instead of spilling
+#define BROTLI_AMD_FLAG_ENGINE_ONLY 32u  // set by the host where sixteen-wave blocks (one per CU) serve more streams than
+                                         // there are CUs: a large metablock the command engine cannot take (literals that
+                                         // depend on context) ends the decode the same way, and the stream continues in a
+                                         // launch of small blocks, several to a CU -- one wave decodes such a metablock
+                                         // wherever it runs, so what counts for it is streams in flight
 #define BROTLI_AMD_RESULT_RETRY_ARENA 4  // (never reaches the caller of the C ABI)
 #define BROTLI_AMD_SPEC_SCRATCH 65536u   // bytes at the end of each block's global scratch that the helper waves use for
                                          // speculatively decoded literals (the table arena is the part in front of it)

@@ -2614,6 +2614,7 @@ done:
 }
 
 // Marshals the stream state into the argument block, runs the loop, takes the results back.
+constexpr uint32_t ENGINE_ONLY_MIN_MLEN = 32768;  // (BROTLI_AMD_FLAG_ENGINE_ONLY: smaller metablocks are decoded where they are)
 __device__ __forceinline__ int run_commands(Stream& s) {
   HotArgs h;
   h.br = s.br; h.ar = s.ar; h.out = s.out; h.dict = s.dict;
@@ -2643,6 +2644,9 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     for (uint32_t bt = 0; bt < nbt0; bt++) {
       uint32_t mine = ar_.ld8_lane<false>(ctx_map + (bt << 6) + lane_id());
       if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
+    }
+    if (!ctx_never && (rfl(s.flags) & BROTLI_AMD_FLAG_ENGINE_ONLY) && rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN) {
+      s.num_metablocks--; return E_RETRY_ARENA;  // (see the flag; nothing of this metablock has been output yet)
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
   } else {

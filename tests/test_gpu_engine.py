@@ -202,3 +202,59 @@ def test_emitter_vectors(pkg):
         datas += dd; caps += cc
     _check_against_oracle(pkg, datas, caps, 0, "emitter vectors")
     _check_against_oracle(pkg, datas, caps, 1, "emitter vectors, large windows allowed")
+
+
+def test_engine_blocks_serving_more_streams_than_cus(pkg):
+    """A batch of more large streams than the device has CUs (up to three per CU) gets engine blocks that take the streams
+    one after the other; streams whose metablocks the engine cannot take (context-modelled text) come back and continue in
+    a launch of small blocks.  Mixed batch: the bench's long-back-reference make-up, the reference's text fixtures, both
+    whole, with short buffers, truncated and damaged."""
+    import json
+    import torch
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    if not w.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rnd = random.Random(2024)
+    m = {e["name"]: e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))}
+    pool = []
+    for k in range(6):
+        raw = w.long_backref_stream(7000 + k, 768 << 10)
+        pool.append((w.brotli_compress(raw, 5, 22), len(raw)))
+    for name in ("alice29.txt.compressed", "asyoulik.txt.compressed", "lcet10.txt.compressed", "plrabn12.txt.compressed"):
+        pool.append((open(os.path.join(ROOT, "tests", "golden", "testdata", name), "rb").read(), m[name]["size"]))
+    assert sum(len(c) for c, _ in pool) // len(pool) >= 32768
+    n = cus + cus // 4
+    datas, caps = [], []
+    for i in range(n):
+        c, size = pool[i % len(pool)]
+        kind = rnd.random()
+        if kind < 0.7:
+            datas.append(c); caps.append(size)
+        elif kind < 0.8:
+            datas.append(c); caps.append(rnd.randrange(1, size))
+        elif kind < 0.9:
+            datas.append(c[:rnd.randrange(1, len(c))]); caps.append(size)
+        else:
+            d = bytearray(c); d[rnd.randrange(len(d))] ^= 1 << rnd.randrange(8)
+            datas.append(bytes(d)); caps.append(size)
+    batch = pkg.Batch(n)
+    results, outs = batch.decode_host(datas, caps, 1)
+    came_back = batch.last_second_pass_count()
+    batch.close()
+    assert came_back >= n // 4, came_back  # (the text streams; fewer would mean the batch did not get engine blocks)
+    memo = {}
+    bad = []
+    for i, (d, cap) in enumerate(zip(datas, caps)):
+        key = (d, cap)
+        if key not in memo:
+            memo[key] = oracle.decode(d, cap, 1)
+        info, exp = memo[key]
+        r = results[i]
+        ok = (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp)
+        if ok and info.result == 1:
+            ok = r.consumed == info.consumed and r.num_commands == info.num_commands and r.num_metablocks == info.num_metablocks
+        if not ok:
+            bad.append((i, (r.result, r.error_code, r.decoded_size), (info.result, info.error_code, info.decoded_size), len(d), cap))
+    assert not bad, (len(bad), bad[:10])
