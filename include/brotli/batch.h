@@ -40,6 +40,13 @@ typedef struct BrotliAmdResult {
 #define BROTLI_AMD_BATCH_NO_CANNY 2u     /* BROTLI_DECODER_PARAM_DISABLE_RING_BUFFER_REALLOCATION */
 #define BROTLI_AMD_BATCH_SPILL_IN_PLACE 16u /* no second launch with a larger LDS arena for streams whose prefix-code tables
                                               do not fit the arena of the first: they spill to global memory (slower) */
+#define BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT 64u /* A stream whose output buffer is too small is reported NEEDS_MORE_OUTPUT as soon
+                                              as the buffer is full.  Without this flag such streams get the reference's
+                                              verdict: the reference decodes into its ring buffer and only notices the full
+                                              buffer at the next flush point (decode.rs:1693-1738), so an error or the end of
+                                              the input in front of that point is what it reports; the batch decodes those
+                                              streams a second time, into scratch memory with room up to that point (up to
+                                              one window per stream, 2 GiB at a time), inside BrotliAmdBatchWait. */
 
 /* Creates a batch context on the current HIP device for up to max_streams streams per call.
  * lds_arena_bytes = 0 and grid_blocks = 0 select the defaults.  NULL when no device is usable. */

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("BROTLI_AMD_LIB") or os.path.join(_HERE, "libbrotli_de
 RESULT_ERROR, RESULT_SUCCESS, RESULT_NEEDS_MORE_INPUT, RESULT_NEEDS_MORE_OUTPUT = 0, 1, 2, 3
 FLAG_LARGE_WINDOW, FLAG_NO_CANNY = 1, 2
 FLAG_SPILL_IN_PLACE = 16  # BROTLI_AMD_BATCH_SPILL_IN_PLACE: no second launch with a larger LDS arena
+FLAG_EAGER_OUTPUT_LIMIT = 64  # BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT: NEEDS_MORE_OUTPUT where the buffer ends, no second look (batch.h)
 PARAM_DISABLE_RING_BUFFER_REALLOCATION, PARAM_LARGE_WINDOW = 0, 1
 
 # every symbol include/brotli/decode.h and include/brotli/batch.h declare

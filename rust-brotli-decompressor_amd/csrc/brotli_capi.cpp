@@ -122,6 +122,9 @@ struct BrotliAmdBatch {
   // staging for BrotliAmdBatchDecodeHost
   uint8_t* d_stage_in = nullptr; size_t stage_in_cap = 0;
   uint8_t* d_stage_out = nullptr; size_t stage_out_cap = 0;
+  // streams that ran out of output get the reference's verdict (settle_output_limits): set by the batch entry points
+  bool exact_limit = false;
+  uint8_t* d_settle = nullptr; size_t settle_cap = 0; uint32_t last_settle_count = 0;
 };
 
 namespace {
@@ -226,6 +229,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
 // a launch whose blocks have a larger LDS arena (fewer blocks per CU): a first pass packed more than eight blocks to a
 // CU is followed by one with eight, then by the configured arena, then by the largest block the device allows, where
 // spilling to global memory is allowed; each pass takes only what the one before could not hold.
+int run_retry_descs(BrotliAmdBatch* b, uint32_t m, uint32_t arena, uint32_t grid_max, int waves);
 int retry_with_larger_arenas(BrotliAmdBatch* b) {
   b->last_retry_count = 0;
   b->retry_ms = 0.0f;
@@ -243,13 +247,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
       b->last_retry_count = m;
       many_came_back = level > 4u && m > b->n / 16;
     }
-    if (!b->d_retry_descs) {
-      bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
-      ok = ok && hip_ok(hipMalloc(&b->d_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipMalloc(retry status)");
-      ok = ok && hip_ok(hipHostMalloc(&b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipHostMalloc(retry descs)");
-      ok = ok && hip_ok(hipHostMalloc(&b->h_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipHostMalloc(retry status)");
-      if (!ok) return -1;
-    }
+    if (!b->h_retry_descs && run_retry_descs(b, 0, b->max_arena, b->retry_grid_max, 4) != 0) return -1;  // (allocates the pass's buffers)
     // shape of this pass
     uint32_t arena, grid_max; int waves; bool last;
     if (level > 8u && small_arena(b, 8) > b->cur_arena) { level = 8; arena = small_arena(b, 8); grid_max = b->cus * 8u; waves = 1; last = false; }
@@ -261,18 +259,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
       d.resume = b->h_status[idx[j]].resume;
       b->h_retry_descs[j] = d;
     }
-    const uint32_t grid = std::min(m, grid_max);
-    hipStream_t stream = b->last_stream;
-    if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
-    if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
-    if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t) * 16, stream), "hipMemsetAsync(queue)")) return -1;
-    if (!hip_ok(hipEventRecord(b->ev2, stream), "hipEventRecord")) return -1;
-    if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, arena,
-                                         b->d_dict, stream, waves), "brotli_amd_decode_kernel launch (larger arena)")) return -1;
-    if (!hip_ok(hipEventRecord(b->ev3, stream), "hipEventRecord")) return -1;
-    if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
-    if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
-    { float ms = 0.0f; if (hipEventElapsedTime(&ms, b->ev2, b->ev3) == hipSuccess) b->retry_ms += ms; }
+    if (run_retry_descs(b, m, arena, grid_max, waves) != 0) return -1;
     for (uint32_t j = 0; j < m; j++) {
       BrotliAmdStreamStatus& first = b->h_status[idx[j]];
       BrotliAmdStreamStatus next = b->h_retry_status[j];
@@ -283,6 +270,87 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
       first = next;
     }
     if (last) { if (many_came_back) b->per_cu_cap = 4; return 0; }
+  }
+  return 0;
+}
+
+// m descriptors in h_retry_descs -> h_retry_status, in a launch of the given shape on the job's stream (kernel time added to retry_ms)
+int run_retry_descs(BrotliAmdBatch* b, uint32_t m, uint32_t arena, uint32_t grid_max, int waves) {
+  if (!b->d_retry_descs) {
+    bool ok = hip_ok(hipMalloc(&b->d_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipMalloc(retry descs)");
+    ok = ok && hip_ok(hipMalloc(&b->d_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipMalloc(retry status)");
+    ok = ok && hip_ok(hipHostMalloc(&b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * b->max_streams), "hipHostMalloc(retry descs)");
+    ok = ok && hip_ok(hipHostMalloc(&b->h_retry_status, sizeof(BrotliAmdStreamStatus) * b->max_streams), "hipHostMalloc(retry status)");
+    if (!ok) return -1;
+  }
+  if (m == 0) return 0;
+  const uint32_t grid = std::min(m, grid_max);
+  hipStream_t stream = b->last_stream;
+  if (!ensure_scratch(b, std::max(grid, b->grid))) return -1;
+  if (!hip_ok(hipMemcpyAsync(b->d_retry_descs, b->h_retry_descs, sizeof(BrotliAmdStreamDesc) * m, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(retry descs)")) return -1;
+  if (!hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t) * 16, stream), "hipMemsetAsync(queue)")) return -1;
+  if (!hip_ok(hipEventRecord(b->ev2, stream), "hipEventRecord")) return -1;
+  if (!hip_ok(brotli_amd_launch_decode(b->d_retry_descs, b->d_retry_status, m, b->d_queue, b->d_scratch, kScratchPerBlock, grid, arena,
+                                       b->d_dict, stream, waves), "brotli_amd_decode_kernel launch (later pass)")) return -1;
+  if (!hip_ok(hipEventRecord(b->ev3, stream), "hipEventRecord")) return -1;
+  if (!hip_ok(hipMemcpyAsync(b->h_retry_status, b->d_retry_status, sizeof(BrotliAmdStreamStatus) * m, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(retry status)")) return -1;
+  if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return -1;
+  { float ms = 0.0f; if (hipEventElapsedTime(&ms, b->ev2, b->ev3) == hipSuccess) b->retry_ms += ms; }
+  return 0;
+}
+
+// What the reference reports for a stream whose output buffer is too small depends on what the stream does up to its next
+// ring-buffer flush point: it decodes into its ring and only notices the full buffer when it flushes (decode.rs:1693-1738;
+// the driver ignores NEEDS_MORE_OUTPUT from the flush it forces when the input ends, decode.rs BrotliDecompressStream), so
+// an error or the end of the input in front of that point wins over NEEDS_MORE_OUTPUT.  The kernel stops where the
+// buffer ends; the streams it reports NEEDS_MORE_OUTPUT for are decoded once more, into scratch memory with room up to
+// the flush point, and that outcome is mapped (the bytes in the caller's buffer stay: they are the same).
+constexpr size_t kSettleChunkBytes = (size_t)2 << 30;
+int settle_output_limits(BrotliAmdBatch* b) {
+  b->last_settle_count = 0;
+  std::vector<uint32_t> idx;
+  for (uint32_t i = 0; i < b->n; i++)
+    if (b->h_status[i].result == BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT && b->h_status[i].ring_bytes != 0) idx.push_back(i);
+  size_t at = 0;
+  while (at < idx.size()) {
+    // a chunk of streams whose scratch outputs fit the budget together (a single stream beyond it keeps the kernel's verdict)
+    std::vector<uint32_t> part; std::vector<size_t> off, cap2s; size_t total = 0;
+    for (; at < idx.size(); at++) {
+      const BrotliAmdStreamDesc& d0 = b->h_descs[idx[at]];
+      const uint64_t rb = b->h_status[idx[at]].ring_bytes, cap2 = (d0.out_cap / rb + 1) * rb;
+      const size_t need = (size_t)((cap2 + 255) & ~(uint64_t)255);
+      if (need > kSettleChunkBytes) continue;
+      if (total + need > kSettleChunkBytes && !part.empty()) break;
+      part.push_back(idx[at]); off.push_back(total); cap2s.push_back((size_t)cap2); total += need;
+    }
+    if (part.empty()) continue;
+    if (total > b->settle_cap) {
+      if (b->d_settle) (void)hipFree(b->d_settle);
+      b->d_settle = nullptr; b->settle_cap = 0;
+      if (hipMalloc(&b->d_settle, total) != hipSuccess) { (void)hipGetLastError(); return 0; }  // (no memory for it: the kernel's verdict stands)
+      b->settle_cap = total;
+    }
+    const uint32_t m = (uint32_t)part.size();
+    if (!b->h_retry_descs && run_retry_descs(b, 0, b->max_arena, b->retry_grid_max, 4) != 0) return -1;
+    for (uint32_t j = 0; j < m; j++) {
+      BrotliAmdStreamDesc d = b->h_descs[part[j]];
+      d.flags &= ~(BROTLI_AMD_FLAG_NO_SPILL | BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_RESUME);
+      d.out = b->d_settle + off[j]; d.out_cap = cap2s[j];
+      b->h_retry_descs[j] = d;
+    }
+    if (run_retry_descs(b, m, b->max_arena, b->retry_grid_max, 4) != 0) return -1;
+    for (uint32_t j = 0; j < m; j++) {
+      BrotliAmdStreamStatus& st = b->h_status[part[j]];
+      const BrotliAmdStreamStatus& st2 = b->h_retry_status[j];
+      const uint64_t cap = b->h_descs[part[j]].out_cap;
+      if (st2.result == BROTLI_DECODER_RESULT_ERROR || (st2.result == BROTLI_DECODER_RESULT_NEEDS_MORE_INPUT && st2.produced <= cap2s[j])) {
+        const uint64_t produced = st.produced;
+        st = st2;
+        st.decoded_size = std::min<uint64_t>(st2.decoded_size, cap);
+        st.produced = produced;  // (bytes in the caller's buffer)
+      }
+    }
+    b->last_settle_count += m;
   }
   return 0;
 }
@@ -350,6 +418,7 @@ extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (b->h_retry_status) (void)hipHostFree(b->h_retry_status);
   if (b->d_stage_in) (void)hipFree(b->d_stage_in);
   if (b->d_stage_out) (void)hipFree(b->d_stage_out);
+  if (b->d_settle) (void)hipFree(b->d_settle);
   if (b->h_descs) (void)hipHostFree(b->h_descs);
   if (b->h_status) (void)hipHostFree(b->h_status);
   if (b->h_order) (void)hipHostFree(b->h_order);
@@ -371,6 +440,7 @@ extern "C" int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* b, uint32_t n, const v
     d.out = static_cast<uint8_t*>(d_out[i]); d.out_cap = out_caps[i];
     d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY | BROTLI_AMD_BATCH_SPILL_IN_PLACE);
   }
+  b->exact_limit = !(flags & BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT);
   return submit(b, n, static_cast<hipStream_t>(hip_stream));
 }
 
@@ -389,6 +459,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
   if (!hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * b->n, hipMemcpyDeviceToHost, b->last_stream), "hipMemcpyAsync(status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize")) return -1;
   if (retry_with_larger_arenas(b) != 0) return -1;
+  if (b->exact_limit && settle_output_limits(b) != 0) return -1;
   if (results) {
     for (uint32_t i = 0; i < b->n; i++) {
       const BrotliAmdStreamStatus& s = b->h_status[i];
@@ -443,6 +514,7 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
     d.out = b->d_stage_out + out_off[i]; d.out_cap = out_caps[i];
     d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY | BROTLI_AMD_BATCH_SPILL_IN_PLACE);
   }
+  b->exact_limit = !(flags & BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT);
   if (submit(b, n, nullptr) != 0) return -1;
   std::vector<BrotliAmdResult> local;
   if (!results) { local.resize(n); results = local.data(); }
@@ -581,7 +653,7 @@ BrotliDecoderReturnInfo oneshot_decode(const uint8_t* in, size_t n_in, uint8_t* 
     // again with room up to that point and map the outcome.
     uint32_t wbits = peek_window_bits(in, n_in);
     if (wbits) {
-      size_t rb = (size_t)1 << wbits;
+      size_t rb = st.ring_bytes ? (size_t)st.ring_bytes : (size_t)1 << wbits;  // (the emulated ring: smaller than the window for a short last metablock)
       size_t cap2 = (cap / rb + 1) * rb;
       BrotliAmdStreamStatus st2;
       if (grow(&o.d_out, &o.out_cap, cap2) && run_once(o, n_in, cap2, flags, &st2)) {

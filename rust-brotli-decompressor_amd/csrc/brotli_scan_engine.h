@@ -256,12 +256,16 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         // group), then their literals (lane i the i-th literal of the entry: out of S through J*, the entries' chains side
         // by side), then the copies' stores.  Two entries at a time where the batch has at most 32, else four.
 #define SC_EXEC(NS) do { \
-        uint32_t hold[NS], x0[NS], cn[NS], off[NS], q[NS]; \
+        uint32_t hold[NS], x0[NS], cn[NS], off[NS], q[NS], nl[NS]; \
+        u32x4 xe[NS]; \
+        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {  /* the entries: one 16-byte read each, all under way before the first is looked at */ \
+          const uint32_t k = me + t * SC_WAVES; \
+          xe[t] = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[xb + ((k < k_exec ? k : 0u) << 4)]); \
+        } \
         _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { \
           const uint32_t k = me + t * SC_WAVES; \
-          const uint32_t xa = xb + ((k < k_exec ? k : 0u) << 4); \
-          x0[t] = rfl(lds_ld32(xa)); cn[t] = rfl(lds_ld32(xa + 4u)); off[t] = rfl(lds_ld32(xa + 12u)); hold[t] = 0; \
-          const uint32_t dist = rfl(lds_ld32(xa + 8u)); \
+          x0[t] = rfl(xe[t].x); cn[t] = rfl(xe[t].y); off[t] = rfl(xe[t].w); hold[t] = 0; \
+          const uint32_t dist = rfl(xe[t].z); \
           if (k >= k_exec) { x0[t] = 0u; cn[t] = 0u; } \
           if (cn[t] == 0u || (x0[t] >> 31) != 0u) { cn[t] = 0u; continue; } \
           gu8* const dst = o + off[t] + ((x0[t] >> 16) & 63u); gu8* const src = dst - dist; \
@@ -275,7 +279,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           } \
         } \
         uint32_t nmax = 0; \
-        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { q[t] = x0[t] & SC_M; const uint32_t n_ = (x0[t] >> 16) & 63u; nmax = n_ > nmax ? n_ : nmax; } \
+        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { q[t] = x0[t] & SC_M; nl[t] = (x0[t] >> 16) & 63u; nmax = nl[t] > nmax ? nl[t] : nmax; } \
         if (nmax != 0u) { \
           SC_XHOP(NS, 1u, lds_ld8(sb + SC_J1 + (q[t] & SC_M))) \
           if (nmax > 2u) { SC_XHOP(NS, 2u, lds_ld8(sb + SC_J2 + (q[t] & SC_M))) } \
@@ -283,13 +287,17 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           if (nmax > 8u) { SC_XHOP(NS, 8u, lds_ld8(sb + SC_J8 + (q[t] & SC_M))) } \
           if (nmax > 16u) { SC_XHOP(NS, 16u, lds_ld8(sb + SC_J16 + (q[t] & SC_M))) } \
           if (nmax > 32u) { SC_XHOP(NS, 32u, lds_ld16(sb + SC_J32 + ((q[t] & SC_M) << 1))) } \
-          _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) \
-            if (lane < ((x0[t] >> 16) & 63u)) o[off[t] + lane] = (uint8_t)lds_ld8(sb + SC_S + (q[t] & SC_M)); \
+          uint32_t sy[NS]; \
+          _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) sy[t] = lds_ld8(sb + SC_S + (q[t] & SC_M)); \
+          _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if (lane < nl[t]) o[off[t] + lane] = (uint8_t)sy[t]; \
         } \
         _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) \
-          if (cn[t] != 0u && lane < cn[t]) o[off[t] + ((x0[t] >> 16) & 63u) + lane] = (uint8_t)hold[t]; \
+          if (cn[t] != 0u && lane < cn[t]) o[off[t] + nl[t] + lane] = (uint8_t)hold[t]; \
       } while (0)
-#define SC_XHOP(NS, BIT, EXPR) _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if ((lane & BIT) && lane < ((x0[t] >> 16) & 63u)) q[t] += EXPR;
+        // (a hop: the reads of all entries first, then the additions -- one LDS round trip per level, not one per entry and
+        // level; lanes that do not hop read somewhere inside the ring and drop what they get)
+#define SC_XHOP(NS, BIT, EXPR) { uint32_t hop_[NS]; _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) hop_[t] = EXPR; \
+        _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) q[t] += ((lane & BIT) != 0u) ? hop_[t] : 0u; }
         if (k_exec <= 2u * SC_WAVES) { if (me < k_exec) SC_EXEC(2u); }
         else SC_EXEC(4u);
 #undef SC_XHOP

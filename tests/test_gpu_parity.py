@@ -249,6 +249,49 @@ def test_mutated_corpus_streams_match_oracle(pkg, seed):
     _check_against_oracle(pkg, datas, caps, 1, "mutated corpus seed %d" % seed)
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_damaged_streams_with_buffers_that_are_too_small(pkg, seed):
+    """What the reference reports for a stream that runs out of output depends on what the stream does up to its next
+    ring-buffer flush point (an error or the end of the input in front of it wins over NEEDS_MORE_OUTPUT): damaged and
+    truncated streams with output buffers of every size get the oracle's verdict from the batch entry points; with
+    BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT they are reported NEEDS_MORE_OUTPUT where the buffer ends."""
+    import param_corpus
+    streams = [(c, len(r)) for _, c, r in param_corpus.committed() if 200 < len(c) < 60000]
+    m = [e for e in _manifest() if e["name"] != "rnd_chunk.br" and 2000 < e["csize"] < 200000 and e.get("size", 0) > 100]
+    streams += [(_data(e["name"]), e["size"]) for e in m]
+    rnd = random.Random(seed)
+    datas, caps = [], []
+    for _ in range(1500):
+        c, n = rnd.choice(streams)
+        d = bytearray(c)
+        k = rnd.random()
+        if k < 0.45:
+            d = d[:rnd.randrange(1, len(d))]
+        elif k < 0.9:
+            for _ in range(rnd.choice([1, 1, 2])):
+                pos = rnd.randrange(len(d) // 8, len(d))
+                d[pos] ^= 1 << rnd.randrange(8)
+        datas.append(bytes(d))
+        caps.append(rnd.choice([rnd.randrange(1, n + 1), rnd.randrange(1, n + 1), n - 1, n // 2, max(1, n - rnd.randrange(1, 70000))]))
+    batch = pkg.Batch(len(datas))
+    results, outs = batch.decode_host(datas, caps, 1)
+    eager, _ = batch.decode_host(datas, caps, 1 | pkg.FLAG_EAGER_OUTPUT_LIMIT)
+    batch.close()
+    bad, settled = [], 0
+    for i, (d, cap) in enumerate(zip(datas, caps)):
+        info, exp = oracle.decode(d, cap, 1)
+        r = results[i]
+        if (r.result, r.error_code, r.decoded_size, outs[i]) != (info.result, info.error_code, info.decoded_size, exp):
+            bad.append((i, (r.result, r.error_code, r.decoded_size), (info.result, info.error_code, info.decoded_size), len(d), cap))
+        if eager[i].result == 3 and r.result != 3:
+            settled += 1
+            assert eager[i].decoded_size == cap
+        else:
+            assert (eager[i].result, eager[i].error_code, eager[i].decoded_size) == (r.result, r.error_code, r.decoded_size), i
+    assert not bad, (len(bad), bad[:10])
+    assert settled > 20, settled  # (the case exists in this sample)
+
+
 def test_bench_workload_streams_tight_buffers_and_damage(pkg):
     """the bench workloads' own streams (long literal runs, copies of more than 1 KiB: the lean loop's limits): valid
     streams with output buffers that are exact, one short, half, ...; damaged streams with roomy buffers"""

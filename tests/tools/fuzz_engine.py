@@ -47,6 +47,7 @@ for seed in range(first, first + nseeds):
             pos = rnd.randrange(0, len(d) + 1); d[pos:pos] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 4)))
         else:
             a = rnd.randrange(0, len(d)); b_ = min(len(d), a + rnd.randrange(1, 64)); del d[a:b_]
+        if k >= 0.15 and rnd.random() < 0.3: cap = rnd.randrange(1, n + 4096)  # (damage and a buffer that may be too small: the reference's verdict, batch.h)
         datas.append(bytes(d)); caps.append(cap)
     b = pkg.Batch(len(datas)); res, outs = b.decode_host(datas, caps, 1); b.close()
     for i, (d, cap) in enumerate(zip(datas, caps)):
