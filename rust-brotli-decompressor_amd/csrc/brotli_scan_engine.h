@@ -66,9 +66,8 @@ constexpr uint32_t SC_J8 = SC_J4 + SC_R;
 constexpr uint32_t SC_J16 = SC_J8 + SC_R;
 constexpr uint32_t SC_J32 = SC_J16 + SC_R;        // u16
 constexpr uint32_t SC_REC = SC_J32 + 2 * SC_R;    // 8 bytes per bit of two steps
-constexpr uint32_t SC_D2 = SC_REC + 8 * SC_N2;    // u16 per bit: bits to the command after next (0: not known)
-constexpr uint32_t SC_D4 = SC_D2 + 2 * SC_N2;     // u16: bits to the fourth command from here
-constexpr uint32_t SC_XL = SC_D4 + 2 * SC_N2;     // 2 x SC_GROUP x 64 x 16: the group being executed and the one being posted
+constexpr uint32_t SC_D24 = SC_REC + 8 * SC_N2;   // u32 per bit: D2 = bits to the command after next (low half), D4 = bits to the fourth command from here (high half); 0: not known
+constexpr uint32_t SC_XL = SC_D24 + 4 * SC_N2;    // 2 x SC_GROUP x 64 x 16: the group being executed and the one being posted
 constexpr uint32_t SC_BYTES = SC_XL + 2 * SC_GROUP * 1024;
 static_assert(SC_S % 16 == 0 && SC_REC % 16 == 0 && SC_XL % 16 == 0, "alignment");
 static_assert(SC_WAVES * HL_SLOT <= 8 * SC_N2, "the literal rounds' slots of a sixteen-wave block lie on REC");
@@ -318,8 +317,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d3[u] != 0u && p[u] + d3[u] < f_rec) ? SC_DLT(p[u] + d3[u]) : 0u; d4[u] = t ? d3[u] + t : 0u; }
 #undef SC_DLT
         _Pragma("unroll") for (int u = 0; u < 2; u++) {
-          lds_st16(sb + SC_D2 + ((p[u] & (SC_N2 - 1u)) << 1), d2[u]);
-          lds_st16(sb + SC_D4 + ((p[u] & (SC_N2 - 1u)) << 1), d4[u]);
+          lds_st32(sb + SC_D24 + ((p[u] & (SC_N2 - 1u)) << 2), d2[u] | (d4[u] << 16));
         }
       }
       f_d = f_rec;
@@ -542,21 +540,18 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             SC_APPEND(run_copy, (kind << 30) | (val & 0x3FFFFFFFu), 0xC0000000u);
             b = man_end; in_run = false;
           }
-          // four commands per LDS round trip where D4 knows the way
-          while (K <= 60u && b < walk_limit) {
-            const uint32_t d4 = rfl(lds_ld16(sb + SC_D4 + ((b & (SC_N2 - 1u)) << 1)));
-            if (d4 == 0u) break;
-            SC_ANCHOR(b, 4u);
-            b += d4;
+          // one LDS round trip per hop: four commands where D4 knows the way, two where D2 does (the end of a region,
+          // mostly), else one (D2 / D4 and the command's own length are asked for together)
+          while (K < 64u && b < walk_limit) {
+            const uint32_t d24_ = lds_ld32(sb + SC_D24 + ((b & (SC_N2 - 1u)) << 2)), rec_ = lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3));
+            const uint32_t d24 = rfl(d24_), delta = rfl(rec_) & 0x7FFu;
+            if (K <= 60u && (d24 >> 16) != 0u) { SC_ANCHOR(b, 4u); b += d24 >> 16; }
+            else if (K <= 62u && (d24 & 0xFFFFu) != 0u) { SC_ANCHOR(b, 2u); b += d24 & 0xFFFFu; }
+            else if (delta != 0u) { SC_ANCHOR(b, 1u); b += delta; }
+            else break;
           }
           if (K >= 64u) break;
           if (b >= walk_limit) { step_done = true; break; }
-          if (K <= 62u) {  // two commands where D2 knows the way (the end of a region, mostly)
-            const uint32_t d2h = rfl(lds_ld16(sb + SC_D2 + ((b & (SC_N2 - 1u)) << 1)));
-            if (d2h != 0u) { SC_ANCHOR(b, 2u); b += d2h; continue; }
-          }
-          const uint32_t delta = rfl(lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3))) & 0x7FFu;
-          if (delta != 0u) { SC_ANCHOR(b, 1u); b += delta; continue; }
           // not in REC: a command to walk by hand.  The batch so far goes first, so that the counts below are exact.
           if (K != 0u) break;
           uint32_t lo, hi;
@@ -576,7 +571,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           const uint32_t ac = bperm(al << 2, rC);
           if (lane < K && (ac >> 31) == 0u) {
             uint32_t pos = ac;
-            if (j & 2u) pos += lds_ld16(sb + SC_D2 + ((pos & (SC_N2 - 1u)) << 1));
+            if (j & 2u) pos += lds_ld32(sb + SC_D24 + ((pos & (SC_N2 - 1u)) << 2)) & 0xFFFFu;
             if (j & 1u) pos += lds_ld32(sb + SC_REC + ((pos & (SC_N2 - 1u)) << 3)) & 0x7FFu;
             const uint32_t ra = sb + SC_REC + ((pos & (SC_N2 - 1u)) << 3);
             rA = lds_ld32(ra); rB = lds_ld32(ra + 4u); rC = pos;
