@@ -317,7 +317,10 @@ int settle_output_limits(BrotliAmdBatch* b) {
     std::vector<uint32_t> part; std::vector<size_t> off, cap2s; size_t total = 0;
     for (; at < idx.size(); at++) {
       const BrotliAmdStreamDesc& d0 = b->h_descs[idx[at]];
-      const uint64_t rb = b->h_status[idx[at]].ring_bytes, cap2 = (d0.out_cap / rb + 1) * rb;
+      // (one byte short of the flush point: the reference flushes as soon as its ring is full, so a stream that gets that far
+      // is told NEEDS_MORE_OUTPUT there, whatever comes behind)
+      const uint64_t rb = b->h_status[idx[at]].ring_bytes, cap2 = (d0.out_cap / rb + 1) * rb - 1;
+      if (cap2 <= d0.out_cap) continue;  // (the buffer ends right in front of the flush point: nothing more to find out)
       const size_t need = (size_t)((cap2 + 255) & ~(uint64_t)255);
       if (need > kSettleChunkBytes) continue;
       if (total + need > kSettleChunkBytes && !part.empty()) break;
@@ -654,7 +657,7 @@ BrotliDecoderReturnInfo oneshot_decode(const uint8_t* in, size_t n_in, uint8_t* 
     uint32_t wbits = peek_window_bits(in, n_in);
     if (wbits) {
       size_t rb = st.ring_bytes ? (size_t)st.ring_bytes : (size_t)1 << wbits;  // (the emulated ring: smaller than the window for a short last metablock)
-      size_t cap2 = (cap / rb + 1) * rb;
+      size_t cap2 = (cap / rb + 1) * rb - 1;  // (one byte short of the flush point: the reference flushes as soon as its ring is full)
       BrotliAmdStreamStatus st2;
       if (grow(&o.d_out, &o.out_cap, cap2) && run_once(o, n_in, cap2, flags, &st2)) {
         if (st2.result == BROTLI_DECODER_RESULT_ERROR) {

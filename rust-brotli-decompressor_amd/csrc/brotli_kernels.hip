@@ -3037,9 +3037,9 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 #endif
 #ifdef BROTLI_AMD_PROFILE_SCAN
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
-    printf("scan engine: %llu invocations, %llu commands, %llu batches, %llu entries; wave 0 ticks: execute %llu S/J1 %llu J2-32 %llu own copies %llu walk %llu resolve %llu wait for REC %llu D2/D4 %llu\n",
+    printf("scan engine: %llu invocations, %llu commands, %llu batches, %llu entries; wave 0 ticks: execute %llu S/J1 %llu J2-32 %llu own copies %llu walk %llu resolve %llu wait for REC %llu D2/D4 %llu barrier behind S/J1 %llu barriers of J2-32 %llu\n",
            g_scan_prof[17], g_scan_prof[16], g_scan_prof[13], g_scan_prof[12], g_scan_prof[6], g_scan_prof[1], g_scan_prof[2], g_scan_prof[8], g_scan_prof[4],
-           g_scan_prof[5], g_scan_prof[3], g_scan_prof[7]);
+           g_scan_prof[5], g_scan_prof[3], g_scan_prof[7], g_scan_prof[9], g_scan_prof[10]);
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
     printf("kernel ticks of block 0: %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0));
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)

@@ -352,9 +352,10 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         _Pragma("unroll") for (int u = 0; u < 2; u++) { lds_st8(sb + SC_S + (p[u] & SC_M), e[u] >> 4); lds_st8(sb + SC_J1 + (p[u] & SC_M), L[u]); }
       }
       f_1 = t_1;
+      SCAN_PROF(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the group's stores: in memory before anyone reads them as copy sources)
       __syncthreads();
-      SCAN_PROF(1);
+      SCAN_PROF(9);
       // binary lifting, two levels per pass: TO2[p] = position after two FROM-hops, TO4[p] after four
 #define SC_LEVELS(FROM, TO2, TO4, f_to, t_to) \
       for (uint32_t w0 = ((f_to) >> 6) + me; w0 < ((t_to) >> 6); w0 += 2u * SC_WAVES) { \
@@ -367,7 +368,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         _Pragma("unroll") for (int u = 0; u < 2; u++) { lds_st8(sb + TO2 + (p[u] & SC_M), a2[u]); lds_st8(sb + TO4 + (p[u] & SC_M), a4[u]); } \
       } \
       f_to = (t_to); \
-      __syncthreads();
+      SCAN_PROF(2); \
+      __syncthreads(); \
+      SCAN_PROF(10);
       SC_LEVELS(SC_J1, SC_J2, SC_J4, f_4, t_4)
       SC_LEVELS(SC_J4, SC_J8, SC_J16, f_16, t_16)
 #undef SC_LEVELS
@@ -379,8 +382,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         _Pragma("unroll") for (int u = 0; u < 2; u++) lds_st16(sb + SC_J32 + ((p[u] & SC_M) << 1), a[u] + c[u]);
       }
       f_32 = t_32;
-      __syncthreads();
       SCAN_PROF(2);
+      __syncthreads();
+      SCAN_PROF(10);
       if (me != 0) {
         // REC: the command that would start at every bit of [f_rec, e_rec) -- fifteen waves, two windows per wave and pass,
         // stage by stage (wave 0 is walking the step before meanwhile)

@@ -292,6 +292,21 @@ def test_damaged_streams_with_buffers_that_are_too_small(pkg, seed):
     assert settled > 20, settled  # (the case exists in this sample)
 
 
+def test_error_right_behind_a_flush_point(pkg):
+    """found by the engine fuzzer: the first metablock of this (damaged) stream fills the 64 KiB ring exactly, the header
+    behind it is invalid.  The reference flushes as soon as the ring is full, so with less than 64 KiB of output it
+    reports NEEDS_MORE_OUTPUT, with 64 KiB or more the header error (after delivering 64 KiB); the batch entry points'
+    second decode and the one-shot entry point stop one byte short of the flush point to tell the two apart."""
+    d = open(os.path.join(ROOT, "tests", "golden", "regress", "ring_full_then_header_error.br"), "rb").read()
+    caps = [1, 42011, 65535, 65536, 65537, 100000]
+    want = [oracle.decode(d, cap, 1) for cap in caps]
+    assert [(i.result, i.error_code) for i, _ in want] == [(3, 3)] * 3 + [(0, -7)] * 3
+    _check_against_oracle(pkg, [d] * len(caps), caps, 1, "ring full, then a header error")
+    for cap, (oinfo, exp) in zip(caps, want):
+        info, out = pkg.brotli_decode(d, cap)
+        assert (info.result, info.code, info.decoded_size, out) == (oinfo.result, oinfo.error_code, oinfo.decoded_size, exp), cap
+
+
 def test_bench_workload_streams_tight_buffers_and_damage(pkg):
     """the bench workloads' own streams (long literal runs, copies of more than 1 KiB: the lean loop's limits): valid
     streams with output buffers that are exact, one short, half, ...; damaged streams with roomy buffers"""
