@@ -19,7 +19,8 @@ Prints ONE JSON line on rank 0 (contract in the task description), with these ex
                     sample of the same workload: all host threads, one thread, and -- when libbrotlidec.so.1 can
                     be loaded -- Google's C decoder on one thread as a proxy for the reference (a port of it)
   extra_configs  -- (N = 1 only) the other configurations of BASELINE.json, each timed the same way with its own
-                    roofline: C2 1024 x alice29, C4 256 x 4 MiB high-entropy literals, C3 as ONE many-metablock stream
+                    roofline: C2 1024 x alice29, C4 256 x 4 MiB high-entropy literals, C3 as ONE many-metablock stream,
+                    and the metric's streams twice (512 x 4 MiB: more streams than CUs)
 """
 import argparse
 import ctypes
@@ -71,7 +72,7 @@ def build_workload(name, n_unique=None):
         raise SystemExit("unknown workload " + name)
     kind, n, size = m.group(1), int(m.group(2)), int(m.group(3)) << (10 if m.group(4) == "KiB" else 20)
     nu = min(n, n_unique if n_unique else int(os.environ.get("BROTLI_BENCH_UNIQUE", "256")))
-    seed0 = {"longbackref": 1000, "highentropy": 2000}[kind] if (n, size) == (256, 4 << 20) else 3000
+    seed0 = {"longbackref": 1000, "highentropy": 2000}[kind] if (n % 256, size) == (0, 4 << 20) else 3000  # (512 x 4 MiB: the headline's streams, twice)
     u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", nu, size, seed0)
     what = "long back-references" if kind == "longbackref" else "high-entropy literals"
     if (n, size) == (256, 4 << 20):
@@ -331,12 +332,14 @@ def main():
             extra = []
             legs = [("alice29x1024", 10, None)]
             if w.encoder_available():
-                legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1)]
+                legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1), ("longbackref_512x4MiB", 3, None)]
             for name, steps, nu in legs:
                 try:
                     e = time_single_gpu(pkg, torch, dev, name, steps, 1, nu)
                     if name == "longbackref_1x64MiB":
                         e["workload"] = "C3 as ONE stream: 64 MiB, wbits 22, brotli -q5, many metablocks, long back-references (a single stream does not shard: one block of the GPU decodes it)"
+                    if name == "longbackref_512x4MiB":
+                        e["workload"] = "the metric's 256 streams twice: 512 x 4 MiB, two streams per CU (engine blocks take them one after the other)"
                     extra.append(e)
                 except SystemExit as ex:  # a failing leg must not hide the headline
                     extra.append({"workload": name, "error": str(ex)})
