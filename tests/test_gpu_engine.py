@@ -243,7 +243,8 @@ def test_engine_blocks_serving_more_streams_than_cus(pkg):
     results, outs = batch.decode_host(datas, caps, 1)
     came_back = batch.last_second_pass_count()
     batch.close()
-    assert came_back >= n // 4, came_back  # (the text streams; fewer would mean the batch did not get engine blocks)
+    if not os.environ.get("BROTLI_AMD_NO_SCAN") and not os.environ.get("BROTLI_AMD_NO_ENGINE_QUEUE"):
+        assert came_back >= n // 4, came_back  # (the text streams; fewer would mean the batch did not get engine blocks)
     memo = {}
     bad = []
     for i, (d, cap) in enumerate(zip(datas, caps)):
