@@ -129,9 +129,11 @@ BROTLI_DEC_API BrotliDecoderReturnInfo BrotliDecoderDecompressPrealloc(size_t en
 /* ffi/mod.rs:390 -> decode.h:278.  total_out may be NULL; input is never over-consumed on SUCCESS.
  * While output the decoder owes does not fit *available_out, a call consumes no input and returns NEEDS_MORE_OUTPUT
  * (decode.rs:2835-2846).  Cost model of this implementation: the compressed bytes of a call are copied to the device
- * and the stream is decoded again from the last completed metablock boundary, so a metablock delivered in k pieces is
- * decoded up to k times (the reference resumes inside a metablock); an instance keeps about one window plus the
- * metablock in flight on the device, not the whole stream.  The batch and one-shot entry points are the fast paths. */
+ * and a kernel is launched that goes on where the call before got to: it parses the header of the metablock in
+ * flight again (prefix codes are not kept between launches) and continues from the last command boundary that launch
+ * reached, like the reference's resumable state.  A call costs a launch (about a millisecond) plus its bytes; an
+ * instance keeps about one window plus the compressed metablock in flight on the device, not the whole stream.  The
+ * batch and one-shot entry points are the fast paths. */
 BROTLI_DEC_API BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState* state, size_t* available_in, const uint8_t** next_in,
                                                                  size_t* available_out, uint8_t** next_out, size_t* total_out);
 

@@ -40,6 +40,19 @@ typedef struct BrotliAmdResume {
   uint32_t rb_size_log2;  // emulated ring size (0 = not allocated yet), decode.rs:1808-1871
   uint32_t is_last_done;  // last metablock completed (stream finished up to the final padding)
   uint32_t reserved;
+  // A command boundary inside the metablock that starts at bit_pos (mid_valid != 0): where a launch that ran out of
+  // input had got to.  The next launch parses that metablock's header again (the prefix codes are not kept) and goes
+  // on from here instead of from the metablock's first command, so a stream fed in small pieces costs what its bytes
+  // cost, not (pieces x metablock).  The reference keeps the same things across calls in its state (state.rs:255-330:
+  // block lengths and types, distance ring, meta_block_remaining_len, the bit reader).
+  uint32_t mid_valid;
+  int32_t mid_mlen;        // bytes of the metablock still to be produced
+  uint64_t mid_bit_pos;    // bit position of the next command
+  uint64_t mid_out_pos;    // bytes produced in front of it
+  uint32_t mid_bl[3];      // literals / commands / distances left in the current blocks
+  uint32_t mid_types[6];   // second last and last block type, per category (state.rs:429-435)
+  int32_t mid_dist_rb[4];  // last four distances, most recent first
+  uint32_t mid_reserved;
 } BrotliAmdResume;
 
 typedef struct BrotliAmdStreamDesc {

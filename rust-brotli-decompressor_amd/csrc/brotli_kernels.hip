@@ -1917,6 +1917,7 @@ struct HotArgs {
   uint32_t lut_vgpr, bl_vgpr;
   uint64_t spec_scratch;   // global address of the helper waves' literal scratch
   uint64_t num_commands;
+  uint64_t resume_out;     // global address of the status' BrotliAmdResume: command boundaries close to the end of the input are noted there
   uint64_t prof[6];
 };
 
@@ -2175,6 +2176,21 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       if (stage == LS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
     }
     // ---- COMMAND_BEGIN ----
+    if (br.next_dw >= safe_dw) {
+      // Close to the end of the input: should it run out inside this metablock, the next launch goes on from the last
+      // boundary noted here instead of from the metablock's first command (BrotliAmdResume: mid_*).  Any boundary of
+      // this metablock would do; store_resume() forgets them at the next metablock boundary.
+      typedef __attribute__((address_space(1))) BrotliAmdResume gresume;
+      gresume* const r = (gresume*)(uintptr_t)rfl(args->resume_out);
+      const uint64_t bit = br.pos();
+      if (lane < 6u) r->mid_types[lane] = lds_ld32(LDS_HOT + 4u * (H_RING + lane));
+      if (lane == 0) {
+        r->mid_mlen = mlen; r->mid_bit_pos = bit; r->mid_out_pos = P;
+        r->mid_bl[0] = bl0; r->mid_bl[1] = bl1; r->mid_bl[2] = bl2;
+        r->mid_dist_rb[0] = d0; r->mid_dist_rb[1] = d1; r->mid_dist_rb[2] = d2; r->mid_dist_rb[3] = d3;
+        r->mid_valid = 1u;
+      }
+    }
     if (force_checked != 0u) force_checked--;
     if (bl1 == 0) {
       int r;
@@ -2615,7 +2631,7 @@ done:
 
 // Marshals the stream state into the argument block, runs the loop, takes the results back.
 constexpr uint32_t ENGINE_ONLY_MIN_MLEN = 32768;  // (BROTLI_AMD_FLAG_ENGINE_ONLY: smaller metablocks are decoded where they are)
-__device__ __forceinline__ int run_commands(Stream& s) {
+__device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mid_, uint64_t mb_out_pos, BrotliAmdStreamStatus* st) {
   HotArgs h;
   h.br = s.br; h.ar = s.ar; h.out = s.out; h.dict = s.dict;
   h.out_cap = s.out_cap; h.P = s.P; h.next_boundary = s.next_boundary; h.rb_size = s.rb_size;
@@ -2630,6 +2646,31 @@ __device__ __forceinline__ int run_commands(Stream& s) {
     for (int k = 0; k < 21; k++) lds_st32(LDS_HOT + 4u * (uint32_t)k, cold[k]);
   }
   lds_sync();
+  h.resume_out = (uint64_t)(uintptr_t)&st->resume;
+  if (mid_) {
+    typedef __attribute__((address_space(1))) const BrotliAmdResume gcresume;
+    gcresume* const mid = (gcresume*)(uintptr_t)mid_;
+    // This launch continues inside the metablock whose header it has just parsed again: block counts and types, the
+    // distance ring, what is left of MLEN and the bit position are those of the command boundary an earlier launch got
+    // to.  What was produced up to there plus what is left must be the MLEN just read, the block types must exist.
+    const uint64_t mp = rfl(mid->mid_out_pos), mb = rfl(mid->mid_bit_pos);
+    const int32_t mm = (int32_t)rfl((uint32_t)mid->mid_mlen);
+    uint32_t ty[6];
+    bool sane = mm > 0 && mp >= mb_out_pos && (mp - mb_out_pos) + (uint64_t)(uint32_t)mm == (uint64_t)(uint32_t)rfl((uint32_t)s.mlen) && mb >= s.br.pos();
+    for (int k = 0; k < 6; k++) {  // (a category's ring starts as {1, 0} whatever its number of types, state.rs:429-435)
+      ty[k] = rfl(mid->mid_types[k]);
+      sane = sane && (ty[k] <= 1u || ty[k] < (k < 2 ? rfl(s.nbt0) : k < 4 ? rfl(s.nbt1) : rfl(s.nbt2)));
+    }
+    if (!sane) return E_UNREACHABLE;
+    h.P = mp; h.mlen = mm;
+    h.bl0 = rfl(mid->mid_bl[0]); h.bl1 = rfl(mid->mid_bl[1]); h.bl2 = rfl(mid->mid_bl[2]);
+    h.d0 = (int32_t)rfl((uint32_t)mid->mid_dist_rb[0]); h.d1 = (int32_t)rfl((uint32_t)mid->mid_dist_rb[1]);
+    h.d2 = (int32_t)rfl((uint32_t)mid->mid_dist_rb[2]); h.d3 = (int32_t)rfl((uint32_t)mid->mid_dist_rb[3]);
+    if (h.rb_size) h.next_boundary = (mp / h.rb_size + 1) * h.rb_size;
+    if (lane_id() == 0) for (int k = 0; k < 6; k++) lds_st32(LDS_HOT + 4u * (uint32_t)(15 + k), ty[k]);
+    lds_sync();
+    h.br.seek(mb);
+  }
   h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
   h.spec_scratch = (uint64_t)(uintptr_t)(s.ar.glb + s.ar_end);
   h.num_commands = s.num_commands;
@@ -2720,11 +2761,12 @@ __device__ __forceinline__ void store_resume(const Stream& s, const BitReader& b
     r->rb_size_log2 = s.rb_size ? (uint32_t)(63 - __clzll((long long)s.rb_size)) : 0;
     r->is_last_done = 0;
     r->reserved = 0;
+    r->mid_valid = 0;  // (command boundaries noted inside the metablock that ends here are history)
   }
 }
 
 // src/decode.rs:2779-3403 restated for one whole-input call
-__device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64_t in_size, BrotliAmdStreamStatus* st) {
+__device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64_t in_size, BrotliAmdStreamStatus* st, const BrotliAmdResume* mid) {
   if (!have_header) {
     ColdScope c(s);
     BitReader& br = c.br;
@@ -2805,6 +2847,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
       }
       if (!s.is_metadata && s.mlen != 0 && s.rb_size == 0) allocate_ring(s, br);
     }
+    if (mid && (s.is_metadata || s.mlen == 0 || s.is_uncompressed)) return E_UNREACHABLE;  // (the resume block names a command inside a compressed metablock)
     if (!s.is_metadata && s.mlen != 0) {
       if (s.is_uncompressed) {
         TRY(copy_uncompressed(s));
@@ -2851,11 +2894,11 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 #endif
 #ifdef BROTLI_AMD_PROFILE_HDR
         const uint64_t run_t0 = __builtin_amdgcn_s_memtime();
-        int run_e = run_commands(s);
+        int run_e = run_commands(s, mid, s.P, st); mid = nullptr;
         s.prof[5] = (s.prof[5] & 0xFFFFFu) + ((__builtin_amdgcn_s_memtime() - run_t0) >> 8);
         TRY(run_e);
 #else
-        TRY(run_commands(s));
+        { const BrotliAmdResume* const m_ = mid; mid = nullptr; TRY(run_commands(s, m_, s.P, st)); }
 #endif
       }
     }
@@ -2960,7 +3003,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     s.is_last = 0; s.is_uncompressed = 0; s.is_metadata = 0;
     s.br.set_input((uint64_t)d.in, d.in_size);
     const bool resume = (d.flags & BROTLI_AMD_FLAG_RESUME) && d.resume.window_bits != 0;
-    if (resume && (d.resume.out_pos > d.out_cap || d.resume.bit_pos > d.in_size * 8)) {  // a resume block that does not belong to these buffers
+    if (resume && (d.resume.out_pos > d.out_cap || d.resume.bit_pos > d.in_size * 8 ||
+                   (d.resume.mid_valid != 0u && (d.resume.mid_out_pos > d.out_cap || d.resume.mid_bit_pos > d.in_size * 8)))) {  // a resume block that does not belong to these buffers
       if (lane == 0) {
         st->result = 0; st->error_code = E_UNREACHABLE; st->decoded_size = 0; st->consumed = 0; st->produced = 0;
         st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0; st->resume = d.resume;
@@ -2979,7 +3023,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     } else {
       if (lane == 0) {  // no metablock boundary yet (the host looks at window_bits to tell)
         BrotliAmdResume z; z.bit_pos = 0; z.out_pos = 0; z.dist_rb[0] = z.dist_rb[1] = z.dist_rb[2] = z.dist_rb[3] = 0; z.dist_rb_idx = 0;
-        z.window_bits = 0; z.large_window = 0; z.rb_size_log2 = 0; z.is_last_done = 0; z.reserved = 0;
+        z.window_bits = 0; z.large_window = 0; z.rb_size_log2 = 0; z.is_last_done = 0; z.reserved = 0; z.mid_valid = 0;
         st->resume = z;
       }
       s.P = 0;
@@ -2990,7 +3034,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       s.br.seek(0);
     }
 
-    int e = decode_stream(s, resume, d.in_size, st);
+    const bool mid = resume && d.resume.mid_valid != 0u;
+    int e = decode_stream(s, resume, d.in_size, st, mid ? &descs[idx].resume : nullptr);
 
     // result mapping of the one-shot driver (decode.rs:2829-2916, 3382-3397; lib.rs:447-468)
     const bool over = s.br.over();

@@ -5,6 +5,7 @@ import io
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -362,3 +363,47 @@ def test_streaming_memory_stays_bounded(pkg):
     st.close()
     assert total == len(raw) and h.digest() == hashlib.sha256(raw).digest()
     assert peak < (24 << 20), peak  # (the whole stream would be 48 MiB of output and 6 MiB of input)
+
+
+def test_streaming_goes_on_inside_a_metablock(pkg):
+    """A stream fed in small pieces goes on from the command boundary the call before got to (BrotliAmdResume: mid_*),
+    not from the metablock's first command: streams with block switches in all three categories (the emitter's vectors,
+    mapsdatazrh), context-modelled text, long back-references, each in pieces of 1 .. 4096 bytes, whole and with a
+    flipped bit (the piece-wise result must be the one-piece result); and the cost: a 4 MiB stream in 4 KiB pieces takes
+    a hundred launches of a few KiB each, not a hundred of up to 4 MiB."""
+    import json
+    import random
+    import time
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    rnd = random.Random(99)
+    cases = []
+    d = os.path.join(ROOT, "tests", "golden", "emitter")
+    for e in json.load(open(os.path.join(d, "manifest.json"))):
+        cases.append((e["file"], open(os.path.join(d, e["file"]), "rb").read()))
+    for name in ("mapsdatazrh.compressed", "alice29.txt.compressed", "metablock_reset.compressed", "random_then_unicode.compressed"):
+        cases.append((name, _data(name)))
+    if w.encoder_available():
+        cases.append(("long_backref 1 MiB", w.brotli_compress(w.long_backref_stream(31, 1 << 20), 5, 22)))
+        cases.append(("long_backref 256 KiB q9 w18", w.brotli_compress(w.long_backref_stream(32, 256 << 10), 9, 18)))
+    for label, comp in cases:
+        variants = [comp]
+        bad = bytearray(comp); bad[rnd.randrange(len(bad) // 2, len(bad))] ^= 1 << rnd.randrange(8)
+        variants.append(bytes(bad))
+        for v in variants:
+            want = _stream_decode(pkg, v, len(v), 1 << 24)
+            for piece in (rnd.choice([1, 2, 3]) if len(v) < 3000 else rnd.choice([61, 97]), rnd.choice([256, 517, 1000]), 4096):
+                got = _stream_decode(pkg, v, piece, 1 << 16)
+                if want[0] == 1:
+                    assert got[:4] == want[:4], (label, piece, got[:2], want[:2], len(got[2]), len(want[2]))
+                else:  # (every call that ends for want of input delivers what has been decoded: more than one call does)
+                    assert got[:2] == want[:2] and got[2][:len(want[2])] == want[2], (label, piece, got[:2], want[:2], len(got[2]), len(want[2]))
+    if w.encoder_available():
+        raw = w.long_backref_stream(4242, 4 << 20)
+        comp = w.brotli_compress(raw, 5, 22)
+        _stream_decode(pkg, comp[:65536], 4096, 1 << 20)  # (warm-up: device buffers, module load)
+        t0 = time.time()
+        result, code, out, finished, _ = _stream_decode(pkg, comp, 4096, 1 << 20)
+        dt = time.time() - t0
+        assert (result, code, finished) == (1, 1, True) and out == raw
+        assert dt < 0.4, dt  # (0.85 s when every call decoded the metablock from its first command; ~0.1 s now)
