@@ -2928,6 +2928,9 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 #ifdef BROTLI_AMD_PROFILE_SCAN
   const uint64_t scan_prof_t0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef BROTLI_AMD_PROFILE_HDR
+  const uint64_t hdr_prof_t0 = __builtin_amdgcn_s_memtime();
+#endif
   // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
     const uint32_t nw = blockDim.x >> 6, nr = nw < SPEC_MAX_WAVES ? nw : SPEC_MAX_WAVES;  // waves in the block, waves that take part in rounds
@@ -3035,7 +3038,15 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     }
 
     const bool mid = resume && d.resume.mid_valid != 0u;
+#ifdef BROTLI_AMD_PROFILE_HDR
+    const uint64_t hdr_prof_t1 = __builtin_amdgcn_s_memtime();
+#endif
     int e = decode_stream(s, resume, d.in_size, st, mid ? &descs[idx].resume : nullptr);
+#ifdef BROTLI_AMD_PROFILE_HDR
+    if (blockIdx.x == 0 && lane == 0)
+      printf("block 0: %llu ticks before the stream, %llu in it: headers %llu, command loops %llu (x 256)\n", (unsigned long long)(hdr_prof_t1 - hdr_prof_t0),
+             (unsigned long long)(__builtin_amdgcn_s_memtime() - hdr_prof_t1), (unsigned long long)s.prof[4], (unsigned long long)s.prof[5]);
+#endif
 
     // result mapping of the one-shot driver (decode.rs:2829-2916, 3382-3397; lib.rs:447-468)
     const bool over = s.br.over();

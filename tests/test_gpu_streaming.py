@@ -406,4 +406,4 @@ def test_streaming_goes_on_inside_a_metablock(pkg):
         result, code, out, finished, _ = _stream_decode(pkg, comp, 4096, 1 << 20)
         dt = time.time() - t0
         assert (result, code, finished) == (1, 1, True) and out == raw
-        assert dt < 0.4, dt  # (0.85 s when every call decoded the metablock from its first command; ~0.1 s now)
+        assert dt < 0.6, dt  # (0.85 s when every call decoded the metablock from its first command; 0.1 - 0.2 s now)
