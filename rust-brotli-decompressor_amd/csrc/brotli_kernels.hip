@@ -564,7 +564,16 @@ __device__ __forceinline__ uint32_t log2floor_plus1(uint32_t x) { return x ? 32u
 
 // src/decode.rs:868-1013.  Reads one prefix code, builds its table at a fresh arena allocation, returns the
 // arena offset in *tree_off.  The one helper that is a real function call (7 call sites, cold).
+#ifdef BROTLI_AMD_PROFILE_HDR
+__device__ unsigned long long g_hdr_prof[8];  // ticks: code-length code, symbol lengths, build_tree; counts: codes, symbols
+#define HDR_PROF(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane_id() == 0) g_hdr_prof[k] += t_ - hp_t; hp_t = t_; } while (0)
+#else
+#define HDR_PROF(k) do { } while (0)
+#endif
 __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off, bool cold = false) {
+#ifdef BROTLI_AMD_PROFILE_HDR
+  uint64_t hp_t = __builtin_amdgcn_s_memtime();
+#endif
   struct Scope {  // register copies of the reader and the arena, stored back on every exit
     Stream& s; BitReader br; Arena ar;
     __device__ __forceinline__ Scope(Stream& s_) : s(s_), br(s_.br), ar(s_.ar) { COLD_UNIFORMIZE(br.uniformize(); ar.uniformize();) }
@@ -648,6 +657,7 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
         }
       }
     }
+    HDR_PROF(0);
     // symbol code lengths (decode.rs:661-797, 558-658)
     uint32_t symbol = 0, prev_code_len = 8, repeat = 0, repeat_code_len = 0;
     space = 32768;
@@ -683,7 +693,12 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
     }
     if (space != 0) FAIL(br, E_HUFFMAN_SPACE);
     lds_sync();
+    HDR_PROF(1);
+#ifdef BROTLI_AMD_PROFILE_HDR
+    if (blockIdx.x == 0 && lane == 0) { g_hdr_prof[4] += 1; g_hdr_prof[5] += symbol; }
+#endif
     size = build_tree(ar, tree, max_symbol);
+    HDR_PROF(2);
   }
   if (!cold) ar.shrink_to(tree + size * 2);
   return E_SUCCESS;
@@ -3043,6 +3058,9 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 #endif
     int e = decode_stream(s, resume, d.in_size, st, mid ? &descs[idx].resume : nullptr);
 #ifdef BROTLI_AMD_PROFILE_HDR
+    if (blockIdx.x == 0 && lane == 0)
+      printf("prefix codes (complex form): %llu, %llu symbols; ticks: code-length code %llu, symbol lengths %llu, build_tree %llu\n",
+             g_hdr_prof[4], g_hdr_prof[5], g_hdr_prof[0], g_hdr_prof[1], g_hdr_prof[2]);
     if (blockIdx.x == 0 && lane == 0)
       printf("block 0: %llu ticks before the stream, %llu in it: headers %llu, command loops %llu (x 256)\n", (unsigned long long)(hdr_prof_t1 - hdr_prof_t0),
              (unsigned long long)(__builtin_amdgcn_s_memtime() - hdr_prof_t1), (unsigned long long)s.prof[4], (unsigned long long)s.prof[5]);
