@@ -355,6 +355,10 @@ int settle_output_limits(BrotliAmdBatch* b) {
     }
     b->last_settle_count += m;
   }
+  if (b->settle_cap > ((size_t)64 << 20)) {  // (a large scratch buffer is not kept for the next batch)
+    (void)hipFree(b->d_settle);
+    b->d_settle = nullptr; b->settle_cap = 0;
+  }
   return 0;
 }
 
