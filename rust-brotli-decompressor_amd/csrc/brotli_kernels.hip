@@ -3115,7 +3115,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
            g_scan_prof[17], g_scan_prof[16], g_scan_prof[13], g_scan_prof[12], g_scan_prof[6], g_scan_prof[1], g_scan_prof[2], g_scan_prof[8], g_scan_prof[4],
            g_scan_prof[5], g_scan_prof[3], g_scan_prof[7], g_scan_prof[9], g_scan_prof[10]);
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
-    printf("kernel ticks of block 0: %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0));
+    printf("kernel ticks of block 0: %llu; the engine's ticks: %llu steps, %llu that only walk, %llu last ones\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0),
+           g_scan_prof[14], g_scan_prof[15], g_scan_prof[11]);
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
     printf("scan engine exits: input ends %llu, counts/limits %llu, distance %llu, by-hand precheck %llu, long run %llu; invocations that took < 64 commands %llu\n",
            g_scan_prof[18], g_scan_prof[19], g_scan_prof[20], g_scan_prof[21], g_scan_prof[22], g_scan_prof[23]);

@@ -244,6 +244,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
   for (;; par ^= 1u) {
     const uint32_t gx = SCC_GRP + 16u * (par ^ 1u), xl_exec = sb + SC_XL + (par ^ 1u) * (SC_GROUP * 1024u);  // the group to execute
     const uint32_t gp = SCC_GRP + 16u * par, xl_post = sb + SC_XL + par * (SC_GROUP * 1024u);                // the group to post
+    SCAN_COUNT(14, mode == M_STEP ? 1u : 0u); SCAN_COUNT(15, mode == M_SYNC ? 1u : 0u); SCAN_COUNT(11, mode == M_FINAL ? 1u : 0u);
     // ================= part 1 (all waves): the posted group =================
     {
       const uint32_t ng = sc_ctl_ld(sb, gx + SCG_NG);
