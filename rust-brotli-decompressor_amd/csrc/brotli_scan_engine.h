@@ -86,12 +86,21 @@ __device__ __forceinline__ uint32_t sc_ctl_ld(uint32_t sb, uint32_t k) { return 
 __device__ __forceinline__ void sc_ctl_st(uint32_t sb, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[sb + SC_CTL + 4u * k]) = v; }
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
-__device__ unsigned long long g_scan_prof[24];
+__device__ unsigned long long g_scan_prof[28];
+__device__ long long g_scan_late[16];  // per wave: ticks after wave 0 at the last barrier of a step, summed  // ([24]: wave 1's ticks in REC)
 #define SCAN_PROF(k) do { if (me == 0) { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0) sp_acc[k] += _t - sp_t; sp_t = _t; } } while (0)
 #define SCAN_COUNT(k, v) do { if (me == 0 && blockIdx.x == 0) sp_acc[k] += (v); } while (0)
 #else
 #define SCAN_PROF(k) do { } while (0)
 #define SCAN_COUNT(k, v) do { } while (0)
+#endif
+
+// Between the stages of two chains of dependent LDS reads written side by side: the machine scheduler otherwise puts each
+// chain back together (one chain's reads, waits and all, then the other's), and the round trips no longer overlap.
+#ifdef BROTLI_AMD_SCAN_NO_STAGES
+#define SC_STAGE() do { } while (0)
+#else
+#define SC_STAGE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 // inclusive prefix sum over the wave (LLVM's buildScan: row shifts inside rows of 16, then row broadcasts)
@@ -162,9 +171,8 @@ __device__ __forceinline__ ScHead sc_head(uint32_t lo, uint32_t hi, uint32_t cmd
 }
 // Distance symbol + extra bits at lo/hi: ReadDistanceInternal, decode.rs:2066-2131 (no large window: at most 24 extra bits)
 struct ScDist { uint32_t kind, val, bits; };
-__device__ __forceinline__ ScDist sc_dist(uint32_t lo, uint32_t hi, uint32_t dtree_addr, uint32_t postfix_bits, uint32_t num_direct) {
-  uint32_t code, L;
-  sc_lookup(dtree_addr, lo, code, L);
+// (what follows the lookup of the distance symbol `code`, a word of L bits)
+__device__ __forceinline__ ScDist sc_dist_finish(uint32_t code, uint32_t L, uint32_t lo, uint32_t hi, uint32_t postfix_bits, uint32_t num_direct) {
   ScDist d;
   if (code < 16u) { d.kind = SCK_SHORT; d.val = code; d.bits = L; return d; }
   int32_t distval = (int32_t)code - (int32_t)num_direct;
@@ -179,6 +187,11 @@ __device__ __forceinline__ ScDist sc_dist(uint32_t lo, uint32_t hi, uint32_t dtr
   }
   d.kind = SCK_EXPLICIT; d.val = dc - 16u + 1u; d.bits = L + nbits;
   return d;
+}
+__device__ __forceinline__ ScDist sc_dist(uint32_t lo, uint32_t hi, uint32_t dtree_addr, uint32_t postfix_bits, uint32_t num_direct) {
+  uint32_t code, L;
+  sc_lookup(dtree_addr, lo, code, L);
+  return sc_dist_finish(code, L, lo, hi, postfix_bits, num_direct);
 }
 
 // How the engine hands the stream back (state in LDS_LEAN, like lean_commands)
@@ -289,6 +302,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           if (nmax > 32u) { SC_XHOP(NS, 32u, lds_ld16(sb + SC_J32 + ((q[t] & SC_M) << 1))) } \
           uint32_t sy[NS]; \
           _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) sy[t] = lds_ld8(sb + SC_S + (q[t] & SC_M)); \
+          SC_STAGE(); \
           _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if (lane < nl[t]) o[off[t] + lane] = (uint8_t)sy[t]; \
         } \
         _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) \
@@ -297,6 +311,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         // (a hop: the reads of all entries first, then the additions -- one LDS round trip per level, not one per entry and
         // level; lanes that do not hop read somewhere inside the ring and drop what they get)
 #define SC_XHOP(NS, BIT, EXPR) { uint32_t hop_[NS]; _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) hop_[t] = EXPR; \
+        SC_STAGE(); \
         _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) q[t] += ((lane & BIT) != 0u) ? hop_[t] : 0u; }
         if (k_exec <= 2u * SC_WAVES) { if (me < k_exec) SC_EXEC(2u); }
         else SC_EXEC(4u);
@@ -312,10 +327,20 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         uint32_t p[2], d1[2], d2[2], d3[2], d4[2];
         p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (f_rec >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
 #define SC_DLT(pos) (lds_ld32(sb + SC_REC + (((pos) & (SC_N2 - 1u)) << 3)) & 0x7FFu)
+        // (the reads of a stage unconditional -- a lane without a command there reads its own entry again and drops it --, so
+        // that the two windows' reads of a stage go out together)
+        uint32_t t_[2];
         _Pragma("unroll") for (int u = 0; u < 2; u++) d1[u] = SC_DLT(p[u]);
-        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d1[u] != 0u && p[u] + d1[u] < f_rec) ? SC_DLT(p[u] + d1[u]) : 0u; d2[u] = t ? d1[u] + t : 0u; }
-        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d2[u] != 0u && p[u] + d2[u] < f_rec) ? SC_DLT(p[u] + d2[u]) : 0u; d3[u] = t ? d2[u] + t : 0u; }
-        _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t t = (d3[u] != 0u && p[u] + d3[u] < f_rec) ? SC_DLT(p[u] + d3[u]) : 0u; d4[u] = t ? d3[u] + t : 0u; }
+        SC_STAGE();
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const bool on = d1[u] != 0u && p[u] + d1[u] < f_rec; t_[u] = SC_DLT(on ? p[u] + d1[u] : p[u]); t_[u] = on ? t_[u] : 0u; }
+        SC_STAGE();
+        _Pragma("unroll") for (int u = 0; u < 2; u++) d2[u] = t_[u] ? d1[u] + t_[u] : 0u;
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const bool on = d2[u] != 0u && p[u] + d2[u] < f_rec; t_[u] = SC_DLT(on ? p[u] + d2[u] : p[u]); t_[u] = on ? t_[u] : 0u; }
+        SC_STAGE();
+        _Pragma("unroll") for (int u = 0; u < 2; u++) d3[u] = t_[u] ? d2[u] + t_[u] : 0u;
+        _Pragma("unroll") for (int u = 0; u < 2; u++) { const bool on = d3[u] != 0u && p[u] + d3[u] < f_rec; t_[u] = SC_DLT(on ? p[u] + d3[u] : p[u]); t_[u] = on ? t_[u] : 0u; }
+        SC_STAGE();
+        _Pragma("unroll") for (int u = 0; u < 2; u++) d4[u] = t_[u] ? d3[u] + t_[u] : 0u;
 #undef SC_DLT
         _Pragma("unroll") for (int u = 0; u < 2; u++) {
           lds_st32(sb + SC_D24 + ((p[u] & (SC_N2 - 1u)) << 2), d2[u] | (d4[u] << 16));
@@ -339,7 +364,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         uint32_t p[2], x[2], e[2], L[2];
         p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (t_1 >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
         _Pragma("unroll") for (int u = 0; u < 2; u++) x[u] = sc_bits32(sb, p[u]);
+        SC_STAGE();
         _Pragma("unroll") for (int u = 0; u < 2; u++) e[u] = lds_ld16(lit_tree + ((x[u] & 0xFFu) << 1));
+        SC_STAGE();
         _Pragma("unroll") for (int u = 0; u < 2; u++) L[u] = e[u] & 15u;
         if (__ballot(L[0] > ROOT_BITS || L[1] > ROOT_BITS) != 0ull) {
           uint32_t e2[2];
@@ -348,6 +375,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             const uint32_t idx = sec ? (e[u] >> 4) + __builtin_amdgcn_ubfe(x[u], ROOT_BITS, L[u] - ROOT_BITS) : (x[u] & 0xFFu);
             e2[u] = lds_ld16(lit_tree + (idx << 1));
           }
+          SC_STAGE();
           _Pragma("unroll") for (int u = 0; u < 2; u++) if (L[u] > ROOT_BITS) { e[u] = e2[u]; L[u] = ROOT_BITS + (e2[u] & 15u); }
         }
         _Pragma("unroll") for (int u = 0; u < 2; u++) { lds_st8(sb + SC_S + (p[u] & SC_M), e[u] >> 4); lds_st8(sb + SC_J1 + (p[u] & SC_M), L[u]); }
@@ -363,9 +391,13 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         uint32_t p[2], a1[2], a2[2], a3[2], a4[2]; \
         p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < ((t_to) >> 6) ? w0 + SC_WAVES : w0) << 6) + lane; \
         _Pragma("unroll") for (int u = 0; u < 2; u++) a1[u] = lds_ld8(sb + FROM + (p[u] & SC_M)); \
+        SC_STAGE(); \
         _Pragma("unroll") for (int u = 0; u < 2; u++) a2[u] = a1[u] + lds_ld8(sb + FROM + ((p[u] + a1[u]) & SC_M)); \
+        SC_STAGE(); \
         _Pragma("unroll") for (int u = 0; u < 2; u++) a3[u] = a2[u] + lds_ld8(sb + FROM + ((p[u] + a2[u]) & SC_M)); \
+        SC_STAGE(); \
         _Pragma("unroll") for (int u = 0; u < 2; u++) a4[u] = a3[u] + lds_ld8(sb + FROM + ((p[u] + a3[u]) & SC_M)); \
+        SC_STAGE(); \
         _Pragma("unroll") for (int u = 0; u < 2; u++) { lds_st8(sb + TO2 + (p[u] & SC_M), a2[u]); lds_st8(sb + TO4 + (p[u] & SC_M), a4[u]); } \
       } \
       f_to = (t_to); \
@@ -379,7 +411,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         uint32_t p[2], a[2], c[2];
         p[0] = (w0 << 6) + lane; p[1] = ((w0 + SC_WAVES < (t_32 >> 6) ? w0 + SC_WAVES : w0) << 6) + lane;
         _Pragma("unroll") for (int u = 0; u < 2; u++) a[u] = lds_ld8(sb + SC_J16 + (p[u] & SC_M));
+        SC_STAGE();
         _Pragma("unroll") for (int u = 0; u < 2; u++) c[u] = lds_ld8(sb + SC_J16 + ((p[u] + a[u]) & SC_M));
+        SC_STAGE();
         _Pragma("unroll") for (int u = 0; u < 2; u++) lds_st16(sb + SC_J32 + ((p[u] & SC_M) << 1), a[u] + c[u]);
       }
       f_32 = t_32;
@@ -387,6 +421,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
       __syncthreads();
       SCAN_PROF(10);
       if (me != 0) {
+#ifdef BROTLI_AMD_PROFILE_SCAN
+        const uint64_t rec_t0 = __builtin_amdgcn_s_memtime();
+#endif
         // REC: the command that would start at every bit of [f_rec, e_rec) -- fifteen waves, two windows per wave and pass,
         // stage by stage (wave 0 is walking the step before meanwhile)
         for (uint32_t w0 = (f_rec >> 6) + (me - 1u); w0 < (e_rec >> 6); w0 += 2u * (SC_WAVES - 1u)) {
@@ -395,9 +432,11 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           bool ok[2];
           p[0] = (w0 << 6) + lane; p[1] = ((w0 + (SC_WAVES - 1u) < (e_rec >> 6) ? w0 + (SC_WAVES - 1u) : w0) << 6) + lane;
           _Pragma("unroll") for (int u = 0; u < 2; u++) sc_bits64(sb, p[u], lo[u], hi[u]);
+          SC_STAGE();
           {  // heads (sc_head, the two lookups side by side)
             uint32_t e[2], L[2];
             _Pragma("unroll") for (int u = 0; u < 2; u++) e[u] = lds_ld16(cmd_tree + ((lo[u] & 0xFFu) << 1));
+            SC_STAGE();
             _Pragma("unroll") for (int u = 0; u < 2; u++) L[u] = e[u] & 15u;
             if (__ballot(L[0] > ROOT_BITS || L[1] > ROOT_BITS) != 0ull) {
               uint32_t e2[2];
@@ -406,6 +445,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
                 const uint32_t idx = sec ? (e[u] >> 4) + __builtin_amdgcn_ubfe(lo[u], ROOT_BITS, L[u] - ROOT_BITS) : (lo[u] & 0xFFu);
                 e2[u] = lds_ld16(cmd_tree + (idx << 1));
               }
+              SC_STAGE();
               _Pragma("unroll") for (int u = 0; u < 2; u++) if (L[u] > ROOT_BITS) { e[u] = e2[u]; L[u] = ROOT_BITS + (e2[u] & 15u); }
             }
             uint32_t ie[2], ce[2], cc[2];
@@ -416,6 +456,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
               ie[u] = bperm(ins_code << 2, lut_vgpr); ce[u] = bperm((32u + cc[u]) << 2, lut_vgpr);
               h[u].implicit = cmd < 128u ? 1u : 0u;
             }
+            SC_STAGE();
             _Pragma("unroll") for (int u = 0; u < 2; u++) {
               uint64_t w = (((uint64_t)hi[u] << 32) | lo[u]) >> L[u];
               const uint32_t ib = ie[u] >> 16, cb = ce[u] >> 16;
@@ -429,11 +470,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             }
           }
           // the literals are skipped (sc_skip, level by level for both)
-#ifdef BROTLI_AMD_SCAN_BRANCHLESS
-#define SC_HOP(BIT, EXPR) _Pragma("unroll") for (int u = 0; u < 2; u++) { const uint32_t hop_ = EXPR; q[u] += (h[u].insert & BIT) ? hop_ : 0u; }
-#else
-#define SC_HOP(BIT, EXPR) _Pragma("unroll") for (int u = 0; u < 2; u++) if (h[u].insert & BIT) q[u] += EXPR;
-#endif
+          // (a hop: both windows' reads, then both additions; a lane that does not hop drops what it read)
+#define SC_HOP(BIT, EXPR) { uint32_t hop_[2]; _Pragma("unroll") for (int u = 0; u < 2; u++) hop_[u] = EXPR; SC_STAGE(); \
+          _Pragma("unroll") for (int u = 0; u < 2; u++) q[u] += (h[u].insert & BIT) ? hop_[u] : 0u; }
           SC_HOP(1u, lds_ld8(sb + SC_J1 + (q[u] & SC_M)))
           SC_HOP(2u, lds_ld8(sb + SC_J2 + (q[u] & SC_M)))
           SC_HOP(4u, lds_ld8(sb + SC_J4 + (q[u] & SC_M)))
@@ -444,11 +483,26 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           {  // distances
             uint32_t dlo[2], dhi[2];
             _Pragma("unroll") for (int u = 0; u < 2; u++) sc_bits64(sb, q[u], dlo[u], dhi[u]);
+            SC_STAGE();
             ScDist d[2];
-            _Pragma("unroll") for (int u = 0; u < 2; u++) {
-              const uint32_t dtree = h[u].dctx == 0u ? dt0 : h[u].dctx == 1u ? dt1 : h[u].dctx == 2u ? dt2 : dt3;
-              d[u] = sc_dist(dlo[u], dhi[u], dtree, postfix_bits, num_direct);
+            uint32_t dta[2], de[2], dL[2];
+            _Pragma("unroll") for (int u = 0; u < 2; u++) {  // (sc_dist, the two lookups side by side)
+              dta[u] = h[u].dctx == 0u ? dt0 : h[u].dctx == 1u ? dt1 : h[u].dctx == 2u ? dt2 : dt3;
+              de[u] = lds_ld16(dta[u] + ((dlo[u] & 0xFFu) << 1));
             }
+            SC_STAGE();
+            _Pragma("unroll") for (int u = 0; u < 2; u++) dL[u] = de[u] & 15u;
+            if (__ballot(dL[0] > ROOT_BITS || dL[1] > ROOT_BITS) != 0ull) {
+              uint32_t e2[2];
+              _Pragma("unroll") for (int u = 0; u < 2; u++) {
+                const bool sec = dL[u] > ROOT_BITS;
+                const uint32_t idx = sec ? (de[u] >> 4) + __builtin_amdgcn_ubfe(dlo[u], ROOT_BITS, dL[u] - ROOT_BITS) : (dlo[u] & 0xFFu);
+                e2[u] = lds_ld16(dta[u] + (idx << 1));
+              }
+              SC_STAGE();
+              _Pragma("unroll") for (int u = 0; u < 2; u++) if (dL[u] > ROOT_BITS) { de[u] = e2[u]; dL[u] = ROOT_BITS + (e2[u] & 15u); }
+            }
+            _Pragma("unroll") for (int u = 0; u < 2; u++) d[u] = sc_dist_finish(de[u] >> 4, dL[u], dlo[u], dhi[u], postfix_bits, num_direct);
             _Pragma("unroll") for (int u = 0; u < 2; u++) {
               kind[u] = h[u].implicit ? (uint32_t)SCK_IMPLICIT : d[u].kind; val[u] = h[u].implicit ? 0u : d[u].val;
               if (!h[u].implicit) { q[u] += d[u].bits; ok[u] = ok[u] && val[u] < (1u << 26); }
@@ -464,6 +518,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
             lds_st32(ra + 4u, good ? rhi : 0u);
           }
         }
+#ifdef BROTLI_AMD_PROFILE_SCAN
+        if (me == 1u && blockIdx.x == 0 && lane == 0) g_scan_prof[24] += __builtin_amdgcn_s_memtime() - rec_t0;
+#endif
       }
       // (f_rec moves when the step's D2 / D4 are done, below)
     }
@@ -472,6 +529,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
     // (in STEP ticks the barrier behind S / J1 has put everyone's stores of part 1 in memory; in SYNC and FINAL ticks this one does)
     if (mode != M_STEP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     if (me == SC_WAVES - 1u && sc_ctl_ld(sb, gx + SCG_ANYDEP) != 0u) {
+#ifdef BROTLI_AMD_PROFILE_SCAN
+      const uint64_t dep_t0 = __builtin_amdgcn_s_memtime(); uint32_t dep_n = 0;
+#endif
       // copies of the executed group that read the group's own output: one after the other (a wave's stores are visible
       // to its later loads)
       const uint32_t ng = sc_ctl_ld(sb, gx + SCG_NG);
@@ -484,6 +544,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         while (dm) {
           const uint32_t k = (uint32_t)__builtin_ctzll(dm);
           dm &= dm - 1ull;
+#ifdef BROTLI_AMD_PROFILE_SCAN
+          dep_n++;
+#endif
           const uint32_t n = rdlane(xn, k), dist = rdlane(xd, k), dpos = rdlane(xo, k) + ((rdlane(x0, k) >> 16) & 63u);
           gu8* const dst = o + dpos; gu8* const src = dst - dist;
           if (dist < n) {
@@ -502,6 +565,10 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           }
         }
       }
+#ifdef BROTLI_AMD_PROFILE_SCAN
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (blockIdx.x == 0 && lane == 0) { g_scan_prof[25] += __builtin_amdgcn_s_memtime() - dep_t0; g_scan_prof[26] += dep_n; }
+#endif
     }
     if (me == 0) {
       SCAN_PROF(8);
@@ -707,7 +774,16 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
       if (slot < 2u) lds_st32(sb + SC_IN + ((SC_IN_DW + slot) << 2), pre_v);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef BROTLI_AMD_PROFILE_SCAN
+    sc_ctl_st(sb, me < 4u ? me : 15u + me, (uint32_t)__builtin_amdgcn_s_memtime());  // (when each wave gets to the tick's last barrier)
+#endif
     __syncthreads();  // ---- REC of the step is complete; the group is posted ----
+#ifdef BROTLI_AMD_PROFILE_SCAN
+    if (me == 0 && blockIdx.x == 0 && mode == M_STEP) {
+      const uint32_t t0_ = sc_ctl_ld(sb, 0u);
+      for (uint32_t w = 1; w < SC_WAVES; w++) { const int32_t d_ = (int32_t)(sc_ctl_ld(sb, w < 4u ? w : 15u + w) - t0_); if (lane == 0) g_scan_late[w] += (long long)d_; }
+    }
+#endif
     SCAN_PROF(3);
     if (mode == M_STEP) f_rec += SC_N;
     // ---- what comes next (every wave decides the same from the posted flags) ----
