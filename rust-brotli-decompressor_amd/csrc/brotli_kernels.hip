@@ -3117,11 +3117,6 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
     printf("kernel ticks of block 0: %llu; the engine's ticks: %llu steps, %llu that only walk, %llu last ones\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0),
            g_scan_prof[14], g_scan_prof[15], g_scan_prof[11]);
-  if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0) {
-    printf("ticks behind wave 0 at a step's last barrier, waves 1 .. 15:");
-    for (int w = 1; w < 16; w++) printf(" %lld", g_scan_late[w]);
-    printf("\n");
-  }
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0) printf("wave 1's ticks in REC: %llu; the last wave's in copies that depend on the group's own output: %llu for %llu copies\n", g_scan_prof[24], g_scan_prof[25], g_scan_prof[26]);
   if (blockIdx.x == 0 && lane_id() == 0 && g_scan_prof[17] != 0)
     printf("scan engine exits: input ends %llu, counts/limits %llu, distance %llu, by-hand precheck %llu, long run %llu; invocations that took < 64 commands %llu\n",

@@ -86,8 +86,7 @@ __device__ __forceinline__ uint32_t sc_ctl_ld(uint32_t sb, uint32_t k) { return 
 __device__ __forceinline__ void sc_ctl_st(uint32_t sb, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[sb + SC_CTL + 4u * k]) = v; }
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
-__device__ unsigned long long g_scan_prof[28];
-__device__ long long g_scan_late[16];  // per wave: ticks after wave 0 at the last barrier of a step, summed  // ([24]: wave 1's ticks in REC)
+__device__ unsigned long long g_scan_prof[28];  // ([24]: wave 1's ticks in REC, [25] / [26]: the last wave's dependent copies)
 #define SCAN_PROF(k) do { if (me == 0) { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0) sp_acc[k] += _t - sp_t; sp_t = _t; } } while (0)
 #define SCAN_COUNT(k, v) do { if (me == 0 && blockIdx.x == 0) sp_acc[k] += (v); } while (0)
 #else
@@ -774,16 +773,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
       if (slot < 2u) lds_st32(sb + SC_IN + ((SC_IN_DW + slot) << 2), pre_v);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef BROTLI_AMD_PROFILE_SCAN
-    sc_ctl_st(sb, me < 4u ? me : 15u + me, (uint32_t)__builtin_amdgcn_s_memtime());  // (when each wave gets to the tick's last barrier)
-#endif
     __syncthreads();  // ---- REC of the step is complete; the group is posted ----
-#ifdef BROTLI_AMD_PROFILE_SCAN
-    if (me == 0 && blockIdx.x == 0 && mode == M_STEP) {
-      const uint32_t t0_ = sc_ctl_ld(sb, 0u);
-      for (uint32_t w = 1; w < SC_WAVES; w++) { const int32_t d_ = (int32_t)(sc_ctl_ld(sb, w < 4u ? w : 15u + w) - t0_); if (lane == 0) g_scan_late[w] += (long long)d_; }
-    }
-#endif
     SCAN_PROF(3);
     if (mode == M_STEP) f_rec += SC_N;
     // ---- what comes next (every wave decides the same from the posted flags) ----
