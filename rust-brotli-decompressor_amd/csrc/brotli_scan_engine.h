@@ -613,13 +613,21 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           }
           // one LDS round trip per hop: four commands where D4 knows the way, two where D2 does (the end of a region,
           // mostly), else one (D2 / D4 and the command's own length are asked for together)
+          // (the next hop's two reads go out before this hop is written down: the walk is a chain of LDS round trips, and
+          // what lies between two of them is all that can be taken off it; a read at or beyond walk_limit is not used)
+          uint32_t d24_ = lds_ld32(sb + SC_D24 + ((b & (SC_N2 - 1u)) << 2)), rec_ = lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3));
           while (K < 64u && b < walk_limit) {
-            const uint32_t d24_ = lds_ld32(sb + SC_D24 + ((b & (SC_N2 - 1u)) << 2)), rec_ = lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3));
             const uint32_t d24 = rfl(d24_), delta = rfl(rec_) & 0x7FFu;
-            if (K <= 60u && (d24 >> 16) != 0u) { SC_ANCHOR(b, 4u); b += d24 >> 16; }
-            else if (K <= 62u && (d24 & 0xFFFFu) != 0u) { SC_ANCHOR(b, 2u); b += d24 & 0xFFFFu; }
-            else if (delta != 0u) { SC_ANCHOR(b, 1u); b += delta; }
+            uint32_t n_, step_;
+            if (K <= 60u && (d24 >> 16) != 0u) { n_ = 4u; step_ = d24 >> 16; }
+            else if (K <= 62u && (d24 & 0xFFFFu) != 0u) { n_ = 2u; step_ = d24 & 0xFFFFu; }
+            else if (delta != 0u) { n_ = 1u; step_ = delta; }
             else break;
+            const uint32_t b_here = b;
+            b += step_;
+            d24_ = lds_ld32(sb + SC_D24 + ((b & (SC_N2 - 1u)) << 2)); rec_ = lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3));
+            SC_STAGE();
+            SC_ANCHOR(b_here, n_);
           }
           if (K >= 64u) break;
           if (b >= walk_limit) { step_done = true; break; }
