@@ -678,22 +678,20 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         const bool pushes = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
         const uint64_t pm = __ballot(pushes);
         int32_t dist = kind == SCK_EXPLICIT ? (int32_t)val : 0;
+        // the pushing lanes in batch order: lane r of `perm` is the lane of the r-th push (every lane is sent somewhere:
+        // the pushes to their rank, the others behind them, so the scatter is a permutation)
+        const uint32_t npush = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));  // pushes in front of this lane
+        const uint32_t n_all = (uint32_t)__popcll(pm);
+        const uint32_t perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((pushes ? npush : n_all + lane - npush) << 2), (int)lane);
         if (__ballot(need) != 0ull) {
           const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
-          // the pushes in front of this lane, as two halves: the (back + 1)-th last of them is the source
-          const uint64_t below = pm & ((1ull << lane) - 1ull);
-          uint32_t mlo = (uint32_t)below, mhi = (uint32_t)(below >> 32);
-          const uint32_t npush = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+          // the (back + 1)-th last push in front of this lane is the source; the ring the batch started with behind them
           const bool from_carry = npush <= back;
           const uint32_t ci = back - npush;  // (meaningful when from_carry)
           const int32_t carry = ci == 0u ? d0 : ci == 1u ? d1 : ci == 2u ? d2 : d3;
-          _Pragma("unroll") for (uint32_t t = 0; t < 3u; t++) {
-            const bool clr = t < back && !from_carry;
-            const uint32_t h = mhi ? 31u - (uint32_t)__clz(mhi) : 0u, l = mlo ? 31u - (uint32_t)__clz(mlo) : 0u;
-            const uint32_t nhi = mhi & ~(1u << h), nlo = mhi ? mlo : mlo & ~(1u << l);
-            mhi = clr ? nhi : mhi; mlo = clr ? nlo : mlo;
-          }
-          const uint32_t src = from_carry ? 0u : (mhi ? 63u - (uint32_t)__clz(mhi) : mlo ? 31u - (uint32_t)__clz(mlo) : 0u);
+          // (read by every lane: inside a branch the permute would only see the lanes that took it; a lane that takes its value
+          // from the old ring reads some lane and does not look at what it got)
+          const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
           uint32_t resolved = need ? 0u : 1u;
           const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
           while (__ballot(resolved == 0u) != 0ull) {
@@ -737,20 +735,15 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
         if (kp != 0u) { const uint32_t t1 = rdlane(s1, kp - 1u); lit_tot = t1 & 0xFFFFu; cmd_tot = (t1 >> 16) & 0xFFu; dst_tot = t1 >> 24; out_tot = rdlane(s2, kp - 1u); }
         cmd_tot += extra_cmd; dst_tot += extra_dst;
         {  // the ring after the executed lanes: their last pushes in front of the old entries
-          uint64_t pk = pm & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull));
-          uint32_t got = 0;
-          int32_t nv[4] = {0, 0, 0, 0};
-          for (uint32_t t = 0; t < 4u; t++) {
-            if (pk == 0ull) break;
-            const uint32_t l = sc_msb64(pk);
-            nv[t] = (int32_t)rdlane((uint32_t)dist, l);
-            pk &= ~(1ull << l); got++;
+          const uint32_t got = (uint32_t)__popcll(pm & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)));
+          if (got != 0u) {
+            const uint32_t dperm = bperm(perm << 2, (uint32_t)dist);  // lane r: the distance of the r-th push
+            const int32_t o0 = d0, o1 = d1, o2 = d2;
+            d0 = (int32_t)rdlane(dperm, got - 1u);
+            d1 = got >= 2u ? (int32_t)rdlane(dperm, got - 2u) : o0;
+            d2 = got >= 3u ? (int32_t)rdlane(dperm, got - 3u) : got == 2u ? o0 : o1;
+            d3 = got >= 4u ? (int32_t)rdlane(dperm, got - 4u) : got == 3u ? o0 : got == 2u ? o1 : o2;
           }
-          const int32_t o0 = d0, o1 = d1, o2 = d2;
-          if (got == 1u) { d0 = nv[0]; d1 = o0; d2 = o1; d3 = o2; }
-          else if (got == 2u) { d0 = nv[0]; d1 = nv[1]; d2 = o0; d3 = o1; }
-          else if (got == 3u) { d0 = nv[0]; d1 = nv[1]; d2 = nv[2]; d3 = o0; }
-          else if (got == 4u) { d0 = nv[0]; d1 = nv[1]; d2 = nv[2]; d3 = nv[3]; }
         }
         if (kp != 0u) {
           // the batch for the executing waves; a copy whose source reaches into the group's own output is wave 0's (bit 31)
