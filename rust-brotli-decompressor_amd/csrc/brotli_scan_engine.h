@@ -618,11 +618,11 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_) {
           uint32_t d24_ = lds_ld32(sb + SC_D24 + ((b & (SC_N2 - 1u)) << 2)), rec_ = lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3));
           while (K < 64u && b < walk_limit) {
             const uint32_t d24 = rfl(d24_), delta = rfl(rec_) & 0x7FFu;
-            uint32_t n_, step_;
-            if (K <= 60u && (d24 >> 16) != 0u) { n_ = 4u; step_ = d24 >> 16; }
-            else if (K <= 62u && (d24 & 0xFFFFu) != 0u) { n_ = 2u; step_ = d24 & 0xFFFFu; }
-            else if (delta != 0u) { n_ = 1u; step_ = delta; }
-            else break;
+            // (selects, not branches: the scalar unit does them in a handful of instructions)
+            const uint32_t d4_ = K <= 60u ? d24 >> 16 : 0u, d2_ = K <= 62u ? d24 & 0xFFFFu : 0u;
+            const uint32_t step_ = d4_ != 0u ? d4_ : d2_ != 0u ? d2_ : delta;
+            const uint32_t n_ = d4_ != 0u ? 4u : d2_ != 0u ? 2u : 1u;
+            if (step_ == 0u) break;
             const uint32_t b_here = b;
             b += step_;
             d24_ = lds_ld32(sb + SC_D24 + ((b & (SC_N2 - 1u)) << 2)); rec_ = lds_ld32(sb + SC_REC + ((b & (SC_N2 - 1u)) << 3));
