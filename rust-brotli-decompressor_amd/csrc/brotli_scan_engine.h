@@ -17,14 +17,16 @@
 //               packed with the bit distance to the next command
 //     D2 / D4   bits from this bit to the second / fourth command after the one that would start here
 //   pass 2:
-//     walk      wave 0 follows the stream's real chain through D4 / REC: one LDS round trip per four commands; the lanes
-//               behind such an anchor find their own command (64 entries a batch, up to SC_GROUP batches a tick)
+//     walk      wave 0 follows the stream's real chain through D4 / D2 / REC: one LDS round trip per four commands, the
+//               next hop's words asked for before the current hop is written down; the lanes behind such an anchor find
+//               their own command (64 entries a batch, up to SC_GROUP batches a tick)
 //     resolve   wave 0, lane = command: output offsets (prefix sums), block counts, the distance ring
 //               (decode.rs:2017-2049) and every limit the reference checks; the first command that needs anything
-//               unusual (dictionary word, overlapping copy, block switch, end of the metablock / output / ring segment)
+//               unusual (dictionary word, invalid distance, block switch, end of the metablock / output / ring segment)
 //               ends the engine's part in front of it and the checked command loop takes over for that command
 //     execute   all waves: literals out of S through J*, and the LZ77 copies (decode.rs:2641-2680) whose source lies in
-//               front of the group; copies that read the group's own output are done afterwards, in order, by wave 0
+//               front of the group; copies that read the group's own output (overlapping ones among them, as pattern
+//               fills) are done afterwards, in order, by the last wave
 //   The passes overlap: while the other fifteen waves build REC for step s, wave 0 walks and resolves the region of
 //   step s - 1 (REC, D2 and D4 are double-buffered), and what it posts is executed by everyone at the start of step s + 1.
 //
