@@ -113,6 +113,78 @@ extern "C" {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// batches (include/brotli/batch.h; not in the reference: many independent streams in one launch, buffers in device or
+// host memory) -- untested source like the rest of this crate
+// ---------------------------------------------------------------------------------------------------
+#[repr(C)]
+pub struct BrotliAmdBatch {
+    _private: [u8; 0],
+}
+
+/// batch.h: BrotliAmdResult
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct BrotliAmdResult {
+    pub result: i32,
+    pub error_code: i32,
+    pub decoded_size: u64,
+    pub consumed: u64,
+    pub produced: u64,
+    pub num_metablocks: u32,
+    pub spilled_metablocks: u32,
+    pub num_commands: u64,
+}
+
+pub const BROTLI_AMD_BATCH_LARGE_WINDOW: u32 = 1;
+pub const BROTLI_AMD_BATCH_NO_CANNY: u32 = 2;
+pub const BROTLI_AMD_BATCH_SPILL_IN_PLACE: u32 = 16;
+pub const BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT: u32 = 64;
+
+extern "C" {
+    pub fn BrotliAmdBatchCreate(max_streams: u32, lds_arena_bytes: u32, grid_blocks: u32) -> *mut BrotliAmdBatch;
+    pub fn BrotliAmdBatchDestroy(batch: *mut BrotliAmdBatch);
+    /// device pointers; asynchronous on `hip_stream` (a `hipStream_t`, may be null) until `BrotliAmdBatchWait`
+    pub fn BrotliAmdBatchDecodeDevice(
+        batch: *mut BrotliAmdBatch, n: u32, d_in: *const *const c_void, in_sizes: *const size_t, d_out: *const *mut c_void,
+        out_caps: *const size_t, flags: u32, hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn BrotliAmdBatchRelaunch(batch: *mut BrotliAmdBatch, hip_stream: *mut c_void) -> c_int;
+    pub fn BrotliAmdBatchWait(batch: *mut BrotliAmdBatch, results: *mut BrotliAmdResult) -> c_int;
+    /// host pointers; synchronous
+    pub fn BrotliAmdBatchDecodeHost(
+        batch: *mut BrotliAmdBatch, n: u32, input: *const *const u8, in_sizes: *const size_t, output: *const *mut u8,
+        out_caps: *const size_t, flags: u32, results: *mut BrotliAmdResult,
+    ) -> c_int;
+    pub fn BrotliAmdBatchLastKernelMs(batch: *mut BrotliAmdBatch) -> f32;
+    pub fn BrotliAmdBatchLastSecondPassCount(batch: *mut BrotliAmdBatch) -> u32;
+    pub fn BrotliAmdLastError() -> *const c_char;
+}
+
+/// Decodes `inputs[i]` into `outputs[i]` (host memory) in one launch; `None` when the device or the runtime failed
+/// (`BrotliAmdLastError`).
+pub fn decode_batch(inputs: &[&[u8]], outputs: &mut [&mut [u8]], flags: u32) -> Option<Vec<BrotliAmdResult>> {
+    assert_eq!(inputs.len(), outputs.len());
+    let n = inputs.len();
+    let in_ptrs: Vec<*const u8> = inputs.iter().map(|s| s.as_ptr()).collect();
+    let in_sizes: Vec<size_t> = inputs.iter().map(|s| s.len()).collect();
+    let out_ptrs: Vec<*mut u8> = outputs.iter_mut().map(|s| s.as_mut_ptr()).collect();
+    let out_caps: Vec<size_t> = outputs.iter().map(|s| s.len()).collect();
+    let mut results = vec![BrotliAmdResult::default(); n];
+    unsafe {
+        let b = BrotliAmdBatchCreate(n.max(1) as u32, 0, 0);
+        if b.is_null() {
+            return None;
+        }
+        let rc = BrotliAmdBatchDecodeHost(b, n as u32, in_ptrs.as_ptr(), in_sizes.as_ptr(), out_ptrs.as_ptr(), out_caps.as_ptr(), flags, results.as_mut_ptr());
+        BrotliAmdBatchDestroy(b);
+        if rc != 0 {
+            return None;
+        }
+    }
+    Some(results)
+}
+
+// ---------------------------------------------------------------------------------------------------
 // the crate's one-shot function (src/lib.rs:447-468): BrotliResult + bytes written
 // ---------------------------------------------------------------------------------------------------
 /// `brotli_decode(input, output)` of the reference: decodes a whole stream into `output`
