@@ -34,6 +34,8 @@ typedef struct BrotliAmdResult {
   uint32_t num_metablocks;
   uint32_t spilled_metablocks; /* metablocks whose tables did not fit the LDS arena (slower path; raise lds_arena_bytes) */
   uint64_t num_commands;
+  uint32_t engine_commands;    /* of num_commands, how many a command engine took (blocks of sixteen waves, one stream a CU) */
+  uint32_t reserved;
 } BrotliAmdResult;
 
 #define BROTLI_AMD_BATCH_LARGE_WINDOW 1u /* accept large-window streams (reference one-shot default, lib.rs:457) */

@@ -41,7 +41,8 @@ class ReturnInfo(ctypes.Structure):  # BrotliDecoderReturnInfo, reference src/li
 class BatchResult(ctypes.Structure):  # BrotliAmdResult
     _fields_ = [("result", ctypes.c_int32), ("error_code", ctypes.c_int32), ("decoded_size", ctypes.c_uint64),
                 ("consumed", ctypes.c_uint64), ("produced", ctypes.c_uint64), ("num_metablocks", ctypes.c_uint32),
-                ("spilled_metablocks", ctypes.c_uint32), ("num_commands", ctypes.c_uint64)]
+                ("spilled_metablocks", ctypes.c_uint32), ("num_commands", ctypes.c_uint64),
+                ("engine_commands", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 def build(force=False):

@@ -265,6 +265,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
       BrotliAmdStreamStatus next = b->h_retry_status[j];
       next.num_metablocks += first.num_metablocks;  // (the metablock a pass stopped in front of is counted by the pass that decodes it)
       next.num_commands += first.num_commands;
+      next.engine_commands += first.engine_commands;
       next.peak_trees = std::max(next.peak_trees, first.peak_trees); next.peak_map_bytes = std::max(next.peak_map_bytes, first.peak_map_bytes);
       next.any_compressed |= first.any_compressed;
       first = next;
@@ -473,6 +474,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
       BrotliAmdResult& r = results[i];
       r.result = s.result; r.error_code = s.error_code; r.decoded_size = s.decoded_size; r.consumed = s.consumed;
       r.produced = s.produced; r.num_metablocks = s.num_metablocks; r.spilled_metablocks = s.spilled_metablocks; r.num_commands = s.num_commands;
+      r.engine_commands = s.engine_commands; r.reserved = 0;
     }
   }
   return 0;

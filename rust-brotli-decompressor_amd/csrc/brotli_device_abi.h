@@ -80,7 +80,8 @@ typedef struct BrotliAmdStreamStatus {
   // and one u32, huffman/mod.rs:61-72), bytes of context modes and maps alive in one metablock at most (decode.rs:1295,
   // 3155), the emulated ring buffer (decode.rs:1843-1855), and whether any compressed metablock was started (the block
   // type and block length trees, decode.rs:2958-2969)
-  uint32_t peak_trees, peak_map_bytes, any_compressed, reserved2;
+  uint32_t peak_trees, peak_map_bytes, any_compressed;
+  uint32_t engine_commands;  // of num_commands, how many a command engine took (blocks of sixteen waves): lets tests prove which path ran
   uint64_t ring_bytes;
 } BrotliAmdStreamStatus;
 

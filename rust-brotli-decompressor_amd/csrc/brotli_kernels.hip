@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "brotli_device_abi.h"
 #define BROTLI_TABLE_QUAL __constant__ const
@@ -423,6 +424,7 @@ struct Stream {
   uint32_t bl_vgpr;        // per-lane: block length code LUT image
   uint32_t num_metablocks, num_spilled;
   uint64_t num_commands;
+  uint32_t engine_commands;
   uint32_t peak_trees, peak_maps, any_compressed;  // what the reference's allocators would have been asked for (see BrotliAmdStreamStatus)
 #ifdef BROTLI_AMD_PROFILE
   uint64_t prof[6];
@@ -967,7 +969,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   helper's answer, round moved.
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
        HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */ };
-enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4 };  // HC_KIND
+enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
        // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
@@ -1136,6 +1138,10 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
 }
 
 __device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
+__device__ __noinline__ uint32_t path_engine(const uint32_t me_);
+// which command engine blocks of sixteen waves use: 0 = the path engine where it applies (brotli_path_engine.h), 1 = the scan
+// engine only (experiments, A/B tests: BROTLI_AMD_ENGINE=scan)
+__device__ uint32_t g_engine_mode = 0;
 
 __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */, gu8* scratch_sym) {
   const uint32_t lane = lane_id();
@@ -1155,6 +1161,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     lds_acquire();
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
+    if (kind == HK_PATH) { path_engine(me); continue; }
     if (kind != HK_ROUND) return;
     if (rfl(me) >= hc_ld(HC_NW)) continue;                // (rounds are for the first eight waves of a block)
     spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
@@ -1615,6 +1622,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 }
 
 #include "brotli_scan_engine.h"
+#include "brotli_path_engine.h"
 
 // The pending copy of the lean loop lives in registers the compiler does not know about: v[120:123] (16 bytes per lane)
 // and v124 (one byte per lane), named in inline asm only.  As C++ variables they were shuffled through other registers
@@ -1932,6 +1940,7 @@ struct HotArgs {
   uint32_t lut_vgpr, bl_vgpr;
   uint64_t spec_scratch;   // global address of the helper waves' literal scratch
   uint64_t num_commands;
+  uint32_t engine_commands, reserved_;  // commands a command engine (scan or path) took
   uint64_t resume_out;     // global address of the status' BrotliAmdResume: command boundaries close to the end of the input are noted there
   uint64_t prof[6];
 };
@@ -1974,6 +1983,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   const uint32_t postfix_bits = rfl(args->postfix_bits), num_direct = rfl(args->num_direct);
   const uint32_t lut_vgpr = args->lut_vgpr, bl_vgpr = args->bl_vgpr;  // per-lane LUT images
   uint64_t num_commands = rfl(args->num_commands);
+  uint32_t engine_commands = rfl(args->engine_commands);
   int result = E_SUCCESS;
   uint64_t prof_cmd = 0, prof_lit = 0, prof_dist = 0, prof_copy = 0, prof_t = PROF_T();
   (void)prof_cmd; (void)prof_lit; (void)prof_dist; (void)prof_copy; (void)prof_t;
@@ -2075,7 +2085,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       const uint64_t abs_bit = br.pos() + BitReader::skip_bits();
       const uint64_t origin = abs_bit & ~63ull;
       const uint64_t avail = BitReader::total_bits() + BitReader::skip_bits() - origin;
-      if (avail >= 8u * SC_N && (origin >> 5) < 0xFFFFFFFFull) {
+      // the path engine where the four distance contexts share one prefix code (its states do not carry the context)
+      const bool use_path = dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && g_engine_mode == 0u;
+      if (avail >= (use_path ? 2u * PE_MIN_INPUT : 8u * SC_N) && (origin >> 5) < 0xFFFFFFFFull) {
         FLUSH_LITERALS();
         FLUSH_PENDING();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the other waves read the output as copy sources
@@ -2092,10 +2104,11 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         sc_ctl_st(sb, SCC_DT0, LDS_FIXED + dt0); sc_ctl_st(sb, SCC_DT0 + 1, LDS_FIXED + dt1); sc_ctl_st(sb, SCC_DT0 + 2, LDS_FIXED + dt2); sc_ctl_st(sb, SCC_DT0 + 3, LDS_FIXED + dt3);
         sc_ctl_st(sb, SCC_POSTFIX, postfix_bits); sc_ctl_st(sb, SCC_NUM_DIRECT, num_direct);
         sc_ctl_st(sb, SCC_OUT_LO, (uint32_t)(uintptr_t)out); sc_ctl_st(sb, SCC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
-        hc_st(HC_KIND, HK_SCAN);
+        hc_st(HC_KIND, use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
-        const uint32_t took = rfl(scan_engine(0));
+        const uint32_t took = use_path ? rfl(path_engine(0)) : rfl(scan_engine(0));
+        engine_commands += took;
         {  // the literal rounds' mailbox words lie in the engine's rings: back to their idle state
           const uint32_t hb_ = hc_ld(HC_BASE);
           for (uint32_t t = lane; t < SC_WAVES * 16u; t += 64u) lds_st32(hb_ + (t >> 4) * HL_SLOT + HL_CTL + 4u * (t & 15u), 0u);
@@ -2632,6 +2645,7 @@ done:
   args->P = P; args->next_boundary = next_boundary; args->mlen = mlen;
   args->d0 = d0; args->d1 = d1; args->d2 = d2; args->d3 = d3;
   args->num_commands = num_commands;
+  args->engine_commands = engine_commands;
 #ifdef BROTLI_AMD_PROFILE
   if (lane == 0 && blockIdx.x == 0) printf("lean exits by stage: %u %u %u %u %u %u %u %u\n", prof_stage[0], prof_stage[1], prof_stage[2], prof_stage[3], prof_stage[4], prof_stage[5], prof_stage[6], prof_stage[7]);
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
@@ -2689,6 +2703,7 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
   h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
   h.spec_scratch = (uint64_t)(uintptr_t)(s.ar.glb + s.ar_end);
   h.num_commands = s.num_commands;
+  h.engine_commands = s.engine_commands;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
   int e;
@@ -2715,6 +2730,7 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
   s.P = rfl(h.P); s.next_boundary = rfl(h.next_boundary); s.mlen = rfl(h.mlen);
   s.dist_rb0 = rfl(h.d0); s.dist_rb1 = rfl(h.d1); s.dist_rb2 = rfl(h.d2); s.dist_rb3 = rfl(h.d3);
   s.num_commands = rfl(h.num_commands);
+  s.engine_commands = rfl(h.engine_commands);
 #ifdef BROTLI_AMD_PROFILE
   s.prof[0] += h.prof[0]; s.prof[1] += h.prof[1]; s.prof[2] += h.prof[2]; s.prof[3] += h.prof[3]; s.prof[4] += h.prof[4]; s.prof[5] += h.prof[5];
 #endif
@@ -2976,7 +2992,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       if (lane == 0) {
         BrotliAmdStreamStatus* st = status + idx;
         st->result = 0; st->error_code = E_UNREACHABLE; st->decoded_size = 0; st->consumed = 0; st->produced = 0;
-        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0;
+        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0; st->engine_commands = 0;
       }
     }
   }
@@ -3011,7 +3027,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     s.in_bytes = as_global<gcu8>(d.in);
     s.flags = d.flags;
     s.lut_vgpr = lut; s.bl_vgpr = bl;
-    s.num_metablocks = 0; s.num_spilled = 0; s.num_commands = 0;
+    s.num_metablocks = 0; s.num_spilled = 0; s.num_commands = 0; s.engine_commands = 0;
     s.peak_trees = 0; s.peak_maps = 0; s.any_compressed = 0;
     s.mlen = 0;
 #ifdef BROTLI_AMD_PROFILE
@@ -3025,7 +3041,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
                    (d.resume.mid_valid != 0u && (d.resume.mid_out_pos > d.out_cap || d.resume.mid_bit_pos > d.in_size * 8)))) {  // a resume block that does not belong to these buffers
       if (lane == 0) {
         st->result = 0; st->error_code = E_UNREACHABLE; st->decoded_size = 0; st->consumed = 0; st->produced = 0;
-        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0; st->resume = d.resume;
+        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0; st->engine_commands = 0; st->resume = d.resume;
       }
       continue;
     }
@@ -3087,6 +3103,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       st->produced = s.P;
       st->num_metablocks = s.num_metablocks;
       st->num_commands = s.num_commands;
+      st->engine_commands = s.engine_commands;
       st->spilled_metablocks = s.num_spilled;
       st->peak_trees = s.peak_trees; st->peak_map_bytes = s.peak_maps; st->ring_bytes = s.rb_size; st->any_compressed = s.any_compressed;
 #ifdef BROTLI_AMD_PROFILE
@@ -3137,6 +3154,14 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   // (sixteen waves: a block with the command engine; otherwise at most eight)
   const uint32_t waves = no_helpers || helper_waves < 2 ? 1u : (uint32_t)helper_waves >= SC_WAVES ? SC_WAVES : (uint32_t)helper_waves > 8u ? 8u : (uint32_t)helper_waves;
   size_t smem = (size_t)LDS_FIXED + lds_arena_bytes + brotli_amd_lds_helper_bytes(waves);
+  {  // BROTLI_AMD_ENGINE=scan: the round-2 command engine only (A/B tests); the symbol is per device
+    static const char* const eng = getenv("BROTLI_AMD_ENGINE");
+    if (eng != nullptr) {
+      const uint32_t mode = strcmp(eng, "scan") == 0 ? 1u : 0u;
+      hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
+      if (e2 != hipSuccess) return e2;
+    }
+  }
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
   // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four

@@ -1,0 +1,692 @@
+// brotli_path_engine.h -- the path engine: the command engine of round 3 (included by brotli_kernels.hip inside its
+// namespace, behind brotli_scan_engine.h, whose per-lane parsers it shares).
+//
+// What it replaces: the same serial walk as the scan engine (src/decode.rs:2359-2726, ProcessCommandsInternal, for
+// metablocks whose literals do not depend on context), for the same blocks of sixteen waves that own one stream.  The scan
+// engine parses a command at EVERY bit and lifts a literal-skip table over every bit; 92 % of the bits of the metric's
+// streams are literal code words, and a command starts at one bit in a hundred.  The path engine does the work in proportion
+// to what is there, region by region (PE_RBL stream bits, everything in LDS):
+//
+//   J1     the length of the literal code word that would start at every bit (decode.rs:378-398), eight bits per lane
+//   path   the chain of literal code words from the region's first bit -- the LITERAL PATH: wherever the stream is inside a
+//          literal run longer than a few symbols, its code words are the path's (prefix codes re-synchronise).  One lane
+//          per 32 bits follows J1 from a guessed entry; the guesses are replaced by the exits of the chunks before until
+//          nothing changes (what does not settle in PE_SYNC_ROUNDS rounds cuts the region short, nothing else).  Ranks by
+//          prefix sum: por[rank] = bit, lit[rank] = the literal.  "n literals on from a bit of the path" is one lookup.
+//   REC    a STATE is (bit, kind): kind E = "a distance code starts here, then a command" (decode.rs:2066-2131,
+//          2134-2189), kind I = "a command starts here" (the command before had an implicit distance).  The record of a
+//          state is the state its command's literal run ends in: head parsed, the run followed through J1 until it is on
+//          the path (a few hops), the rest of it by rank.  Records are computed for every path bit as kind E (where literal
+//          runs that met the path end), then for the states those records lead to that are not path states (runs that ended
+//          before they met the path, implicit distances) -- round by round until nothing new turns up (the CLOSURE).  The
+//          stream's own chain never leaves that set: its first state is seeded, and a record's successor is in the set by
+//          construction.  ~27 records per real command instead of the scan engine's 96, and no lifting tables.
+//   walk   wave 0 follows next[] from the region's entry eight commands a hop (NEXT8), the lanes behind an anchor fill in
+//          theirs; a record that hit a cap (hops, closure room) is evaluated by the walker itself, uncapped.
+//   details / resolve / execute
+//          lane = command: each real command is parsed once more for its fields, then exactly the scan engine's resolve
+//          (offsets, block counts, distance ring of decode.rs:2017-2049, every limit; the first command that needs the
+//          checked loop ends the engine's part in front of it), then literals (out of lit[] by rank; the few before the run
+//          met the path are decoded again) and LZ77 copies (decode.rs:2641-2680), the ones that read the region's own
+//          output last and in order.
+//
+// Nothing depends on a guess: a record is the exact parse of its state or a marker (END: the parse leaves the region;
+// BYHAND: a cap was hit), and the walk starts at the stream's real position.
+#pragma once
+
+constexpr uint32_t PE_RBL = 32768;                // stream bits per region (local bit 0 = the dword the entry lies in)
+constexpr uint32_t PE_CHUNKS = PE_RBL / 32;       // one lane per chunk of 32 bits: the whole block
+constexpr uint32_t PE_RANKS = 6656;               // path positions of a region at most (the region is cut where they run out)
+constexpr uint32_t PE_WCAP = 8192;                // closure states at most (records that would need more say BYHAND)
+constexpr uint32_t PE_STATES = PE_RANKS + PE_WCAP;
+constexpr uint32_t PE_HOPCAP = 16;                // hops through J1 a record may take before its run is on the path
+constexpr uint32_t PE_SYNC_ROUNDS = 24;           // rounds the chunk entries get to settle
+constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
+constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
+static_assert(PE_CHUNKS == 64u * SC_WAVES, "one chunk per lane of the block");
+
+// LDS layout, offsets from the engine's base (the scan engine's: the two never run at the same time)
+constexpr uint32_t PE_CTL = 0;                                    // 512: control words (the first 32 as the scan engine's)
+constexpr uint32_t PE_IN = 512;                                   // the region's input: PE_RBL / 32 + 6 dwords
+constexpr uint32_t PE_J1F = PE_IN + (PE_RBL / 32 + 8) * 4;        // code length at every bit, bit 7: on the path; later NEXT8
+constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per state: the state eight commands on
+constexpr uint32_t PE_PM = PE_J1F + PE_RBL + 64;                  // u32 per chunk: which of its bits are on the path; later OFF
+constexpr uint32_t PE_OFF = PE_PM;                                // u32 per listed command: where its output starts (from the region's)
+constexpr uint32_t PE_CB = PE_PM + PE_CHUNKS * 4;                 // u16 per chunk: path positions in front of it
+constexpr uint32_t PE_EX = PE_CB + PE_CHUNKS * 2 + 16;            // 2 x u8 per chunk: where the chain leaves it (two buffers)
+constexpr uint32_t PE_POR = PE_EX + 2 * PE_CHUNKS + 16;           // u16 per rank: its bit
+constexpr uint32_t PE_LIT = PE_POR + PE_RANKS * 2;                // u8 per rank: its literal
+constexpr uint32_t PE_NEXT = PE_LIT + PE_RANKS;                   // u16 per state: the state its command's literals end in
+constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2;              // u16 per closure state: bit | kind << 15; later the commands' records
+constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes per listed command
+constexpr uint32_t PE_LIST = PE_WST + PE_WCAP * 2;                // u16 per listed command (+ 1): its state as bit | kind << 15
+constexpr uint32_t PE_SCR = PE_LIST + (PE_CMDS + 8) * 2;          // 256: block-wide scan scratch
+constexpr uint32_t PE_BYTES = PE_SCR + 256;
+static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
+static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_CMDS * 16 <= PE_WCAP * 2 && PE_CMDS * 4 <= PE_CHUNKS * 4, "overlays");
+static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0, "alignment");
+
+enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
+// control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
+enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_WSUM = 80 /* + wave: 16 words */ };
+
+#ifdef BROTLI_AMD_PROFILE_SCAN
+__device__ unsigned long long g_path_prof[40];
+#define PE_PROF(k) do { if (me == 0) { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0) pp_acc[k] += _t - pp_t; pp_t = _t; } } while (0)
+#define PE_COUNT(k, v) do { if (me == 0 && blockIdx.x == 0) pp_acc[k] += (v); } while (0)
+#else
+#define PE_PROF(k) do { } while (0)
+#define PE_COUNT(k, v) do { } while (0)
+#endif
+
+typedef __attribute__((address_space(3))) uint32_t pe_lds_u32;
+__device__ __forceinline__ uint32_t pe_ctl_ld(uint32_t pb, uint32_t k) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * k])); }
+__device__ __forceinline__ void pe_ctl_st(uint32_t pb, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * k]) = v; }
+__device__ __forceinline__ uint32_t pe_atomic_add(uint32_t addr, uint32_t v) {
+  return __hip_atomic_fetch_add(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t pe_atomic_min(uint32_t addr, uint32_t v) {
+  return __hip_atomic_fetch_min(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the 64 stream bits from local bit p of the region
+__device__ __forceinline__ void pe_bits64(uint32_t pb, uint32_t p, uint32_t& lo, uint32_t& hi) {
+  const uint32_t q = pb + PE_IN + ((p >> 5) << 2), sh = p & 31u;
+  const uint32_t a0 = lds_ld32(q), a1 = lds_ld32(q + 4u), a2 = lds_ld32(q + 8u);
+  lo = __builtin_amdgcn_alignbit(a1, a0, sh);
+  hi = __builtin_amdgcn_alignbit(a2, a1, sh);
+}
+__device__ __forceinline__ uint32_t pe_bits32(uint32_t pb, uint32_t p) {
+  const uint32_t q = pb + PE_IN + ((p >> 5) << 2);
+  return __builtin_amdgcn_alignbit(lds_ld32(q + 4u), lds_ld32(q), p & 31u);
+}
+
+// What every phase needs to know about the region (uniform)
+struct PeCtx {
+  uint32_t pb, lit_tree, cmd_tree, dtree, postfix_bits, num_direct, lut_vgpr;
+  uint32_t L;    // bits of the region that may be parsed (a record needs 128 in front of it)
+  uint32_t Lp;   // the path ends in front of this bit
+  uint32_t Rn;   // path positions
+};
+// A state's record, with everything the later phases want from the same parse.
+struct PeParse {
+  uint32_t code;     // 0: next state is path state `next` (a rank); 1: next state is `next` = bit | kind << 15, not a path state; 2: END; 3: BYHAND
+  uint32_t next;
+  uint32_t p, x;     // the command's first bit, its literals' first bit
+  uint32_t insert, copy, implicit;
+  uint32_t u, ry;    // literals before the run is on the path, rank of the first one that is (meaningful when u < insert)
+  uint32_t dkind, dval;  // kind E: the distance code parsed at the state's bit (the distance of the command BEFORE)
+};
+// rank of path bit y
+__device__ __forceinline__ uint32_t pe_rank(uint32_t pb, uint32_t y) {
+  return lds_ld16(pb + PE_CB + ((y >> 5) << 1)) + (uint32_t)__builtin_popcount(lds_ld32(pb + PE_PM + ((y >> 5) << 2)) & ((1u << (y & 31u)) - 1u));
+}
+// The record of state (pos, kind).  Every lane of the wave must call it (the parsers use cross-lane permutes); `on` says
+// whether the lane has a state.  CAPPED: the hop limit of the table rounds; J1: hop through the J1 table (else: decode the
+// literal code words again, for the phases that run when J1's room holds NEXT8).
+template <bool CAPPED, bool J1>
+__device__ __forceinline__ PeParse pe_eval(const PeCtx& c, uint32_t pos, uint32_t kind, bool on) {
+  PeParse r;
+  const uint32_t pb = c.pb;
+  bool ok = on && pos + 128u <= c.L;
+  const uint32_t q = ok ? pos : 0u;
+  uint32_t lo, hi;
+  uint32_t p = q;
+  r.dkind = SCK_IMPLICIT; r.dval = 0;
+  if (__ballot(ok && kind == 0u) != 0ull) {
+    pe_bits64(pb, q, lo, hi);
+    const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
+    if (kind == 0u) { p = q + d.bits; r.dkind = d.kind; r.dval = d.val; }
+  }
+  pe_bits64(pb, p, lo, hi);
+  const ScHead h = sc_head(lo, hi, c.cmd_tree, c.lut_vgpr);
+  r.p = p; r.x = p + h.bits; r.insert = h.insert; r.copy = h.copy; r.implicit = h.implicit;
+  // the literal run: hop by hop until it is on the path (or over), the rest by rank
+  uint32_t y = r.x, n = h.insert, hops = 0, f = 0;
+  for (;;) {
+    const uint32_t yc = y < c.Lp ? y : 0u;
+    bool onp;
+    if (J1) { f = lds_ld8(pb + PE_J1F + yc); onp = (f & 0x80u) != 0u; }
+    else onp = ((lds_ld32(pb + PE_PM + ((yc >> 5) << 2)) >> (yc & 31u)) & 1u) != 0u;
+    const bool go = ok && n != 0u && y < c.Lp && !onp && (!CAPPED || hops < PE_HOPCAP);
+    if (__ballot(go) == 0ull) break;
+    uint32_t len;
+    if (J1) len = f & 15u;
+    else { uint32_t sy; sc_lookup(c.lit_tree, pe_bits32(pb, yc), sy, len); }
+    if (go) { y += len; n--; hops++; }
+  }
+  r.u = hops;
+  const bool inside = y < c.Lp;
+  const uint32_t yc = inside ? y : 0u;
+  const bool onp = ((lds_ld32(pb + PE_PM + ((yc >> 5) << 2)) >> (yc & 31u)) & 1u) != 0u;
+  const uint32_t rk = pe_rank(pb, yc);
+  r.ry = rk;
+  uint32_t code, next;
+  if (!ok || !inside) { code = 2u; next = 0u; }
+  else if (n != 0u) {
+    if (!onp) { code = 3u; next = 0u; }
+    else if (rk + n >= c.Rn) { code = 2u; next = 0u; }
+    else {
+      const uint32_t q2 = lds_ld16(pb + PE_POR + ((rk + n) << 1));
+      if (h.implicit) { code = 1u; next = q2 | 0x8000u; } else { code = 0u; next = rk + n; }
+    }
+  } else if (!h.implicit && onp) { code = 0u; next = rk; }
+  else { code = 1u; next = y | (h.implicit ? 0x8000u : 0u); }
+  r.code = code; r.next = next;
+  return r;
+}
+
+// One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
+// Returns (wave 0) the number of commands it took; exit form and state in LDS_LEAN as the scan engine leaves them.
+__device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
+  const uint32_t lane = lane_id();
+  const uint32_t me = rfl(me_);
+  const uint32_t T = threadIdx.x;
+  const uint32_t pb = hc_ld(HC_SCAN_BASE);
+  __syncthreads();  // the parameters are in place
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  uint64_t pp_acc[32] = {}; uint64_t pp_t = __builtin_amdgcn_s_memtime();
+#endif
+  PeCtx c;
+  c.pb = pb;
+  c.lit_tree = pe_ctl_ld(pb, SCC_LIT_TREE); c.cmd_tree = pe_ctl_ld(pb, SCC_CMD_TREE); c.dtree = pe_ctl_ld(pb, SCC_DT0);
+  c.postfix_bits = pe_ctl_ld(pb, SCC_POSTFIX); c.num_direct = pe_ctl_ld(pb, SCC_NUM_DIRECT);
+  const uint32_t base_dw = pe_ctl_ld(pb, SCC_BASE_DW), in_limit = pe_ctl_ld(pb, SCC_IN_LIMIT);
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)pe_ctl_ld(pb, SCC_OUT_LO) | ((uint64_t)pe_ctl_ld(pb, SCC_OUT_HI) << 32));
+  gcu32* const in_dw = BitReader::base() + base_dw;
+  const uint32_t limit_dw = (in_limit + 31u) >> 5;
+  c.lut_vgpr = 0;
+  if (lane < 24) c.lut_vgpr = (uint32_t)kInsBase[lane] | ((uint32_t)kInsExtra[lane] << 16);
+  else if (lane >= 32 && lane < 56) c.lut_vgpr = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
+
+  // ---- wave 0: the stream's state (uniform) ----
+  uint32_t b = pe_ctl_ld(pb, SCC_ENTRY);  // next command (bits from the engine's origin)
+  uint64_t P = 0; uint32_t quota = 0, bl0 = 0, bl1 = 0, bl2 = 0, ncmd = 0; int32_t mlen = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, max_backward = 0;
+  if (me == 0) {
+    P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+    quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
+    bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
+    d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
+    max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
+  }
+
+  for (;;) {
+    // ================= the region =================
+    if (me == 0) {
+      const uint32_t lbdw = b >> 5;
+      const uint32_t avail = in_limit - (lbdw << 5);
+      const bool go = b < in_limit && avail >= PE_MIN_INPUT && quota >= SC_MIN_QUOTA && bl1 != 0u;
+      pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, b & 31u); pe_ctl_st(pb, PEC_L, avail < PE_RBL ? avail : PE_RBL);
+      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
+      pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
+      pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P >> 32));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the region before: its stores are in memory before anyone reads them as copy sources)
+    __syncthreads();
+    if (pe_ctl_ld(pb, PEC_GO) == 0u) break;
+    const uint32_t lbdw = pe_ctl_ld(pb, PEC_LBDW), le = pe_ctl_ld(pb, PEC_LE);
+    c.L = pe_ctl_ld(pb, PEC_L);
+    const uint64_t P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+    PE_COUNT(20, 1);
+    // ---- input ----
+    for (uint32_t i = T; i < PE_RBL / 32u + 6u; i += 64u * SC_WAVES) lds_st32(pb + PE_IN + (i << 2), lbdw + i < limit_dw ? in_dw[lbdw + i] : 0u);
+    __syncthreads();
+    PE_PROF(0);
+    // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
+    for (uint32_t g = T; g < PE_RBL / 8u; g += 64u * SC_WAVES) {
+      const uint32_t pos0 = g << 3;
+      const uint32_t v = pe_bits32(pb, pos0);
+      uint32_t e[8], Lw[8];
+      _Pragma("unroll") for (int j = 0; j < 8; j++) e[j] = lds_ld16(c.lit_tree + (((v >> j) & 0xFFu) << 1));
+      _Pragma("unroll") for (int j = 0; j < 8; j++) Lw[j] = e[j] & 15u;
+      bool any2 = false;
+      _Pragma("unroll") for (int j = 0; j < 8; j++) any2 = any2 || Lw[j] > ROOT_BITS;
+      if (__ballot(any2) != 0ull) {
+        _Pragma("unroll") for (int j = 0; j < 8; j++) {
+          if (Lw[j] > ROOT_BITS) {
+            const uint32_t idx = (e[j] >> 4) + __builtin_amdgcn_ubfe(v >> j, ROOT_BITS, Lw[j] - ROOT_BITS);
+            Lw[j] = ROOT_BITS + (lds_ld16(c.lit_tree + (idx << 1)) & 15u);
+          }
+        }
+      }
+      const uint32_t w0 = Lw[0] | (Lw[1] << 8) | (Lw[2] << 16) | (Lw[3] << 24), w1 = Lw[4] | (Lw[5] << 8) | (Lw[6] << 16) | (Lw[7] << 24);
+      lds_st32(pb + PE_J1F + pos0, w0); lds_st32(pb + PE_J1F + pos0 + 4u, w1);
+    }
+    __syncthreads();
+    PE_PROF(1);
+    // ---- the path: chunk T's chain from its entry; entries settle round by round ----
+    const uint32_t cbase = T << 5;
+    uint32_t pm = 0, eo = T == 0u ? le : 0u, ex = 0;
+    {
+      uint32_t y = eo;
+      while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
+      ex = y - 32u;
+    }
+    lds_st8(pb + PE_EX + T, ex);
+    uint32_t buf = 0, rounds = 0;
+    for (;;) {
+      __syncthreads();
+      const uint32_t neo = T == 0u ? le : lds_ld8(pb + PE_EX + buf * PE_CHUNKS + T - 1u);
+      bool changed = false;
+      if (neo != eo) {
+        eo = neo;
+        if (neo < 32u && ((pm >> neo) & 1u) != 0u) pm &= ~((1u << neo) - 1u);  // the new entry is on the old chain: its tail stays
+        else {
+          uint32_t y = neo; pm = 0;
+          while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
+          changed = (y - 32u) != ex; ex = y - 32u;
+        }
+      }
+      buf ^= 1u;
+      lds_st8(pb + PE_EX + buf * PE_CHUNKS + T, ex);
+      // did any exit change?  (three flag words in rotation: the one cleared now was last read two rounds ago)
+      const uint32_t fw = pb + PE_CTL + 4u * (PEC_CHG + rounds % 3u);
+      if (T == 0u) lds_st32(pb + PE_CTL + 4u * (PEC_CHG + (rounds + 1u) % 3u), 0u);
+      if (__ballot(changed) != 0ull && lane == 0) lds_st32(fw, 1u);
+      rounds++;
+      __syncthreads();
+      if (rfl(lds_ld32(fw)) == 0u) break;
+      if (rounds >= PE_SYNC_ROUNDS) {
+        // not settled: the path is exact up to the first chunk whose entry is not the exit of the chunk before
+        __syncthreads();
+        const uint32_t neo2 = T == 0u ? le : lds_ld8(pb + PE_EX + buf * PE_CHUNKS + T - 1u);
+        if (neo2 != eo) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T);
+        break;
+      }
+    }
+    PE_COUNT(21, rounds);
+    // bits at or beyond L - 16 are not path positions (a code word there may reach beyond the input)
+    {
+      const uint32_t lim = c.L > 16u ? c.L - 16u : 0u;
+      if (cbase + 32u > lim) pm = cbase >= lim ? 0u : pm & ((1u << (lim - cbase)) - 1u);
+    }
+    __syncthreads();
+    if (T >= pe_ctl_ld(pb, PEC_TMIN)) pm = 0;
+    // ranks: exclusive prefix sum of the chunks' counts over the block
+    uint32_t cnt = (uint32_t)__builtin_popcount(pm);
+    uint32_t incl = sc_scan(cnt);
+    if (lane == 63u) lds_st32(pb + PE_CTL + 4u * (PEC_WSUM + me), incl);
+    __syncthreads();
+    uint32_t wbase = 0;
+    {
+      const uint32_t ws = lane < SC_WAVES ? lds_ld32(pb + PE_CTL + 4u * (PEC_WSUM + lane)) : 0u;
+      const uint32_t wi = sc_scan(ws);
+      wbase = rdlane(wi - ws, me);
+    }
+    uint32_t cb = wbase + incl - cnt;
+    if (cb + cnt > PE_RANKS) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T);  // the ranks run out inside this chunk: the region ends in front of it
+    __syncthreads();
+    const uint32_t tmin = pe_ctl_ld(pb, PEC_TMIN);
+    if (T >= tmin) { pm = 0; cnt = 0; }
+    if (T == tmin || (tmin == PE_CHUNKS && T == PE_CHUNKS - 1u)) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_RN]) = T == tmin ? cb : cb + cnt;
+    lds_st32(pb + PE_PM + (T << 2), pm); lds_st16(pb + PE_CB + (T << 1), cb);
+    {
+      uint32_t m = pm, r = cb;
+      while (m != 0u) {
+        const uint32_t o = (uint32_t)__builtin_ctz(m); m &= m - 1u;
+        const uint32_t pos = cbase + o;
+        lds_st16(pb + PE_POR + (r << 1), pos);
+        lds_st8(pb + PE_J1F + pos, lds_ld8(pb + PE_J1F + pos) | 0x80u);
+        uint32_t sy, ln; sc_lookup(c.lit_tree, pe_bits32(pb, pos), sy, ln);
+        lds_st8(pb + PE_LIT + r, sy);
+        r++;
+      }
+    }
+    if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry
+    __syncthreads();
+    c.Rn = pe_ctl_ld(pb, PEC_RN);
+    {
+      const uint32_t lim = c.L > 16u ? c.L - 16u : 0u, cut = tmin << 5;
+      c.Lp = lim < cut ? lim : cut;
+    }
+    PE_PROF(2);
+    PE_COUNT(22, c.Rn);
+    // ---- records ----
+    // (appending a closure state: one LDS atomic per wave)
+#define PE_STORE_NEXT(id_, on_, r_) do { \
+      const bool app_ = (on_) && (r_).code == 1u; \
+      const uint64_t am_ = __ballot(app_); \
+      uint32_t slot_ = 0; \
+      if (am_ != 0ull) { \
+        uint32_t base_ = 0; \
+        if (lane == 0) base_ = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, (uint32_t)__popcll(am_)); \
+        base_ = rfl(base_); \
+        slot_ = base_ + __builtin_amdgcn_mbcnt_hi((uint32_t)(am_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am_, 0u)); \
+      } \
+      if (on_) { \
+        uint32_t nx_ = (r_).code == 0u ? (r_).next : (r_).code == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND; \
+        if (app_ && slot_ < PE_WCAP) { lds_st16(pb + PE_WST + (slot_ << 1), (r_).next); nx_ = PE_RANKS + slot_; } \
+        lds_st16(pb + PE_NEXT + ((id_) << 1), nx_); \
+      } } while (0)
+    {  // every path position as kind E: lane T takes the positions of its chunk
+      uint32_t m = pm, r = cb;
+      while (__ballot(m != 0u) != 0ull) {
+        const bool on = m != 0u;
+        const uint32_t o = on ? (uint32_t)__builtin_ctz(m) : 0u;
+        m &= m - 1u;
+        const PeParse pr = pe_eval<true, true>(c, cbase + o, 0u, on);
+        PE_STORE_NEXT(r, on, pr);
+        r++;
+      }
+    }
+    PE_PROF(3);
+    {  // the closure: the states the records lead to that are not path states, round by round
+      uint32_t begin = 0, nrounds = 0; (void)nrounds;
+      for (;;) {
+        __syncthreads();
+        uint32_t end = pe_ctl_ld(pb, PEC_WN);
+        end = end < PE_WCAP ? end : PE_WCAP;
+        if (begin >= end) break;
+        __syncthreads();  // (everyone has read the count before anyone appends again)
+        for (uint32_t k0 = begin + 64u * me; k0 < end; k0 += 64u * SC_WAVES) {
+          const uint32_t k = k0 + lane;
+          const bool on = k < end;
+          const uint32_t st = on ? lds_ld16(pb + PE_WST + (k << 1)) : 0u;
+          const PeParse pr = pe_eval<true, true>(c, st & 0x7FFFu, st >> 15, on);
+          PE_STORE_NEXT(PE_RANKS + k, on, pr);
+        }
+        begin = end; nrounds++;
+      }
+      PE_COUNT(23, nrounds); PE_COUNT(24, begin);
+    }
+#undef PE_STORE_NEXT
+    const uint32_t wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
+    PE_PROF(4);
+    // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
+    for (uint32_t i = T; i < PE_RANKS + wn; i += 64u * SC_WAVES) {
+      if (i >= c.Rn && i < PE_RANKS) continue;
+      uint32_t a = i;
+      _Pragma("unroll") for (int h = 0; h < 8; h++) a = a < PEN_FIRST_SPECIAL ? lds_ld16(pb + PE_NEXT + (a << 1)) : (uint32_t)PEN_NONE;
+      // (written behind a barrier: J1's room is still being read by nobody, the records are complete)
+      lds_st16(pb + PE_N8 + (i << 1), a < PEN_FIRST_SPECIAL ? a : (uint32_t)PEN_NONE);
+    }
+    __syncthreads();
+    PE_PROF(5);
+    // ---- the walk (wave 0): the stream's states in order, LIST[k] = bit | kind << 15 of the state command k starts from ----
+    if (me == 0) {
+      uint32_t m = 0;          // commands listed
+      uint32_t id = PE_RANKS;  // the current state's id, or PEN_NONE when it has none (reached by hand)
+      uint32_t desc = le | 0x8000u;
+      uint32_t na = 0;         // anchors of eight-command hops: LIST[m .. m + 7] filled afterwards
+      uint32_t av_m = 0, av_id = 0;  // lane a: anchor a's first list index and state id
+      while (m < PE_CMDS) {
+        if (id != PEN_NONE) {
+          const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
+          if (n8 < PEN_FIRST_SPECIAL && m + 8u <= PE_CMDS && na < 64u) {
+            asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(av_m), "+v"(av_id) : "s"(m), "s"(id), "s"(na) : "m0");
+            na++; m += 8u; id = n8;
+            continue;
+          }
+          // one command: the state goes on the list, its record says where the chain goes
+          if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
+          const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
+          if (nx == PEN_END) break;
+          if (nx != PEN_BYHAND) { if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc); m++; id = nx; continue; }
+        }
+        // a record that hit a cap, or a state that has none (reached by hand): the walker evaluates it itself, uncapped
+        PE_COUNT(25, 1);
+        const PeParse pr = pe_eval<false, false>(c, desc & 0x7FFFu, desc >> 15, true);
+        const uint32_t code = rfl(pr.code), nxt = rfl(pr.next);
+        id = PEN_NONE;
+        if (code >= 2u) break;  // the command's literals leave the region: this state closes the list
+        if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
+        m++;
+        if (code == 0u) id = nxt; else desc = nxt;
+      }
+      // the state the walk stopped at closes the list (the last command's distance is read there)
+      if (id != PEN_NONE) { if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1))); }
+      if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
+      // the lanes behind an anchor: seven more states each
+      for (uint32_t a0 = 0; a0 < na; a0 += 8u) {
+        const uint32_t a = a0 + (lane >> 3), j = lane & 7u;
+        const bool on = a < na;
+        const uint32_t am = bperm((on ? a : 0u) << 2, av_m);
+        uint32_t s = bperm((on ? a : 0u) << 2, av_id);
+        _Pragma("unroll") for (uint32_t h = 0; h < 7u; h++) if (h < j) s = lds_ld16(pb + PE_NEXT + (s << 1));
+        const uint32_t dsc = s < PE_RANKS ? lds_ld16(pb + PE_POR + (s << 1)) : lds_ld16(pb + PE_WST + ((s - PE_RANKS) << 1));
+        if (on) lds_st16(pb + PE_LIST + ((am + j) << 1), dsc);
+      }
+      // the last command needs its distance: 64 bits at the closing state
+      if (m != 0u && (desc >> 15) == 0u && (desc & 0x7FFFu) + 64u > c.L) m--;
+      pe_ctl_st(pb, PEC_M, m);
+      PE_COUNT(26, m); PE_COUNT(27, na);
+    }
+    __syncthreads();
+    PE_PROF(6);
+    const uint32_t m = pe_ctl_ld(pb, PEC_M);
+    // ---- details: lane = command; its fields from the state it starts from, its distance from the state after ----
+    // (the records overlay the closure's states: every lane reads its two list entries, then a barrier, then the stores)
+    {
+      uint32_t w0[PE_CMDS / (64u * SC_WAVES)], w1[PE_CMDS / (64u * SC_WAVES)], w2[PE_CMDS / (64u * SC_WAVES)], w3[PE_CMDS / (64u * SC_WAVES)];
+      _Pragma("unroll") for (uint32_t it = 0; it < PE_CMDS / (64u * SC_WAVES); it++) {
+        const uint32_t k = T + it * 64u * SC_WAVES;
+        w0[it] = w1[it] = w2[it] = w3[it] = 0;
+        if (__ballot(k < m) == 0ull) continue;
+        const bool on = k < m;
+        const uint32_t s0 = on ? lds_ld16(pb + PE_LIST + (k << 1)) : 0u, s1 = on ? lds_ld16(pb + PE_LIST + ((k + 1u) << 1)) : 0u;
+        const PeParse pr = pe_eval<false, false>(c, s0 & 0x7FFFu, s0 >> 15, on);
+        uint32_t kind = SCK_IMPLICIT, val = 0;
+        if (__ballot(on && (s1 >> 15) == 0u) != 0ull) {
+          uint32_t lo, hi;
+          pe_bits64(pb, on ? (s1 & 0x7FFFu) : 0u, lo, hi);
+          const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
+          if ((s1 >> 15) == 0u) { kind = d.kind; val = d.val; }
+        }
+        // a command the fields do not hold goes to the checked loop (bit 30 of w0: the resolve stops in front of it)
+        const bool odd = pr.u > 255u || pr.insert >= 0x10000u || val >= (1u << 30) || pr.code >= 2u;
+        w0[it] = pr.x | ((pr.u & 255u) << 15) | (odd ? 1u << 30 : 0u);
+        w1[it] = (pr.insert & 0xFFFFu) | (pr.ry << 16);
+        w2[it] = pr.copy;
+        w3[it] = (kind << 30) | (val & 0x3FFFFFFFu);
+      }
+      __syncthreads();
+      _Pragma("unroll") for (uint32_t it = 0; it < PE_CMDS / (64u * SC_WAVES); it++) {
+        const uint32_t k = T + it * 64u * SC_WAVES;
+        if (k < m) { const uint32_t ra = pb + PE_REC + (k << 4); lds_st32(ra, w0[it]); lds_st32(ra + 4u, w1[it]); lds_st32(ra + 8u, w2[it]); lds_st32(ra + 12u, w3[it]); }
+      }
+    }
+    __syncthreads();
+    PE_PROF(7);
+    // ---- resolve (wave 0): lane = command, 64 a batch; exactly the scan engine's ----
+    if (me == 0) {
+      uint32_t kp_total = 0, any_dep = 0;
+      bool stop = false;
+      for (uint32_t k0 = 0; k0 < m && !stop; k0 += 64u) {
+        const uint32_t K = m - k0 < 64u ? m - k0 : 64u;
+        const bool active = lane < K;
+        const uint32_t ra = pb + PE_REC + ((k0 + (active ? lane : 0u)) << 4);
+        const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), r2 = lds_ld32(ra + 8u), r3 = lds_ld32(ra + 12u);
+        const uint32_t ins = active ? r1 & 0xFFFFu : 0u, copy = active ? r2 : 0u;
+        const uint32_t kind = active ? r3 >> 30 : (uint32_t)SCK_NONE, val = r3 & 0x3FFFFFFFu;
+        const bool odd = ((r0 >> 30) & 1u) != 0u;
+        const uint32_t isdist = (kind == SCK_EXPLICIT || kind == SCK_SHORT) ? 1u : 0u;
+        const uint32_t lit_incl = sc_scan(ins);
+        const uint32_t s1 = sc_scan((active ? 1u : 0u) | (isdist << 16));
+        const uint32_t cmd_incl = s1 & 0xFFFFu, dst_incl = s1 >> 16;
+        // (a sum of 64 copy lengths stays below 2^31: lengths of 2^24 and more are `odd` below)
+        const bool big = copy >= (1u << 24);
+        const uint32_t s2 = sc_scan(ins + (big ? 0u : copy));
+        const uint32_t out_excl = s2 - (ins + (big ? 0u : copy));
+        bool ok = !odd && !big && lit_incl <= bl0 && cmd_incl <= bl1 && dst_incl <= bl2 && s2 < quota;
+        // the distance ring (TakeDistanceFromRingBuffer, decode.rs:2017-2049): short codes read the last four distances
+        // that were pushed; a lane whose source is itself a short code waits for it
+        const bool need = kind == SCK_SHORT || kind == SCK_IMPLICIT;
+        const uint32_t code = kind == SCK_SHORT ? val : 0u;
+        const bool pushes = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
+        const uint64_t pmk = __ballot(pushes);
+        int32_t dist = kind == SCK_EXPLICIT ? (int32_t)val : 0;
+        const uint32_t npush = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmk, 0u));  // pushes in front of this lane
+        const uint32_t n_all = (uint32_t)__popcll(pmk);
+        const uint32_t perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((pushes ? npush : n_all + lane - npush) << 2), (int)lane);
+        if (__ballot(need) != 0ull) {
+          const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
+          const bool from_carry = npush <= back;
+          const uint32_t ci = back - npush;  // (meaningful when from_carry)
+          const int32_t carry = ci == 0u ? d0 : ci == 1u ? d1 : ci == 2u ? d2 : d3;
+          const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
+          uint32_t resolved = need ? 0u : 1u;
+          const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
+          while (__ballot(resolved == 0u) != 0ull) {
+            const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dist);
+            const uint32_t sr = bperm(src << 2, resolved);
+            const bool can = resolved == 0u && (from_carry || sr != 0u);
+            int32_t v = from_carry ? carry : sv;
+            const int32_t vp = v + mag, vm = v - mag;
+            v = code == 0u ? v : (code & 1u) ? vp : (vm <= 0 ? 0x7fffffff : vm);
+            dist = can ? v : dist; resolved = can ? 1u : resolved;
+          }
+        }
+        {
+          // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
+          const uint64_t pk = P + out_excl + ins;
+          const int32_t maxd = pk < (uint64_t)(uint32_t)max_backward ? (int32_t)pk : max_backward;
+          ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
+        }
+        const uint64_t stopmask = __ballot(active && !ok);
+        const uint32_t kp = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
+        if (kp < K) stop = true;
+        uint32_t lit_tot = 0, cmd_tot = 0, dst_tot = 0, out_tot = 0;
+        if (kp != 0u) { lit_tot = rdlane(lit_incl, kp - 1u); const uint32_t t1 = rdlane(s1, kp - 1u); cmd_tot = t1 & 0xFFFFu; dst_tot = t1 >> 16; out_tot = rdlane(s2, kp - 1u); }
+        {  // the ring after the executed lanes: their last pushes in front of the old entries
+          const uint32_t got = (uint32_t)__popcll(pmk & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)));
+          if (got != 0u) {
+            const uint32_t dperm = bperm(perm << 2, (uint32_t)dist);  // lane r: the distance of the r-th push
+            const int32_t o0 = d0, o1 = d1, o2 = d2;
+            d0 = (int32_t)rdlane(dperm, got - 1u);
+            d1 = got >= 2u ? (int32_t)rdlane(dperm, got - 2u) : o0;
+            d2 = got >= 3u ? (int32_t)rdlane(dperm, got - 3u) : got == 2u ? o0 : o1;
+            d3 = got >= 4u ? (int32_t)rdlane(dperm, got - 4u) : got == 3u ? o0 : got == 2u ? o1 : o2;
+          }
+        }
+        if (kp != 0u) {
+          // a copy whose source reaches into the region's own output is done afterwards, in order (bit 31 of w0)
+          const uint64_t rel = (P - P0) + out_excl;
+          const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
+          if (__ballot(lane < kp && dep != 0u) != 0ull) any_dep = 1u;
+          if (lane < kp) {
+            lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 12u, (uint32_t)dist);
+            lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
+          }
+        }
+        P += out_tot; bl0 -= lit_tot; bl1 -= cmd_tot; bl2 -= dst_tot; quota -= out_tot; mlen -= (int32_t)out_tot; ncmd += cmd_tot;
+        kp_total += kp;
+      }
+      pe_ctl_st(pb, PEC_KP, kp_total); pe_ctl_st(pb, PEC_ANYDEP, any_dep);
+      // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
+      // of the state it starts from)
+      {
+        const uint32_t st = rfl(lds_ld16(pb + PE_LIST + (kp_total << 1)));
+        uint32_t pbit = st & 0x7FFFu;
+        if ((st >> 15) == 0u) {
+          uint32_t lo, hi;
+          pe_bits64(pb, pbit, lo, hi);
+          const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
+          pbit += rfl(d.bits);
+        }
+        b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
+      }
+      // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
+      pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
+    }
+    __syncthreads();
+    PE_PROF(8);
+    const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
+    PE_COUNT(28, kp);
+    // ---- execute ----
+    {
+      gu8* const o = out + P0;
+      // (a) the literals in front of the path: lane = command, decoded again one after the other
+      for (uint32_t k0 = 64u * me; k0 < kp; k0 += 64u * SC_WAVES) {
+        const uint32_t k = k0 + lane;
+        const bool on = k < kp;
+        const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
+        const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u);
+        uint32_t u = on ? (r0 >> 15) & 255u : 0u;
+        const uint32_t ins = r1 & 0xFFFFu;
+        u = u < ins ? u : ins;
+        uint32_t y = r0 & 0x7FFFu;
+        gu8* dst = o + lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
+        while (__ballot(u != 0u) != 0ull) {
+          uint32_t sy, ln;
+          sc_lookup(c.lit_tree, pe_bits32(pb, u != 0u ? y : 0u), sy, ln);
+          if (u != 0u) { *dst = (uint8_t)sy; dst++; y += ln; u--; }
+        }
+      }
+      // (b) wave w takes commands w, w + 16, ...: the literals on the path out of lit[], then the copy if its source lies
+      // in front of the region's output
+      for (uint32_t k = me; k < kp; k += SC_WAVES) {
+        const uint32_t ra = pb + PE_REC + (k << 4);
+        const uint32_t r0 = rfl(lds_ld32(ra)), r1 = rfl(lds_ld32(ra + 4u)), cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
+        const uint32_t off = rfl(lds_ld32(pb + PE_OFF + (k << 2)));
+        const uint32_t ins = r1 & 0xFFFFu, ry = r1 >> 16;
+        uint32_t u = (r0 >> 15) & 255u; u = u < ins ? u : ins;
+        gu8* const lp = o + off + u;
+        const uint32_t n = ins - u;
+        const uint32_t la = pb + PE_LIT + ry;
+        for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
+        if (cn != 0u && (r0 >> 31) == 0u) {
+          gu8* const dst = o + off + ins; gu8* const src = dst - dist;
+          if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
+          else {
+            const uint32_t n16 = cn >> 4;
+            for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+            const uint32_t tail = n16 << 4;
+            if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
+          }
+        }
+      }
+      PE_PROF(9);
+      // (c) copies that read the region's own output: one after the other (a wave's stores are visible to its later loads)
+      if (pe_ctl_ld(pb, PEC_ANYDEP) != 0u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (me == SC_WAVES - 1u) {
+          for (uint32_t k0 = 0; k0 < kp; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            const uint32_t ra = pb + PE_REC + ((k < kp ? k : 0u) << 4);
+            const uint32_t x0 = lds_ld32(ra), x1 = lds_ld32(ra + 4u), xn = lds_ld32(ra + 8u), xd = lds_ld32(ra + 12u), xo = lds_ld32(pb + PE_OFF + ((k < kp ? k : 0u) << 2));
+            uint64_t dm = __ballot(k < kp && (x0 >> 31) != 0u);
+            while (dm) {
+              const uint32_t kk = (uint32_t)__builtin_ctzll(dm);
+              dm &= dm - 1ull;
+              const uint32_t n = rdlane(xn, kk), dist = rdlane(xd, kk), dpos = rdlane(xo, kk) + (rdlane(x1, kk) & 0xFFFFu);
+              gu8* const dst = o + dpos; gu8* const src = dst - dist;
+              if (dist < n) {
+                // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
+                if (dist >= 64u) { for (uint32_t q = lane; q < n + lane; q += 64u) if (q < n) dst[q] = src[q]; }  // a step reads what earlier steps wrote
+                else {
+                  uint32_t mm = lane % dist; const uint32_t step = 64u % dist;
+                  for (uint32_t q = 0; q < n; q += 64u) { if (q + lane < n) dst[q + lane] = src[mm]; mm += step; if (mm >= dist) mm -= dist; }
+                }
+              } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
+              else {
+                const uint32_t n16 = n >> 4;
+                for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+                const uint32_t tail = n16 << 4;
+                if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+              }
+            }
+          }
+        }
+      }
+      PE_PROF(10);
+    }
+    if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
+  if (me != 0) return 0;
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += ncmd; g_path_prof[33] += 1; }
+#endif
+  // ---- hand the stream back in front of the next command (LDS_LEAN, as the scan engine does) ----
+  if (lane == 0) {
+    LEAN_ST(L_SC_POS_LO, b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_BEGIN);
+    LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota); LEAN_ST(L_MLEN, mlen);
+    LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
+    LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
+    LEAN_ST(L_INSERT, 0u); LEAN_ST(L_COPY, 0u); LEAN_ST(L_DCODE, 0); LEAN_ST(L_DCTX, 0u); LEAN_ST(L_LITS_LEFT, 0u);
+  }
+  lds_sync();
+  return ncmd;
+}

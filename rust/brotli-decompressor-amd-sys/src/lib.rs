@@ -133,6 +133,8 @@ pub struct BrotliAmdResult {
     pub num_metablocks: u32,
     pub spilled_metablocks: u32,
     pub num_commands: u64,
+    pub engine_commands: u32,
+    pub reserved: u32,
 }
 
 pub const BROTLI_AMD_BATCH_LARGE_WINDOW: u32 = 1;
