@@ -3139,6 +3139,18 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("scan engine exits: input ends %llu, counts/limits %llu, distance %llu, by-hand precheck %llu, long run %llu; invocations that took < 64 commands %llu\n",
            g_scan_prof[18], g_scan_prof[19], g_scan_prof[20], g_scan_prof[21], g_scan_prof[22], g_scan_prof[23]);
 #endif
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  if (blockIdx.x == 0 && lane_id() == 0 && g_path_prof[33] != 0) {
+    printf("\npath engine: %llu invocations, %llu regions, %llu commands (%llu listed, %llu executed); wave 0 ticks per region: input %llu J1 %llu path %llu records %llu closure %llu next8 %llu walk %llu details %llu resolve %llu execute %llu own copies %llu\n",
+           g_path_prof[33], g_path_prof[20], g_path_prof[32], g_path_prof[26], g_path_prof[28], g_path_prof[0] / g_path_prof[20], g_path_prof[1] / g_path_prof[20], g_path_prof[2] / g_path_prof[20],
+           g_path_prof[3] / g_path_prof[20], g_path_prof[4] / g_path_prof[20], g_path_prof[5] / g_path_prof[20], g_path_prof[6] / g_path_prof[20], g_path_prof[7] / g_path_prof[20],
+           g_path_prof[8] / g_path_prof[20], g_path_prof[9] / g_path_prof[20], g_path_prof[10] / g_path_prof[20]);
+    printf("\npath engine per region: %llu path positions, %llu closure states in %llu.%llu rounds, %llu.%llu sync rounds, %llu anchors; states by hand %llu in all (%llu records met that said so); records that hit the hop cap %llu, the closure cap %llu\n",
+           g_path_prof[22] / g_path_prof[20], g_path_prof[24] / g_path_prof[20], g_path_prof[23] / g_path_prof[20], (g_path_prof[23] * 10 / g_path_prof[20]) % 10,
+           g_path_prof[21] / g_path_prof[20], (g_path_prof[21] * 10 / g_path_prof[20]) % 10, g_path_prof[27] / g_path_prof[20], g_path_prof[25], g_path_prof[31], g_path_prof[29], g_path_prof[30]);
+    printf("\npath engine closure: block rounds %llu (%llu ticks each), wave-0 tails %llu (%llu ticks each), uncapped passes %llu (%llu ticks each)\n", g_path_prof[14], g_path_prof[11] / (g_path_prof[14] + 1), g_path_prof[15], g_path_prof[12] / (g_path_prof[15] + 1), g_path_prof[16], g_path_prof[13] / (g_path_prof[16] + 1));
+  }
+#endif
   // no more streams: the helper waves may go
   hc_st(HC_KIND, 2);
   lds_release();

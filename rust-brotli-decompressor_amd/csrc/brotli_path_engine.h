@@ -39,7 +39,7 @@ constexpr uint32_t PE_CHUNKS = PE_RBL / 32;       // one lane per chunk of 32 bi
 constexpr uint32_t PE_RANKS = 6656;               // path positions of a region at most (the region is cut where they run out)
 constexpr uint32_t PE_WCAP = 8192;                // closure states at most (records that would need more say BYHAND)
 constexpr uint32_t PE_STATES = PE_RANKS + PE_WCAP;
-constexpr uint32_t PE_HOPCAP = 16;                // hops through J1 a record may take before its run is on the path
+constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluation takes; a run that needs more goes on in the lane's next evaluation
 constexpr uint32_t PE_SYNC_ROUNDS = 24;           // rounds the chunk entries get to settle
 constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
@@ -60,8 +60,9 @@ constexpr uint32_t PE_NEXT = PE_LIT + PE_RANKS;                   // u16 per sta
 constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2;              // u16 per closure state: bit | kind << 15; later the commands' records
 constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes per listed command
 constexpr uint32_t PE_LIST = PE_WST + PE_WCAP * 2;                // u16 per listed command (+ 1): its state as bit | kind << 15
-constexpr uint32_t PE_SCR = PE_LIST + (PE_CMDS + 8) * 2;          // 256: block-wide scan scratch
-constexpr uint32_t PE_BYTES = PE_SCR + 256;
+constexpr uint32_t PE_OVF = PE_LIST + (PE_CMDS + 8) * 2;          // u16 per record that hit the hop cap: its state's id
+constexpr uint32_t PE_OVFCAP = 1024;
+constexpr uint32_t PE_BYTES = PE_OVF + PE_OVFCAP * 2;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_CMDS * 16 <= PE_WCAP * 2 && PE_CMDS * 4 <= PE_CHUNKS * 4, "overlays");
 static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0, "alignment");
@@ -69,13 +70,15 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_WSUM = 80 /* + wave: 16 words */ };
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_TAILEND = 99, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
 #define PE_PROF(k) do { if (me == 0) { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0) pp_acc[k] += _t - pp_t; pp_t = _t; } } while (0)
 #define PE_COUNT(k, v) do { if (me == 0 && blockIdx.x == 0) pp_acc[k] += (v); } while (0)
+#define PE_LANECOUNT(k, cond) do { if (blockIdx.x == 0 && (cond)) atomicAdd(&g_path_prof[k], 1ull); } while (0)
 #else
+#define PE_LANECOUNT(k, cond) do { } while (0)
 #define PE_PROF(k) do { } while (0)
 #define PE_COUNT(k, v) do { } while (0)
 #endif
@@ -110,6 +113,7 @@ struct PeCtx {
 };
 // A state's record, with everything the later phases want from the same parse.
 struct PeParse {
+  uint32_t hy, hn;   // code 3: where the run stands (bit, literals left)
   uint32_t code;     // 0: next state is path state `next` (a rank); 1: next state is `next` = bit | kind << 15, not a path state; 2: END; 3: BYHAND
   uint32_t next;
   uint32_t p, x;     // the command's first bit, its literals' first bit
@@ -121,59 +125,168 @@ struct PeParse {
 __device__ __forceinline__ uint32_t pe_rank(uint32_t pb, uint32_t y) {
   return lds_ld16(pb + PE_CB + ((y >> 5) << 1)) + (uint32_t)__builtin_popcount(lds_ld32(pb + PE_PM + ((y >> 5) << 2)) & ((1u << (y & 31u)) - 1u));
 }
-// The record of state (pos, kind).  Every lane of the wave must call it (the parsers use cross-lane permutes); `on` says
-// whether the lane has a state.  CAPPED: the hop limit of the table rounds; J1: hop through the J1 table (else: decode the
-// literal code words again, for the phases that run when J1's room holds NEXT8).
+// The records of NS states per lane, side by side: state t of the lane is (pos[t], kind[t]); `on[t]` says whether it is one.
+// Every lane of the wave must call it (the parsers use cross-lane permutes).  The chains of dependent LDS reads of the NS
+// states are written stage by stage, so that their round trips overlap (an evaluation is some twenty of them in a row).
+// CAPPED: the hop limit of the table rounds; J1: hop through the J1 table (else: decode the literal code words again, for
+// the phases that run when J1's room holds NEXT8).
+// FULL: every field of the parse; otherwise only what the records need (where the run ends, no values).
+// A capped evaluation that ran out of hops says code 3 and leaves where it stands in r.hy / r.hn / r.implicit: given back
+// through `res`, the next call goes on from there (RESUME).
+struct PeResume { bool on; uint32_t y, n, implicit; };
+template <uint32_t NS, bool CAPPED, bool J1, bool RESUME = false, bool FULL = true>
+__device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[NS], const uint32_t (&kind)[NS], const bool (&on)[NS], PeParse (&r)[NS], const PeResume* res = nullptr) {
+  const uint32_t pb = c.pb;
+  bool ok[NS]; uint32_t q[NS], p[NS], lo[NS], hi[NS];
+  bool any_e = false;
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    ok[t] = on[t] && pos[t] + 128u <= c.L; q[t] = ok[t] ? pos[t] : 0u; p[t] = q[t];
+    r[t].dkind = SCK_IMPLICIT; r[t].dval = 0;
+    any_e = any_e || (ok[t] && kind[t] == 0u);
+  }
+  if (__ballot(any_e) != 0ull) {
+    // the distance code at the state's bit (sc_dist, the NS lookups side by side)
+    uint32_t e[NS], Ld[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { if (FULL) pe_bits64(pb, q[t], lo[t], hi[t]); else { lo[t] = pe_bits32(pb, q[t]); hi[t] = 0u; } }
+    SC_STAGE();
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = lds_ld16(c.dtree + ((lo[t] & 0xFFu) << 1));
+    SC_STAGE();
+    bool sec = false;
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { Ld[t] = e[t] & 15u; sec = sec || Ld[t] > ROOT_BITS; }
+    if (__ballot(sec) != 0ull) {
+      uint32_t e2[NS];
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+        const bool s2 = Ld[t] > ROOT_BITS;
+        const uint32_t idx = s2 ? (e[t] >> 4) + __builtin_amdgcn_ubfe(lo[t], ROOT_BITS, Ld[t] - ROOT_BITS) : (lo[t] & 0xFFu);
+        e2[t] = lds_ld16(c.dtree + (idx << 1));
+      }
+      SC_STAGE();
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if (Ld[t] > ROOT_BITS) { e[t] = e2[t]; Ld[t] = ROOT_BITS + (e2[t] & 15u); }
+    }
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      if (FULL) {
+        const ScDist d = sc_dist_finish(e[t] >> 4, Ld[t], lo[t], hi[t], c.postfix_bits, c.num_direct);
+        if (kind[t] == 0u) { p[t] = q[t] + d.bits; r[t].dkind = d.kind; r[t].dval = d.val; }
+      } else {  // only the code's length: the symbol's bits and its extra bits (ReadDistanceInternal, decode.rs:2099-2128)
+        const uint32_t code = e[t] >> 4;
+        const int32_t dv = (int32_t)code - (int32_t)c.num_direct;
+        const uint32_t nb = (code >= 16u && dv >= 0) ? (((uint32_t)dv >> c.postfix_bits) >> 1) + 1u : 0u;
+        if (kind[t] == 0u) p[t] = q[t] + Ld[t] + nb;
+      }
+    }
+  }
+  // the command's head (sc_head)
+  uint32_t y[NS], n[NS], imp[NS];
+  {
+    uint32_t e[NS], Lh[NS], ie[NS], ce[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) pe_bits64(pb, p[t], lo[t], hi[t]);
+    SC_STAGE();
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = lds_ld16(c.cmd_tree + ((lo[t] & 0xFFu) << 1));
+    SC_STAGE();
+    bool sec = false;
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { Lh[t] = e[t] & 15u; sec = sec || Lh[t] > ROOT_BITS; }
+    if (__ballot(sec) != 0ull) {
+      uint32_t e2[NS];
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+        const bool s2 = Lh[t] > ROOT_BITS;
+        const uint32_t idx = s2 ? (e[t] >> 4) + __builtin_amdgcn_ubfe(lo[t], ROOT_BITS, Lh[t] - ROOT_BITS) : (lo[t] & 0xFFu);
+        e2[t] = lds_ld16(c.cmd_tree + (idx << 1));
+      }
+      SC_STAGE();
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if (Lh[t] > ROOT_BITS) { e[t] = e2[t]; Lh[t] = ROOT_BITS + (e2[t] & 15u); }
+    }
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      const uint32_t cmd = e[t] >> 4, cell = cmd >> 6;
+      const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
+      const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+      ie[t] = bperm(ins_code << 2, c.lut_vgpr); ce[t] = bperm((32u + copy_code) << 2, c.lut_vgpr);
+      imp[t] = cmd < 128u ? 1u : 0u;
+    }
+    SC_STAGE();
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      uint64_t w = (((uint64_t)hi[t] << 32) | lo[t]) >> Lh[t];
+      const uint32_t ib = ie[t] >> 16, cb = ce[t] >> 16;
+      r[t].insert = (ie[t] & 0xFFFFu) + ((uint32_t)w & ((1u << ib) - 1u));
+      w >>= ib;
+      r[t].copy = (ce[t] & 0xFFFFu) + ((uint32_t)w & ((1u << cb) - 1u));
+      r[t].p = p[t]; r[t].x = p[t] + Lh[t] + ib + cb; r[t].implicit = imp[t];
+      y[t] = r[t].x; n[t] = r[t].insert;
+      if (RESUME && res[t].on) { y[t] = res[t].y; n[t] = res[t].n; imp[t] = res[t].implicit; r[t].implicit = imp[t]; }
+    }
+  }
+  // the literal runs: hop by hop until they are on the path (or over), the rest by rank
+  uint32_t hops[NS];
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) hops[t] = 0;
+  if (CAPPED && J1) {
+    // (the table rounds: the bytes of J1 from Lp on carry the path flag -- sentinels --, so a run that reaches them stops
+    // there, and a lane without a state, or whose run starts beyond them, has nothing to hop)
+    uint32_t m[NS]; bool part[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = ok[t] && y[t] < c.Lp; m[t] = part[t] ? n[t] : 0u; }
+    for (uint32_t h = 0; h < PE_HOPCAP; h++) {
+      uint32_t f[NS]; bool any = false;
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) f[t] = lds_ld8(pb + PE_J1F + (m[t] != 0u ? y[t] : 0u));
+      SC_STAGE();
+      bool go[NS];
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { go[t] = m[t] != 0u && (f[t] & 0x80u) == 0u; any = any || go[t]; }
+      if (__ballot(any) == 0ull) break;
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { y[t] += go[t] ? (f[t] & 15u) : 0u; m[t] -= go[t] ? 1u : 0u; }
+    }
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if (part[t]) n[t] = m[t];
+  } else
+  for (;;) {
+    uint32_t f[NS], yc[NS]; bool go[NS]; bool any = false;
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      yc[t] = y[t] < c.Lp ? y[t] : 0u;
+      if (J1) f[t] = lds_ld8(pb + PE_J1F + yc[t]);
+      else f[t] = ((lds_ld32(pb + PE_PM + ((yc[t] >> 5) << 2)) >> (yc[t] & 31u)) & 1u) << 7;
+    }
+    SC_STAGE();
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      go[t] = ok[t] && n[t] != 0u && y[t] < c.Lp && (f[t] & 0x80u) == 0u && (!CAPPED || hops[t] < PE_HOPCAP);
+      any = any || go[t];
+    }
+    if (__ballot(any) == 0ull) break;
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      uint32_t len;
+      if (J1) len = f[t] & 15u;
+      else { uint32_t sy; sc_lookup(c.lit_tree, pe_bits32(pb, yc[t]), sy, len); }
+      if (go[t]) { y[t] += len; n[t]--; hops[t]++; }
+    }
+  }
+  uint32_t pmw[NS], cbw[NS], yc[NS]; bool inside[NS];
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    inside[t] = y[t] < c.Lp; yc[t] = inside[t] ? y[t] : 0u;
+    pmw[t] = lds_ld32(pb + PE_PM + ((yc[t] >> 5) << 2)); cbw[t] = lds_ld16(pb + PE_CB + ((yc[t] >> 5) << 1));
+  }
+  SC_STAGE();
+  uint32_t rk[NS], q2[NS]; bool onp[NS];
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    onp[t] = ((pmw[t] >> (yc[t] & 31u)) & 1u) != 0u;
+    rk[t] = cbw[t] + (uint32_t)__builtin_popcount(pmw[t] & ((1u << (yc[t] & 31u)) - 1u));
+    const uint32_t rr = rk[t] + n[t];
+    q2[t] = lds_ld16(pb + PE_POR + ((rr < c.Rn ? rr : 0u) << 1));
+  }
+  SC_STAGE();
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    r[t].u = hops[t]; r[t].ry = rk[t]; r[t].hy = y[t]; r[t].hn = n[t];
+    uint32_t code, next;
+    if (!ok[t] || !inside[t]) { code = 2u; next = 0u; }
+    else if (n[t] != 0u) {
+      if (!onp[t]) { code = 3u; next = 0u; }
+      else if (rk[t] + n[t] >= c.Rn) { code = 2u; next = 0u; }
+      else if (imp[t]) { code = 1u; next = q2[t] | 0x8000u; }
+      else { code = 0u; next = rk[t] + n[t]; }
+    } else if (!imp[t] && onp[t]) { code = 0u; next = rk[t]; }
+    else { code = 1u; next = y[t] | (imp[t] ? 0x8000u : 0u); }
+    r[t].code = code; r[t].next = next;
+  }
+}
 template <bool CAPPED, bool J1>
 __device__ __forceinline__ PeParse pe_eval(const PeCtx& c, uint32_t pos, uint32_t kind, bool on) {
-  PeParse r;
-  const uint32_t pb = c.pb;
-  bool ok = on && pos + 128u <= c.L;
-  const uint32_t q = ok ? pos : 0u;
-  uint32_t lo, hi;
-  uint32_t p = q;
-  r.dkind = SCK_IMPLICIT; r.dval = 0;
-  if (__ballot(ok && kind == 0u) != 0ull) {
-    pe_bits64(pb, q, lo, hi);
-    const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
-    if (kind == 0u) { p = q + d.bits; r.dkind = d.kind; r.dval = d.val; }
-  }
-  pe_bits64(pb, p, lo, hi);
-  const ScHead h = sc_head(lo, hi, c.cmd_tree, c.lut_vgpr);
-  r.p = p; r.x = p + h.bits; r.insert = h.insert; r.copy = h.copy; r.implicit = h.implicit;
-  // the literal run: hop by hop until it is on the path (or over), the rest by rank
-  uint32_t y = r.x, n = h.insert, hops = 0, f = 0;
-  for (;;) {
-    const uint32_t yc = y < c.Lp ? y : 0u;
-    bool onp;
-    if (J1) { f = lds_ld8(pb + PE_J1F + yc); onp = (f & 0x80u) != 0u; }
-    else onp = ((lds_ld32(pb + PE_PM + ((yc >> 5) << 2)) >> (yc & 31u)) & 1u) != 0u;
-    const bool go = ok && n != 0u && y < c.Lp && !onp && (!CAPPED || hops < PE_HOPCAP);
-    if (__ballot(go) == 0ull) break;
-    uint32_t len;
-    if (J1) len = f & 15u;
-    else { uint32_t sy; sc_lookup(c.lit_tree, pe_bits32(pb, yc), sy, len); }
-    if (go) { y += len; n--; hops++; }
-  }
-  r.u = hops;
-  const bool inside = y < c.Lp;
-  const uint32_t yc = inside ? y : 0u;
-  const bool onp = ((lds_ld32(pb + PE_PM + ((yc >> 5) << 2)) >> (yc & 31u)) & 1u) != 0u;
-  const uint32_t rk = pe_rank(pb, yc);
-  r.ry = rk;
-  uint32_t code, next;
-  if (!ok || !inside) { code = 2u; next = 0u; }
-  else if (n != 0u) {
-    if (!onp) { code = 3u; next = 0u; }
-    else if (rk + n >= c.Rn) { code = 2u; next = 0u; }
-    else {
-      const uint32_t q2 = lds_ld16(pb + PE_POR + ((rk + n) << 1));
-      if (h.implicit) { code = 1u; next = q2 | 0x8000u; } else { code = 0u; next = rk + n; }
-    }
-  } else if (!h.implicit && onp) { code = 0u; next = rk; }
-  else { code = 1u; next = y | (h.implicit ? 0x8000u : 0u); }
-  r.code = code; r.next = next;
-  return r;
+  const uint32_t pos_[1] = {pos}, kind_[1] = {kind}; const bool on_[1] = {on};
+  PeParse r[1];
+  pe_eval_n<1, CAPPED, J1>(c, pos_, kind_, on_, r);
+  return r[0];
 }
 
 // One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
@@ -210,14 +323,16 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
   }
 
+  uint32_t rbl = PE_RBL;  // (wave 0) bits the next region takes: halved where the closure ran out of room, doubled back where it is small
+  uint32_t pre_a = 0, pre_b = 0; bool pre_ok = false;  // the next region's input dwords of this lane, once they are known
   for (;;) {
     // ================= the region =================
     if (me == 0) {
       const uint32_t lbdw = b >> 5;
       const uint32_t avail = in_limit - (lbdw << 5);
       const bool go = b < in_limit && avail >= PE_MIN_INPUT && quota >= SC_MIN_QUOTA && bl1 != 0u;
-      pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, b & 31u); pe_ctl_st(pb, PEC_L, avail < PE_RBL ? avail : PE_RBL);
-      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
+      pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, b & 31u); pe_ctl_st(pb, PEC_L, avail < rbl ? avail : rbl);
+      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
       pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
       pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P >> 32));
     }
@@ -228,8 +343,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     c.L = pe_ctl_ld(pb, PEC_L);
     const uint64_t P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
     PE_COUNT(20, 1);
-    // ---- input ----
-    for (uint32_t i = T; i < PE_RBL / 32u + 6u; i += 64u * SC_WAVES) lds_st32(pb + PE_IN + (i << 2), lbdw + i < limit_dw ? in_dw[lbdw + i] : 0u);
+    // ---- input (asked for behind the resolve of the region before, where there was one) ----
+    if (!pre_ok) { pre_a = lbdw + T < limit_dw ? in_dw[lbdw + T] : 0u; pre_b = (T < 6u && lbdw + 1024u + T < limit_dw) ? in_dw[lbdw + 1024u + T] : 0u; }
+    lds_st32(pb + PE_IN + (T << 2), pre_a);
+    if (T < 6u) lds_st32(pb + PE_IN + ((1024u + T) << 2), pre_b);
+    pre_ok = false;
     __syncthreads();
     PE_PROF(0);
     // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
@@ -332,73 +450,89 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         r++;
       }
     }
-    if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry
+    if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry (lane 0 evaluates it)
     __syncthreads();
     c.Rn = pe_ctl_ld(pb, PEC_RN);
     {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u, cut = tmin << 5;
       c.Lp = lim < cut ? lim : cut;
     }
+    // sentinels: the sixteen bytes of J1 from Lp on carry the path flag, so that the records' hop loops stop there by themselves
+    if (T < 16u) lds_st8(pb + PE_J1F + c.Lp + T, lds_ld8(pb + PE_J1F + c.Lp + T) | 0x80u);
+    __syncthreads();
     PE_PROF(2);
     PE_COUNT(22, c.Rn);
-    // ---- records ----
-    // (appending a closure state: one LDS atomic per wave)
-#define PE_STORE_NEXT(id_, on_, r_) do { \
-      const bool app_ = (on_) && (r_).code == 1u; \
-      const uint64_t am_ = __ballot(app_); \
-      uint32_t slot_ = 0; \
-      if (am_ != 0ull) { \
-        uint32_t base_ = 0; \
-        if (lane == 0) base_ = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, (uint32_t)__popcll(am_)); \
-        base_ = rfl(base_); \
-        slot_ = base_ + __builtin_amdgcn_mbcnt_hi((uint32_t)(am_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am_, 0u)); \
-      } \
-      if (on_) { \
-        uint32_t nx_ = (r_).code == 0u ? (r_).next : (r_).code == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND; \
-        if (app_ && slot_ < PE_WCAP) { lds_st16(pb + PE_WST + (slot_ << 1), (r_).next); nx_ = PE_RANKS + slot_; } \
-        lds_st16(pb + PE_NEXT + ((id_) << 1), nx_); \
-      } } while (0)
-    {  // every path position as kind E: lane T takes the positions of its chunk
-      uint32_t m = pm, r = cb;
-      while (__ballot(m != 0u) != 0ull) {
-        const bool on = m != 0u;
-        const uint32_t o = on ? (uint32_t)__builtin_ctz(m) : 0u;
-        m &= m - 1u;
-        const PeParse pr = pe_eval<true, true>(c, cbase + o, 0u, on);
-        PE_STORE_NEXT(r, on, pr);
-        r++;
-      }
-    }
-    PE_PROF(3);
-    {  // the closure: the states the records lead to that are not path states, round by round
-      uint32_t begin = 0, nrounds = 0; (void)nrounds;
+    // ---- records: every lane keeps two evaluations going side by side.  A lane that is through with a state takes the next
+    // path position (kind E) off a shared counter; a lane whose record leads to a state that is not a path state (the run
+    // ended before it met the path, or the command has an implicit distance) appends that state to the closure and
+    // evaluates it itself next; a lane whose run used up its hops goes on with it next time.  No rounds, no barriers: the
+    // loop ends when the counter is exhausted and no lane has anything left.
+    {
+      uint32_t sid[2] = {0u, 0u}, sps[2] = {0u, 0u}, skd[2] = {0u, 0u}; bool has[2] = {false, false};
+      PeResume rs[2] = {{false, 0u, 0u, 0u}, {false, 0u, 0u, 0u}};
+      if (T == 0u) { has[0] = true; sid[0] = PE_RANKS; sps[0] = le; skd[0] = 1u; }  // the closure's first state: a command starts at the entry
+      uint32_t iters = 0; (void)iters;
       for (;;) {
-        __syncthreads();
-        uint32_t end = pe_ctl_ld(pb, PEC_WN);
-        end = end < PE_WCAP ? end : PE_WCAP;
-        if (begin >= end) break;
-        __syncthreads();  // (everyone has read the count before anyone appends again)
-        for (uint32_t k0 = begin + 64u * me; k0 < end; k0 += 64u * SC_WAVES) {
-          const uint32_t k = k0 + lane;
-          const bool on = k < end;
-          const uint32_t st = on ? lds_ld16(pb + PE_WST + (k << 1)) : 0u;
-          const PeParse pr = pe_eval<true, true>(c, st & 0x7FFFu, st >> 15, on);
-          PE_STORE_NEXT(PE_RANKS + k, on, pr);
+        _Pragma("unroll") for (uint32_t t = 0; t < 2u; t++) {
+          const uint64_t nm = __ballot(!has[t]);
+          if (nm != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_NEXTRANK, (uint32_t)__popcll(nm));
+            base = rfl(base);
+            const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+            if (!has[t] && rr < c.Rn) { has[t] = true; sid[t] = rr; sps[t] = lds_ld16(pb + PE_POR + (rr << 1)); skd[t] = 0u; rs[t].on = false; }
+          }
         }
-        begin = end; nrounds++;
+        if (__ballot(has[0] || has[1]) == 0ull) break;
+        PeParse pr[2];
+        pe_eval_n<2, true, true, true, false>(c, sps, skd, has, pr, rs);
+        iters++;
+        _Pragma("unroll") for (uint32_t t = 0; t < 2u; t++) {
+          const bool app = has[t] && pr[t].code == 1u;
+          const uint64_t am = __ballot(app);
+          uint32_t slot = 0;
+          if (am != 0ull) {  // (appending a closure state: one LDS atomic per wave)
+            uint32_t base = 0;
+            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, (uint32_t)__popcll(am));
+            base = rfl(base);
+            slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+          }
+          if (has[t]) {
+            if (pr[t].code == 3u) { rs[t].on = true; rs[t].y = pr[t].hy; rs[t].n = pr[t].hn; rs[t].implicit = pr[t].implicit; }  // more hops next time
+            else {
+              uint32_t nx = pr[t].code == 0u ? pr[t].next : pr[t].code == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
+              bool goes_on = false;
+              if (app && slot < PE_WCAP) { lds_st16(pb + PE_WST + (slot << 1), pr[t].next); nx = PE_RANKS + slot; goes_on = true; }
+              PE_LANECOUNT(30, app && slot >= PE_WCAP);
+              lds_st16(pb + PE_NEXT + (sid[t] << 1), nx);
+              rs[t].on = false;
+              if (goes_on) { sid[t] = PE_RANKS + slot; sps[t] = pr[t].next & 0x7FFFu; skd[t] = pr[t].next >> 15; }
+              else has[t] = false;
+            }
+          }
+        }
       }
-      PE_COUNT(23, nrounds); PE_COUNT(24, begin);
+      PE_COUNT(23, iters);
     }
-#undef PE_STORE_NEXT
+    __syncthreads();
+    PE_COUNT(24, pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP);
     const uint32_t wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
+    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_WCAP / 4u && rbl < PE_RBL) rbl <<= 1; }
     PE_PROF(4);
     // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
-    for (uint32_t i = T; i < PE_RANKS + wn; i += 64u * SC_WAVES) {
-      if (i >= c.Rn && i < PE_RANKS) continue;
-      uint32_t a = i;
-      _Pragma("unroll") for (int h = 0; h < 8; h++) a = a < PEN_FIRST_SPECIAL ? lds_ld16(pb + PE_NEXT + (a << 1)) : (uint32_t)PEN_NONE;
-      // (written behind a barrier: J1's room is still being read by nobody, the records are complete)
-      lds_st16(pb + PE_N8 + (i << 1), a < PEN_FIRST_SPECIAL ? a : (uint32_t)PEN_NONE);
+    for (uint32_t i0 = T; i0 < PE_RANKS + wn; i0 += 4u * 64u * SC_WAVES) {
+      uint32_t a[4];
+      _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) { const uint32_t i = i0 + t * 64u * SC_WAVES; a[t] = (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) ? i : (uint32_t)PEN_NONE; }
+      _Pragma("unroll") for (int h = 0; h < 8; h++) {
+        uint32_t v[4];
+        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) v[t] = lds_ld16(pb + PE_NEXT + ((a[t] < PEN_FIRST_SPECIAL ? a[t] : 0u) << 1));
+        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) a[t] = a[t] < PEN_FIRST_SPECIAL ? v[t] : (uint32_t)PEN_NONE;
+      }
+      // (written behind a barrier: J1's room is read by nobody any more, the records are complete)
+      _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) {
+        const uint32_t i = i0 + t * 64u * SC_WAVES;
+        if (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) lds_st16(pb + PE_N8 + (i << 1), a[t] < PEN_FIRST_SPECIAL ? a[t] : (uint32_t)PEN_NONE);
+      }
     }
     __syncthreads();
     PE_PROF(5);
@@ -422,6 +556,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
           if (nx == PEN_END) break;
           if (nx != PEN_BYHAND) { if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc); m++; id = nx; continue; }
+          PE_COUNT(31, 1);
         }
         // a record that hit a cap, or a state that has none (reached by hand): the walker evaluates it itself, uncapped
         PE_COUNT(25, 1);
@@ -584,6 +719,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           pbit += rfl(d.bits);
         }
         b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
+        pe_ctl_st(pb, PEC_NEXT_LBDW, b >> 5);
       }
       // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
       pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
@@ -592,28 +728,52 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     PE_PROF(8);
     const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
     PE_COUNT(28, kp);
+    if (pe_ctl_ld(pb, PEC_CONT) != 0u) {  // the next region's input is on its way while this one is executed
+      const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
+      pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + 1024u + T < limit_dw) ? in_dw[nl + 1024u + T] : 0u;
+      pre_ok = true;
+    }
     // ---- execute ----
     {
       gu8* const o = out + P0;
-      // (a) the literals in front of the path: lane = command, decoded again one after the other
+      // (a) lane = command: the literals in front of the path, decoded again one after the other, and the command's copy
+      // where it is short and its source lies in front of the region's output: one 16-byte load, stores in pieces
       for (uint32_t k0 = 64u * me; k0 < kp; k0 += 64u * SC_WAVES) {
         const uint32_t k = k0 + lane;
         const bool on = k < kp;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
-        const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u);
-        uint32_t u = on ? (r0 >> 15) & 255u : 0u;
+        const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
+        const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
         const uint32_t ins = r1 & 0xFFFFu;
+        uint32_t u = on ? (r0 >> 15) & 255u : 0u;
         u = u < ins ? u : ins;
+        // (the region's quota check leaves SC_MIN_QUOTA bytes of room behind P0: sixteen bytes from a source in front of it are inside the buffer)
+        const bool shortcopy = on && (r0 >> 31) == 0u && cn != 0u && cn <= 16u;
+        gu8* const cdst = o + off + ins;
+        u32x4 cv = {0u, 0u, 0u, 0u};
+        if (shortcopy) cv = *reinterpret_cast<gu32x4*>(cdst - dist);
         uint32_t y = r0 & 0x7FFFu;
-        gu8* dst = o + lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
+        gu8* dst = o + off;
         while (__ballot(u != 0u) != 0ull) {
           uint32_t sy, ln;
           sc_lookup(c.lit_tree, pe_bits32(pb, u != 0u ? y : 0u), sy, ln);
           if (u != 0u) { *dst = (uint8_t)sy; dst++; y += ln; u--; }
         }
+        if (shortcopy) {
+          uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
+          _Pragma("unroll") for (uint32_t q = 0; q < 4u; q++) {
+            if (cn >= 4u * q + 4u) *reinterpret_cast<gu32*>(cdst + 4u * q) = w[q];
+            else if (cn > 4u * q) {
+              const uint32_t rest = cn - 4u * q;
+              cdst[4u * q] = (uint8_t)w[q];
+              if (rest > 1u) cdst[4u * q + 1u] = (uint8_t)(w[q] >> 8);
+              if (rest > 2u) cdst[4u * q + 2u] = (uint8_t)(w[q] >> 16);
+            }
+          }
+        }
       }
-      // (b) wave w takes commands w, w + 16, ...: the literals on the path out of lit[], then the copy if its source lies
-      // in front of the region's output
+      // (b) wave w takes commands w, w + 16, ...: the literals on the path out of lit[], then the copy if it is long and its
+      // source lies in front of the region's output
       for (uint32_t k = me; k < kp; k += SC_WAVES) {
         const uint32_t ra = pb + PE_REC + (k << 4);
         const uint32_t r0 = rfl(lds_ld32(ra)), r1 = rfl(lds_ld32(ra + 4u)), cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
@@ -624,7 +784,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         const uint32_t n = ins - u;
         const uint32_t la = pb + PE_LIT + ry;
         for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
-        if (cn != 0u && (r0 >> 31) == 0u) {
+        if (cn > 16u && (r0 >> 31) == 0u) {
           gu8* const dst = o + off + ins; gu8* const src = dst - dist;
           if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
           else {
@@ -677,7 +837,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
   if (me != 0) return 0;
 #ifdef BROTLI_AMD_PROFILE_SCAN
-  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += ncmd; g_path_prof[33] += 1; }
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += ncmd; g_path_prof[33] += 1; }
 #endif
   // ---- hand the stream back in front of the next command (LDS_LEAN, as the scan engine does) ----
   if (lane == 0) {

@@ -107,6 +107,7 @@ static void build_region(const DS* s, uint64_t entry_bit) {
     done = end;
   }
   st_rounds += (uint64_t)rounds; if (g_wn > st_wmax) st_wmax = g_wn;
+  if (getenv("PEM_REGIONS")) fprintf(stderr, "region %llu at bit %llu: ranks %u closure %u rounds %d\n", (unsigned long long)st_regions, (unsigned long long)entry_bit, g_Rn, g_wn, rounds);
   /* the walk: commands of the true chain as this region sees them.  A state whose record says BYHAND (hop cap, closure
    * full) is evaluated by the walker itself, and so are the states behind it until the chain is back on a path state. */
   g_npred = 0; g_ipred = 0;
@@ -162,7 +163,7 @@ int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: path_engine_model <file.br> [region_bits] [hop_cap]\n"); return 2; }
   if (argc > 2) RBL = (uint32_t)atoi(argv[2]);
   if (argc > 3) HOPCAP = (uint32_t)atoi(argv[3]);
-  RANKCAP = RBL * 13 / 64; WCAP = RBL / 4;
+  RANKCAP = RBL * 13 / 64; WCAP = getenv("PEM_WCAP") ? (uint32_t)atoi(getenv("PEM_WCAP")) : RBL / 4;
   FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 2; }
   fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
   uint8_t* in = malloc((size_t)n + 8); if (fread(in, 1, (size_t)n, f) != (size_t)n) return 2; fclose(f);
