@@ -40,8 +40,9 @@ constexpr uint32_t PE_RANKS = 6656;               // path positions of a region 
 constexpr uint32_t PE_WCAP = 8192;                // closure states at most (records that would need more say BYHAND)
 constexpr uint32_t PE_STATES = PE_RANKS + PE_WCAP;
 constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluation takes; a run that needs more goes on in the lane's next evaluation
-constexpr uint32_t PE_SYNC_ROUNDS = 24;           // rounds the chunk entries get to settle
+constexpr uint32_t PE_SYNC_ROUNDS = SC_WAVES + 1;  // rounds between waves the chunk entries get to settle: enough for any code
 constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
+constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this long are stored by their command's lane, four bytes a step
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
 static_assert(PE_CHUNKS == 64u * SC_WAVES, "one chunk per lane of the block");
 
@@ -59,10 +60,14 @@ constexpr uint32_t PE_LIT = PE_POR + PE_RANKS * 2;                // u8 per rank
 constexpr uint32_t PE_NEXT = PE_LIT + PE_RANKS;                   // u16 per state: the state its command's literals end in
 constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2;              // u16 per closure state: bit | kind << 15; later the commands' records
 constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes per listed command
+constexpr uint32_t PE_BLIST = PE_NEXT + 2 * PE_CMDS;                // u16 per command with a long copy from in front of the region or a long literal run: its index
+constexpr uint32_t PE_DLIST = PE_NEXT;                            // u16 per copy that reads the region's own output: its command (the records are dead by then)
 constexpr uint32_t PE_LIST = PE_WST + PE_WCAP * 2;                // u16 per listed command (+ 1): its state as bit | kind << 15
-constexpr uint32_t PE_OVF = PE_LIST + (PE_CMDS + 8) * 2;          // u16 per record that hit the hop cap: its state's id
-constexpr uint32_t PE_OVFCAP = 1024;
-constexpr uint32_t PE_BYTES = PE_OVF + PE_OVFCAP * 2;
+constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
+constexpr uint32_t PE_TAILQ = PE_LIST;                              // u16 per state the bulk of the records left for the thin end (list and anchors are not in use then)
+constexpr uint32_t PE_TAILCAP = 1024;
+constexpr uint32_t PE_TAIL_WAVES = 4;
+constexpr uint32_t PE_BYTES = PE_ANCH + 128 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_CMDS * 16 <= PE_WCAP * 2 && PE_CMDS * 4 <= PE_CHUNKS * 4, "overlays");
 static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0, "alignment");
@@ -70,7 +75,7 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_TAILEND = 99, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -332,7 +337,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t avail = in_limit - (lbdw << 5);
       const bool go = b < in_limit && avail >= PE_MIN_INPUT && quota >= SC_MIN_QUOTA && bl1 != 0u;
       pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, b & 31u); pe_ctl_st(pb, PEC_L, avail < rbl ? avail : rbl);
-      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
+      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
       pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
       pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P >> 32));
     }
@@ -372,7 +377,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     }
     __syncthreads();
     PE_PROF(1);
-    // ---- the path: chunk T's chain from its entry; entries settle round by round ----
+    // ---- the path: chunk T's chain from its entry.  Inside a wave the entries settle through the lanes (a chunk's entry is
+    // the exit of the chunk before: one cross-lane read a step, no barrier); between waves through LDS, a barrier a round.
+    // A wave's entry is exact after as many rounds as waves lie in front of it, so PE_SYNC_ROUNDS rounds make the path exact
+    // whatever the code (one that does not re-synchronise takes them all; the usual case is two).
     const uint32_t cbase = T << 5;
     uint32_t pm = 0, eo = T == 0u ? le : 0u, ex = 0;
     {
@@ -380,39 +388,39 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
       ex = y - 32u;
     }
-    lds_st8(pb + PE_EX + T, ex);
-    uint32_t buf = 0, rounds = 0;
+    uint32_t wave_entry = me == 0u ? le : 0u, rounds = 0;
     for (;;) {
-      __syncthreads();
-      const uint32_t neo = T == 0u ? le : lds_ld8(pb + PE_EX + buf * PE_CHUNKS + T - 1u);
-      bool changed = false;
-      if (neo != eo) {
-        eo = neo;
-        if (neo < 32u && ((pm >> neo) & 1u) != 0u) pm &= ~((1u << neo) - 1u);  // the new entry is on the old chain: its tail stays
-        else {
-          uint32_t y = neo; pm = 0;
-          while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
-          changed = (y - 32u) != ex; ex = y - 32u;
+      for (;;) {  // the wave's own chunks
+        const uint32_t prev_ex = bperm(((lane + 63u) & 63u) << 2, ex);
+        const uint32_t neo = lane == 0u ? wave_entry : prev_ex;
+        bool changed = false;
+        if (neo != eo) {
+          eo = neo;
+          if (((pm >> neo) & 1u) != 0u) pm &= ~((1u << neo) - 1u);  // the new entry is on the old chain: its tail stays
+          else {
+            uint32_t y = neo; pm = 0;
+            while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
+            changed = (y - 32u) != ex; ex = y - 32u;
+          }
         }
+        if (__ballot(changed) == 0ull) break;
       }
-      buf ^= 1u;
-      lds_st8(pb + PE_EX + buf * PE_CHUNKS + T, ex);
-      // did any exit change?  (three flag words in rotation: the one cleared now was last read two rounds ago)
+      // the wave's exit for the wave behind it; another round if any wave's entry moves
+      const uint32_t slot = rounds & 1u;
+      if (lane == 63u) lds_st8(pb + PE_EX + slot * 64u + me, ex);
       const uint32_t fw = pb + PE_CTL + 4u * (PEC_CHG + rounds % 3u);
       if (T == 0u) lds_st32(pb + PE_CTL + 4u * (PEC_CHG + (rounds + 1u) % 3u), 0u);
-      if (__ballot(changed) != 0ull && lane == 0) lds_st32(fw, 1u);
+      __syncthreads();
+      const uint32_t ne = me == 0u ? le : rfl(lds_ld8(pb + PE_EX + slot * 64u + me - 1u));
+      if (ne != wave_entry && lane == 0) lds_st32(fw, 1u);
+      wave_entry = ne;
       rounds++;
       __syncthreads();
       if (rfl(lds_ld32(fw)) == 0u) break;
-      if (rounds >= PE_SYNC_ROUNDS) {
-        // not settled: the path is exact up to the first chunk whose entry is not the exit of the chunk before
-        __syncthreads();
-        const uint32_t neo2 = T == 0u ? le : lds_ld8(pb + PE_EX + buf * PE_CHUNKS + T - 1u);
-        if (neo2 != eo) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T);
-        break;
-      }
+      if (rounds >= PE_SYNC_ROUNDS) { if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TMIN, 0u); break; }  // (cannot happen: see above; no path, no region)
     }
     PE_COUNT(21, rounds);
+    PE_PROF(17);
     // bits at or beyond L - 16 are not path positions (a code word there may reach beyond the input)
     {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u;
@@ -438,16 +446,28 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     if (T >= tmin) { pm = 0; cnt = 0; }
     if (T == tmin || (tmin == PE_CHUNKS && T == PE_CHUNKS - 1u)) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_RN]) = T == tmin ? cb : cb + cnt;
     lds_st32(pb + PE_PM + (T << 2), pm); lds_st16(pb + PE_CB + (T << 1), cb);
+    PE_PROF(18);
     {
+      // the chunk's path positions: bit, literal, flag -- two at a time, out of the chunk's 64 input bits
+      const uint64_t w = (uint64_t)lds_ld32(pb + PE_IN + (T << 2)) | ((uint64_t)lds_ld32(pb + PE_IN + ((T + 1u) << 2)) << 32);
       uint32_t m = pm, r = cb;
       while (m != 0u) {
-        const uint32_t o = (uint32_t)__builtin_ctz(m); m &= m - 1u;
-        const uint32_t pos = cbase + o;
-        lds_st16(pb + PE_POR + (r << 1), pos);
-        lds_st8(pb + PE_J1F + pos, lds_ld8(pb + PE_J1F + pos) | 0x80u);
-        uint32_t sy, ln; sc_lookup(c.lit_tree, pe_bits32(pb, pos), sy, ln);
-        lds_st8(pb + PE_LIT + r, sy);
-        r++;
+        const uint32_t o0 = (uint32_t)__builtin_ctz(m); m &= m - 1u;
+        const bool two = m != 0u;
+        const uint32_t o1 = two ? (uint32_t)__builtin_ctz(m) : o0; m &= m - 1u;
+        const uint32_t x0 = (uint32_t)(w >> o0), x1 = (uint32_t)(w >> o1);
+        uint32_t e0 = lds_ld16(c.lit_tree + ((x0 & 0xFFu) << 1)), e1 = lds_ld16(c.lit_tree + ((x1 & 0xFFu) << 1));
+        uint32_t l0 = e0 & 15u, l1 = e1 & 15u;
+        if (l0 > ROOT_BITS || l1 > ROOT_BITS) {
+          const uint32_t i0 = l0 > ROOT_BITS ? (e0 >> 4) + __builtin_amdgcn_ubfe(x0, ROOT_BITS, l0 - ROOT_BITS) : (x0 & 0xFFu);
+          const uint32_t i1 = l1 > ROOT_BITS ? (e1 >> 4) + __builtin_amdgcn_ubfe(x1, ROOT_BITS, l1 - ROOT_BITS) : (x1 & 0xFFu);
+          const uint32_t f0 = lds_ld16(c.lit_tree + (i0 << 1)), f1 = lds_ld16(c.lit_tree + (i1 << 1));
+          if (l0 > ROOT_BITS) { e0 = f0; l0 = ROOT_BITS + (f0 & 15u); }
+          if (l1 > ROOT_BITS) { e1 = f1; l1 = ROOT_BITS + (f1 & 15u); }
+        }
+        lds_st16(pb + PE_POR + (r << 1), cbase + o0); lds_st8(pb + PE_J1F + cbase + o0, l0 | 0x80u); lds_st8(pb + PE_LIT + r, e0 >> 4);
+        if (two) { lds_st16(pb + PE_POR + ((r + 1u) << 1), cbase + o1); lds_st8(pb + PE_J1F + cbase + o1, l1 | 0x80u); lds_st8(pb + PE_LIT + r + 1u, e1 >> 4); }
+        r += two ? 2u : 1u;
       }
     }
     if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry (lane 0 evaluates it)
@@ -467,27 +487,62 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // ended before it met the path, or the command has an implicit distance) appends that state to the closure and
     // evaluates it itself next; a lane whose run used up its hops goes on with it next time.  No rounds, no barriers: the
     // loop ends when the counter is exhausted and no lane has anything left.
-    {
-      uint32_t sid[2] = {0u, 0u}, sps[2] = {0u, 0u}, skd[2] = {0u, 0u}; bool has[2] = {false, false};
-      PeResume rs[2] = {{false, 0u, 0u, 0u}, {false, 0u, 0u, 0u}};
-      if (T == 0u) { has[0] = true; sid[0] = PE_RANKS; sps[0] = le; skd[0] = 1u; }  // the closure's first state: a command starts at the entry
+    // Two phases of the same loop (two states a lane, then one): the bulk on all waves -- until the counter is exhausted and a wave has less than a quarter
+    // of its slots busy; what it still holds then (chains of states that are not path states, a few per wave) goes on a
+    // list --, and the thin end of it on four waves that take the list's states the way the bulk took path positions.
+    auto records_loop = [&](auto nsl_, const uint32_t phase, const uint32_t tail_n) {
+      constexpr uint32_t NSL = decltype(nsl_)::value;
+      uint32_t sid[NSL], sps[NSL], skd[NSL]; bool has[NSL];
+      PeResume rs[NSL];
+      _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { sid[t] = 0u; sps[t] = 0u; skd[t] = 0u; has[t] = false; rs[t].on = false; rs[t].y = 0u; rs[t].n = 0u; rs[t].implicit = 0u; }
+      if (phase == 0u && T == 0u) { has[0] = true; sid[0] = PE_RANKS; sps[0] = le; skd[0] = 1u; }  // the closure's first state: a command starts at the entry
       uint32_t iters = 0; (void)iters;
+      bool dry = false;  // the source has nothing more for this wave
       for (;;) {
-        _Pragma("unroll") for (uint32_t t = 0; t < 2u; t++) {
+        _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
           const uint64_t nm = __ballot(!has[t]);
-          if (nm != 0ull) {
+          if (nm != 0ull && !dry) {
             uint32_t base = 0;
-            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_NEXTRANK, (uint32_t)__popcll(nm));
+            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * (phase == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), (uint32_t)__popcll(nm));
             base = rfl(base);
             const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-            if (!has[t] && rr < c.Rn) { has[t] = true; sid[t] = rr; sps[t] = lds_ld16(pb + PE_POR + (rr << 1)); skd[t] = 0u; rs[t].on = false; }
+            if (phase == 0u) {
+              if (!has[t] && rr < c.Rn) { has[t] = true; sid[t] = rr; sps[t] = lds_ld16(pb + PE_POR + (rr << 1)); skd[t] = 0u; rs[t].on = false; }
+              if (base + (uint32_t)__popcll(nm) > c.Rn) dry = true;
+            } else {
+              if (!has[t] && rr < tail_n) {
+                const uint32_t id = lds_ld16(pb + PE_TAILQ + (rr << 1));
+                if (id < PEN_FIRST_SPECIAL) {
+                  const uint32_t st = id < PE_RANKS ? lds_ld16(pb + PE_POR + (id << 1)) : lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1));
+                  has[t] = true; sid[t] = id; sps[t] = st & 0x7FFFu; skd[t] = st >> 15; rs[t].on = false;
+                }
+              }
+              if (base + (uint32_t)__popcll(nm) > tail_n) dry = true;
+            }
           }
         }
-        if (__ballot(has[0] || has[1]) == 0ull) break;
-        PeParse pr[2];
-        pe_eval_n<2, true, true, true, false>(c, sps, skd, has, pr, rs);
+        const uint64_t h0 = __ballot(has[0]), h1 = NSL > 1u ? __ballot(has[NSL - 1u]) : 0ull;
+        if ((h0 | h1) == 0ull) break;
+        if (phase == 0u && dry && (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1) < 32u) {
+          // the thin end: what this wave still holds goes on the list
+          const uint32_t cnt = (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1);
+          uint32_t base = 0;
+          if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_TAILN, cnt);
+          base = rfl(base);
+          if (base + cnt <= PE_TAILCAP) {
+            const uint32_t i0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(h0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h0, 0u));
+            const uint32_t i1 = base + (uint32_t)__popcll(h0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(h1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h1, 0u));
+            if (has[0]) lds_st16(pb + PE_TAILQ + (i0 << 1), sid[0]);
+            if (NSL > 1u && has[NSL - 1u]) lds_st16(pb + PE_TAILQ + (i1 << 1), sid[NSL - 1u]);
+            break;
+          }
+          // (the list is full: this wave sees its states through itself; its claim on the list holds no states -- marked so)
+          for (uint32_t i = base + lane; i < base + cnt && i < PE_TAILCAP; i += 64u) lds_st16(pb + PE_TAILQ + (i << 1), PEN_NONE);
+        }
+        PeParse pr[NSL];
+        pe_eval_n<NSL, true, true, true, false>(c, sps, skd, has, pr, rs);
         iters++;
-        _Pragma("unroll") for (uint32_t t = 0; t < 2u; t++) {
+        _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
           const bool app = has[t] && pr[t].code == 1u;
           const uint64_t am = __ballot(app);
           uint32_t slot = 0;
@@ -512,7 +567,13 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           }
         }
       }
-      PE_COUNT(23, iters);
+      PE_COUNT(23 - 12 * phase, iters);
+    };
+    records_loop(std::integral_constant<uint32_t, 2>{}, 0u, 0u);
+    __syncthreads();
+    {
+      const uint32_t tail_n = pe_ctl_ld(pb, PEC_TAILN) < PE_TAILCAP ? pe_ctl_ld(pb, PEC_TAILN) : PE_TAILCAP;
+      if (me < PE_TAIL_WAVES && tail_n != 0u) records_loop(std::integral_constant<uint32_t, 1>{}, 1u, tail_n);
     }
     __syncthreads();
     PE_COUNT(24, pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP);
@@ -538,57 +599,47 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     PE_PROF(5);
     // ---- the walk (wave 0): the stream's states in order, LIST[k] = bit | kind << 15 of the state command k starts from ----
     if (me == 0) {
-      uint32_t m = 0;          // commands listed
-      uint32_t id = PE_RANKS;  // the current state's id, or PEN_NONE when it has none (reached by hand)
-      uint32_t desc = le | 0x8000u;
-      uint32_t na = 0;         // anchors of eight-command hops: LIST[m .. m + 7] filled afterwards
-      uint32_t av_m = 0, av_id = 0;  // lane a: anchor a's first list index and state id
-      while (m < PE_CMDS) {
-        if (id != PEN_NONE) {
-          const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
-          if (n8 < PEN_FIRST_SPECIAL && m + 8u <= PE_CMDS && na < 64u) {
-            asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(av_m), "+v"(av_id) : "s"(m), "s"(id), "s"(na) : "m0");
-            na++; m += 8u; id = n8;
-            continue;
-          }
-          // one command: the state goes on the list, its record says where the chain goes
-          if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
-          const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
-          if (nx == PEN_END) break;
-          if (nx != PEN_BYHAND) { if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc); m++; id = nx; continue; }
-          PE_COUNT(31, 1);
-        }
-        // a record that hit a cap, or a state that has none (reached by hand): the walker evaluates it itself, uncapped
-        PE_COUNT(25, 1);
-        const PeParse pr = pe_eval<false, false>(c, desc & 0x7FFFu, desc >> 15, true);
-        const uint32_t code = rfl(pr.code), nxt = rfl(pr.next);
-        id = PEN_NONE;
-        if (code >= 2u) break;  // the command's literals leave the region: this state closes the list
+      // first the hops of eight commands (NEXT8 knows the way wherever the next eight records are ordinary ones: everywhere but
+      // at the region's end), the anchors in two registers; then command by command up to the first record that is no way on
+      // (END: the run leaves the region; BYHAND: the closure ran out of room -- the next region starts there)
+      uint32_t id = PE_RANKS, na = 0, av0 = 0, av1 = 0;
+      for (;;) {
+        const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
+        if (n8 >= PEN_FIRST_SPECIAL || na >= 120u) break;
+        if (na < 64u) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(av0) : "s"(id), "s"(na) : "m0");
+        else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(av1) : "s"(id), "s"(na - 64u) : "m0");
+        na++; id = n8;
+      }
+      lds_st32(pb + PE_ANCH + (lane << 2), av0); lds_st32(pb + PE_ANCH + ((64u + lane) << 2), av1);
+      uint32_t m = 8u * na, desc;
+      for (;;) {
+        if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
+        const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
+        if (nx >= PEN_FIRST_SPECIAL || m >= PE_CMDS) break;
         if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
-        m++;
-        if (code == 0u) id = nxt; else desc = nxt;
+        m++; id = nx;
       }
       // the state the walk stopped at closes the list (the last command's distance is read there)
-      if (id != PEN_NONE) { if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1))); }
       if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
-      // the lanes behind an anchor: seven more states each
-      for (uint32_t a0 = 0; a0 < na; a0 += 8u) {
-        const uint32_t a = a0 + (lane >> 3), j = lane & 7u;
-        const bool on = a < na;
-        const uint32_t am = bperm((on ? a : 0u) << 2, av_m);
-        uint32_t s = bperm((on ? a : 0u) << 2, av_id);
-        _Pragma("unroll") for (uint32_t h = 0; h < 7u; h++) if (h < j) s = lds_ld16(pb + PE_NEXT + (s << 1));
-        const uint32_t dsc = s < PE_RANKS ? lds_ld16(pb + PE_POR + (s << 1)) : lds_ld16(pb + PE_WST + ((s - PE_RANKS) << 1));
-        if (on) lds_st16(pb + PE_LIST + ((am + j) << 1), dsc);
-      }
       // the last command needs its distance: 64 bits at the closing state
       if (m != 0u && (desc >> 15) == 0u && (desc & 0x7FFFu) + 64u > c.L) m--;
-      pe_ctl_st(pb, PEC_M, m);
+      pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
       PE_COUNT(26, m); PE_COUNT(27, na);
     }
     __syncthreads();
     PE_PROF(6);
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
+    {  // the commands behind an anchor: thread 8 a + j follows anchor a's state j records on
+      const uint32_t na = pe_ctl_ld(pb, PEC_NA);
+      if (T < na * 8u) {
+        const uint32_t j = T & 7u;
+        uint32_t st = lds_ld32(pb + PE_ANCH + ((T >> 3) << 2));
+        for (uint32_t h = 0; h < j; h++) st = lds_ld16(pb + PE_NEXT + (st << 1));
+        const uint32_t dsc = st < PE_RANKS ? lds_ld16(pb + PE_POR + (st << 1)) : lds_ld16(pb + PE_WST + ((st - PE_RANKS) << 1));
+        lds_st16(pb + PE_LIST + (T << 1), dsc);
+      }
+    }
+    __syncthreads();
     // ---- details: lane = command; its fields from the state it starts from, its distance from the state after ----
     // (the records overlay the closure's states: every lane reads its two list entries, then a barrier, then the stores)
     {
@@ -624,7 +675,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     PE_PROF(7);
     // ---- resolve (wave 0): lane = command, 64 a batch; exactly the scan engine's ----
     if (me == 0) {
-      uint32_t kp_total = 0, any_dep = 0;
+      uint32_t kp_total = 0, any_dep = 0, nbig = 0;
       bool stop = false;
       for (uint32_t k0 = 0; k0 < m && !stop; k0 += 64u) {
         const uint32_t K = m - k0 < 64u ? m - k0 : 64u;
@@ -697,7 +748,20 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           // a copy whose source reaches into the region's own output is done afterwards, in order (bit 31 of w0)
           const uint64_t rel = (P - P0) + out_excl;
           const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
-          if (__ballot(lane < kp && dep != 0u) != 0ull) any_dep = 1u;
+          const uint64_t dmk = __ballot(lane < kp && dep != 0u);
+          if (dmk != 0ull) {
+            if (lane < kp && dep != 0u) lds_st16(pb + PE_DLIST + ((any_dep + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmk, 0u))) << 1), k0 + lane);
+            any_dep += (uint32_t)__popcll(dmk);
+          }
+          {  // commands the lane = command pass of the execute phase leaves to a wave of their own
+            uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
+            const bool bigc = lane < kp && ((copy > 16u && dep == 0u) || ins - uu > PE_LANE_LITS);
+            const uint64_t bmk = __ballot(bigc);
+            if (bmk != 0ull) {
+              if (bigc) lds_st16(pb + PE_BLIST + ((nbig + __builtin_amdgcn_mbcnt_hi((uint32_t)(bmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmk, 0u))) << 1), k0 + lane);
+              nbig += (uint32_t)__popcll(bmk);
+            }
+          }
           if (lane < kp) {
             lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 12u, (uint32_t)dist);
             lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
@@ -706,7 +770,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         P += out_tot; bl0 -= lit_tot; bl1 -= cmd_tot; bl2 -= dst_tot; quota -= out_tot; mlen -= (int32_t)out_tot; ncmd += cmd_tot;
         kp_total += kp;
       }
-      pe_ctl_st(pb, PEC_KP, kp_total); pe_ctl_st(pb, PEC_ANYDEP, any_dep);
+      pe_ctl_st(pb, PEC_KP, kp_total); pe_ctl_st(pb, PEC_ANYDEP, any_dep); pe_ctl_st(pb, PEC_NBIG, nbig);
       // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
       // of the state it starts from)
       {
@@ -736,16 +800,17 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // ---- execute ----
     {
       gu8* const o = out + P0;
-      // (a) lane = command: the literals in front of the path, decoded again one after the other, and the command's copy
-      // where it is short and its source lies in front of the region's output: one 16-byte load, stores in pieces
+      // (a) lane = command: the literals in front of the path, decoded again one after the other; the literals on the path out
+      // of lit[], four bytes a step; the command's copy where it is short and its source lies in front of the region's
+      // output (one 16-byte load, stores in pieces)
       for (uint32_t k0 = 64u * me; k0 < kp; k0 += 64u * SC_WAVES) {
         const uint32_t k = k0 + lane;
         const bool on = k < kp;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
         const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
         const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
-        const uint32_t ins = r1 & 0xFFFFu;
-        uint32_t u = on ? (r0 >> 15) & 255u : 0u;
+        const uint32_t ins = on ? r1 & 0xFFFFu : 0u, ry = r1 >> 16;
+        uint32_t u = (r0 >> 15) & 255u;
         u = u < ins ? u : ins;
         // (the region's quota check leaves SC_MIN_QUOTA bytes of room behind P0: sixteen bytes from a source in front of it are inside the buffer)
         const bool shortcopy = on && (r0 >> 31) == 0u && cn != 0u && cn <= 16u;
@@ -754,10 +819,17 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         if (shortcopy) cv = *reinterpret_cast<gu32x4*>(cdst - dist);
         uint32_t y = r0 & 0x7FFFu;
         gu8* dst = o + off;
+        uint32_t n = ins - u; n = n <= PE_LANE_LITS ? n : 0u;   // (longer runs: a wave of their own, below)
         while (__ballot(u != 0u) != 0ull) {
           uint32_t sy, ln;
           sc_lookup(c.lit_tree, pe_bits32(pb, u != 0u ? y : 0u), sy, ln);
           if (u != 0u) { *dst = (uint8_t)sy; dst++; y += ln; u--; }
+        }
+        uint32_t la = pb + PE_LIT + ry;
+        while (__ballot(n != 0u) != 0ull) {
+          const uint32_t b0 = lds_ld8(la), b1 = lds_ld8(la + 1u), b2 = lds_ld8(la + 2u), b3 = lds_ld8(la + 3u);
+          if (n >= 4u) { *reinterpret_cast<gu32*>(dst) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); dst += 4; la += 4u; n -= 4u; }
+          else if (n != 0u) { dst[0] = (uint8_t)b0; if (n > 1u) dst[1] = (uint8_t)b1; if (n > 2u) dst[2] = (uint8_t)b2; n = 0u; }
         }
         if (shortcopy) {
           uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
@@ -772,20 +844,76 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           }
         }
       }
-      // (b) wave w takes commands w, w + 16, ...: the literals on the path out of lit[], then the copy if it is long and its
-      // source lies in front of the region's output
-      for (uint32_t k = me; k < kp; k += SC_WAVES) {
-        const uint32_t ra = pb + PE_REC + (k << 4);
-        const uint32_t r0 = rfl(lds_ld32(ra)), r1 = rfl(lds_ld32(ra + 4u)), cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
-        const uint32_t off = rfl(lds_ld32(pb + PE_OFF + (k << 2)));
-        const uint32_t ins = r1 & 0xFFFFu, ry = r1 >> 16;
-        uint32_t u = (r0 >> 15) & 255u; u = u < ins ? u : ins;
-        gu8* const lp = o + off + u;
-        const uint32_t n = ins - u;
-        const uint32_t la = pb + PE_LIT + ry;
-        for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
-        if (cn > 16u && (r0 >> 31) == 0u) {
-          gu8* const dst = o + off + ins; gu8* const src = dst - dist;
+      // (b) the commands listed for it get a wave each: long literal runs out of lit[], long copies whose source lies in front
+      // of the region's output
+      {
+        const uint32_t nbig = pe_ctl_ld(pb, PEC_NBIG);
+        for (uint32_t j = me; j < nbig; j += SC_WAVES) {
+          const uint32_t k = rfl(lds_ld16(pb + PE_BLIST + (j << 1)));
+          const uint32_t ra = pb + PE_REC + (k << 4);
+          const uint32_t r0 = rfl(lds_ld32(ra)), r1 = rfl(lds_ld32(ra + 4u)), cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
+          const uint32_t off = rfl(lds_ld32(pb + PE_OFF + (k << 2)));
+          const uint32_t ins = r1 & 0xFFFFu, ry = r1 >> 16;
+          uint32_t u = (r0 >> 15) & 255u; u = u < ins ? u : ins;
+          const uint32_t n = ins - u;
+          if (n > PE_LANE_LITS) {
+            gu8* const lp = o + off + u;
+            const uint32_t la = pb + PE_LIT + ry;
+            for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
+          }
+          if (cn > 16u && (r0 >> 31) == 0u) {
+            gu8* const dst = o + off + ins; gu8* const src = dst - dist;
+            if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
+            else {
+              const uint32_t n16 = cn >> 4;
+              for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+              const uint32_t tail = n16 << 4;
+              if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
+            }
+          }
+        }
+      }
+      PE_PROF(9);
+      // (c) copies that read the region's own output: one after the other (a wave's stores are visible to its later loads)
+      const uint32_t ndep = pe_ctl_ld(pb, PEC_ANYDEP);
+      if (ndep != 0u) {
+        // Which of them only read what (a) and (b) wrote -- literals and copies from in front of the region?  Those whose
+        // source does not touch the destination of an earlier dependent copy (destinations lie in command order: a binary
+        // search), and that do not overlap themselves.  They go side by side, one wave each (bit 29 of w0); the rest in order.
+        for (uint32_t j = T; j < ndep; j += 64u * SC_WAVES) {
+          const uint32_t k = lds_ld16(pb + PE_DLIST + (j << 1));
+          const uint32_t ra = pb + PE_REC + (k << 4);
+          const uint32_t cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
+          const uint32_t dst = lds_ld32(pb + PE_OFF + (k << 2)) + (lds_ld32(ra + 4u) & 0xFFFFu);
+          bool ready = dist >= cn && dist <= dst;  // (a source that begins in front of the region reads only what is complete)
+          if (dist >= cn) {
+            const uint32_t s_lo = dist <= dst ? dst - dist : 0u, s_hi = dst + cn - dist;  // the source's part inside the region
+            // the first earlier dependent copy whose destination ends behind s_lo
+            uint32_t lo_ = 0, hi_ = j;
+            while (lo_ < hi_) {
+              const uint32_t mid = (lo_ + hi_) >> 1;
+              const uint32_t km = lds_ld16(pb + PE_DLIST + (mid << 1));
+              const uint32_t de = lds_ld32(pb + PE_OFF + (km << 2)) + (lds_ld32(pb + PE_REC + (km << 4) + 4u) & 0xFFFFu) + lds_ld32(pb + PE_REC + (km << 4) + 8u);
+              if (de > s_lo) hi_ = mid; else lo_ = mid + 1u;
+            }
+            ready = true;
+            if (lo_ < j) {
+              const uint32_t km = lds_ld16(pb + PE_DLIST + (lo_ << 1));
+              const uint32_t ds = lds_ld32(pb + PE_OFF + (km << 2)) + (lds_ld32(pb + PE_REC + (km << 4) + 4u) & 0xFFFFu);
+              ready = ds >= s_hi;
+            }
+          }
+          if (ready) lds_st32(ra, lds_ld32(ra) | (1u << 29));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (uint32_t j = me; j < ndep; j += SC_WAVES) {
+          const uint32_t k = rfl(lds_ld16(pb + PE_DLIST + (j << 1)));
+          const uint32_t ra = pb + PE_REC + (k << 4);
+          const uint32_t r0 = rfl(lds_ld32(ra));
+          if (((r0 >> 29) & 1u) == 0u) continue;
+          const uint32_t cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
+          gu8* const dst = o + rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (rfl(lds_ld32(ra + 4u)) & 0xFFFFu); gu8* const src = dst - dist;
           if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
           else {
             const uint32_t n16 = cn >> 4;
@@ -794,21 +922,23 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
           }
         }
-      }
-      PE_PROF(9);
-      // (c) copies that read the region's own output: one after the other (a wave's stores are visible to its later loads)
-      if (pe_ctl_ld(pb, PEC_ANYDEP) != 0u) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (me == SC_WAVES - 1u) {
+#ifdef BROTLI_AMD_PROFILE_SCAN
+          const uint64_t dep_t0 = __builtin_amdgcn_s_memtime(); uint32_t dep_n = 0;
+#endif
           for (uint32_t k0 = 0; k0 < kp; k0 += 64u) {
             const uint32_t k = k0 + lane;
             const uint32_t ra = pb + PE_REC + ((k < kp ? k : 0u) << 4);
             const uint32_t x0 = lds_ld32(ra), x1 = lds_ld32(ra + 4u), xn = lds_ld32(ra + 8u), xd = lds_ld32(ra + 12u), xo = lds_ld32(pb + PE_OFF + ((k < kp ? k : 0u) << 2));
-            uint64_t dm = __ballot(k < kp && (x0 >> 31) != 0u);
+            uint64_t dm = __ballot(k < kp && (x0 >> 31) != 0u && ((x0 >> 29) & 1u) == 0u);
             while (dm) {
               const uint32_t kk = (uint32_t)__builtin_ctzll(dm);
               dm &= dm - 1ull;
+#ifdef BROTLI_AMD_PROFILE_SCAN
+              dep_n++;
+#endif
               const uint32_t n = rdlane(xn, kk), dist = rdlane(xd, kk), dpos = rdlane(xo, kk) + (rdlane(x1, kk) & 0xFFFFu);
               gu8* const dst = o + dpos; gu8* const src = dst - dist;
               if (dist < n) {
@@ -827,6 +957,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
               }
             }
           }
+#ifdef BROTLI_AMD_PROFILE_SCAN
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (blockIdx.x == 0 && lane == 0) { atomicAdd(&g_path_prof[34], (unsigned long long)(__builtin_amdgcn_s_memtime() - dep_t0)); atomicAdd(&g_path_prof[35], (unsigned long long)dep_n); }
+#endif
         }
       }
       PE_PROF(10);
