@@ -67,18 +67,18 @@ def build_workload(name, n_unique=None):
     if m or not w.encoder_available():
         n = int(m.group(1)) if m else 1024
         return "%d x alice29.txt.compressed (reference fixture, wbits 22)" % n, w.fixture_streams("alice29.txt.compressed"), n
-    m = re.fullmatch(r"(longbackref|highentropy)_(\d+)x(\d+)(KiB|MiB)", name)
+    m = re.fullmatch(r"(longbackref|highentropy)(?:q(\d+))?_(\d+)x(\d+)(KiB|MiB)", name)
     if not m:
         raise SystemExit("unknown workload " + name)
-    kind, n, size = m.group(1), int(m.group(2)), int(m.group(3)) << (10 if m.group(4) == "KiB" else 20)
+    kind, quality, n, size = m.group(1), int(m.group(2) or 5), int(m.group(3)), int(m.group(4)) << (10 if m.group(5) == "KiB" else 20)
     nu = min(n, n_unique if n_unique else int(os.environ.get("BROTLI_BENCH_UNIQUE", "256")))
     seed0 = {"longbackref": 1000, "highentropy": 2000}[kind] if (n % 256, size) == (0, 4 << 20) else 3000  # (512 x 4 MiB: the headline's streams, twice)
-    u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", nu, size, seed0)
+    u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", nu, size, seed0, quality=quality)
     what = "long back-references" if kind == "longbackref" else "high-entropy literals"
     if (n, size) == (256, 4 << 20):
-        label = "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q5, %s (%d distinct streams)" % (what, nu)
+        label = "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q%d, %s (%d distinct streams)" % (quality, what, nu)
     else:
-        label = "%d x %d KiB streams, wbits 22, brotli -q5, %s (%d distinct streams)" % (n, size >> 10, what, nu)
+        label = "%d x %d KiB streams, wbits 22, brotli -q%d, %s (%d distinct streams)" % (n, size >> 10, quality, what, nu)
     return label, u, n
 
 
@@ -129,6 +129,18 @@ class DeviceJob:
             if hashlib.sha256(host[j * self.out_stride: j * self.out_stride + sz].tobytes()).hexdigest() != sha:
                 raise SystemExit("stream %d is not bit-exact" % i)
         return [[r.result, r.error_code, r.decoded_size, r.consumed] for r in res]
+
+    def poison(self):
+        """every output byte overwritten with a pattern no stream decodes to: what is hashed afterwards was written since"""
+        self.d_out.fill_(0xA5)
+        self.torch.cuda.synchronize()
+
+    def verify(self):
+        host = self.d_out.cpu().numpy()
+        for j, i in enumerate(self.indices):
+            _, sz, sha = self.unique[i % len(self.unique)]
+            if hashlib.sha256(host[j * self.out_stride: j * self.out_stride + sz].tobytes()).hexdigest() != sha:
+                raise SystemExit("stream %d is not bit-exact after the timed steps" % i)
 
     def step(self):
         if not self.indices:
@@ -225,7 +237,15 @@ def cpu_baseline(unique, budget_s=10.0):
                     assert r[0] == 1
                 dt = time.time() - t
                 bestp = dt if bestp is None else min(bestp, dt)
-            out["libbrotlidec_proxy"] = {"value_1thread": round(total1 / bestp / 1e6, 1), "unit": "MB/s decompressed",
+            from concurrent.futures import ThreadPoolExecutor
+            bestn = None
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                for _ in range(3):
+                    t = time.time()
+                    assert all(r[0] == 1 for r in ex.map(lambda cs: ref.decode(cs[0], cs[1] + 64), sample))
+                    dt = time.time() - t
+                    bestn = dt if bestn is None else min(bestn, dt)
+            out["libbrotlidec_proxy"] = {"value_1thread": round(total1 / bestp / 1e6, 1), "value": round(total / bestn / 1e6, 1), "cores": cores, "unit": "MB/s decompressed",
                                          "note": "Google libbrotlidec 1.0.9 through ctypes, one thread, %d streams, best of 3: a proxy for the "
                                                  "reference (a port of it); the reference itself was not run" % k1}
     except Exception as e:  # noqa: BLE001 -- the proxy is optional
@@ -279,6 +299,7 @@ def main():
 
     for _ in range(args.warmup):
         job.step()
+    job.poison()  # (outside the timed region) the outputs hashed behind the timed steps are the timed steps' own
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -290,6 +311,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    job.verify()
 
     # per-stream status words back to every rank (the gather of sharding.py), the step time as the maximum over ranks
     status = sharding.gather_status(np.array(status_rows, dtype=np.int64).reshape(-1, sharding.STATUS_COLS), mine, n_total, dev if world > 1 else "cpu")
@@ -303,12 +325,13 @@ def main():
         value = total_raw * args.steps / elapsed_max / 1e6
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         # HBM bytes per launch from the PMC passes of the committed profile (same command, separate rocprofv3 runs)
-        traffic = None
-        for prof in ("pmc_r02.json", "pmc_r01.json"):
+        traffic, traffic_source = None, None
+        for prof in ("pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if pmc["workload"] == desc[0]:
                     traffic = pmc["traffic_bytes_per_launch"]
+                    traffic_source = "profiles/%s: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), not measured in this run" % prof
                     break
             except (OSError, KeyError, ValueError):
                 pass
@@ -323,16 +346,34 @@ def main():
                        "second_pass_streams": job.second_pass},
             "roofline": roofline(job.comp_total, job.raw_total, mean_kernel_ms, traffic),
         }
+        out["roofline"]["traffic_source"] = traffic_source
+        out["config"]["outputs_poisoned_before_and_hashed_after_the_timed_steps"] = True
     job.close()
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:  # (a host-side baseline: rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(unique)
+            try:  # the same batch from pageable host memory and back (BrotliAmdBatchDecodeHost): PCIe-inclusive, never the `value`
+                datas = [unique[i % len(unique)][0] for i in range(per_gpu)]
+                caps_h = [unique[i % len(unique)][1] for i in range(per_gpu)]
+                hb = pkg.Batch(per_gpu)
+                hb.decode_host(datas[:8], caps_h[:8], pkg.FLAG_LARGE_WINDOW)  # (staging buffers allocated)
+                th = time.perf_counter()
+                res_h, outs_h = hb.decode_host(datas, caps_h, pkg.FLAG_LARGE_WINDOW)
+                dt_h = time.perf_counter() - th
+                hb.close()
+                assert all(r.result == 1 for r in res_h)
+                out["host_buffers"] = {"value": round(sum(caps_h) / dt_h / 1e6, 1), "unit": "MB/s decompressed", "seconds": round(dt_h, 4),
+                                       "note": "BrotliAmdBatchDecodeHost: upload from and download to pageable host memory included (through the ctypes binding, which also copies the outputs into Python bytes)"}
+                del outs_h
+            except Exception as ex:  # noqa: BLE001 -- an optional leg
+                out["host_buffers"] = {"error": str(ex)[:120]}
         if not args.no_extra and desc[0] == "longbackref_256x4MiB":
             import workloads as w
             extra = []
             legs = [("alice29x1024", 10, None)]
             if w.encoder_available():
-                legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1), ("longbackref_512x4MiB", 3, None)]
+                legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1), ("longbackref_512x4MiB", 3, None),
+                         ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None)]
             for name, steps, nu in legs:
                 try:
                     e = time_single_gpu(pkg, torch, dev, name, steps, 1, nu)
@@ -340,6 +381,10 @@ def main():
                         e["workload"] = "C3 as ONE stream: 64 MiB, wbits 22, brotli -q5, many metablocks, long back-references (a single stream does not shard: one block of the GPU decodes it)"
                     if name == "longbackref_512x4MiB":
                         e["workload"] = "the metric's 256 streams twice: 512 x 4 MiB, two streams per CU (engine blocks take them one after the other)"
+                    if name == "longbackrefq9_256x4MiB":
+                        e["workload"] = "the metric's data compressed with brotli -q9 (SURVEY 8d asks for both): " + e["workload"]
+                    if name == "longbackref_1024x1MiB":
+                        e["workload"] = "the metric's make-up cut into 1024 x 1 MiB streams (four streams per CU: the one-wave path): " + e["workload"]
                     extra.append(e)
                 except SystemExit as ex:  # a failing leg must not hide the headline
                     extra.append({"workload": name, "error": str(ex)})

@@ -45,7 +45,7 @@ constexpr uint32_t kDefaultLdsPerBlock = 36 * 1024;
 thread_local std::string g_last_error;
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
-std::atomic<bool> g_scan_blocks_ok{getenv("BROTLI_AMD_NO_SCAN") == nullptr};
+static const bool g_engine_wanted = getenv("BROTLI_AMD_NO_SCAN") == nullptr;  // (whether a device can hold such a block is decided per batch context, at its creation)
 constexpr uint64_t kEngineQueueMinBytes = 32768;  // mean compressed size from which a batch of cus < n <= 3 cus streams gets engine blocks
 constexpr uint32_t kScanArena = 40960;  // table arena of such a block (with the engine's rings: about 108 KiB of LDS)
 
@@ -124,6 +124,8 @@ struct BrotliAmdBatch {
   uint8_t* d_stage_out = nullptr; size_t stage_out_cap = 0;
   // streams that ran out of output get the reference's verdict (settle_output_limits): set by the batch entry points
   bool exact_limit = false;
+  // blocks of sixteen waves with a command engine: the device's LDS holds one (decided at creation), nothing has refused one since
+  bool engine_ok = false;
   uint8_t* d_settle = nullptr; size_t settle_cap = 0; uint32_t last_settle_count = 0;
 };
 
@@ -146,10 +148,14 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   hipError_t le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
                                            b->d_dict, stream, (int)b->waves);
   if (le != hipSuccess && b->waves == 16u) {
-    // the device does not give one block the LDS the command engine wants: blocks of eight waves from now on
+    // the device refused a block of sixteen waves with the engine's LDS although its properties allow one: this context goes
+    // on with blocks of eight waves, and says so (BrotliAmdLastError); streams are no longer sent back for engine blocks
     (void)hipGetLastError();
-    g_scan_blocks_ok = false;
+    g_last_error = std::string("engine blocks refused (") + hipGetErrorString(le) + "): eight-wave blocks from now on";
+    b->engine_ok = false;
     b->waves = 8;
+    for (uint32_t i = 0; i < b->n; i++) b->h_descs[i].flags &= ~BROTLI_AMD_FLAG_ENGINE_ONLY;
+    if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * b->n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
     le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena, b->d_dict, stream, 8);
   }
   if (!hip_ok(le, "brotli_amd_decode_kernel launch")) return -1;
@@ -193,18 +199,22 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   // against 33 / 44 with two eight-wave blocks per CU, while 1024 streams are faster four to a CU).  Metablocks the
   // engine cannot take go back and continue in a launch of small blocks (BROTLI_AMD_FLAG_ENGINE_ONLY).
   static const bool no_wide = getenv("BROTLI_AMD_NO_ENGINE_QUEUE") != nullptr;  // (experiments)
+  // (whether a block of sixteen waves fits is settled first: only then is the grid cut down to one block per CU)
+  uint32_t arena16 = 0;
+  bool can16 = false;
+  if (b->engine_ok) {
+    const uint32_t h16 = brotli_amd_lds_helper_bytes(16);
+    const size_t room = b->lds_per_cu > (size_t)b->lds_fixed + h16 ? b->lds_per_cu - b->lds_fixed - h16 : 0;
+    arena16 = b->auto_arena ? (uint32_t)std::min<size_t>(kScanArena, room & ~(size_t)15) : b->cur_arena;
+    can16 = arena16 <= room && (!b->auto_arena || arena16 >= 16384u);
+  }
   bool engine_queue = false;
-  if (g_scan_blocks_ok.load() && !no_wide && b->auto_arena && b->grid > b->cus && n <= 3u * b->cus) {
+  if (can16 && !no_wide && b->auto_arena && b->grid > b->cus && n <= 3u * b->cus) {
     uint64_t in_total = 0;
     for (uint32_t i = 0; i < n; i++) in_total += b->h_descs[i].in_size;
     if (in_total / n >= kEngineQueueMinBytes) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
   }
-  if (g_scan_blocks_ok.load() && b->grid <= b->cus) {
-    const uint32_t h16 = brotli_amd_lds_helper_bytes(16);
-    const size_t room = b->lds_per_cu > (size_t)b->lds_fixed + h16 ? b->lds_per_cu - b->lds_fixed - h16 : 0;
-    const uint32_t arena = b->auto_arena ? (uint32_t)std::min<size_t>(kScanArena, room & ~(size_t)15) : b->cur_arena;
-    if (arena <= room && (!b->auto_arena || arena >= 16384u)) { b->cur_arena = arena; b->waves = 16; }
-  }
+  if (can16 && b->grid <= b->cus) { b->cur_arena = arena16; b->waves = 16; }
   engine_queue = engine_queue && b->waves == 16u;
   for (uint32_t i = 0; i < n; i++)
     b->h_descs[i].flags = engine_queue ? b->h_descs[i].flags | BROTLI_AMD_FLAG_ENGINE_ONLY : b->h_descs[i].flags & ~BROTLI_AMD_FLAG_ENGINE_ONLY;
@@ -387,6 +397,7 @@ extern "C" BrotliAmdBatch* BrotliAmdBatchCreate(uint32_t max_streams, uint32_t l
   b->per_cu_cap = (uint32_t)kMaxBlocksPerCu;
   b->cus = (uint32_t)prop.multiProcessorCount; b->lds_fixed = fixed; b->lds_helper = helper; b->lds_helper8 = brotli_amd_lds_helper_bytes(8); b->lds_per_cu = lds_cu;
   b->block_max = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
+  b->engine_ok = g_engine_wanted && lds_cu >= (size_t)fixed + brotli_amd_lds_helper_bytes(16) + 16384u;
   {  // the arena of the second pass: the largest block the device allows (at most 64 KiB: two such blocks per CU at least)
     uint32_t big = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536, 65536);
     b->max_arena = big > fixed + helper ? (big - fixed - helper) & ~15u : 0;

@@ -43,6 +43,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
 
 #include "brotli_device_abi.h"
 #define BROTLI_TABLE_QUAL __constant__ const
@@ -3177,6 +3178,10 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
       if (e2 != hipSuccess) return e2;
     }
   }
+  // The attribute belongs to the function, not to the launch: callers on several threads use different block shapes, so setting it
+  // and launching is one critical section (the launch itself is asynchronous).
+  static std::mutex launch_mutex;
+  std::lock_guard<std::mutex> lock(launch_mutex);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
   // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four

@@ -259,3 +259,117 @@ def test_engine_blocks_serving_more_streams_than_cus(pkg):
         if not ok:
             bad.append((i, (r.result, r.error_code, r.decoded_size), (info.result, info.error_code, info.decoded_size), len(d), cap))
     assert not bad, (len(bad), bad[:10])
+
+
+def _metric_streams(n, size=1 << 20):
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    if not w.encoder_available():
+        pytest.skip("libbrotlienc not available")
+    return w.make_streams("long_backref", n, size, 1000)
+
+
+def test_the_engine_takes_the_commands_of_the_streams_it_is_built_for(pkg):
+    """Which path ran?  `engine_commands` of the status word: in a batch of at most one stream per CU, streams of the metric's
+    make-up (literals that do not depend on context) must go through a command engine for at least 90 % of their commands.
+    A launch that fell back to blocks without the engine (or an engine that hands everything back) fails here, loudly."""
+    streams = _metric_streams(6)
+    datas = [s[0] for s in streams]; caps = [s[1] for s in streams]
+    batch = pkg.Batch(len(datas))
+    results, outs = batch.decode_host(datas, caps, 1)
+    batch.close()
+    for (c, n, sha), r, out in zip(streams, results, outs):
+        info, exp = oracle.decode(c, n, 1)
+        assert (r.result, r.error_code, r.decoded_size, r.num_commands) == (1, 1, n, info.num_commands) and out == exp
+        assert r.engine_commands >= 0.9 * r.num_commands, (r.engine_commands, r.num_commands)
+
+
+_AB_SCRIPT = r"""
+import importlib.util, json, os, sys
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+import workloads as w
+spec = importlib.util.spec_from_file_location("rust_brotli_decompressor_amd", os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec); sys.modules["rust_brotli_decompressor_amd"] = pkg; spec.loader.exec_module(pkg)
+import hashlib
+streams = w.make_streams("long_backref", 4, 1 << 20, 1000)
+datas = [s[0] for s in streams]
+datas.append(datas[0][: len(datas[0]) // 2])                      # truncated
+bad = bytearray(datas[1]); bad[len(bad) // 3] ^= 4; datas.append(bytes(bad))  # damaged
+caps = [s[1] for s in streams] + [streams[0][1], streams[1][1]]
+caps[2] -= 1                                                      # one byte short
+b = pkg.Batch(len(datas))
+res, outs = b.decode_host(datas, caps, 1)
+b.close()
+print(json.dumps([[r.result, r.error_code, r.decoded_size, r.consumed, r.num_commands, r.engine_commands, hashlib.sha256(o).hexdigest()] for r, o in zip(res, outs)]))
+"""
+
+
+def test_the_engines_and_the_one_wave_path_agree(pkg):
+    """The same batch (whole, truncated, damaged, one byte short) three times in fresh processes: default (path engine), the
+    scan engine only (BROTLI_AMD_ENGINE=scan), no engine blocks at all (BROTLI_AMD_NO_SCAN=1) -- same status words and bytes;
+    extra to, not instead of, the comparison with the oracle above."""
+    import json
+    import subprocess
+    _metric_streams(1)  # (skips without an encoder)
+    rows = {}
+    for name, env in (("path", {}), ("scan", {"BROTLI_AMD_ENGINE": "scan"}), ("none", {"BROTLI_AMD_NO_SCAN": "1"})):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", _AB_SCRIPT, ROOT], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    strip = lambda rs: [r[:5] + r[6:] for r in rs]  # everything but engine_commands
+    assert strip(rows["path"]) == strip(rows["scan"]) == strip(rows["none"])
+    assert all(r[5] == 0 for r in rows["none"]), rows["none"]
+    assert all(r[5] >= 0.9 * r[4] for r in rows["path"][:2]) and all(r[5] >= 0.9 * r[4] for r in rows["scan"][:2]), (rows["path"], rows["scan"])
+
+
+def test_batches_and_one_shot_calls_from_several_threads(pkg):
+    """Contexts of different block shapes launched from several threads at once (engine blocks of sixteen waves, small
+    batches of one-wave blocks, one-shot calls): setting the kernel's LDS attribute and launching is one critical section
+    (a launch between another thread's set and launch got the wrong attribute)."""
+    import threading
+    streams = _metric_streams(3, 256 << 10)
+    gold = os.path.join(ROOT, "tests", "golden", "testdata")
+    alice = open(os.path.join(gold, "alice29.txt.compressed"), "rb").read()
+    a_info, a_exp = oracle.decode(alice, 200000, 1)
+    errors = []
+
+    def big():
+        try:
+            for _ in range(6):
+                b = pkg.Batch(3)
+                res, outs = b.decode_host([s[0] for s in streams], [s[1] for s in streams], 1)
+                b.close()
+                for (c, n, sha), r, o in zip(streams, res, outs):
+                    if (r.result, r.decoded_size) != (1, n) or hashlib.sha256(o).hexdigest() != sha or r.engine_commands < 0.9 * r.num_commands:
+                        errors.append(("big", r.result, r.error_code, r.decoded_size, r.engine_commands, r.num_commands))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("big", repr(ex)))
+
+    def many():
+        try:
+            for _ in range(6):
+                b = pkg.Batch(2048)
+                res, outs = b.decode_host([alice] * 2048, [200000] * 2048, 1)
+                b.close()
+                if any((r.result, r.decoded_size) != (1, a_info.decoded_size) for r in res) or outs[7] != a_exp or outs[2047] != a_exp:
+                    errors.append(("many", [(r.result, r.error_code) for r in res if r.result != 1][:3]))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("many", repr(ex)))
+
+    def oneshot():
+        try:
+            for _ in range(40):
+                info, out = pkg.brotli_decode(alice, 200000)
+                if info.result != 1 or out != a_exp:
+                    errors.append(("oneshot", info.result, info.code))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("oneshot", repr(ex)))
+
+    ts = [threading.Thread(target=f) for f in (big, many, oneshot, big, oneshot)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
