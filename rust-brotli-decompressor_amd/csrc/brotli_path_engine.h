@@ -75,7 +75,7 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -337,7 +337,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t avail = in_limit - (lbdw << 5);
       const bool go = b < in_limit && avail >= PE_MIN_INPUT && quota >= SC_MIN_QUOTA && bl1 != 0u;
       pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, b & 31u); pe_ctl_st(pb, PEC_L, avail < rbl ? avail : rbl);
-      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
+      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
       pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
       pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P >> 32));
     }
@@ -417,7 +417,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       rounds++;
       __syncthreads();
       if (rfl(lds_ld32(fw)) == 0u) break;
-      if (rounds >= PE_SYNC_ROUNDS) { if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TMIN, 0u); break; }  // (cannot happen: see above; no path, no region)
+      if (rounds >= PE_SYNC_ROUNDS) { if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TMIN, 0u); __syncthreads(); break; }  // (cannot happen: see above; no path, no region)
     }
     PE_COUNT(21, rounds);
     PE_PROF(17);
@@ -426,8 +426,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u;
       if (cbase + 32u > lim) pm = cbase >= lim ? 0u : pm & ((1u << (lim - cbase)) - 1u);
     }
-    __syncthreads();
-    if (T >= pe_ctl_ld(pb, PEC_TMIN)) pm = 0;
+    if (T >= pe_ctl_ld(pb, PEC_TMIN)) pm = 0;  // (only the entries' failure to settle writes it before this point -- in front of the loop's last barrier)
     // ranks: exclusive prefix sum of the chunks' counts over the block
     uint32_t cnt = (uint32_t)__builtin_popcount(pm);
     uint32_t incl = sc_scan(cnt);
@@ -471,15 +470,15 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
     }
     if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry (lane 0 evaluates it)
-    __syncthreads();
-    c.Rn = pe_ctl_ld(pb, PEC_RN);
     {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u, cut = tmin << 5;
       c.Lp = lim < cut ? lim : cut;
     }
     // sentinels: the sixteen bytes of J1 from Lp on carry the path flag, so that the records' hop loops stop there by themselves
+    // (no path position lies there: nobody else writes them)
     if (T < 16u) lds_st8(pb + PE_J1F + c.Lp + T, lds_ld8(pb + PE_J1F + c.Lp + T) | 0x80u);
     __syncthreads();
+    c.Rn = pe_ctl_ld(pb, PEC_RN);
     PE_PROF(2);
     PE_COUNT(22, c.Rn);
     // ---- records: every lane keeps two evaluations going side by side.  A lane that is through with a state takes the next
@@ -641,34 +640,25 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     }
     __syncthreads();
     // ---- details: lane = command; its fields from the state it starts from, its distance from the state after ----
-    // (the records overlay the closure's states: every lane reads its two list entries, then a barrier, then the stores)
-    {
-      uint32_t w0[PE_CMDS / (64u * SC_WAVES)], w1[PE_CMDS / (64u * SC_WAVES)], w2[PE_CMDS / (64u * SC_WAVES)], w3[PE_CMDS / (64u * SC_WAVES)];
-      _Pragma("unroll") for (uint32_t it = 0; it < PE_CMDS / (64u * SC_WAVES); it++) {
-        const uint32_t k = T + it * 64u * SC_WAVES;
-        w0[it] = w1[it] = w2[it] = w3[it] = 0;
-        if (__ballot(k < m) == 0ull) continue;
-        const bool on = k < m;
-        const uint32_t s0 = on ? lds_ld16(pb + PE_LIST + (k << 1)) : 0u, s1 = on ? lds_ld16(pb + PE_LIST + ((k + 1u) << 1)) : 0u;
-        const PeParse pr = pe_eval<false, false>(c, s0 & 0x7FFFu, s0 >> 15, on);
-        uint32_t kind = SCK_IMPLICIT, val = 0;
-        if (__ballot(on && (s1 >> 15) == 0u) != 0ull) {
-          uint32_t lo, hi;
-          pe_bits64(pb, on ? (s1 & 0x7FFFu) : 0u, lo, hi);
-          const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
-          if ((s1 >> 15) == 0u) { kind = d.kind; val = d.val; }
-        }
-        // a command the fields do not hold goes to the checked loop (bit 30 of w0: the resolve stops in front of it)
-        const bool odd = pr.u > 255u || pr.insert >= 0x10000u || val >= (1u << 30) || pr.code >= 2u;
-        w0[it] = pr.x | ((pr.u & 255u) << 15) | (odd ? 1u << 30 : 0u);
-        w1[it] = (pr.insert & 0xFFFFu) | (pr.ry << 16);
-        w2[it] = pr.copy;
-        w3[it] = (kind << 30) | (val & 0x3FFFFFFFu);
+    // (the records overlay the closure's states, which nothing reads any more: the walk's list holds bit and kind)
+    for (uint32_t k0 = 64u * me; k0 < m; k0 += 64u * SC_WAVES) {
+      const uint32_t k = k0 + lane;
+      const bool on = k < m;
+      const uint32_t s0 = on ? lds_ld16(pb + PE_LIST + (k << 1)) : 0u, s1 = on ? lds_ld16(pb + PE_LIST + ((k + 1u) << 1)) : 0u;
+      const PeParse pr = pe_eval<false, false>(c, s0 & 0x7FFFu, s0 >> 15, on);
+      uint32_t kind = SCK_IMPLICIT, val = 0;
+      if (__ballot(on && (s1 >> 15) == 0u) != 0ull) {
+        uint32_t lo, hi;
+        pe_bits64(pb, on ? (s1 & 0x7FFFu) : 0u, lo, hi);
+        const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
+        if ((s1 >> 15) == 0u) { kind = d.kind; val = d.val; }
       }
-      __syncthreads();
-      _Pragma("unroll") for (uint32_t it = 0; it < PE_CMDS / (64u * SC_WAVES); it++) {
-        const uint32_t k = T + it * 64u * SC_WAVES;
-        if (k < m) { const uint32_t ra = pb + PE_REC + (k << 4); lds_st32(ra, w0[it]); lds_st32(ra + 4u, w1[it]); lds_st32(ra + 8u, w2[it]); lds_st32(ra + 12u, w3[it]); }
+      // a command the fields do not hold goes to the checked loop (bit 30 of w0: the resolve stops in front of it)
+      const bool odd = pr.u > 255u || pr.insert >= 0x10000u || val >= (1u << 30) || pr.code >= 2u;
+      if (on) {
+        const uint32_t ra = pb + PE_REC + (k << 4);
+        lds_st32(ra, pr.x | ((pr.u & 255u) << 15) | (odd ? 1u << 30 : 0u)); lds_st32(ra + 4u, (pr.insert & 0xFFFFu) | (pr.ry << 16));
+        lds_st32(ra + 8u, pr.copy); lds_st32(ra + 12u, (kind << 30) | (val & 0x3FFFFFFFu));
       }
     }
     __syncthreads();
@@ -676,6 +666,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // ---- resolve (wave 0): lane = command, 64 a batch; exactly the scan engine's ----
     if (me == 0) {
       uint32_t kp_total = 0, any_dep = 0, nbig = 0;
+      if (lane < 16u) lds_st32(pb + PE_CTL + 4u * (PEC_BKP + lane), 0u);  // (batches the resolve does not reach execute nothing)
       bool stop = false;
       for (uint32_t k0 = 0; k0 < m && !stop; k0 += 64u) {
         const uint32_t K = m - k0 < 64u ? m - k0 : 64u;
@@ -769,7 +760,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
         P += out_tot; bl0 -= lit_tot; bl1 -= cmd_tot; bl2 -= dst_tot; quota -= out_tot; mlen -= (int32_t)out_tot; ncmd += cmd_tot;
         kp_total += kp;
+        // the batch is ready for the wave that executes it (the records' stores above are this wave's, and in order)
+        pe_ctl_st(pb, PEC_BKP + (k0 >> 6), kp);
+        pe_ctl_st(pb, PEC_READY, (k0 >> 6) + 1u);
       }
+      pe_ctl_st(pb, PEC_READY, 16u);
       pe_ctl_st(pb, PEC_KP, kp_total); pe_ctl_st(pb, PEC_ANYDEP, any_dep); pe_ctl_st(pb, PEC_NBIG, nbig);
       // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
       // of the state it starts from)
@@ -788,24 +783,19 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
       pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
     }
-    __syncthreads();
-    PE_PROF(8);
-    const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
-    PE_COUNT(28, kp);
-    if (pe_ctl_ld(pb, PEC_CONT) != 0u) {  // the next region's input is on its way while this one is executed
-      const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
-      pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + 1024u + T < limit_dw) ? in_dw[nl + 1024u + T] : 0u;
-      pre_ok = true;
-    }
     // ---- execute ----
     {
       gu8* const o = out + P0;
       // (a) lane = command: the literals in front of the path, decoded again one after the other; the literals on the path out
       // of lit[], four bytes a step; the command's copy where it is short and its source lies in front of the region's
       // output (one 16-byte load, stores in pieces)
-      for (uint32_t k0 = 64u * me; k0 < kp; k0 += 64u * SC_WAVES) {
-        const uint32_t k = k0 + lane;
-        const bool on = k < kp;
+      // (the waves behind wave 0 take the batches as its resolve hands them over: no barrier in between)
+      if (me != 0u)
+      for (uint32_t bi = me - 1u; bi * 64u < m; bi += SC_WAVES - 1u) {
+        while (pe_ctl_ld(pb, PEC_READY) <= bi) __builtin_amdgcn_s_sleep(2);
+        const uint32_t kpb = pe_ctl_ld(pb, PEC_BKP + bi);
+        const uint32_t k = bi * 64u + lane;
+        const bool on = lane < kpb;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
         const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
         const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
@@ -843,6 +833,15 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             }
           }
         }
+      }
+      __syncthreads();
+      PE_PROF(8);
+      const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
+      PE_COUNT(28, kp);
+      if (pe_ctl_ld(pb, PEC_CONT) != 0u) {  // the next region's input is on its way while the rest of this one is executed
+        const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
+        pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + 1024u + T < limit_dw) ? in_dw[nl + 1024u + T] : 0u;
+        pre_ok = true;
       }
       // (b) the commands listed for it get a wave each: long literal runs out of lit[], long copies whose source lies in front
       // of the region's output
