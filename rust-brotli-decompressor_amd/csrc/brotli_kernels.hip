@@ -2119,6 +2119,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
         br.seek(pos);
+        const uint64_t P_before = P;
         P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
         quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
         bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
@@ -2126,7 +2127,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         num_commands += took;
         lit_pos = P;
         force_checked = 1u;
-        if (took < 64u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
+        // (an invocation that got nowhere -- few commands AND few bytes: a long literal run is one command -- makes the next ones rarer)
+        if (took < 64u && P - P_before < 4096u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
         insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
         distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
         lds_sync();
@@ -3151,6 +3153,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
            g_path_prof[22] / g_path_prof[20], g_path_prof[24] / g_path_prof[20], g_path_prof[23] / g_path_prof[20], (g_path_prof[23] * 10 / g_path_prof[20]) % 10,
            g_path_prof[21] / g_path_prof[20], (g_path_prof[21] * 10 / g_path_prof[20]) % 10, g_path_prof[27] / g_path_prof[20], g_path_prof[25], g_path_prof[31], g_path_prof[29], g_path_prof[30]);
     printf("\npath engine dependent copies: %llu per region, the last wave's ticks in them %llu per region\n", g_path_prof[35] / g_path_prof[20], g_path_prof[34] / g_path_prof[20]);
+    printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);
     printf("\npath engine closure: block rounds %llu (%llu ticks each), wave-0 tails %llu (%llu ticks each), uncapped passes %llu (%llu ticks each)\n", g_path_prof[14], g_path_prof[11] / (g_path_prof[14] + 1), g_path_prof[15], g_path_prof[12] / (g_path_prof[15] + 1), g_path_prof[16], g_path_prof[13] / (g_path_prof[16] + 1));
   }

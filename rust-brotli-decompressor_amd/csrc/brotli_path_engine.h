@@ -43,12 +43,13 @@ constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluat
 constexpr uint32_t PE_SYNC_ROUNDS = SC_WAVES + 1;  // rounds between waves the chunk entries get to settle: enough for any code
 constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
 constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this long are stored by their command's lane, four bytes a step
+constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own: the path's literals are the run's
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
 static_assert(PE_CHUNKS == 64u * SC_WAVES, "one chunk per lane of the block");
 
 // LDS layout, offsets from the engine's base (the scan engine's: the two never run at the same time)
-constexpr uint32_t PE_CTL = 0;                                    // 512: control words (the first 32 as the scan engine's)
-constexpr uint32_t PE_IN = 512;                                   // the region's input: PE_RBL / 32 + 6 dwords
+constexpr uint32_t PE_CTL = 0;                                    // 1024: control words (the first 32 as the scan engine's), the stream's state
+constexpr uint32_t PE_IN = 1024;                                   // the region's input: PE_RBL / 32 + 6 dwords
 constexpr uint32_t PE_J1F = PE_IN + (PE_RBL / 32 + 8) * 4;        // code length at every bit, bit 7: on the path; later NEXT8
 constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per state: the state eight commands on
 constexpr uint32_t PE_PM = PE_J1F + PE_RBL + 64;                  // u32 per chunk: which of its bits are on the path; later OFF
@@ -75,7 +76,7 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -107,6 +108,36 @@ __device__ __forceinline__ void pe_bits64(uint32_t pb, uint32_t p, uint32_t& lo,
 __device__ __forceinline__ uint32_t pe_bits32(uint32_t pb, uint32_t p) {
   const uint32_t q = pb + PE_IN + ((p >> 5) << 2);
   return __builtin_amdgcn_alignbit(lds_ld32(q + 4u), lds_ld32(q), p & 31u);
+}
+
+
+// The stream's state (wave 0's, uniform).  It lives in LDS between the places that use it -- the region's set-up, the
+// resolve, a literal run's regions, the hand-over --, so that the registers it would take do not spill in the loops between.
+struct PeStream {
+  uint64_t P; uint32_t quota, bl0, bl1, bl2, ncmd, b, rbl, run_on, run_rem, run_copy, run_implicit, run_dctx;
+  int32_t mlen, d0, d1, d2, d3, max_backward;
+  uint32_t first;  // the invocation's first region is still to come
+};
+__device__ __forceinline__ PeStream pe_st_load(uint32_t pb) {
+  PeStream st;
+  // (one LDS read for all of it: lane k reads word k, the fields come out of the lanes)
+  const uint32_t v = *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * (PEC_STATE + lane_id())]);
+  st.P = (uint64_t)rdlane(v, 0) | ((uint64_t)rdlane(v, 1) << 32);
+  st.quota = rdlane(v, 2); st.bl0 = rdlane(v, 3); st.bl1 = rdlane(v, 4); st.bl2 = rdlane(v, 5);
+  st.ncmd = rdlane(v, 6); st.b = rdlane(v, 7); st.rbl = rdlane(v, 8); st.run_on = rdlane(v, 9);
+  st.run_rem = rdlane(v, 10); st.run_copy = rdlane(v, 11); st.run_implicit = rdlane(v, 12); st.run_dctx = rdlane(v, 13);
+  st.mlen = (int32_t)rdlane(v, 14); st.d0 = (int32_t)rdlane(v, 15); st.d1 = (int32_t)rdlane(v, 16);
+  st.d2 = (int32_t)rdlane(v, 17); st.d3 = (int32_t)rdlane(v, 18); st.max_backward = (int32_t)rdlane(v, 19); st.first = rdlane(v, 20);
+  return st;
+}
+__device__ __forceinline__ void pe_st_store(uint32_t pb, const PeStream& st) {
+  const uint32_t a = PEC_STATE;
+  pe_ctl_st(pb, a, (uint32_t)st.P); pe_ctl_st(pb, a + 1, (uint32_t)(st.P >> 32));
+  pe_ctl_st(pb, a + 2, st.quota); pe_ctl_st(pb, a + 3, st.bl0); pe_ctl_st(pb, a + 4, st.bl1); pe_ctl_st(pb, a + 5, st.bl2);
+  pe_ctl_st(pb, a + 6, st.ncmd); pe_ctl_st(pb, a + 7, st.b); pe_ctl_st(pb, a + 8, st.rbl); pe_ctl_st(pb, a + 9, st.run_on);
+  pe_ctl_st(pb, a + 10, st.run_rem); pe_ctl_st(pb, a + 11, st.run_copy); pe_ctl_st(pb, a + 12, st.run_implicit); pe_ctl_st(pb, a + 13, st.run_dctx);
+  pe_ctl_st(pb, a + 14, (uint32_t)st.mlen); pe_ctl_st(pb, a + 15, (uint32_t)st.d0); pe_ctl_st(pb, a + 16, (uint32_t)st.d1);
+  pe_ctl_st(pb, a + 17, (uint32_t)st.d2); pe_ctl_st(pb, a + 18, (uint32_t)st.d3); pe_ctl_st(pb, a + 19, (uint32_t)st.max_backward); pe_ctl_st(pb, a + 20, st.first);
 }
 
 // What every phase needs to know about the region (uniform)
@@ -294,6 +325,25 @@ __device__ __forceinline__ PeParse pe_eval(const PeCtx& c, uint32_t pos, uint32_
   return r[0];
 }
 
+
+// A command with a long literal run gets regions of its own (wave 0, uniform): the region's path starts at the run's first
+// literal, every path position is one of its literals, no records (ReadCommandInternal here, the literals in the run's
+// regions, the distance and the copy in the checked loop: decode.rs:2134-2189, 2393-2462).  `hp` is the local bit of the
+// command's head; on success the stream stands at the run's first literal.
+#ifdef BROTLI_AMD_NO_TRYRUN
+#define PE_TRY_RUN(st_, hp_) do { } while (0)
+#else
+#define PE_TRY_RUN(st_, hp_) do { \
+    uint32_t lo_, hi_; \
+    pe_bits64(pb, (hp_), lo_, hi_); \
+    const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr); \
+    const uint32_t hins_ = rfl(h_.insert), hbits_ = rfl(h_.bits); \
+    if (hins_ >= PE_RUN_MIN && hbits_ != 0u && (st_).bl1 != 0u && (rfl(h_.implicit) != 0u || (st_).bl2 != 0u)) { \
+      (st_).run_on = 1u; (st_).run_rem = hins_; (st_).run_copy = rfl(h_.copy); (st_).run_implicit = rfl(h_.implicit); (st_).run_dctx = rfl(h_.dctx); \
+      (st_).bl1 -= 1u; (st_).ncmd += 1u; (st_).b += hbits_; \
+    } } while (0)
+#endif
+
 // One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
 // Returns (wave 0) the number of commands it took; exit form and state in LDS_LEAN as the scan engine leaves them.
 __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
@@ -317,29 +367,35 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   if (lane < 24) c.lut_vgpr = (uint32_t)kInsBase[lane] | ((uint32_t)kInsExtra[lane] << 16);
   else if (lane >= 32 && lane < 56) c.lut_vgpr = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
 
-  // ---- wave 0: the stream's state (uniform) ----
-  uint32_t b = pe_ctl_ld(pb, SCC_ENTRY);  // next command (bits from the engine's origin)
-  uint64_t P = 0; uint32_t quota = 0, bl0 = 0, bl1 = 0, bl2 = 0, ncmd = 0; int32_t mlen = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0, max_backward = 0;
+  // ---- wave 0: the stream's state (uniform), into its LDS words ----
   if (me == 0) {
-    P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
-    quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
-    bl0 = LEAN_LD(L_BL0); bl1 = LEAN_LD(L_BL1); bl2 = LEAN_LD(L_BL2);
-    d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
-    max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
+    PeStream st;
+    st.b = pe_ctl_ld(pb, SCC_ENTRY);  // next command (bits from the engine's origin)
+    st.P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+    st.quota = LEAN_LD(L_QUOTA); st.mlen = (int32_t)LEAN_LD(L_MLEN);
+    st.bl0 = LEAN_LD(L_BL0); st.bl1 = LEAN_LD(L_BL1); st.bl2 = LEAN_LD(L_BL2);
+    st.d0 = (int32_t)LEAN_LD(L_D0); st.d1 = (int32_t)LEAN_LD(L_D1); st.d2 = (int32_t)LEAN_LD(L_D2); st.d3 = (int32_t)LEAN_LD(L_D3);
+    st.max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
+    st.ncmd = 0;
+    // a literal run that gets regions of its own: literals still to come, then the command's copy length, distance kind, context
+    st.run_on = 0; st.run_rem = 0; st.run_copy = 0; st.run_implicit = 0; st.run_dctx = 0;
+    st.rbl = PE_RBL;  // bits the next region takes: halved where the closure ran out of room, doubled back where it is small
+    st.first = 1u;
+    pe_st_store(pb, st);
   }
-
-  uint32_t rbl = PE_RBL;  // (wave 0) bits the next region takes: halved where the closure ran out of room, doubled back where it is small
   uint32_t pre_a = 0, pre_b = 0; bool pre_ok = false;  // the next region's input dwords of this lane, once they are known
   for (;;) {
     // ================= the region =================
     if (me == 0) {
-      const uint32_t lbdw = b >> 5;
+      const PeStream st = pe_st_load(pb);
+      const uint32_t lbdw = st.b >> 5;
       const uint32_t avail = in_limit - (lbdw << 5);
-      const bool go = b < in_limit && avail >= PE_MIN_INPUT && quota >= SC_MIN_QUOTA && bl1 != 0u;
-      pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, b & 31u); pe_ctl_st(pb, PEC_L, avail < rbl ? avail : rbl);
+      const bool go = st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
+      pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, st.b & 31u); pe_ctl_st(pb, PEC_L, avail < st.rbl ? avail : st.rbl);
       pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
       pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
-      pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P >> 32));
+      pe_ctl_st(pb, PEC_P0_LO, (uint32_t)st.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(st.P >> 32));
+      pe_ctl_st(pb, PEC_MODE, st.run_on); pe_ctl_st(pb, PEC_ENT, st.b & 31u);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the region before: its stores are in memory before anyone reads them as copy sources)
     __syncthreads();
@@ -355,6 +411,17 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     pre_ok = false;
     __syncthreads();
     PE_PROF(0);
+    if (me == 0 && pe_ctl_ld(pb, PEC_STATE + 20) != 0u) {
+      // the invocation's first region: is its first command one with a long literal run?  (later regions know from the resolve
+      // of the region before)
+      PeStream st = pe_st_load(pb);
+      st.first = 0u;
+      if (c.L >= 256u) {
+        PE_TRY_RUN(st, le);
+        if (st.run_on != 0u) { pe_ctl_st(pb, PEC_MODE, 1u); pe_ctl_st(pb, PEC_ENT, st.b - (lbdw << 5)); }
+      }
+      pe_st_store(pb, st);
+    }
     // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
     for (uint32_t g = T; g < PE_RBL / 8u; g += 64u * SC_WAVES) {
       const uint32_t pos0 = g << 3;
@@ -382,17 +449,18 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // A wave's entry is exact after as many rounds as waves lie in front of it, so PE_SYNC_ROUNDS rounds make the path exact
     // whatever the code (one that does not re-synchronise takes them all; the usual case is two).
     const uint32_t cbase = T << 5;
-    uint32_t pm = 0, eo = T == 0u ? le : 0u, ex = 0;
+    const uint32_t ent = pe_ctl_ld(pb, PEC_ENT), et = ent >> 5, eoff = ent & 31u;  // the path's first bit: the entry, or a long run's first literal
+    uint32_t pm = 0, eo = T == et ? eoff : 0u, ex = 0;
     {
       uint32_t y = eo;
       while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
       ex = y - 32u;
     }
-    uint32_t wave_entry = me == 0u ? le : 0u, rounds = 0;
+    uint32_t wave_entry = 0u, rounds = 0;
     for (;;) {
       for (;;) {  // the wave's own chunks
         const uint32_t prev_ex = bperm(((lane + 63u) & 63u) << 2, ex);
-        const uint32_t neo = lane == 0u ? wave_entry : prev_ex;
+        const uint32_t neo = T == et ? eoff : lane == 0u ? wave_entry : prev_ex;
         bool changed = false;
         if (neo != eo) {
           eo = neo;
@@ -411,7 +479,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t fw = pb + PE_CTL + 4u * (PEC_CHG + rounds % 3u);
       if (T == 0u) lds_st32(pb + PE_CTL + 4u * (PEC_CHG + (rounds + 1u) % 3u), 0u);
       __syncthreads();
-      const uint32_t ne = me == 0u ? le : rfl(lds_ld8(pb + PE_EX + slot * 64u + me - 1u));
+      const uint32_t ne = me == 0u ? 0u : rfl(lds_ld8(pb + PE_EX + slot * 64u + me - 1u));
       if (ne != wave_entry && lane == 0) lds_st32(fw, 1u);
       wave_entry = ne;
       rounds++;
@@ -425,6 +493,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u;
       if (cbase + 32u > lim) pm = cbase >= lim ? 0u : pm & ((1u << (lim - cbase)) - 1u);
+      if (T < et) pm = 0;  // (chunks in front of the path's first bit)
     }
     if (T >= pe_ctl_ld(pb, PEC_TMIN)) pm = 0;  // (only the entries' failure to settle writes it before this point -- in front of the loop's last barrier)
     // ranks: exclusive prefix sum of the chunks' counts over the block
@@ -481,6 +550,45 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     c.Rn = pe_ctl_ld(pb, PEC_RN);
     PE_PROF(2);
     PE_COUNT(22, c.Rn);
+    if (pe_ctl_ld(pb, PEC_MODE) != 0u) {
+      // ---- a region of a long literal run: the path's literals, as many as the run, the literal block, the output limits and
+      // the region hold (one short of each limit: what happens AT a limit is the checked loop's), go out; the next region
+      // starts behind them ----
+      if (me == 0) {
+        const PeStream st = pe_st_load(pb);
+        uint32_t take = st.run_rem;
+        const uint32_t cap1 = c.Rn != 0u ? c.Rn - 1u : 0u, cap2 = st.quota > 1u ? st.quota - 1u : 0u;
+        take = take < cap1 ? take : cap1; take = take < st.bl0 ? take : st.bl0; take = take < cap2 ? take : cap2;
+        pe_ctl_st(pb, PEC_TAKE, take);
+      }
+      __syncthreads();
+      const uint32_t take = pe_ctl_ld(pb, PEC_TAKE);
+      {
+        gu8* const o = out + P0;
+        for (uint32_t i = T << 2; i < take; i += 4u * 64u * SC_WAVES) {
+          const uint32_t v = lds_ld32(pb + PE_LIT + i);
+          if (i + 4u <= take) *reinterpret_cast<gu32*>(o + i) = v;
+          else { o[i] = (uint8_t)v; if (i + 1u < take) o[i + 1u] = (uint8_t)(v >> 8); if (i + 2u < take) o[i + 2u] = (uint8_t)(v >> 16); }
+        }
+      }
+      if (me == 0) {
+        PeStream st = pe_st_load(pb);
+        st.P += take; st.quota -= take; st.bl0 -= take; st.mlen -= (int32_t)take; st.run_rem -= take;
+        const uint32_t np = take != 0u ? rfl(lds_ld16(pb + PE_POR + (take << 1))) : ent;
+        st.b = (lbdw << 5) + np;
+        pe_ctl_st(pb, PEC_CONT, (take != 0u && st.run_rem != 0u) ? 1u : 0u); pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
+        PE_COUNT(19, take);
+        pe_st_store(pb, st);
+      }
+      __syncthreads();
+      if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
+      {
+        const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
+        pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + 1024u + T < limit_dw) ? in_dw[nl + 1024u + T] : 0u;
+        pre_ok = true;
+      }
+      continue;
+    }
     // ---- records: every lane keeps two evaluations going side by side.  A lane that is through with a state takes the next
     // path position (kind E) off a shared counter; a lane whose record leads to a state that is not a path state (the run
     // ended before it met the path, or the command has an implicit distance) appends that state to the closure and
@@ -577,7 +685,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     __syncthreads();
     PE_COUNT(24, pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP);
     const uint32_t wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
-    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_WCAP / 4u && rbl < PE_RBL) rbl <<= 1; }
+    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pb, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_WCAP / 4u && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pb, PEC_STATE + 8, rbl); }
     PE_PROF(4);
     // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
     for (uint32_t i0 = T; i0 < PE_RANKS + wn; i0 += 4u * 64u * SC_WAVES) {
@@ -665,6 +773,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     PE_PROF(7);
     // ---- resolve (wave 0): lane = command, 64 a batch; exactly the scan engine's ----
     if (me == 0) {
+      PeStream st = pe_st_load(pb);
       uint32_t kp_total = 0, any_dep = 0, nbig = 0;
       if (lane < 16u) lds_st32(pb + PE_CTL + 4u * (PEC_BKP + lane), 0u);  // (batches the resolve does not reach execute nothing)
       bool stop = false;
@@ -684,7 +793,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         const bool big = copy >= (1u << 24);
         const uint32_t s2 = sc_scan(ins + (big ? 0u : copy));
         const uint32_t out_excl = s2 - (ins + (big ? 0u : copy));
-        bool ok = !odd && !big && lit_incl <= bl0 && cmd_incl <= bl1 && dst_incl <= bl2 && s2 < quota;
+        bool ok = !odd && !big && lit_incl <= st.bl0 && cmd_incl <= st.bl1 && dst_incl <= st.bl2 && s2 < st.quota;
         // the distance ring (TakeDistanceFromRingBuffer, decode.rs:2017-2049): short codes read the last four distances
         // that were pushed; a lane whose source is itself a short code waits for it
         const bool need = kind == SCK_SHORT || kind == SCK_IMPLICIT;
@@ -699,7 +808,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
           const bool from_carry = npush <= back;
           const uint32_t ci = back - npush;  // (meaningful when from_carry)
-          const int32_t carry = ci == 0u ? d0 : ci == 1u ? d1 : ci == 2u ? d2 : d3;
+          const int32_t carry = ci == 0u ? st.d0 : ci == 1u ? st.d1 : ci == 2u ? st.d2 : st.d3;
           const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
           uint32_t resolved = need ? 0u : 1u;
           const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
@@ -715,8 +824,8 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
         {
           // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
-          const uint64_t pk = P + out_excl + ins;
-          const int32_t maxd = pk < (uint64_t)(uint32_t)max_backward ? (int32_t)pk : max_backward;
+          const uint64_t pk = st.P + out_excl + ins;
+          const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
           ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
         }
         const uint64_t stopmask = __ballot(active && !ok);
@@ -728,16 +837,16 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           const uint32_t got = (uint32_t)__popcll(pmk & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)));
           if (got != 0u) {
             const uint32_t dperm = bperm(perm << 2, (uint32_t)dist);  // lane r: the distance of the r-th push
-            const int32_t o0 = d0, o1 = d1, o2 = d2;
-            d0 = (int32_t)rdlane(dperm, got - 1u);
-            d1 = got >= 2u ? (int32_t)rdlane(dperm, got - 2u) : o0;
-            d2 = got >= 3u ? (int32_t)rdlane(dperm, got - 3u) : got == 2u ? o0 : o1;
-            d3 = got >= 4u ? (int32_t)rdlane(dperm, got - 4u) : got == 3u ? o0 : got == 2u ? o1 : o2;
+            const int32_t o0 = st.d0, o1 = st.d1, o2 = st.d2;
+            st.d0 = (int32_t)rdlane(dperm, got - 1u);
+            st.d1 = got >= 2u ? (int32_t)rdlane(dperm, got - 2u) : o0;
+            st.d2 = got >= 3u ? (int32_t)rdlane(dperm, got - 3u) : got == 2u ? o0 : o1;
+            st.d3 = got >= 4u ? (int32_t)rdlane(dperm, got - 4u) : got == 3u ? o0 : got == 2u ? o1 : o2;
           }
         }
         if (kp != 0u) {
           // a copy whose source reaches into the region's own output is done afterwards, in order (bit 31 of w0)
-          const uint64_t rel = (P - P0) + out_excl;
+          const uint64_t rel = (st.P - P0) + out_excl;
           const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
           const uint64_t dmk = __ballot(lane < kp && dep != 0u);
           if (dmk != 0ull) {
@@ -758,7 +867,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
           }
         }
-        P += out_tot; bl0 -= lit_tot; bl1 -= cmd_tot; bl2 -= dst_tot; quota -= out_tot; mlen -= (int32_t)out_tot; ncmd += cmd_tot;
+        st.P += out_tot; st.bl0 -= lit_tot; st.bl1 -= cmd_tot; st.bl2 -= dst_tot; st.quota -= out_tot; st.mlen -= (int32_t)out_tot; st.ncmd += cmd_tot;
         kp_total += kp;
         // the batch is ready for the wave that executes it (the records' stores above are this wave's, and in order)
         pe_ctl_st(pb, PEC_BKP + (k0 >> 6), kp);
@@ -769,19 +878,22 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
       // of the state it starts from)
       {
-        const uint32_t st = rfl(lds_ld16(pb + PE_LIST + (kp_total << 1)));
-        uint32_t pbit = st & 0x7FFFu;
-        if ((st >> 15) == 0u) {
+        const uint32_t dsc = rfl(lds_ld16(pb + PE_LIST + (kp_total << 1)));
+        uint32_t pbit = dsc & 0x7FFFu;
+        if ((dsc >> 15) == 0u) {
           uint32_t lo, hi;
           pe_bits64(pb, pbit, lo, hi);
           const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
           pbit += rfl(d.bits);
         }
-        b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
-        pe_ctl_st(pb, PEC_NEXT_LBDW, b >> 5);
+        st.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
+        // the region went through whole and the next one starts at a command with a long literal run: the next regions are the run's
+        if (kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(st, pbit);
+        pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
       }
       // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
       pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
+      pe_st_store(pb, st);
     }
     // ---- execute ----
     {
@@ -970,16 +1082,33 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
   if (me != 0) return 0;
 #ifdef BROTLI_AMD_PROFILE_SCAN
-  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += ncmd; g_path_prof[33] += 1; }
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += pe_ctl_ld(pb, PEC_STATE + 6); g_path_prof[33] += 1; }
 #endif
   // ---- hand the stream back in front of the next command (LDS_LEAN, as the scan engine does) ----
+  const PeStream st_ = pe_st_load(pb);
+  PeStream st = st_;
+  if (st.run_on != 0u) {
+    // inside a command whose literal run had regions of its own: the checked loop finishes its literals (what the limits kept
+    // back, or none), its distance and its copy; the reference takes a command's whole insert length off when it reads the
+    // command (decode.rs:2388)
+    st.mlen -= (int32_t)st.run_rem;
+    if (lane == 0) {
+      LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_LITERALS_REST);
+      LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
+      LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
+      LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
+      LEAN_ST(L_INSERT, st.run_rem); LEAN_ST(L_COPY, st.run_copy); LEAN_ST(L_DCODE, st.run_implicit ? 0 : -1); LEAN_ST(L_DCTX, st.run_dctx); LEAN_ST(L_LITS_LEFT, st.run_rem);
+    }
+    lds_sync();
+    return st.ncmd;
+  }
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_BEGIN);
-    LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota); LEAN_ST(L_MLEN, mlen);
-    LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
-    LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_BEGIN);
+    LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
+    LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
+    LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
     LEAN_ST(L_INSERT, 0u); LEAN_ST(L_COPY, 0u); LEAN_ST(L_DCODE, 0); LEAN_ST(L_DCTX, 0u); LEAN_ST(L_LITS_LEFT, 0u);
   }
   lds_sync();
-  return ncmd;
+  return st.ncmd;
 }
