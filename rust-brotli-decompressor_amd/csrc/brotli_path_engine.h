@@ -450,27 +450,38 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // whatever the code (one that does not re-synchronise takes them all; the usual case is two).
     const uint32_t cbase = T << 5;
     const uint32_t ent = pe_ctl_ld(pb, PEC_ENT), et = ent >> 5, eoff = ent & 31u;  // the path's first bit: the entry, or a long run's first literal
-    uint32_t pm = 0, eo = T == et ? eoff : 0u, ex = 0;
+    // The chunk's 32 code lengths in registers, and from them -- back to front, every index a constant -- where a chain
+    // entering at each of its bits leaves it: xt nibble y = bits into the next chunk of the chain through bit y.
+    uint32_t jw[8];
     {
-      uint32_t y = eo;
-      while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
-      ex = y - 32u;
+      const u32x4 a = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_J1F + cbase]);
+      const u32x4 bq = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_J1F + cbase + 16u]);
+      jw[0] = a.x; jw[1] = a.y; jw[2] = a.z; jw[3] = a.w; jw[4] = bq.x; jw[5] = bq.y; jw[6] = bq.z; jw[7] = bq.w;
     }
+    uint32_t xt[4] = {0u, 0u, 0u, 0u};
+    _Pragma("unroll") for (int y = 31; y >= 0; y--) {
+      const uint32_t len = (jw[y >> 2] >> ((y & 3) * 8)) & 15u;
+      const uint32_t t = (uint32_t)y + len;
+      // (t < 32: the exit is the one of bit t, which is already there)
+      const uint32_t tc = t & 31u;
+      const uint32_t dsel = tc < 8u ? xt[0] : tc < 16u ? xt[1] : tc < 24u ? xt[2] : xt[3];
+      const uint32_t ex_t = (dsel >> ((tc & 7u) * 4u)) & 15u;
+      const uint32_t exy = t >= 32u ? t - 32u : ex_t;
+      xt[y >> 3] |= exy << ((y & 7) * 4);
+    }
+    auto exit_of = [&](uint32_t e) -> uint32_t {
+      const uint32_t dsel = e < 8u ? xt[0] : e < 16u ? xt[1] : e < 24u ? xt[2] : xt[3];
+      return (dsel >> ((e & 7u) * 4u)) & 15u;
+    };
+    uint32_t eo = T == et ? eoff : 0u, ex = exit_of(eo);
     uint32_t wave_entry = 0u, rounds = 0;
     for (;;) {
-      for (;;) {  // the wave's own chunks
+      for (;;) {  // the wave's own chunks: a chunk's entry is the exit of the chunk before
         const uint32_t prev_ex = bperm(((lane + 63u) & 63u) << 2, ex);
         const uint32_t neo = T == et ? eoff : lane == 0u ? wave_entry : prev_ex;
-        bool changed = false;
-        if (neo != eo) {
-          eo = neo;
-          if (((pm >> neo) & 1u) != 0u) pm &= ~((1u << neo) - 1u);  // the new entry is on the old chain: its tail stays
-          else {
-            uint32_t y = neo; pm = 0;
-            while (y < 32u) { pm |= 1u << y; y += lds_ld8(pb + PE_J1F + cbase + y) & 15u; }
-            changed = (y - 32u) != ex; ex = y - 32u;
-          }
-        }
+        const uint32_t nex = exit_of(neo);
+        const bool changed = nex != ex;
+        eo = neo; ex = nex;
         if (__ballot(changed) == 0ull) break;
       }
       // the wave's exit for the wave behind it; another round if any wave's entry moves
@@ -486,6 +497,17 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       __syncthreads();
       if (rfl(lds_ld32(fw)) == 0u) break;
       if (rounds >= PE_SYNC_ROUNDS) { if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TMIN, 0u); __syncthreads(); break; }  // (cannot happen: see above; no path, no region)
+    }
+    // the chunk's own path positions: the chain from its entry, out of the registers
+    uint32_t pm = 0;
+    {
+      uint32_t y = eo;
+      while (y < 32u) {
+        pm |= 1u << y;
+        const uint32_t k = y >> 2;
+        const uint32_t d = k < 4u ? (k < 2u ? (k == 0u ? jw[0] : jw[1]) : (k == 2u ? jw[2] : jw[3])) : (k < 6u ? (k == 4u ? jw[4] : jw[5]) : (k == 6u ? jw[6] : jw[7]));
+        y += (d >> ((y & 3u) * 8u)) & 15u;
+      }
     }
     PE_COUNT(21, rounds);
     PE_PROF(17);
