@@ -62,6 +62,7 @@ constexpr uint32_t PE_NEXT = PE_LIT + PE_RANKS;                   // u16 per sta
 constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2;              // u16 per closure state: bit | kind << 15; later the commands' records
 constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes per listed command
 constexpr uint32_t PE_BLIST = PE_NEXT + 2 * PE_CMDS;                // u16 per command with a long copy from in front of the region or a long literal run: its index
+constexpr uint32_t PE_RS = PE_NEXT + 4 * PE_CMDS;                   // 64 bytes per batch of the resolve: its sums, the ring it ends with, its list counts
 constexpr uint32_t PE_DLIST = PE_NEXT;                            // u16 per copy that reads the region's own output: its command (the records are dead by then)
 constexpr uint32_t PE_LIST = PE_WST + PE_WCAP * 2;                // u16 per listed command (+ 1): its state as bit | kind << 15
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
@@ -793,113 +794,154 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     }
     __syncthreads();
     PE_PROF(7);
-    // ---- resolve (wave 0): lane = command, 64 a batch; exactly the scan engine's ----
-    if (me == 0) {
-      PeStream st = pe_st_load(pb);
-      uint32_t kp_total = 0, any_dep = 0, nbig = 0;
-      if (lane < 16u) lds_st32(pb + PE_CTL + 4u * (PEC_BKP + lane), 0u);  // (batches the resolve does not reach execute nothing)
-      bool stop = false;
-      for (uint32_t k0 = 0; k0 < m && !stop; k0 += 64u) {
-        const uint32_t K = m - k0 < 64u ? m - k0 : 64u;
-        const bool active = lane < K;
-        const uint32_t ra = pb + PE_REC + ((k0 + (active ? lane : 0u)) << 4);
-        const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), r2 = lds_ld32(ra + 8u), r3 = lds_ld32(ra + 12u);
-        const uint32_t ins = active ? r1 & 0xFFFFu : 0u, copy = active ? r2 : 0u;
-        const uint32_t kind = active ? r3 >> 30 : (uint32_t)SCK_NONE, val = r3 & 0x3FFFFFFFu;
-        const bool odd = ((r0 >> 30) & 1u) != 0u;
-        const uint32_t isdist = (kind == SCK_EXPLICIT || kind == SCK_SHORT) ? 1u : 0u;
-        const uint32_t lit_incl = sc_scan(ins);
-        const uint32_t s1 = sc_scan((active ? 1u : 0u) | (isdist << 16));
-        const uint32_t cmd_incl = s1 & 0xFFFFu, dst_incl = s1 >> 16;
-        // (a sum of 64 copy lengths stays below 2^31: lengths of 2^24 and more are `odd` below)
-        const bool big = copy >= (1u << 24);
-        const uint32_t s2 = sc_scan(ins + (big ? 0u : copy));
-        const uint32_t out_excl = s2 - (ins + (big ? 0u : copy));
-        bool ok = !odd && !big && lit_incl <= st.bl0 && cmd_incl <= st.bl1 && dst_incl <= st.bl2 && s2 < st.quota;
-        // the distance ring (TakeDistanceFromRingBuffer, decode.rs:2017-2049): short codes read the last four distances
-        // that were pushed; a lane whose source is itself a short code waits for it
-        const bool need = kind == SCK_SHORT || kind == SCK_IMPLICIT;
-        const uint32_t code = kind == SCK_SHORT ? val : 0u;
-        const bool pushes = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
-        const uint64_t pmk = __ballot(pushes);
-        int32_t dist = kind == SCK_EXPLICIT ? (int32_t)val : 0;
-        const uint32_t npush = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmk, 0u));  // pushes in front of this lane
-        const uint32_t n_all = (uint32_t)__popcll(pmk);
-        const uint32_t perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((pushes ? npush : n_all + lane - npush) << 2), (int)lane);
-        if (__ballot(need) != 0ull) {
-          const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
-          const bool from_carry = npush <= back;
-          const uint32_t ci = back - npush;  // (meaningful when from_carry)
-          const int32_t carry = ci == 0u ? st.d0 : ci == 1u ? st.d1 : ci == 2u ? st.d2 : st.d3;
-          const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
-          uint32_t resolved = need ? 0u : 1u;
-          const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
-          while (__ballot(resolved == 0u) != 0ull) {
-            const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dist);
-            const uint32_t sr = bperm(src << 2, resolved);
-            const bool can = resolved == 0u && (from_carry || sr != 0u);
-            int32_t v = from_carry ? carry : sv;
-            const int32_t vp = v + mag, vm = v - mag;
-            v = code == 0u ? v : (code & 1u) ? vp : (vm <= 0 ? 0x7fffffff : vm);
-            dist = can ? v : dist; resolved = can ? 1u : resolved;
-          }
+    // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
+    // of it -- the sums (literals, commands, distances, output bytes) and the distance ring (decode.rs:2017-2049) -- goes
+    // through LDS: every batch resolves its ring against an UNKNOWN ring at its start (a distance is a constant, or one of
+    // the four entries it started with plus a small delta), leaves its sums and the ring it ends with in that form, and
+    // after a barrier every wave puts the batches in front of it together.  Then every limit the reference checks, as in
+    // the scan engine; the first command that needs the checked loop ends the engine's part in front of it.
+    const uint32_t nb = (m + 63u) >> 6;
+    uint32_t my_exec = 0;  // commands of this wave's batch that are executed
+    {
+      const PeStream st = pe_st_load(pb);
+      const bool mine = me < nb;
+      const uint32_t k0 = me << 6;
+      const uint32_t K = mine ? (m - k0 < 64u ? m - k0 : 64u) : 0u;
+      const bool active = lane < K;
+      const uint32_t ra = pb + PE_REC + ((mine ? k0 + (active ? lane : 0u) : 0u) << 4);
+      const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), r2 = lds_ld32(ra + 8u), r3 = lds_ld32(ra + 12u);
+      const uint32_t ins = active ? r1 & 0xFFFFu : 0u, copy = active ? r2 : 0u;
+      const uint32_t kind = active ? r3 >> 30 : (uint32_t)SCK_NONE, val = r3 & 0x3FFFFFFFu;
+      const bool odd = ((r0 >> 30) & 1u) != 0u;
+      const uint32_t isdist = (kind == SCK_EXPLICIT || kind == SCK_SHORT) ? 1u : 0u;
+      const uint32_t lit_incl = sc_scan(ins);
+      const uint32_t s1 = sc_scan((active ? 1u : 0u) | (isdist << 16));
+      // (a sum of 64 copy lengths stays below 2^31: lengths of 2^24 and more are `odd` below)
+      const bool big = copy >= (1u << 24);
+      const uint32_t s2 = sc_scan(ins + (big ? 0u : copy));
+      const uint32_t out_excl = s2 - (ins + (big ? 0u : copy));
+      // the ring, against an unknown ring at the batch's start: (dtag, dval) = entry dtag of that ring plus dval, or (4, the distance)
+      const bool need = kind == SCK_SHORT || kind == SCK_IMPLICIT;
+      const uint32_t code = kind == SCK_SHORT ? val : 0u;
+      const bool pushes = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
+      const uint64_t pmk = __ballot(pushes);
+      uint32_t dtag = kind == SCK_EXPLICIT ? 4u : 0u; int32_t dval = kind == SCK_EXPLICIT ? (int32_t)val : 0;
+      const uint32_t npush = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmk, 0u));  // pushes in front of this lane
+      const uint32_t n_all = (uint32_t)__popcll(pmk);
+      const uint32_t perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((pushes ? npush : n_all + lane - npush) << 2), (int)lane);
+      if (__ballot(need) != 0ull) {
+        const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
+        const bool from_carry = npush <= back;
+        const uint32_t ci = back - npush;  // (meaningful when from_carry)
+        const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
+        uint32_t resolved = need ? 0u : 1u;
+        const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
+        while (__ballot(resolved == 0u) != 0ull) {
+          const uint32_t stg = bperm(src << 2, dtag);
+          const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dval);
+          const uint32_t sr = bperm(src << 2, resolved);
+          const bool can = resolved == 0u && (from_carry || sr != 0u);
+          const uint32_t bt = from_carry ? ci : stg;
+          const int32_t bv = from_carry ? 0 : sv;
+          const int32_t nv = code == 0u ? bv : (code & 1u) ? bv + mag : bv - mag;  // (a result <= 0 is invalid: seen once the ring is known)
+          dtag = can ? bt : dtag; dval = can ? nv : dval; resolved = can ? 1u : resolved;
         }
+      }
+      // the batch's sums and the ring it ends with (all its pushes: a batch that stops short is the last one that counts)
+      const uint32_t rs = pb + PE_RS + (me << 6);
+      if (mine) {
+        const uint32_t tperm = bperm(perm << 2, dtag), vperm = bperm(perm << 2, (uint32_t)dval);  // lane r: the r-th push
+        if (lane == 0) {
+          lds_st32(rs, rdlane(lit_incl, 63)); lds_st32(rs + 4u, rdlane(s1, 63)); lds_st32(rs + 8u, rdlane(s2, 63));
+        }
+        _Pragma("unroll") for (uint32_t r = 0; r < 4u; r++) {
+          const uint32_t tg = n_all > r ? rdlane(tperm, (n_all - 1u - r) & 63u) : r - n_all;
+          const uint32_t vl = n_all > r ? rdlane(vperm, (n_all - 1u - r) & 63u) : 0u;
+          if (lane == 0) { lds_st32(rs + 16u + 8u * r, tg); lds_st32(rs + 20u + 8u * r, vl); }
+        }
+      }
+      if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_KP, m);
+      __syncthreads();
+      // what lies in front of this batch
+      uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
+      int32_t d0 = st.d0, d1 = st.d1, d2 = st.d2, d3 = st.d3;
+      for (uint32_t j = 0; j < me && mine; j++) {
+        const uint32_t rj = pb + PE_RS + (j << 6);
+        const uint32_t w = lds_ld32(rj + (lane < 12u ? lane << 2 : 0u));   // (one read: lane k word k)
+        c_lit += rdlane(w, 0); const uint32_t t1 = rdlane(w, 1); c_cmd += t1 & 0xFFFFu; c_dst += t1 >> 16; c_out += rdlane(w, 2);
+        const int32_t o0 = d0, o1 = d1, o2 = d2, o3 = d3;
+#define PE_RING_AT(tg_, vl_) ((tg_) == 4u ? (int32_t)(vl_) : ((tg_) == 0u ? o0 : (tg_) == 1u ? o1 : (tg_) == 2u ? o2 : o3) + (int32_t)(vl_))
+        d0 = PE_RING_AT(rdlane(w, 4), rdlane(w, 5)); d1 = PE_RING_AT(rdlane(w, 6), rdlane(w, 7));
+        d2 = PE_RING_AT(rdlane(w, 8), rdlane(w, 9)); d3 = PE_RING_AT(rdlane(w, 10), rdlane(w, 11));
+#undef PE_RING_AT
+      }
+      const int32_t dist = dtag == 4u ? dval : (dtag == 0u ? d0 : dtag == 1u ? d1 : dtag == 2u ? d2 : d3) + dval;
+      const uint32_t lit_a = c_lit + lit_incl, cmd_a = c_cmd + (s1 & 0xFFFFu), dst_a = c_dst + (s1 >> 16);
+      const uint64_t out_a = (uint64_t)c_out + s2;
+      bool ok = !odd && !big && lit_a <= st.bl0 && cmd_a <= st.bl1 && dst_a <= st.bl2 && out_a < (uint64_t)st.quota;
+      const uint64_t rel = (uint64_t)c_out + out_excl;   // where the command's output starts, from the region's
+      {
+        // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
+        const uint64_t pk = st.P + rel + ins;
+        const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
+        ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
+      }
+      const uint64_t stopmask = __ballot(active && !ok);
+      const uint32_t kpb = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
+      if (mine && kpb < K && lane == 0) pe_atomic_min(pb + PE_CTL + 4u * PEC_KP, k0 + kpb);
+      // a copy whose source reaches into the region's own output is done afterwards (bit 31 of w0); long items get a wave
+      const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
+      uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
+      const bool bigc = (copy > 16u && dep == 0u) || ins - uu > PE_LANE_LITS;
+      const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc);
+      if (mine && lane == 0) lds_st32(rs + 48u, (uint32_t)__popcll(dmk) | ((uint32_t)__popcll(bmk) << 16));
+      __syncthreads();
+      const uint32_t kp_total = pe_ctl_ld(pb, PEC_KP);
+      my_exec = !mine || kp_total <= k0 ? 0u : (kp_total - k0 < K ? kp_total - k0 : K);
+      if (mine && my_exec != 0u) {
+        // (every batch in front of one that executes anything went through whole: its counts are its lists' lengths)
+        uint32_t c_dep = 0, c_big = 0;
         {
-          // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
-          const uint64_t pk = st.P + out_excl + ins;
-          const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
-          ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
+          const uint32_t w = lane < me ? lds_ld32(pb + PE_RS + (lane << 6) + 48u) : 0u;
+          const uint32_t sum = sc_scan(w);  // (two 16-bit sums side by side: at most 1024 each)
+          const uint32_t tot = rdlane(sum, 63);
+          c_dep = tot & 0xFFFFu; c_big = tot >> 16;
         }
-        const uint64_t stopmask = __ballot(active && !ok);
-        const uint32_t kp = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
-        if (kp < K) stop = true;
-        uint32_t lit_tot = 0, cmd_tot = 0, dst_tot = 0, out_tot = 0;
-        if (kp != 0u) { lit_tot = rdlane(lit_incl, kp - 1u); const uint32_t t1 = rdlane(s1, kp - 1u); cmd_tot = t1 & 0xFFFFu; dst_tot = t1 >> 16; out_tot = rdlane(s2, kp - 1u); }
-        {  // the ring after the executed lanes: their last pushes in front of the old entries
+        const uint64_t dm2 = dmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull)), bm2 = bmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull));
+        if (lane < my_exec) {
+          if (dep != 0u) lds_st16(pb + PE_DLIST + ((c_dep + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm2, 0u))) << 1), k0 + lane);
+          if (bigc) lds_st16(pb + PE_BLIST + ((c_big + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm2, 0u))) << 1), k0 + lane);
+          lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 12u, (uint32_t)dist);
+          lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
+        }
+        // the batch the engine's part ends in leaves the stream's state: sums up to there, the ring behind its executed pushes
+        const bool last = kp_total <= k0 + K;
+        if (last) {
+          const uint32_t kp = my_exec;
+          const uint32_t lit_tot = c_lit + rdlane(lit_incl, kp - 1u), t1 = rdlane(s1, kp - 1u), out_tot = c_out + rdlane(s2, kp - 1u);
+          const uint32_t cmd_tot = c_cmd + (t1 & 0xFFFFu), dst_tot = c_dst + (t1 >> 16);
           const uint32_t got = (uint32_t)__popcll(pmk & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)));
+          int32_t e0 = d0, e1 = d1, e2 = d2, e3 = d3;
           if (got != 0u) {
             const uint32_t dperm = bperm(perm << 2, (uint32_t)dist);  // lane r: the distance of the r-th push
-            const int32_t o0 = st.d0, o1 = st.d1, o2 = st.d2;
-            st.d0 = (int32_t)rdlane(dperm, got - 1u);
-            st.d1 = got >= 2u ? (int32_t)rdlane(dperm, got - 2u) : o0;
-            st.d2 = got >= 3u ? (int32_t)rdlane(dperm, got - 3u) : got == 2u ? o0 : o1;
-            st.d3 = got >= 4u ? (int32_t)rdlane(dperm, got - 4u) : got == 3u ? o0 : got == 2u ? o1 : o2;
+            e0 = (int32_t)rdlane(dperm, got - 1u);
+            e1 = got >= 2u ? (int32_t)rdlane(dperm, got - 2u) : d0;
+            e2 = got >= 3u ? (int32_t)rdlane(dperm, got - 3u) : got == 2u ? d0 : d1;
+            e3 = got >= 4u ? (int32_t)rdlane(dperm, got - 4u) : got == 3u ? d0 : got == 2u ? d1 : d2;
           }
+          PeStream sn = st;
+          sn.P += out_tot; sn.bl0 -= lit_tot; sn.bl1 -= cmd_tot; sn.bl2 -= dst_tot; sn.quota -= out_tot; sn.mlen -= (int32_t)out_tot; sn.ncmd += cmd_tot;
+          sn.d0 = e0; sn.d1 = e1; sn.d2 = e2; sn.d3 = e3;
+          pe_st_store(pb, sn);
+          pe_ctl_st(pb, PEC_ANYDEP, c_dep + (uint32_t)__popcll(dm2)); pe_ctl_st(pb, PEC_NBIG, c_big + (uint32_t)__popcll(bm2));
         }
-        if (kp != 0u) {
-          // a copy whose source reaches into the region's own output is done afterwards, in order (bit 31 of w0)
-          const uint64_t rel = (st.P - P0) + out_excl;
-          const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
-          const uint64_t dmk = __ballot(lane < kp && dep != 0u);
-          if (dmk != 0ull) {
-            if (lane < kp && dep != 0u) lds_st16(pb + PE_DLIST + ((any_dep + __builtin_amdgcn_mbcnt_hi((uint32_t)(dmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dmk, 0u))) << 1), k0 + lane);
-            any_dep += (uint32_t)__popcll(dmk);
-          }
-          {  // commands the lane = command pass of the execute phase leaves to a wave of their own
-            uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
-            const bool bigc = lane < kp && ((copy > 16u && dep == 0u) || ins - uu > PE_LANE_LITS);
-            const uint64_t bmk = __ballot(bigc);
-            if (bmk != 0ull) {
-              if (bigc) lds_st16(pb + PE_BLIST + ((nbig + __builtin_amdgcn_mbcnt_hi((uint32_t)(bmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmk, 0u))) << 1), k0 + lane);
-              nbig += (uint32_t)__popcll(bmk);
-            }
-          }
-          if (lane < kp) {
-            lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 12u, (uint32_t)dist);
-            lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
-          }
-        }
-        st.P += out_tot; st.bl0 -= lit_tot; st.bl1 -= cmd_tot; st.bl2 -= dst_tot; st.quota -= out_tot; st.mlen -= (int32_t)out_tot; st.ncmd += cmd_tot;
-        kp_total += kp;
-        // the batch is ready for the wave that executes it (the records' stores above are this wave's, and in order)
-        pe_ctl_st(pb, PEC_BKP + (k0 >> 6), kp);
-        pe_ctl_st(pb, PEC_READY, (k0 >> 6) + 1u);
       }
-      pe_ctl_st(pb, PEC_READY, 16u);
-      pe_ctl_st(pb, PEC_KP, kp_total); pe_ctl_st(pb, PEC_ANYDEP, any_dep); pe_ctl_st(pb, PEC_NBIG, nbig);
-      // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
-      // of the state it starts from)
-      {
+      if (kp_total == 0u && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); }  // (nothing executed: the state stays)
+      __syncthreads();
+      if (me == 0) {
+        // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
+        // of the state it starts from)
+        PeStream sn = pe_st_load(pb);
         const uint32_t dsc = rfl(lds_ld16(pb + PE_LIST + (kp_total << 1)));
         uint32_t pbit = dsc & 0x7FFFu;
         if ((dsc >> 15) == 0u) {
@@ -908,14 +950,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
           pbit += rfl(d.bits);
         }
-        st.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
+        sn.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
         // the region went through whole and the next one starts at a command with a long literal run: the next regions are the run's
-        if (kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(st, pbit);
-        pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
+        if (kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
+        pe_ctl_st(pb, PEC_NEXT_LBDW, sn.b >> 5);
+        // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
+        pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
+        pe_st_store(pb, sn);
       }
-      // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
-      pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
-      pe_st_store(pb, st);
     }
     // ---- execute ----
     {
@@ -923,13 +965,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // (a) lane = command: the literals in front of the path, decoded again one after the other; the literals on the path out
       // of lit[], four bytes a step; the command's copy where it is short and its source lies in front of the region's
       // output (one 16-byte load, stores in pieces)
-      // (the waves behind wave 0 take the batches as its resolve hands them over: no barrier in between)
-      if (me != 0u)
-      for (uint32_t bi = me - 1u; bi * 64u < m; bi += SC_WAVES - 1u) {
-        while (pe_ctl_ld(pb, PEC_READY) <= bi) __builtin_amdgcn_s_sleep(2);
-        const uint32_t kpb = pe_ctl_ld(pb, PEC_BKP + bi);
-        const uint32_t k = bi * 64u + lane;
-        const bool on = lane < kpb;
+      // (every wave the batch it resolved)
+      if (my_exec != 0u) {
+        const uint32_t k = (me << 6) + lane;
+        const bool on = lane < my_exec;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
         const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
         const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
