@@ -629,25 +629,28 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       uint32_t iters = 0; (void)iters;
       bool dry = false;  // the source has nothing more for this wave
       for (;;) {
-        _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
-          const uint64_t nm = __ballot(!has[t]);
-          if (nm != 0ull && !dry) {
+        {  // free slots take new states off the source: one LDS atomic per wave and pass for all of them
+          uint64_t nm[NSL]; uint32_t want = 0;
+          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { nm[t] = __ballot(!has[t]); want += (uint32_t)__popcll(nm[t]); }
+          if (want != 0u && !dry) {
+            const uint32_t limit = phase == 0u ? c.Rn : tail_n;
             uint32_t base = 0;
-            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * (phase == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), (uint32_t)__popcll(nm));
+            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * (phase == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), want);
             base = rfl(base);
-            const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-            if (phase == 0u) {
-              if (!has[t] && rr < c.Rn) { has[t] = true; sid[t] = rr; sps[t] = lds_ld16(pb + PE_POR + (rr << 1)); skd[t] = 0u; rs[t].on = false; }
-              if (base + (uint32_t)__popcll(nm) > c.Rn) dry = true;
-            } else {
-              if (!has[t] && rr < tail_n) {
-                const uint32_t id = lds_ld16(pb + PE_TAILQ + (rr << 1));
-                if (id < PEN_FIRST_SPECIAL) {
-                  const uint32_t st = id < PE_RANKS ? lds_ld16(pb + PE_POR + (id << 1)) : lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1));
-                  has[t] = true; sid[t] = id; sps[t] = st & 0x7FFFu; skd[t] = st >> 15; rs[t].on = false;
-                }
-              }
-              if (base + (uint32_t)__popcll(nm) > tail_n) dry = true;
+            if (base + want > limit) dry = true;
+            uint32_t idv[NSL]; bool take[NSL];
+            _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
+              const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm[t], 0u));
+              base += (uint32_t)__popcll(nm[t]);
+              take[t] = !has[t] && rr < limit;
+              idv[t] = rr;
+              if (phase != 0u) idv[t] = take[t] ? lds_ld16(pb + PE_TAILQ + (rr << 1)) : (uint32_t)PEN_NONE;
+            }
+            _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
+              take[t] = take[t] && idv[t] < PEN_FIRST_SPECIAL;
+              const uint32_t idc = take[t] ? idv[t] : 0u;
+              const uint32_t stv = idc < PE_RANKS ? lds_ld16(pb + PE_POR + (idc << 1)) : lds_ld16(pb + PE_WST + ((idc - PE_RANKS) << 1));
+              if (take[t]) { has[t] = true; sid[t] = idc; sps[t] = stv & 0x7FFFu; skd[t] = stv >> 15; rs[t].on = false; }
             }
           }
         }
@@ -672,27 +675,31 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         PeParse pr[NSL];
         pe_eval_n<NSL, true, true, true, false>(c, sps, skd, has, pr, rs);
         iters++;
-        _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
-          const bool app = has[t] && pr[t].code == 1u;
-          const uint64_t am = __ballot(app);
-          uint32_t slot = 0;
-          if (am != 0ull) {  // (appending a closure state: one LDS atomic per wave)
+        {
+          bool app[NSL]; uint64_t am[NSL]; uint32_t slot[NSL]; uint32_t wantw = 0;
+          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { app[t] = has[t] && pr[t].code == 1u; am[t] = __ballot(app[t]); wantw += (uint32_t)__popcll(am[t]); slot[t] = 0; }
+          if (wantw != 0u) {  // (appending closure states: one LDS atomic per wave and pass)
             uint32_t base = 0;
-            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, (uint32_t)__popcll(am));
+            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, wantw);
             base = rfl(base);
-            slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+            _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
+              slot[t] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am[t], 0u));
+              base += (uint32_t)__popcll(am[t]);
+            }
           }
-          if (has[t]) {
-            if (pr[t].code == 3u) { rs[t].on = true; rs[t].y = pr[t].hy; rs[t].n = pr[t].hn; rs[t].implicit = pr[t].implicit; }  // more hops next time
-            else {
-              uint32_t nx = pr[t].code == 0u ? pr[t].next : pr[t].code == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
-              bool goes_on = false;
-              if (app && slot < PE_WCAP) { lds_st16(pb + PE_WST + (slot << 1), pr[t].next); nx = PE_RANKS + slot; goes_on = true; }
-              PE_LANECOUNT(30, app && slot >= PE_WCAP);
-              lds_st16(pb + PE_NEXT + (sid[t] << 1), nx);
-              rs[t].on = false;
-              if (goes_on) { sid[t] = PE_RANKS + slot; sps[t] = pr[t].next & 0x7FFFu; skd[t] = pr[t].next >> 15; }
-              else has[t] = false;
+          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
+            if (has[t]) {
+              if (pr[t].code == 3u) { rs[t].on = true; rs[t].y = pr[t].hy; rs[t].n = pr[t].hn; rs[t].implicit = pr[t].implicit; }  // more hops next time
+              else {
+                uint32_t nx = pr[t].code == 0u ? pr[t].next : pr[t].code == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
+                bool goes_on = false;
+                if (app[t] && slot[t] < PE_WCAP) { lds_st16(pb + PE_WST + (slot[t] << 1), pr[t].next); nx = PE_RANKS + slot[t]; goes_on = true; }
+                PE_LANECOUNT(30, app[t] && slot[t] >= PE_WCAP);
+                lds_st16(pb + PE_NEXT + (sid[t] << 1), nx);
+                rs[t].on = false;
+                if (goes_on) { sid[t] = PE_RANKS + slot[t]; sps[t] = pr[t].next & 0x7FFFu; skd[t] = pr[t].next >> 15; }
+                else has[t] = false;
+              }
             }
           }
         }
