@@ -68,7 +68,14 @@ constexpr uint32_t PE_LIST = PE_WST + PE_WCAP * 2;                // u16 per lis
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
 constexpr uint32_t PE_TAILQ = PE_LIST;                              // u16 per state the bulk of the records left for the thin end (list and anchors are not in use then)
 constexpr uint32_t PE_TAILCAP = 1024;
-constexpr uint32_t PE_TAIL_WAVES = 4;
+#ifndef BROTLI_AMD_PE_TAIL_WAVES
+#define BROTLI_AMD_PE_TAIL_WAVES 16
+#endif
+#ifndef BROTLI_AMD_PE_TAIL_AT
+#define BROTLI_AMD_PE_TAIL_AT 80
+#endif
+constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see the thin end of the records through
+constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
 constexpr uint32_t PE_BYTES = PE_ANCH + 128 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_CMDS * 16 <= PE_WCAP * 2 && PE_CMDS * 4 <= PE_CHUNKS * 4, "overlays");
@@ -619,7 +626,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // loop ends when the counter is exhausted and no lane has anything left.
     // Two phases of the same loop (two states a lane, then one): the bulk on all waves -- until the counter is exhausted and a wave has less than a quarter
     // of its slots busy; what it still holds then (chains of states that are not path states, a few per wave) goes on a
-    // list --, and the thin end of it on four waves that take the list's states the way the bulk took path positions.
+    // list --, and the thin end of it with ONE state a lane (half the instructions a pass: what is left are chains, a pass
+    // is one link of each), the waves taking the list's states the way the bulk took path positions.  (Measured: handing
+    // over below 80 busy slots of 128, all sixteen waves in the second phase: 7.64 ms against 7.92 with 32 / four waves.)
     auto records_loop = [&](auto nsl_, const uint32_t phase, const uint32_t tail_n) {
       constexpr uint32_t NSL = decltype(nsl_)::value;
       uint32_t sid[NSL], sps[NSL], skd[NSL]; bool has[NSL];
@@ -656,7 +665,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
         const uint64_t h0 = __ballot(has[0]), h1 = NSL > 1u ? __ballot(has[NSL - 1u]) : 0ull;
         if ((h0 | h1) == 0ull) break;
-        if (phase == 0u && dry && (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1) < 32u) {
+        if (phase == 0u && dry && (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1) < PE_TAIL_AT) {
           // the thin end: what this wave still holds goes on the list
           const uint32_t cnt = (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1);
           uint32_t base = 0;
