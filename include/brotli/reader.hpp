@@ -25,8 +25,8 @@ struct UnexpectedEof : std::runtime_error { using std::runtime_error::runtime_er
 template <class R>
 class Decompressor {
  public:
-  Decompressor(R source, size_t buffer_size = 4096, bool large_window = true)
-      : src_(std::move(source)), buf_(buffer_size ? buffer_size : 4096), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
+  Decompressor(R source, size_t buffer_size = 1u << 20, bool large_window = true)  // (every call of the streaming ABI is a kernel launch: 1 MiB amortises it)
+      : src_(std::move(source)), buf_(buffer_size ? buffer_size : (1u << 20)), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
     if (!state_) throw std::bad_alloc();
     // native constructors of the reference accept large-window streams (src/state.rs:394)
     if (large_window) BrotliDecoderSetParameter(state_, BROTLI_DECODER_PARAM_LARGE_WINDOW, 1);

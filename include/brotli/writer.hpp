@@ -20,8 +20,8 @@ namespace brotli_amd {
 template <class W>
 class DecompressorWriter {
  public:
-  DecompressorWriter(W sink, size_t buffer_size = 4096, bool large_window = true)
-      : sink_(std::move(sink)), buf_(buffer_size ? buffer_size : 4096), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
+  DecompressorWriter(W sink, size_t buffer_size = 1u << 20, bool large_window = true)  // (every call of the streaming ABI is a kernel launch: 1 MiB amortises it)
+      : sink_(std::move(sink)), buf_(buffer_size ? buffer_size : (1u << 20)), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
     if (!state_) throw std::bad_alloc();
     if (large_window) BrotliDecoderSetParameter(state_, BROTLI_DECODER_PARAM_LARGE_WINDOW, 1);
   }

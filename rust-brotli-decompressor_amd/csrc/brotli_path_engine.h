@@ -715,7 +715,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
       PE_COUNT(23 - 12 * phase, iters);
     };
-    records_loop(std::integral_constant<uint32_t, 2>{}, 0u, 0u);
+#ifndef BROTLI_AMD_PE_BULK_NS
+#define BROTLI_AMD_PE_BULK_NS 2
+#endif
+    records_loop(std::integral_constant<uint32_t, BROTLI_AMD_PE_BULK_NS>{}, 0u, 0u);
     __syncthreads();
     {
       const uint32_t tail_n = pe_ctl_ld(pb, PEC_TAILN) < PE_TAILCAP ? pe_ctl_ld(pb, PEC_TAILN) : PE_TAILCAP;

@@ -295,6 +295,12 @@ impl<R: Read> Read for Decompressor<R> {
                     if self.offset == self.len {
                         self.offset = 0;
                         self.len = 0;
+                    } else if self.len == self.buffer.len() {
+                        // a full buffer with an unconsumed tail (the decoder keeps less than eight bytes back): move the tail to
+                        // the front so that there is room to read into (reader.rs:258-269, copy_to_front)
+                        self.buffer.copy_within(self.offset..self.len, 0);
+                        self.len -= self.offset;
+                        self.offset = 0;
                     }
                     let n = self.input.read(&mut self.buffer[self.len..])?;
                     if n == 0 {
