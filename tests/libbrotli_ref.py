@@ -124,3 +124,27 @@ def encode_stream(chunks, params=None, ops=None) -> bytes:
         return bytes(out)
     finally:
         _enc.BrotliEncoderDestroyInstance(st)
+
+
+class StreamDecoder:
+    """A libbrotlidec instance fed call by call: step(pending bytes, out_cap) -> (result, consumed, produced bytes)"""
+
+    def __init__(self, large_window=True):
+        self.st = _dec.BrotliDecoderCreateInstance(None, None, None)
+        if large_window:
+            _dec.BrotliDecoderSetParameter(self.st, 1, 1)
+
+    def step(self, data: bytes, out_cap: int):
+        inbuf = ctypes.create_string_buffer(data, max(1, len(data)))
+        out = ctypes.create_string_buffer(max(1, out_cap))
+        avail_in = ctypes.c_size_t(len(data)); next_in = ctypes.c_void_p(ctypes.addressof(inbuf))
+        avail_out = ctypes.c_size_t(out_cap); next_out = ctypes.c_void_p(ctypes.addressof(out))
+        total = ctypes.c_size_t(0)
+        res = _dec.BrotliDecoderDecompressStream(self.st, ctypes.byref(avail_in), ctypes.byref(next_in), ctypes.byref(avail_out),
+                                                 ctypes.byref(next_out), ctypes.byref(total))
+        return res, len(data) - avail_in.value, out.raw[:out_cap - avail_out.value]
+
+    def close(self):
+        if self.st:
+            _dec.BrotliDecoderDestroyInstance(self.st)
+            self.st = None
