@@ -2126,7 +2126,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         d0 = (int32_t)LEAN_LD(L_D0); d1 = (int32_t)LEAN_LD(L_D1); d2 = (int32_t)LEAN_LD(L_D2); d3 = (int32_t)LEAN_LD(L_D3);
         num_commands += took;
         lit_pos = P;
-        force_checked = 1u;
+        force_checked = form == SCX_BEGIN ? 1u : 0u;  // (the command the engine stopped IN FRONT OF goes through the checked stages; one it stopped inside is on its way through them already)
         // (an invocation that got nowhere -- few commands AND few bytes: a long literal run is one command -- makes the next ones rarer)
         if (took < 64u && P - P_before < 4096u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
         insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
