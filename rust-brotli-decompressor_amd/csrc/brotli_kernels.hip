@@ -971,7 +971,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   helper's answer, round moved.
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
        HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */ };
-enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5 };  // HC_KIND
+enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
        // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
@@ -1143,7 +1143,133 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
 __device__ __noinline__ uint32_t path_engine(const uint32_t me_);
 // which command engine blocks of sixteen waves use: 0 = the path engine where it applies (brotli_path_engine.h), 1 = the scan
 // engine only (experiments, A/B tests: BROTLI_AMD_ENGINE=scan)
-__device__ uint32_t g_engine_mode = 0;
+__device__ uint32_t g_engine_mode = 2;
+
+
+// ===================================== parse / copy split (context-modelled metablocks) =====================================
+// A metablock whose literals depend on context cannot be parsed ahead of its output by more than the output allows: the
+// tree of a literal is a function of the two bytes before it (decode.rs:2463-2551), which after a copy come out of the
+// output.  What CAN leave the decoding wave is everything that moves bytes (decode.rs:2641-2720): in a block with helper
+// waves the decoding wave only PARSES such a metablock (lean_split_commands) and leaves one 16-byte record per command in
+// an LDS ring -- literals (bytes in a second ring), copy length, resolved distance -- and wave 1 of the block EXECUTES
+// the records in order: literal stores, LZ77 loads and stores.  The parser never waits for a store; the two context
+// bytes behind a copy are fetched from the copy's SOURCE (out[P - dist + n - 2 ..], asked for when the distance is
+// known, used a command later) once the copier says that part of the output is in memory, else the parser waits for
+// the copier to catch up.  Everything the lean loop does not take (limits, dictionary words, block switches) ends the
+// split: the parser waits until the ring is drained and goes through the checked stages as before.
+//   control words (CW_*, in the body of wave slot 3; the record ring is the body of slot 1, the literal ring of slot 2 --
+//   the literal rounds that own these slots never run inside a context-modelled metablock):
+//   records posted (parser), records / literal bytes taken out of the rings, records whose stores have completed and the
+//   output position below which everything is in memory (copier), stop request / acknowledgement, output address.
+enum { CW_HEAD = 0, CW_TAIL = 1, CW_LIT_TAIL = 2, CW_DONE_SEQ = 3, CW_DONE_P = 4, CW_STOP = 5, CW_OUT_LO = 6, CW_OUT_HI = 7, CW_WORDS = 8 };
+enum { SPR_COPY = 0, SPR_SETP = 1 };  // record kinds: literals + copy; the copier's output position (the parser came back from the checked stages)
+constexpr uint32_t SP_RECS = 64u, SP_LIT_BYTES = 1024u;
+constexpr uint32_t SP_MAX_INSERT = 256u;      // longer literal runs go through the checked stages
+constexpr uint32_t SP_MIN_MLEN = 4096u;       // smaller metablocks are not worth waking the copier for
+constexpr uint32_t SP_SPIN_CAP = 1u << 24;    // polls of the parser before it gives the stream up (never seen)
+static_assert(SP_RECS * 16u <= HL_SLOT - HL_MASK && SP_LIT_BYTES <= HL_SLOT - HL_MASK, "the rings live in the bodies of wave slots");
+__device__ __forceinline__ uint32_t sp_rec_base() { return hc_ld(HC_BASE) + HL_SLOT + HL_MASK; }
+__device__ __forceinline__ uint32_t sp_lit_base() { return hc_ld(HC_BASE) + 2u * HL_SLOT + HL_MASK; }
+__device__ __forceinline__ uint32_t sp_ctl_base() { return hc_ld(HC_BASE) + 3u * HL_SLOT + HL_MASK; }
+__device__ __forceinline__ uint32_t sp_ld(uint32_t ctl, uint32_t k) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * k])); }
+__device__ __forceinline__ void sp_st(uint32_t ctl, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * k]) = v; }
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+__device__ unsigned long long g_split_prof[16];
+#define SPLIT_PROF(k, t0) do { if (blockIdx.x == 0 && lane_id() == 0) g_split_prof[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#define SPLIT_COUNT(k, v) do { if (blockIdx.x == 0 && lane_id() == 0) g_split_prof[k] += (v); } while (0)
+#define SPLIT_T() __builtin_amdgcn_s_memtime()
+#else
+#define SPLIT_PROF(k, t0) do { } while (0)
+#define SPLIT_COUNT(k, v) do { } while (0)
+#define SPLIT_T() 0ull
+#endif
+
+// Wave 1 of the block while the decoding wave parses a context-modelled metablock.
+__device__ __noinline__ void copier_wave() {
+  const uint32_t lane = lane_id();
+  const uint32_t rec = sp_rec_base(), lit = sp_lit_base(), ctl = sp_ctl_base();
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)sp_ld(ctl, CW_OUT_LO) | ((uint64_t)sp_ld(ctl, CW_OUT_HI) << 32));
+  uint64_t P = 0;
+  uint32_t tail = 0, lit_tail = 0, idle = 0;
+  bool quiet = false;
+  for (;;) {
+    const uint32_t head = sp_ld(ctl, CW_HEAD);
+    if (head == tail) {
+      if (!quiet) {  // nothing to do: everything so far is in memory once the stores have been acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sp_st(ctl, CW_DONE_P, (uint32_t)P);
+        lds_release();
+        sp_st(ctl, CW_DONE_SEQ, tail);
+        quiet = true;
+      }
+      if (sp_ld(ctl, CW_STOP) != 0u) break;
+      idle++;
+      if (idle < 64u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
+      continue;
+    }
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+    const uint64_t busy_t0 = SPLIT_T();
+#endif
+    idle = 0; quiet = false;
+    lds_acquire();
+    while (tail != head) {
+      uint32_t w = 0;
+      if (lane < 4u) w = lds_ld32(rec + ((tail & (SP_RECS - 1u)) << 4) + 4u * lane);
+      const uint32_t w0 = rdlane(w, 0), w1 = rdlane(w, 1), w2 = rdlane(w, 2), w3 = rdlane(w, 3);
+      tail++;
+      if ((w0 & 0xFFu) == (uint32_t)SPR_SETP) {
+        P = (uint64_t)w1 | ((uint64_t)w2 << 32);
+        sp_st(ctl, CW_TAIL, tail);
+        continue;
+      }
+      const uint32_t ins = w0 >> 8;
+      for (uint32_t k = 0; k < ins; k += 64u) {
+        if (k + lane < ins) { const uint32_t b = lds_ld8(lit + ((w3 + k + lane) & (SP_LIT_BYTES - 1u))); out[P + k + lane] = (uint8_t)b; }
+      }
+      P += ins;
+      lit_tail += ins;
+      if (lane == 0) {  // the ring entries are free again (LDS operations of a wave execute in order: the reads above are done)
+        *reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * CW_LIT_TAIL]) = lit_tail;
+        *reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * CW_TAIL]) = tail;
+      }
+      // ---- the copy: chunks of up to 64 lanes; a chunk reads what lies `span` bytes before it, a multiple of the distance that
+      // is at least the chunk's length (a copy that overlaps itself repeats its first `dist` bytes: decode.rs:2641-2720) ----
+      uint32_t rem = w1, span = w2, done = 0;
+      const uint32_t dist = w2;
+      uint64_t dst = P;
+      bool first = true;
+      while (rem != 0u) {
+        uint32_t bytes;
+        if (span >= 64u && rem >= 16u) {
+          uint32_t n16 = rem >> 4;
+          if (n16 > 64u) n16 = 64u;
+          if (n16 > (span >> 4)) n16 = span >> 4;
+          bytes = n16 << 4;
+          u32x4 v = {0, 0, 0, 0};
+          if (lane < n16) v = *reinterpret_cast<gu32x4*>(out + dst - span + (uint64_t)lane * 16u);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory");
+          if (first) { sp_st(ctl, CW_DONE_P, (uint32_t)P); sp_st(ctl, CW_DONE_SEQ, tail - 1u); first = false; }
+          if (lane < n16) *reinterpret_cast<gu32x4*>(out + dst + (uint64_t)lane * 16u) = v;
+        } else {
+          bytes = rem < 64u ? rem : 64u;
+          if (bytes > span) bytes = span;
+          uint32_t b = 0;
+          if (lane < bytes) b = (out + dst - span)[lane];
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(b) :: "memory");
+          if (first) { sp_st(ctl, CW_DONE_P, (uint32_t)P); sp_st(ctl, CW_DONE_SEQ, tail - 1u); first = false; }
+          if (lane < bytes) (out + dst)[lane] = (uint8_t)b;
+        }
+        dst += bytes; rem -= bytes; done += bytes;
+        while (span < 64u && done + dist >= 2u * span) span <<= 1;
+      }
+      P = dst;
+      SPLIT_COUNT(12, 1);
+    }
+    SPLIT_PROF(5, busy_t0);
+  }
+  lds_release();
+  sp_st(ctl, CW_STOP, 2u);
+}
 
 __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */, gu8* scratch_sym) {
   const uint32_t lane = lane_id();
@@ -1164,6 +1290,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
     if (kind == HK_PATH) { path_engine(me); continue; }
+    if (kind == HK_SPLIT) { if (rfl(me) == 1u) copier_wave(); continue; }  // the others go back to sleep
     if (kind != HK_ROUND) return;
     if (rfl(me) >= hc_ld(HC_NW)) continue;                // (rounds are for the first eight waves of a block)
     spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
@@ -1925,6 +2052,246 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
   return rfl(stage);
 }
 
+
+// ===================================== split lean loop: the parser =====================================
+// lean_commands<false> without the part that moves bytes (see "parse / copy split" above): the same stages, the same
+// hand-over to process_commands (L_STAGE ...), but a command that stays clear of every limit becomes a record for the
+// copier wave.  Returns with the ring drained: whatever the records produced is in memory.
+enum { L_SP_HEAD = L_COUNT, L_SP_LIT = L_COUNT + 1, L_SP_COUNT = L_COUNT + 2 };
+static_assert(L_SP_COUNT * 4 <= 192, "LDS_LEAN too small");
+#define SP_CTX_REG "v125"
+__device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
+  const uint32_t lane = lane_id();
+  const Arena a = {nullptr, 0xFFFFFFFFu, 0u};
+  BitReader br;
+  br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+  br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
+  br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
+  uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+  uint32_t quota = LEAN_LD(L_QUOTA);
+  int32_t mlen = (int32_t)LEAN_LD(L_MLEN);
+  uint32_t bl0 = LEAN_LD(L_BL0), bl1 = LEAN_LD(L_BL1), bl2 = LEAN_LD(L_BL2);
+  int32_t d0 = (int32_t)LEAN_LD(L_D0), d1 = (int32_t)LEAN_LD(L_D1), d2 = (int32_t)LEAN_LD(L_D2), d3 = (int32_t)LEAN_LD(L_D3);
+  uint32_t ncmd = 0;
+  const uint32_t cmd_tree = LEAN_LD(L_CMD_TREE), lit_tree = LEAN_LD(L_LIT_TREE);
+  const uint32_t dt0 = LEAN_LD(L_DT0), dt1 = LEAN_LD(L_DT1), dt2 = LEAN_LD(L_DT2), dt3 = LEAN_LD(L_DT3);
+  const int32_t max_backward = (int32_t)LEAN_LD(L_MAX_BACKWARD);
+  const uint32_t postfix_bits = LEAN_LD(L_POSTFIX), num_direct = LEAN_LD(L_NUM_DIRECT);
+  const bool dlut_ok = postfix_bits == 0u && num_direct == 16u;
+  uint32_t dlut;
+  {
+    const uint32_t dv = (lane - 16u) & 63u, nb = (dv >> 1) + 1u;
+    dlut = nb | ((((2u + (dv & 1u)) << nb) - 3u) << 5);
+  }
+  const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
+  uint32_t lit_reg = 0, lit_n = 0;
+  uint32_t p1 = LEAN_LD(L_P1), p2 = LEAN_LD(L_P2);
+  // where the two bytes before P are: p1/p2 (ctx_regs), on their way from the last copy's source into SP_CTX_REG (ctx_pend),
+  // or in memory once the copier has caught up
+  bool ctx_regs = LEAN_LD(L_CTX_REGS) != 0u, ctx_pend = false;
+  const uint32_t trivial = LEAN_LD(L_TRIVIAL), ctx_lut = LEAN_LD(L_CTX_LUT);
+  const uint32_t lut0v = lds_ld32(ctx_lut + 4u * lane), lut1v = lds_ld32(ctx_lut + 256u + 4u * lane);
+  const uint32_t sp_rec = sp_rec_base(), sp_lit = sp_lit_base(), sp_ctl = sp_ctl_base();
+  uint32_t sp_head = LEAN_LD(L_SP_HEAD), lit_head = LEAN_LD(L_SP_LIT);
+  uint32_t sp_tail_c = sp_ld(sp_ctl, CW_TAIL), lit_tail_c = sp_ld(sp_ctl, CW_LIT_TAIL);
+  uint32_t failed = 0;
+  uint32_t stage = LS_BEGIN;
+  int32_t insert_len = 0, copy_len = 0, distance_code = 0;
+  uint32_t distance_context = 0, lits_left = 0;
+  uint32_t rec_ins = 0, rec_lit = lit_head;  // literals decoded but not posted yet, and where their bytes start in the ring
+
+  // one record: lanes 0..3 write its four words, then the head moves (LDS operations of a wave execute in order)
+#define SP_POST(W0_, W1_, W2_, W3_) do { \
+    if (sp_head - sp_tail_c >= SP_RECS - 1u) { const uint64_t t_ = SPLIT_T(); uint32_t spins_ = 0; \
+      do { __builtin_amdgcn_s_sleep(1); sp_tail_c = sp_ld(sp_ctl, CW_TAIL); if (++spins_ > SP_SPIN_CAP) { failed = 1; break; } } while (sp_head - sp_tail_c >= SP_RECS - 1u); \
+      SPLIT_PROF(0, t_); } \
+    const uint32_t wv_ = lane == 0u ? (uint32_t)(W0_) : lane == 1u ? (uint32_t)(W1_) : lane == 2u ? (uint32_t)(W2_) : (uint32_t)(W3_); \
+    if (lane < 4u) lds_st32(sp_rec + ((sp_head & (SP_RECS - 1u)) << 4) + 4u * lane, wv_); \
+    sp_head++; \
+    lds_release(); \
+    sp_st(sp_ctl, CW_HEAD, sp_head); } while (0)
+  // the copier has executed every record and its stores have completed
+#define SP_DRAIN() do { const uint64_t t_ = SPLIT_T(); uint32_t spins_ = 0; \
+    while (sp_ld(sp_ctl, CW_DONE_SEQ) != sp_head) { __builtin_amdgcn_s_sleep(1); if (++spins_ > SP_SPIN_CAP) { failed = 1; break; } } \
+    lds_acquire(); SPLIT_PROF(1, t_); } while (0)
+  // literals collected in lit_reg go to the literal ring
+#define SP_LIT_FLUSH() do { if (lit_n) { if (lane < lit_n) lds_st8(sp_lit + ((lit_head + lane) & (SP_LIT_BYTES - 1u)), lit_reg); lit_head += lit_n; lit_n = 0; } } while (0)
+
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  const uint64_t split_t0 = SPLIT_T();
+#endif
+  SP_POST(SPR_SETP, (uint32_t)P, (uint32_t)(P >> 32), 0u);
+
+  br.need32();
+  uint32_t next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+
+  for (;;) {
+    if (bl1 == 0 || br.next_dw >= safe_dw || failed) { stage = LS_BEGIN; break; }
+    // how far the copier's stores have got (asked for now, looked at when this command's distance is known)
+    const uint32_t done_v = *reinterpret_cast<lds_vu32*>(&g_smem[sp_ctl + 4u * CW_DONE_P]);
+    uint32_t cmd;
+    {
+      uint32_t e = rfl(next_root);
+      uint32_t len = e & 15u;
+      if (len > ROOT_BITS) {
+        uint32_t idx = (e >> 4) + (((uint32_t)br.buf >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
+        e = rfl(lds_ld16(LDS_FIXED + cmd_tree + (idx << 1)));
+        len = ROOT_BITS + (e & 15u);
+      }
+      br.drop(len);
+      cmd = e >> 4;
+    }
+    uint32_t cell = cmd >> 6;
+    uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
+    uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+    uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
+    distance_code = cmd < 128 ? 0 : -1;
+    distance_context = copy_code > 2 ? 3u : copy_code;
+    insert_len = (int32_t)((ie & 0xFFFFu) + br.read24(ie >> 16));
+    copy_len = (int32_t)((ce & 0xFFFFu) + br.read24(ce >> 16));
+    bl1--;
+    ncmd++;
+    lits_left = (uint32_t)insert_len;
+    rec_ins = 0; rec_lit = lit_head;
+    if (insert_len != 0) {
+      if ((uint32_t)insert_len > quota || (uint32_t)insert_len > bl0 || (uint32_t)insert_len > SP_MAX_INSERT) { stage = LS_AFTER_HEAD; break; }
+      mlen -= insert_len;
+      uint32_t i = (uint32_t)insert_len;
+      if (!ctx_regs) {
+        if (ctx_pend) {  // the last copy's source bytes, asked for when its distance was known
+          const uint64_t t_ = SPLIT_T();
+          asm volatile("s_waitcnt vmcnt(0)\n\tv_readlane_b32 %0, " SP_CTX_REG ", 0\n\tv_readlane_b32 %1, " SP_CTX_REG ", 1" : "=s"(p1), "=s"(p2) :: "memory");
+          SPLIT_PROF(2, t_); SPLIT_COUNT(8, 1);
+        } else {  // they were not in memory yet when the copy was posted (or the copy repeats itself): wait for the copier
+          SP_DRAIN();
+          SPLIT_COUNT(9, 1);
+          const uint64_t t_ = SPLIT_T();
+          p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u;
+          p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u;
+          SPLIT_PROF(3, t_);
+        }
+        ctx_regs = true; ctx_pend = false;
+      }
+      if (lit_head + i - lit_tail_c > SP_LIT_BYTES) {  // room in the literal ring
+        const uint64_t t_ = SPLIT_T(); uint32_t spins_ = 0;
+        do { __builtin_amdgcn_s_sleep(1); lit_tail_c = sp_ld(sp_ctl, CW_LIT_TAIL); if (++spins_ > SP_SPIN_CAP) { failed = 1; break; } } while (lit_head + i - lit_tail_c > SP_LIT_BYTES);
+        SPLIT_PROF(0, t_);
+      }
+      while (i > 0 && br.next_dw < safe_dw) {
+        uint32_t tree = lit_tree;
+        if (!trivial) {
+          const uint32_t context = ((rdlane(lut0v, p1 >> 2) >> ((p1 & 3u) << 3)) | (rdlane(lut1v, p2 >> 2) >> ((p2 & 3u) << 3))) & 0xFFu;
+          tree = rdlane(ctx_tree_v, context);
+        }
+        uint32_t lit = read_symbol<true>(br, a, tree);
+        p2 = p1; p1 = lit;
+        lit_reg = (lane == lit_n) ? lit : lit_reg;
+        lit_n++;
+        if (lit_n == 64) SP_LIT_FLUSH();
+        i--;
+      }
+      SP_LIT_FLUSH();
+      const uint32_t done = (uint32_t)insert_len - i;
+      P += done; bl0 -= done; quota -= done;
+      rec_ins = done;
+      lits_left = i;
+      if (i != 0) { stage = LS_LITERALS_REST; break; }
+      if (quota == 0) { stage = LS_LITERALS_AT_LIMIT; break; }
+    }
+    // ---- distance (ReadDistanceInternal, decode.rs:2066-2131; see process_commands) ----
+    if (distance_code >= 0) {
+      distance_context = 1;
+      distance_code = d0;
+    } else {
+      if (bl2 == 0) { stage = LS_DISTANCE; break; }
+      uint32_t dtree = distance_context == 0 ? dt0 : distance_context == 1 ? dt1 : distance_context == 2 ? dt2 : dt3;
+      uint32_t code = read_symbol<true>(br, a, dtree);
+      distance_context = 0;
+      if (code < 16) {
+        if (code == 0) {
+          distance_code = d0;
+          distance_context = 1;
+        } else {
+          uint32_t sh = code << 1;
+          uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
+          int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
+          int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+          if (code & 1u) v += mag;
+          else { v -= mag; if (v <= 0) v = 0x7fffffff; }
+          distance_code = v;
+        }
+      } else if (dlut_ok && code < 64u) {
+        const uint32_t de = rdlane(dlut, code);
+        distance_code = (int32_t)((de >> 5) + br.read(de & 31u));
+      } else {
+        int32_t distval = (int32_t)code - (int32_t)num_direct;
+        int32_t dc = (int32_t)code;
+        if (distval >= 0) {
+          int32_t postfix = distval & (int32_t)mask_bits(postfix_bits);
+          distval >>= postfix_bits;
+          uint32_t nbits = ((uint32_t)distval >> 1) + 1;
+          uint32_t bits = br.read(nbits);
+          int64_t offset = (int64_t)(int32_t)((((uint32_t)(distval & 1) + 2u) << nbits) - 4u);
+          dc = (int32_t)(((offset + (int64_t)bits) << postfix_bits) + postfix + (int64_t)num_direct);
+        }
+        distance_code = (int32_t)((uint32_t)dc - 16u + 1u);
+      }
+      bl2--;
+      if (br.next_dw > br.end_dw) { stage = LS_NEEDS_INPUT; break; }
+    }
+    br.need32();
+    next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+    // ---- the copy becomes a record: an LZ77 reference (not the dictionary) inside the quota ----
+    {
+      const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
+      const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
+      if (distance_code > max_distance || distance_code <= 0 || n > quota) { stage = LS_POST_DISTANCE; break; }
+      if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
+      mlen -= copy_len;
+      SP_POST((uint32_t)SPR_COPY | (rec_ins << 8), n, dist, rec_lit);
+      rec_ins = 0;
+      // the two bytes before the next command's first literal are the last two of this copy = of its source, if that is
+      // in memory already and the copy does not repeat itself (copy lengths start at 2)
+      ctx_regs = false; ctx_pend = false;
+      const uint64_t s2 = P + n - 2u - dist;  // (>= 0: dist <= P)
+      if (dist >= n && (int32_t)(rfl(done_v) - (uint32_t)(s2 + 2u)) >= 0) {
+        asm volatile("s_mov_b64 exec, 3\n\tglobal_load_ubyte " SP_CTX_REG ", %0, %1\n\ts_mov_b64 exec, -1" :: "v"(1u - lane), "s"(out + s2) : "memory", SP_CTX_REG);
+        ctx_pend = true;
+      }
+      P += n;
+      quota -= n;
+      if (quota == 0) { stage = LS_COMMAND_DONE; break; }
+    }
+  }
+  // literals of a command that did not get to its copy here: a record of their own
+  if (rec_ins != 0u) SP_POST((uint32_t)SPR_COPY | (rec_ins << 8), 0u, 1u, rec_lit);
+  if (!ctx_regs && ctx_pend) {
+    asm volatile("s_waitcnt vmcnt(0)\n\tv_readlane_b32 %0, " SP_CTX_REG ", 0\n\tv_readlane_b32 %1, " SP_CTX_REG ", 1" : "=s"(p1), "=s"(p2) :: "memory");
+    ctx_regs = true;
+  }
+  SP_DRAIN();
+  SPLIT_PROF(4, split_t0); SPLIT_COUNT(10, 1); SPLIT_COUNT(11, ncmd); SPLIT_COUNT(13 + (stage > 2u ? 2u : stage), 0); SPLIT_COUNT(7, stage == LS_POST_DISTANCE ? 1 : 0);
+#undef SP_POST
+#undef SP_DRAIN
+#undef SP_LIT_FLUSH
+  if (failed) hc_st(HC_FAILED, 1);
+  lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
+  if (lane == 0) {
+    LEAN_ST(L_CHUNK_BASE, br.chunk_base);
+    LEAN_ST(L_P1, p1); LEAN_ST(L_P2, p2); LEAN_ST(L_CTX_REGS, ctx_regs ? 1u : 0u);
+    LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+    LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
+    LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
+    LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
+    LEAN_ST(L_INSERT, insert_len); LEAN_ST(L_COPY, copy_len); LEAN_ST(L_DCODE, distance_code); LEAN_ST(L_DCTX, distance_context);
+    LEAN_ST(L_LITS_LEFT, lits_left);
+    LEAN_ST(L_SP_HEAD, sp_head); LEAN_ST(L_SP_LIT, lit_head);
+  }
+  lds_sync();
+  return rfl(stage);
+}
+
 // ===================================== the command loop (hot path) =====================================
 // Argument block of the command loop.  The loop is a real function (one per table placement) so that it gets a
 // register allocation of its own: everything uniform lives in SGPRs for the whole metablock and nothing of the
@@ -2078,6 +2445,20 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
   const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
   uint32_t scan_fails = 0;
+  // ---- parse / copy split: in a block with helper waves, wave 1 executes what this wave parses of a context-modelled metablock
+  // (copier_wave, lean_split_commands).  It stays engaged, idle while the checked stages run, until the metablock is done.
+  bool split_on = false;
+  if (LDS_ONLY && !CTX_NEVER && hc_ld(HC_NW_ALL) >= 4u && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS && mlen >= (int32_t)SP_MIN_MLEN && (g_engine_mode & 2u) == 0u) {
+    const uint32_t ctl = sp_ctl_base();
+    lds_sync();
+    if (lane < (uint32_t)CW_WORDS)
+      lds_st32(ctl + 4u * lane, lane == (uint32_t)CW_OUT_LO ? (uint32_t)(uintptr_t)out : lane == (uint32_t)CW_OUT_HI ? (uint32_t)((uint64_t)(uintptr_t)out >> 32) : 0u);
+    if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); }
+    hc_st(HC_KIND, (uint32_t)HK_SPLIT);
+    lds_release();
+    hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
+    split_on = true;
+  }
   uint32_t force_checked = 0;  // commands that go through the checked stages before the engine (or the lean loop) is tried again:
                                // the command the engine stopped at, more of them after invocations that got nowhere
 
@@ -2088,7 +2469,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       const uint64_t origin = abs_bit & ~63ull;
       const uint64_t avail = BitReader::total_bits() + BitReader::skip_bits() - origin;
       // the path engine where the four distance contexts share one prefix code (its states do not carry the context)
-      const bool use_path = dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && g_engine_mode == 0u;
+      const bool use_path = dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && (g_engine_mode & 1u) == 0u;
       if (avail >= (use_path ? 2u * PE_MIN_INPUT : 8u * SC_N) && (origin >> 5) < 0xFFFFFFFFull) {
         FLUSH_LITERALS();
         FLUSH_PENDING();
@@ -2163,7 +2544,16 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         }
       }
       lds_sync();
-      uint32_t stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+      uint32_t stage;
+      if (!CTX_NEVER && split_on) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what this wave has stored is in memory before the copier reads it as a copy's source
+        sp_st(sp_ctl_base(), CW_DONE_P, (uint32_t)P);       // (the copier is idle: it says so again only after the next record)
+        stage = rfl(lean_split_commands(lut_vgpr, ctx_tree_v));
+        if (hc_ld(HC_FAILED) != 0u) STOP(E_UNREACHABLE);    // the copier did not answer (never seen)
+        engine_commands += LEAN_LD(L_NCMD_LO);
+      } else {
+        stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+      }
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
       br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
@@ -2643,6 +3033,14 @@ command_done:
 done:
   FLUSH_LITERALS();
   FLUSH_PENDING();
+  if (split_on) {  // the copier goes back to sleep (HC_KIND stays: a helper that looks late must find nothing to do)
+    const uint32_t ctl = sp_ctl_base();
+    sp_st(ctl, CW_STOP, 1u);
+    for (uint32_t spins = 0; sp_ld(ctl, CW_STOP) != 2u; spins++) {
+      if (spins > SP_SPIN_CAP) { hc_st(HC_KIND, (uint32_t)HK_NO_ROUNDS); result = E_UNREACHABLE; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
 #undef FLUSH_LITERALS
 #undef FLUSH_PENDING
   args->br = br;
@@ -3125,6 +3523,13 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
            g_lean_prof[5] / g_lean_prof[4], g_lean_prof[6] / g_lean_prof[4], g_lean_prof[0] / g_lean_prof[4],
            g_lean_prof[1] / g_lean_prof[4], g_lean_prof[2] / g_lean_prof[4], g_lean_prof[3] / g_lean_prof[4]);
 #endif
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  if (blockIdx.x == 0 && lane_id() == 0 && g_split_prof[10] != 0)
+    printf("split: %llu parser invocations (%llu left at a distance the lean loop does not take), %llu commands, %llu records executed; parser ticks %llu: ring full %llu, drains %llu, "
+           "context from the copy's source: %llu waits of %llu ticks; context after a drain: %llu, loads %llu ticks; copier busy ticks %llu\n",
+           g_split_prof[10], g_split_prof[7], g_split_prof[11], g_split_prof[12], g_split_prof[4], g_split_prof[0], g_split_prof[1], g_split_prof[8], g_split_prof[2],
+           g_split_prof[9], g_split_prof[3], g_split_prof[5]);
+#endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
   if (blockIdx.x == 0 && lane_id() == 0)
     printf("spec rounds %llu lits %llu bits %llu ticks: chunk0 %llu wait %llu resolve %llu move %llu seek %llu\n", g_spec_prof[5], g_spec_prof[6], g_spec_prof[7],
@@ -3176,7 +3581,8 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   {  // BROTLI_AMD_ENGINE=scan: the round-2 command engine only (A/B tests); the symbol is per device
     static const char* const eng = getenv("BROTLI_AMD_ENGINE");
     if (eng != nullptr) {
-      const uint32_t mode = strcmp(eng, "scan") == 0 ? 1u : 0u;
+      // bit 0: the scan engine only; bit 1: no parse / copy split of context-modelled metablocks (the default until it pays: "split" turns it on)
+      const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : 2u;
       hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
       if (e2 != hipSuccess) return e2;
     }
