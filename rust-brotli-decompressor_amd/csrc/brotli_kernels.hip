@@ -970,7 +970,8 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   move wanted for round, first literal of the chunk to move, where to (offset from the output), how many; and the
 //   helper's answer, round moved.
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
-       HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */ };
+       HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */,
+       HC_EXT_BASE = 13 /* LDS base of the command-record ring of the parse / copy split (SPX_BYTES, in the free tail of the table arena); 0 = this metablock has none */ };
 enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
@@ -1174,15 +1175,36 @@ __device__ __forceinline__ uint32_t sp_ctl_base() { return hc_ld(HC_BASE) + 3u *
 __device__ __forceinline__ uint32_t sp_ld(uint32_t ctl, uint32_t k) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * k])); }
 __device__ __forceinline__ void sp_st(uint32_t ctl, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * k]) = v; }
 #ifdef BROTLI_AMD_PROFILE_SPLIT
-__device__ unsigned long long g_split_prof[16];
+__device__ unsigned long long g_split_prof[24];
 #define SPLIT_PROF(k, t0) do { if (blockIdx.x == 0 && lane_id() == 0) g_split_prof[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define SPLIT_COUNT(k, v) do { if (blockIdx.x == 0 && lane_id() == 0) g_split_prof[k] += (v); } while (0)
 #define SPLIT_T() __builtin_amdgcn_s_memtime()
+#define SPLIT_LAP(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); lap_acc[k] += t_ - lap_t; lap_t = t_; } while (0)
 #else
-#define SPLIT_PROF(k, t0) do { } while (0)
+#define SPLIT_LAP(k) do { } while (0)
+#define SPLIT_PROF(k, t0) do { (void)(t0); } while (0)
 #define SPLIT_COUNT(k, v) do { } while (0)
 #define SPLIT_T() 0ull
 #endif
+
+
+// ---- command records ahead of the parser (wave 2 of the block, rec_wave) ----
+// What the parser's chain costs is its instruction count (one wave issues an instruction every ~8 clocks), and two thirds of
+// a text stream's commands have no literals: command symbol, extra bits, distance symbol, extra bits -- nothing that depends
+// on the output.  Wave 2 parses the command that WOULD start at every bit of the stream in front of the parser (64 positions
+// an instruction, ReadCommandInternal + ReadDistanceInternal per lane: sc_head / sc_dist of the scan engine) into a ring of
+// 8-byte records indexed by bit position; the parser takes the record at its position instead of parsing (a command with
+// literals: its head only) and parses by hand wherever there is no usable record.  A record is the exact parse of its
+// position or marked unusable -- nothing depends on a guess.
+//   record: word 0 = copy length (16 bits) | bits of the command (head, or head + distance) << 16 | flags; word 1 = insert
+//   length (commands with literals), else the distance (explicit) or the distance symbol (ring codes 0..15).
+constexpr uint32_t SPX_POS = 1024u;                   // ring size in stream bits
+constexpr uint32_t SPX_CTL_BYTES = 256u;
+constexpr uint32_t SPX_BYTES = SPX_CTL_BYTES + SPX_POS * 8u;
+enum { XW_FRONT = 0 /* u64: positions below are written (low), for parameter epoch (high) */, XW_POS = 2 /* the parser's position (lags) */,
+       XW_EPOCH = 3, XW_STOP = 4, XW_ORIGIN_DW = 5, XW_LIMIT = 6, XW_CMD_TREE = 7, XW_DT0 = 8, XW_POSTFIX = 12, XW_NUM_DIRECT = 13, XW_WORDS = 14 };
+enum { XR_VALID = 1u << 23, XR_LITERALS = 1u << 24, XR_IMPLICIT = 1u << 25, XR_DCTX_SHIFT = 26, XR_SHORT = 1u << 28 };
+__device__ __noinline__ void rec_wave();
 
 // Wave 1 of the block while the decoding wave parses a context-modelled metablock.
 __device__ __noinline__ void copier_wave() {
@@ -1203,13 +1225,13 @@ __device__ __noinline__ void copier_wave() {
         quiet = true;
       }
       if (sp_ld(ctl, CW_STOP) != 0u) break;
+      // (a SIMD issues one scalar instruction every four clocks for ALL its waves, and the parser of another block lives on
+      // this one: a poll every 64 clocks took a third of them)
       idle++;
-      if (idle < 64u) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
+      if (idle < 16u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
       continue;
     }
-#ifdef BROTLI_AMD_PROFILE_SPLIT
     const uint64_t busy_t0 = SPLIT_T();
-#endif
     idle = 0; quiet = false;
     lds_acquire();
     while (tail != head) {
@@ -1290,7 +1312,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
     if (kind == HK_PATH) { path_engine(me); continue; }
-    if (kind == HK_SPLIT) { if (rfl(me) == 1u) copier_wave(); continue; }  // the others go back to sleep
+    if (kind == HK_SPLIT) { if (rfl(me) == 1u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave(); continue; }  // the others go back to sleep
     if (kind != HK_ROUND) return;
     if (rfl(me) >= hc_ld(HC_NW)) continue;                // (rounds are for the first eight waves of a block)
     spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
@@ -2053,11 +2075,72 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
 }
 
 
+
+// Wave 2 of the block while the decoding wave parses a context-modelled metablock: command records ahead of it (see above).
+__device__ __noinline__ void rec_wave() {
+  const uint32_t lane = lane_id();
+  const uint32_t xb = hc_ld(HC_EXT_BASE), ring = xb + SPX_CTL_BYTES;
+  gcu32* const in = BitReader::base();
+  uint32_t lut = 0;  // per-lane image of the insert / copy code tables (as the decoding wave's)
+  if (lane < 24) lut = (uint32_t)kInsBase[lane] | ((uint32_t)kInsExtra[lane] << 16);
+  else if (lane >= 32 && lane < 56) lut = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
+  const uint32_t origin_dw = sp_ld(xb, XW_ORIGIN_DW), limit = sp_ld(xb, XW_LIMIT);
+  uint32_t epoch = 0, F = 0, cmd_tree = 0, dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0, postfix_bits = 0, num_direct = 0, idle = 0;
+  for (;;) {
+    if (sp_ld(xb, XW_STOP) != 0u) break;
+    const uint32_t ep = sp_ld(xb, XW_EPOCH);
+    const uint32_t pos = sp_ld(xb, XW_POS);
+    if (ep != epoch) {  // new prefix codes (a block switch): everything from the parser's position on again
+      lds_acquire();
+      epoch = ep;
+      cmd_tree = sp_ld(xb, XW_CMD_TREE); dt0 = sp_ld(xb, XW_DT0); dt1 = sp_ld(xb, XW_DT0 + 1); dt2 = sp_ld(xb, XW_DT0 + 2); dt3 = sp_ld(xb, XW_DT0 + 3);
+      postfix_bits = sp_ld(xb, XW_POSTFIX); num_direct = sp_ld(xb, XW_NUM_DIRECT);
+      F = sp_ld(xb, XW_POS) & ~63u;
+    }
+    if (epoch == 0u) { __builtin_amdgcn_s_sleep(8); continue; }
+    if (F < (pos & ~63u)) F = pos & ~63u;  // the parser went ahead (literals, commands by hand)
+    if (F + 64u > limit || F + 64u > pos + (SPX_POS - 64u)) {  // the end of what may be read, or a lap ahead of the parser
+      idle++;  // (a lap is some forty commands: the parser is a long way off; polling costs the parser on this SIMD its issue slots)
+      if (idle < 4u) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(64);
+      continue;
+    }
+    idle = 0;
+    // the 64 stream bits from this lane's position
+    const uint32_t p = F + lane, sh = p & 31u;
+    gcu32* const q = in + origin_dw + (p >> 5);
+    const uint32_t a0 = q[0], a1 = q[1], a2 = q[2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(a1, a0, sh), hi = __builtin_amdgcn_alignbit(a2, a1, sh);
+    const ScHead h = sc_head(lo, hi, cmd_tree, lut);
+    uint32_t w0 = (h.copy & 0xFFFFu) | (h.dctx << XR_DCTX_SHIFT), w1 = h.insert, bits = h.bits;
+    bool valid = h.copy < 65536u;
+    if (h.insert != 0u) w0 |= XR_LITERALS | (h.implicit ? XR_IMPLICIT : 0u);
+    else if (h.implicit) w0 |= XR_IMPLICIT;
+    else {
+      const uint64_t w = (((uint64_t)hi << 32) | lo) >> h.bits;
+      const uint32_t dtree = h.dctx == 0u ? dt0 : h.dctx == 1u ? dt1 : h.dctx == 2u ? dt2 : dt3;
+      const ScDist d = sc_dist((uint32_t)w, (uint32_t)(w >> 32), dtree, postfix_bits, num_direct);
+      bits += d.bits;
+      w1 = d.val;
+      if (d.kind == SCK_SHORT) w0 |= XR_SHORT;
+    }
+    valid = valid && bits <= 64u;
+    w0 |= (bits & 127u) << 16;
+    if (valid) w0 |= XR_VALID;
+    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[ring + ((p & (SPX_POS - 1u)) << 3)]) = ((uint64_t)w1 << 32) | w0;
+    F += 64u;
+    lds_release();
+    if (lane == 0) *reinterpret_cast<volatile __attribute__((address_space(3))) uint64_t*>(&g_smem[xb + 4u * XW_FRONT]) = ((uint64_t)epoch << 32) | F;
+  }
+  lds_release();
+  sp_st(xb, XW_STOP, 2u);
+}
+
 // ===================================== split lean loop: the parser =====================================
 // lean_commands<false> without the part that moves bytes (see "parse / copy split" above): the same stages, the same
 // hand-over to process_commands (L_STAGE ...), but a command that stays clear of every limit becomes a record for the
 // copier wave.  Returns with the ring drained: whatever the records produced is in memory.
-enum { L_SP_HEAD = L_COUNT, L_SP_LIT = L_COUNT + 1, L_SP_COUNT = L_COUNT + 2 };
+enum { L_SP_HEAD = L_COUNT, L_SP_LIT = L_COUNT + 1, L_SP_ORIGIN = L_COUNT + 2 /* dword the record ring's positions count from */,
+       L_SP_REC = L_COUNT + 3 /* command records (rec_wave) in use */, L_SP_COUNT = L_COUNT + 4 };
 static_assert(L_SP_COUNT * 4 <= 192, "LDS_LEAN too small");
 #define SP_CTX_REG "v125"
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
@@ -2100,17 +2183,50 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
   int32_t insert_len = 0, copy_len = 0, distance_code = 0;
   uint32_t distance_context = 0, lits_left = 0;
   uint32_t rec_ins = 0, rec_lit = lit_head;  // literals decoded but not posted yet, and where their bytes start in the ring
+  // command records (rec_wave): positions are stream bits from dword origin_dw; front_c: positions below have a record
+  const uint32_t xb = hc_ld(HC_EXT_BASE), xring = xb + SPX_CTL_BYTES;
+  const bool rec_on = LEAN_LD(L_SP_REC) != 0u;
+  const uint32_t origin_bits = LEAN_LD(L_SP_ORIGIN) << 5;
+  uint32_t my_epoch = 0, front_c = 0;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 rec_v = {0u, 0u};
+  bool rec_ok = false;
+  if (rec_on) {
+    // the prefix codes the records are parsed with: new ones (the first time, after a block switch) start a new epoch
+    my_epoch = sp_ld(xb, XW_EPOCH);
+    const bool same = my_epoch != 0u && sp_ld(xb, XW_CMD_TREE) == LDS_FIXED + cmd_tree && sp_ld(xb, XW_DT0) == LDS_FIXED + dt0 && sp_ld(xb, XW_DT0 + 1) == LDS_FIXED + dt1 &&
+                      sp_ld(xb, XW_DT0 + 2) == LDS_FIXED + dt2 && sp_ld(xb, XW_DT0 + 3) == LDS_FIXED + dt3;
+    sp_st(xb, XW_POS, br.next_dw * 32u - br.cnt - origin_bits);
+    if (!same) {
+      sp_st(xb, XW_CMD_TREE, LDS_FIXED + cmd_tree); sp_st(xb, XW_DT0, LDS_FIXED + dt0); sp_st(xb, XW_DT0 + 1, LDS_FIXED + dt1);
+      sp_st(xb, XW_DT0 + 2, LDS_FIXED + dt2); sp_st(xb, XW_DT0 + 3, LDS_FIXED + dt3);
+      sp_st(xb, XW_POSTFIX, postfix_bits); sp_st(xb, XW_NUM_DIRECT, num_direct);
+      my_epoch++;
+      lds_release();
+      sp_st(xb, XW_EPOCH, my_epoch);
+    }
+  }
+  // ask for the record of the command that starts where the reader stands (looked at when the command is begun)
+#define SP_REC_REQUEST() do { rec_ok = false; \
+    if (rec_on) { const uint32_t rel_ = br.next_dw * 32u - br.cnt - origin_bits; \
+      if ((ncmd & 3u) == 0u) sp_st(xb, XW_POS, rel_); \
+      if (rel_ < 0x40000000u) { \
+        if (rel_ >= front_c) { const uint64_t f_ = *reinterpret_cast<volatile __attribute__((address_space(3))) uint64_t*>(&g_smem[xb + 4u * XW_FRONT]); \
+          front_c = rfl((uint32_t)(f_ >> 32)) == my_epoch ? rfl((uint32_t)f_) : 0u; lds_acquire(); SPLIT_COUNT(14, 1); } \
+        if (rel_ < front_c) { rec_v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(&g_smem[xring + ((rel_ & (SPX_POS - 1u)) << 3)]); rec_ok = true; } } } } while (0)
 
-  // one record: lanes 0..3 write its four words, then the head moves (LDS operations of a wave execute in order)
+  // one record: lane 0 writes its four words, then the head (LDS operations of a wave execute in order)
 #define SP_POST(W0_, W1_, W2_, W3_) do { \
     if (sp_head - sp_tail_c >= SP_RECS - 1u) { const uint64_t t_ = SPLIT_T(); uint32_t spins_ = 0; \
       do { __builtin_amdgcn_s_sleep(1); sp_tail_c = sp_ld(sp_ctl, CW_TAIL); if (++spins_ > SP_SPIN_CAP) { failed = 1; break; } } while (sp_head - sp_tail_c >= SP_RECS - 1u); \
       SPLIT_PROF(0, t_); } \
-    const uint32_t wv_ = lane == 0u ? (uint32_t)(W0_) : lane == 1u ? (uint32_t)(W1_) : lane == 2u ? (uint32_t)(W2_) : (uint32_t)(W3_); \
-    if (lane < 4u) lds_st32(sp_rec + ((sp_head & (SP_RECS - 1u)) << 4) + 4u * lane, wv_); \
+    const u32x4 wv_ = {(uint32_t)(W0_), (uint32_t)(W1_), (uint32_t)(W2_), (uint32_t)(W3_)}; \
+    const uint32_t ra_ = sp_rec + ((sp_head & (SP_RECS - 1u)) << 4); \
     sp_head++; \
-    lds_release(); \
-    sp_st(sp_ctl, CW_HEAD, sp_head); } while (0)
+    asm volatile("" ::: "memory");  /* (the literal bytes are written; no hardware wait: DS operations stay in order) */ \
+    if (lane == 0) { *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(&g_smem[ra_]) = wv_; \
+                     asm volatile("" ::: "memory"); \
+                     *reinterpret_cast<lds_vu32*>(&g_smem[sp_ctl + 4u * CW_HEAD]) = sp_head; } } while (0)
   // the copier has executed every record and its stores have completed
 #define SP_DRAIN() do { const uint64_t t_ = SPLIT_T(); uint32_t spins_ = 0; \
     while (sp_ld(sp_ctl, CW_DONE_SEQ) != sp_head) { __builtin_amdgcn_s_sleep(1); if (++spins_ > SP_SPIN_CAP) { failed = 1; break; } } \
@@ -2118,38 +2234,76 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
   // literals collected in lit_reg go to the literal ring
 #define SP_LIT_FLUSH() do { if (lit_n) { if (lane < lit_n) lds_st8(sp_lit + ((lit_head + lane) & (SP_LIT_BYTES - 1u)), lit_reg); lit_head += lit_n; lit_n = 0; } } while (0)
 
-#ifdef BROTLI_AMD_PROFILE_SPLIT
   const uint64_t split_t0 = SPLIT_T();
-#endif
   SP_POST(SPR_SETP, (uint32_t)P, (uint32_t)(P >> 32), 0u);
 
   br.need32();
   uint32_t next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+  SP_REC_REQUEST();
 
+  // a distance symbol 1..15: one of the last four distances, +- up to 3 (TakeDistanceFromRingBuffer, decode.rs:2017-2049)
+  auto ring_distance = [&](uint32_t code) -> int32_t {
+    const uint32_t sh = code << 1;
+    const uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
+    int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
+    const int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+    if (code & 1u) v += mag;
+    else { v -= mag; if (v <= 0) v = 0x7fffffff; }
+    return v;
+  };
+
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  uint64_t lap_acc[6] = {0, 0, 0, 0, 0, 0}; uint64_t lap_t = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
+    SPLIT_LAP(5);
     if (bl1 == 0 || br.next_dw >= safe_dw || failed) { stage = LS_BEGIN; break; }
     // how far the copier's stores have got (asked for now, looked at when this command's distance is known)
     const uint32_t done_v = *reinterpret_cast<lds_vu32*>(&g_smem[sp_ctl + 4u * CW_DONE_P]);
-    uint32_t cmd;
-    {
-      uint32_t e = rfl(next_root);
-      uint32_t len = e & 15u;
-      if (len > ROOT_BITS) {
-        uint32_t idx = (e >> 4) + (((uint32_t)br.buf >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
-        e = rfl(lds_ld16(LDS_FIXED + cmd_tree + (idx << 1)));
-        len = ROOT_BITS + (e & 15u);
+    bool have_dist = false;
+    uint32_t rec_lo = 0, rec_hi = 0;
+    if (rec_ok) { rec_lo = rfl(rec_v.x); rec_hi = rfl(rec_v.y); }
+    // a record that is the exact parse of this position (an explicit distance needs its block count)
+    if ((rec_lo & XR_VALID) != 0u && ((rec_lo & (XR_LITERALS | XR_IMPLICIT)) != 0u || bl2 != 0u)) {
+      SPLIT_COUNT(15, 1);
+      copy_len = (int32_t)(rec_lo & 0xFFFFu);
+      distance_context = (rec_lo >> XR_DCTX_SHIFT) & 3u;
+      distance_code = (rec_lo & XR_IMPLICIT) ? 0 : -1;
+      insert_len = 0;
+      if (rec_lo & XR_LITERALS) insert_len = (int32_t)rec_hi;
+      else if (!(rec_lo & XR_IMPLICIT)) {
+        have_dist = true;
+        distance_context = 0;
+        if (rec_lo & XR_SHORT) {
+          if (rec_hi == 0u) { distance_code = d0; distance_context = 1; }
+          else distance_code = ring_distance(rec_hi);
+        } else distance_code = (int32_t)rec_hi;
+        bl2--;
       }
-      br.drop(len);
-      cmd = e >> 4;
+      br.advance((rec_lo >> 16) & 127u);
+    } else {
+      uint32_t cmd;
+      {
+        uint32_t e = rfl(next_root);
+        uint32_t len = e & 15u;
+        if (len > ROOT_BITS) {
+          uint32_t idx = (e >> 4) + (((uint32_t)br.buf >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
+          e = rfl(lds_ld16(LDS_FIXED + cmd_tree + (idx << 1)));
+          len = ROOT_BITS + (e & 15u);
+        }
+        br.drop(len);
+        cmd = e >> 4;
+      }
+      uint32_t cell = cmd >> 6;
+      uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
+      uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+      uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
+      distance_code = cmd < 128 ? 0 : -1;
+      distance_context = copy_code > 2 ? 3u : copy_code;
+      insert_len = (int32_t)((ie & 0xFFFFu) + br.read24(ie >> 16));
+      copy_len = (int32_t)((ce & 0xFFFFu) + br.read24(ce >> 16));
     }
-    uint32_t cell = cmd >> 6;
-    uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
-    uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
-    uint32_t ie = rdlane(lut_vgpr, ins_code), ce = rdlane(lut_vgpr, 32u + copy_code);
-    distance_code = cmd < 128 ? 0 : -1;
-    distance_context = copy_code > 2 ? 3u : copy_code;
-    insert_len = (int32_t)((ie & 0xFFFFu) + br.read24(ie >> 16));
-    copy_len = (int32_t)((ce & 0xFFFFu) + br.read24(ce >> 16));
+    SPLIT_LAP(0);
     bl1--;
     ncmd++;
     lits_left = (uint32_t)insert_len;
@@ -2199,8 +2353,10 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
       if (i != 0) { stage = LS_LITERALS_REST; break; }
       if (quota == 0) { stage = LS_LITERALS_AT_LIMIT; break; }
     }
+    SPLIT_LAP(1);
     // ---- distance (ReadDistanceInternal, decode.rs:2066-2131; see process_commands) ----
-    if (distance_code >= 0) {
+    if (have_dist) {
+    } else if (distance_code >= 0) {
       distance_context = 1;
       distance_code = d0;
     } else {
@@ -2212,15 +2368,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
         if (code == 0) {
           distance_code = d0;
           distance_context = 1;
-        } else {
-          uint32_t sh = code << 1;
-          uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
-          int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
-          int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
-          if (code & 1u) v += mag;
-          else { v -= mag; if (v <= 0) v = 0x7fffffff; }
-          distance_code = v;
-        }
+        } else distance_code = ring_distance(code);
       } else if (dlut_ok && code < 64u) {
         const uint32_t de = rdlane(dlut, code);
         distance_code = (int32_t)((de >> 5) + br.read(de & 31u));
@@ -2240,13 +2388,16 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
       bl2--;
       if (br.next_dw > br.end_dw) { stage = LS_NEEDS_INPUT; break; }
     }
+    SPLIT_LAP(2);
     br.need32();
     next_root = lds_ld16(LDS_FIXED + cmd_tree + (((uint32_t)br.buf & 0xFFu) << 1));
+    SP_REC_REQUEST();
     // ---- the copy becomes a record: an LZ77 reference (not the dictionary) inside the quota ----
     {
       const uint32_t n = (uint32_t)copy_len, dist = (uint32_t)distance_code;
       const int32_t max_distance = (P < (uint64_t)(uint32_t)max_backward) ? (int32_t)P : max_backward;
       if (distance_code > max_distance || distance_code <= 0 || n > quota) { stage = LS_POST_DISTANCE; break; }
+    SPLIT_LAP(3);
       if (distance_context == 0) { d3 = d2; d2 = d1; d1 = d0; d0 = distance_code; }
       mlen -= copy_len;
       SP_POST((uint32_t)SPR_COPY | (rec_ins << 8), n, dist, rec_lit);
@@ -2259,6 +2410,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
         asm volatile("s_mov_b64 exec, 3\n\tglobal_load_ubyte " SP_CTX_REG ", %0, %1\n\ts_mov_b64 exec, -1" :: "v"(1u - lane), "s"(out + s2) : "memory", SP_CTX_REG);
         ctx_pend = true;
       }
+    SPLIT_LAP(4);
       P += n;
       quota -= n;
       if (quota == 0) { stage = LS_COMMAND_DONE; break; }
@@ -2271,10 +2423,15 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
     ctx_regs = true;
   }
   SP_DRAIN();
-  SPLIT_PROF(4, split_t0); SPLIT_COUNT(10, 1); SPLIT_COUNT(11, ncmd); SPLIT_COUNT(13 + (stage > 2u ? 2u : stage), 0); SPLIT_COUNT(7, stage == LS_POST_DISTANCE ? 1 : 0);
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  if (blockIdx.x == 0 && lane == 0) for (int k = 0; k < 6; k++) g_split_prof[16 + k] += lap_acc[k];
+#endif
+  SPLIT_PROF(4, split_t0); SPLIT_COUNT(10, 1); SPLIT_COUNT(11, ncmd); SPLIT_COUNT(7, stage == LS_POST_DISTANCE ? 1 : 0);
 #undef SP_POST
 #undef SP_DRAIN
 #undef SP_LIT_FLUSH
+#undef SP_REC_REQUEST
+  if (rec_on) sp_st(xb, XW_POS, br.next_dw * 32u - br.cnt - origin_bits);
   if (failed) hc_st(HC_FAILED, 1);
   lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
   if (lane == 0) {
@@ -2453,7 +2610,16 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     lds_sync();
     if (lane < (uint32_t)CW_WORDS)
       lds_st32(ctl + 4u * lane, lane == (uint32_t)CW_OUT_LO ? (uint32_t)(uintptr_t)out : lane == (uint32_t)CW_OUT_HI ? (uint32_t)((uint64_t)(uintptr_t)out >> 32) : 0u);
-    if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); }
+    // wave 2 parses command records ahead of this wave (rec_wave) where the launch left room for their ring (no large window:
+    // a record's distance has at most 24 extra bits); positions count from the dword the reader is in now
+    const uint32_t free_at = (a.top + 15u) & ~15u;
+    const uint32_t xb = a.lds_limit >= free_at + SPX_BYTES ? LDS_FIXED + free_at : 0u;  // (the tables of this metablock are built: what is left of the LDS arena is free)
+    hc_st(HC_EXT_BASE, xb);
+    const uint32_t origin_dw = (br.next_dw - ((br.cnt + 31u) >> 5)) & ~1u;
+    const bool rec_on = xb != 0u && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u;
+    if (xb != 0u && lane < (uint32_t)XW_WORDS)
+      lds_st32(xb + 4u * lane, lane == (uint32_t)XW_ORIGIN_DW ? origin_dw : lane == (uint32_t)XW_LIMIT && rec_on ? ((br.end_dw - origin_dw - 8u) << 5) & ~63u : 0u);
+    if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); LEAN_ST(L_SP_ORIGIN, origin_dw); LEAN_ST(L_SP_REC, rec_on ? 1u : 0u); }
     hc_st(HC_KIND, (uint32_t)HK_SPLIT);
     lds_release();
     hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
@@ -3036,7 +3202,9 @@ done:
   if (split_on) {  // the copier goes back to sleep (HC_KIND stays: a helper that looks late must find nothing to do)
     const uint32_t ctl = sp_ctl_base();
     sp_st(ctl, CW_STOP, 1u);
-    for (uint32_t spins = 0; sp_ld(ctl, CW_STOP) != 2u; spins++) {
+    const uint32_t xb = hc_ld(HC_EXT_BASE);
+    if (xb != 0u) sp_st(xb, XW_STOP, 1u);
+    for (uint32_t spins = 0; sp_ld(ctl, CW_STOP) != 2u || (xb != 0u && sp_ld(xb, XW_STOP) != 2u); spins++) {
       if (spins > SP_SPIN_CAP) { hc_st(HC_KIND, (uint32_t)HK_NO_ROUNDS); result = E_UNREACHABLE; break; }
       __builtin_amdgcn_s_sleep(2);
     }
@@ -3526,9 +3694,13 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 #ifdef BROTLI_AMD_PROFILE_SPLIT
   if (blockIdx.x == 0 && lane_id() == 0 && g_split_prof[10] != 0)
     printf("split: %llu parser invocations (%llu left at a distance the lean loop does not take), %llu commands, %llu records executed; parser ticks %llu: ring full %llu, drains %llu, "
-           "context from the copy's source: %llu waits of %llu ticks; context after a drain: %llu, loads %llu ticks; copier busy ticks %llu\n",
+           "context from the copy's source: %llu waits of %llu ticks; context after a drain: %llu, loads %llu ticks; copier busy ticks %llu; commands out of records %llu, looks at the records' frontier %llu; waves %u, record ring at %u (arena %u)\n",
            g_split_prof[10], g_split_prof[7], g_split_prof[11], g_split_prof[12], g_split_prof[4], g_split_prof[0], g_split_prof[1], g_split_prof[8], g_split_prof[2],
-           g_split_prof[9], g_split_prof[3], g_split_prof[5]);
+           g_split_prof[9], g_split_prof[3], g_split_prof[5], g_split_prof[15], g_split_prof[14], hc_ld(HC_NW_ALL), hc_ld(HC_EXT_BASE), lds_arena_bytes);
+  if (blockIdx.x == 0 && lane_id() == 0 && g_split_prof[10] != 0)
+    printf("split parser ticks per command: head %llu, literals %llu, distance %llu, next root + record request + checks %llu, post %llu, context fetch + tail %llu, loop top %llu\n",
+           g_split_prof[16] / g_split_prof[11], g_split_prof[17] / g_split_prof[11], g_split_prof[18] / g_split_prof[11], g_split_prof[19] / g_split_prof[11],
+           g_split_prof[20] / g_split_prof[11], g_split_prof[21] / g_split_prof[11], 0ull);
 #endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
   if (blockIdx.x == 0 && lane_id() == 0)
