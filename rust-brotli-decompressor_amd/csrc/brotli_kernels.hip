@@ -1312,7 +1312,10 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
     if (kind == HK_PATH) { path_engine(me); continue; }
-    if (kind == HK_SPLIT) { if (rfl(me) == 1u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave(); continue; }  // the others go back to sleep
+    if (kind == HK_SPLIT) {  // a context-modelled metablock: wave 1 copies (if asked to), wave 2 parses command records; the others go back to sleep
+      if (rfl(me) == 1u && (g_engine_mode & 2u) == 0u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave();
+      continue;
+    }
     if (kind != HK_ROUND) return;
     if (rfl(me) >= hc_ld(HC_NW)) continue;                // (rounds are for the first eight waves of a block)
     spec_chunk(me, hc_ld(HC_DW0) + me * (SPEC_WINDOWS * 2u), hc_ld(HC_SHIFT), hc_ld(HC_TREE), mine, 0u);
@@ -1525,6 +1528,10 @@ enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI,
        L_D3, L_NCMD_LO, L_NCMD_HI, L_CMD_TREE, L_LIT_TREE, L_DT0, L_DT1, L_DT2, L_DT3, L_MAX_BACKWARD, L_POSTFIX, L_NUM_DIRECT, L_OUT_LO,
        L_OUT_HI, L_INSERT, L_COPY, L_DCODE, L_DCTX, L_LITS_LEFT, L_P1, L_P2, L_CTX_REGS, L_TRIVIAL, L_CTX_LUT, L_CHUNK_BASE, L_SPEC_LO, L_SPEC_HI, L_COUNT };
 static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
+// (parse / copy split and command records, see copier_wave / rec_wave)
+enum { L_SP_HEAD = L_COUNT, L_SP_LIT = L_COUNT + 1, L_SP_ORIGIN = L_COUNT + 2 /* dword the record ring's positions count from */,
+       L_SP_REC = L_COUNT + 3 /* command records (rec_wave) in use */, L_SP_COUNT = L_COUNT + 4 };
+static_assert(L_SP_COUNT * 4 <= 192, "LDS_LEAN too small");
 enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
        LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7, LS_LITERAL_ROUNDS = 8 };
 #define LEAN_LD(k) rfl(lds_ld32(LDS_LEAN + 4u * (uint32_t)(k)))
@@ -2075,7 +2082,6 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_commands(uin
 }
 
 
-
 // Wave 2 of the block while the decoding wave parses a context-modelled metablock: command records ahead of it (see above).
 __device__ __noinline__ void rec_wave() {
   const uint32_t lane = lane_id();
@@ -2123,7 +2129,7 @@ __device__ __noinline__ void rec_wave() {
       w1 = d.val;
       if (d.kind == SCK_SHORT) w0 |= XR_SHORT;
     }
-    valid = valid && bits <= 64u;
+    valid = valid && bits <= 63u;  // (all of the command inside the lane's 64 bits; 63: the parser shifts its 64-bit buffer by that much)
     w0 |= (bits & 127u) << 16;
     if (valid) w0 |= XR_VALID;
     *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[ring + ((p & (SPX_POS - 1u)) << 3)]) = ((uint64_t)w1 << 32) | w0;
@@ -2135,13 +2141,417 @@ __device__ __noinline__ void rec_wave() {
   sp_st(xb, XW_STOP, 2u);
 }
 
+// ===================================== record lean loop =====================================
+// A run of commands WITHOUT literals out of their records, in hand-written scalar code (what the compiler makes of the same loop is
+// three times as long: see DESIGN).  One iteration = one command of the plain kind -- a short LZ77 copy that does not repeat itself,
+// clear of every limit -- taken whole out of the record at the reader's position: distance (explicit, implicit, or a ring code:
+// decode.rs:2017-2049), counts, the reader moved on by the record's bits, the copy in flight stored and this one's load issued
+// (its bytes stay in v124 until the next command comes by), the next record asked for.  Leaves in front of the first command that
+// is anything else, with nothing of it touched; `ok` then says whether rx/ry hold that command's record.  P < 2^32 in here.
+#define LEAN_REC_RUN_ASM \
+  "1:\n\t" \
+  "s_cmp_eq_u32 %[ok], 0\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_waitcnt lgkmcnt(0)\n\t" \
+  "v_readfirstlane_b32 s90, %[rx]\n\t" \
+  "v_readfirstlane_b32 s91, %[ry]\n\t" \
+  "s_and_b32 s92, s90, 0x1800000\n\t"           /* valid, no literals */ \
+  "s_cmp_lg_u32 s92, 0x800000\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_cmp_eq_u32 %[bl1], 0\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_cmp_ge_u32 %[ndw], %[lim]\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_and_b32 s92, s90, 0xffff\n\t"              /* s92 = copy length */ \
+  "s_mov_b32 s93, %[d0]\n\t"                    /* s93 = distance, s94 = pushed onto the ring? */ \
+  "s_mov_b32 s94, 0\n\t" \
+  "s_bitcmp1_b32 s90, 25\n\t"                   /* implicit: the last distance */ \
+  "s_cbranch_scc1 3f\n\t" \
+  "s_cmp_eq_u32 %[bl2], 0\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_bitcmp1_b32 s90, 28\n\t" \
+  "s_cbranch_scc1 2f\n\t" \
+  "s_mov_b32 s93, s91\n\t"                      /* explicit */ \
+  "s_mov_b32 s94, 1\n\t" \
+  "s_branch 3f\n" \
+  "2:\n\t"                                      /* ring code s91 = 0 .. 15 */ \
+  "s_cmp_eq_u32 s91, 0\n\t" \
+  "s_cbranch_scc1 3f\n\t" \
+  "s_lshl_b32 s95, s91, 1\n\t" \
+  "s_lshr_b32 s96, 0xaaafff1b, s95\n\t" \
+  "s_and_b32 s96, s96, 3\n\t"                   /* 3 - (how far back) */ \
+  "s_mov_b32 s93, %[d3]\n\t" \
+  "s_cmp_eq_u32 s96, 1\n\t" \
+  "s_cselect_b32 s93, %[d2], s93\n\t" \
+  "s_cmp_eq_u32 s96, 2\n\t" \
+  "s_cselect_b32 s93, %[d1], s93\n\t" \
+  "s_cmp_eq_u32 s96, 3\n\t" \
+  "s_cselect_b32 s93, %[d0], s93\n\t" \
+  "s_lshr_b32 s97, 0xfa5fa500, s95\n\t" \
+  "s_and_b32 s97, s97, 3\n\t" \
+  "s_mov_b32 s94, 1\n\t" \
+  "s_bitcmp1_b32 s91, 0\n\t" \
+  "s_cbranch_scc1 21f\n\t" \
+  "s_sub_i32 s93, s93, s97\n\t" \
+  "s_cmp_gt_i32 s93, 0\n\t" \
+  "s_cselect_b32 s93, s93, 0x7fffffff\n\t" \
+  "s_branch 3f\n" \
+  "21:\n\t" \
+  "s_add_i32 s93, s93, s97\n" \
+  "3:\n\t"                                      /* the plain copy?  0 < distance <= min(P, max_backward), length <= 64, <= distance, < quota */ \
+  "s_min_u32 s95, %[P], %[maxb]\n\t" \
+  "s_cmp_le_i32 s93, 0\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_cmp_gt_u32 s93, s95\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_cmp_gt_u32 s92, 64\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_cmp_lt_u32 s93, s92\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_cmp_ge_u32 s92, %[quota]\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_bfe_u32 s95, s90, 0x10019\n\t"             /* counts: an explicit distance takes one of its block */ \
+  "s_xor_b32 s95, s95, 1\n\t" \
+  "s_sub_u32 %[bl2], %[bl2], s95\n\t" \
+  "s_sub_u32 %[bl1], %[bl1], 1\n\t" \
+  "s_add_u32 %[ncmd], %[ncmd], 1\n\t" \
+  "s_sub_i32 %[mlen], %[mlen], s92\n\t" \
+  "s_cmp_eq_u32 s94, 0\n\t" \
+  "s_cbranch_scc1 4f\n\t" \
+  "s_mov_b32 %[d3], %[d2]\n\t" \
+  "s_mov_b32 %[d2], %[d1]\n\t" \
+  "s_mov_b32 %[d1], %[d0]\n\t" \
+  "s_mov_b32 %[d0], s93\n" \
+  "4:\n\t"                                      /* the reader moves on by the command's bits (<= 64) */ \
+  "s_bfe_u32 s95, s90, 0x70010\n\t" \
+  "s_cmp_le_u32 s95, %[cnt]\n\t" \
+  "s_cbranch_scc1 5f\n\t" \
+  "s_sub_u32 s95, s95, %[cnt]\n\t" \
+  "s_cmp_lt_u32 s95, 32\n\t" \
+  "s_cbranch_scc1 41f\n\t" \
+  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
+  "s_sub_u32 s95, s95, 32\n" \
+  "41:\n\t" \
+  "s_sub_u32 s96, %[ndw], %[cb]\n\t" \
+  "s_mov_b32 s97, 0\n\t" \
+  "v_readlane_b32 s96, %[cur], s96\n\t" \
+  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
+  "s_mov_b32 %[cnt], 32\n\t" \
+  "s_mov_b64 %[buf], s[96:97]\n" \
+  "5:\n\t" \
+  "s_lshr_b64 %[buf], %[buf], s95\n\t" \
+  "s_sub_u32 %[cnt], %[cnt], s95\n\t" \
+  "s_cmp_eq_u32 %[pn], 0\n\t"                   /* the copy in flight goes to memory */ \
+  "s_cbranch_scc1 6f\n\t" \
+  "s_add_u32 s96, %[outlo], %[pp]\n\t" \
+  "s_addc_u32 s97, %[outhi], 0\n\t" \
+  "s_sub_u32 s95, 64, %[pn]\n\t" \
+  "s_waitcnt vmcnt(0)\n\t" \
+  "s_lshr_b64 exec, -1, s95\n\t" \
+  "global_store_byte %[lane], v124, s[96:97]\n\t" \
+  "s_mov_b64 exec, -1\n" \
+  "6:\n\t"                                      /* this one's load */ \
+  "s_add_u32 s96, %[outlo], %[P]\n\t" \
+  "s_addc_u32 s97, %[outhi], 0\n\t" \
+  "s_sub_u32 s96, s96, s93\n\t" \
+  "s_subb_u32 s97, s97, 0\n\t" \
+  "s_sub_u32 s95, 64, s92\n\t" \
+  "s_lshr_b64 exec, -1, s95\n\t" \
+  "global_load_ubyte v124, %[lane], s[96:97]\n\t" \
+  "s_mov_b64 exec, -1\n\t" \
+  "s_mov_b32 %[pn], s92\n\t" \
+  "s_mov_b32 %[pp], %[P]\n\t" \
+  "s_add_u32 %[P], %[P], s92\n\t" \
+  "s_sub_u32 %[quota], %[quota], s92\n\t" \
+  "s_cmp_ge_u32 %[cnt], 32\n\t"                 /* at least 32 bits in the buffer */ \
+  "s_cbranch_scc1 7f\n\t" \
+  "s_sub_u32 s96, %[ndw], %[cb]\n\t" \
+  "s_mov_b32 s97, 0\n\t" \
+  "v_readlane_b32 s96, %[cur], s96\n\t" \
+  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
+  "s_lshl_b64 s[96:97], s[96:97], %[cnt]\n\t" \
+  "s_add_u32 %[cnt], %[cnt], 32\n\t" \
+  "s_or_b64 %[buf], %[buf], s[96:97]\n" \
+  "7:\n\t"                                      /* the next command's record, if wave 2 has written it */ \
+  "s_lshl_b32 s95, %[ndw], 5\n\t" \
+  "s_sub_u32 s95, s95, %[cnt]\n\t" \
+  "s_sub_u32 s95, s95, %[org]\n\t" \
+  "s_mov_b32 %[ok], 0\n\t" \
+  "s_cmp_ge_u32 s95, %[front]\n\t" \
+  "s_cbranch_scc1 9f\n\t" \
+  "s_and_b32 s95, s95, 0x3ff\n\t" \
+  "s_lshl_b32 s95, s95, 3\n\t" \
+  "s_add_u32 s95, s95, %[xring]\n\t" \
+  "v_mov_b32 %[rx], s95\n\t" \
+  "s_mov_b32 %[ok], 1\n\t" \
+  "ds_read_b32 %[ry], %[rx] offset:4\n\t" \
+  "ds_read_b32 %[rx], %[rx]\n\t" \
+  "s_branch 1b\n" \
+  "9:\n\t" \
+  "s_waitcnt lgkmcnt(0)\n"
+static_assert(XR_VALID == 0x800000u && XR_LITERALS == 0x1000000u && XR_IMPLICIT == (1u << 25) && XR_SHORT == (1u << 28) && SPX_POS == 1024u, "LEAN_REC_RUN_ASM spells these out");
+
+// The lean loop of a context-modelled metablock whose command records are there (rec_wave): nothing of a command's head is
+// parsed here, and a command without literals is not parsed at all -- copy length, distance and the bits to skip come out of
+// the record at the reader's position.  Kept small on purpose (the compiler's scalar code for a loop with many ways out is
+// mostly bookkeeping of which way it went): one plain path -- literals of at most 64, then a short LZ77 copy that does not
+// repeat itself, clear of every limit and of the end of the register window -- and everything else is left, at the command
+// boundary (LS_BEGIN) or in front of the distance (LS_DISTANCE / LS_POST_DISTANCE), to the checked stages of process_commands.
+// State and hand-over as lean_commands<false> (decode.rs:2359-2726 for the path it takes).
+__device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands(uint32_t ctx_tree_v) {
+  const uint32_t lane = lane_id();
+  BitReader br;
+  br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
+  br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED); br.end_dw = LEAN_LD(L_END_DW);
+  br.chunk_base = LEAN_LD(L_CHUNK_BASE); br.cur = lds_ld32(LDS_LEANWIN + 4u * lane);
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)LEAN_LD(L_OUT_LO) | ((uint64_t)LEAN_LD(L_OUT_HI) << 32));
+  uint64_t P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
+  uint32_t quota = LEAN_LD(L_QUOTA);
+  int32_t mlen = (int32_t)LEAN_LD(L_MLEN);
+  uint32_t bl0 = LEAN_LD(L_BL0), bl1 = LEAN_LD(L_BL1), bl2 = LEAN_LD(L_BL2);
+  int32_t d0 = (int32_t)LEAN_LD(L_D0), d1 = (int32_t)LEAN_LD(L_D1), d2 = (int32_t)LEAN_LD(L_D2), d3 = (int32_t)LEAN_LD(L_D3);
+  uint32_t ncmd = 0;
+  const uint32_t cmd_tree = LEAN_LD(L_CMD_TREE), lit_tree = LEAN_LD(L_LIT_TREE);
+  const uint32_t dt0 = LEAN_LD(L_DT0), dt1 = LEAN_LD(L_DT1), dt2 = LEAN_LD(L_DT2), dt3 = LEAN_LD(L_DT3);
+  const uint32_t max_backward = LEAN_LD(L_MAX_BACKWARD);
+  const uint32_t postfix_bits = LEAN_LD(L_POSTFIX), num_direct = LEAN_LD(L_NUM_DIRECT);
+  const bool dlut_ok = postfix_bits == 0u && num_direct == 16u;
+  uint32_t dlut;
+  {
+    const uint32_t dv = (lane - 16u) & 63u, nb = (dv >> 1) + 1u;
+    dlut = nb | ((((2u + (dv & 1u)) << nb) - 3u) << 5);  // distance = ((2 + (dv & 1)) << nb) - 4 + bits + 1
+  }
+  // (a command is begun at most fifty dwords into the register window, and no command of the plain path reads more than thirteen:
+  // the window only moves between two commands)
+  const uint32_t safe_dw = br.end_dw > 72u ? br.end_dw - 72u : 0u;
+  uint32_t win_end = br.chunk_base + 50u;
+  // the reader inside the window: a command of the plain path takes at most 2 (head) + 8 (sixteen literals) + 2 (distance) + 1 dwords
+  auto pull = [&]() { const uint32_t dw = rdlane(br.cur, br.next_dw - br.chunk_base); br.buf |= (uint64_t)dw << br.cnt; br.cnt += 32u; br.next_dw++; };
+  auto need32 = [&]() { if (br.cnt < 32u) pull(); };
+  auto advance = [&](uint32_t n) {  // n <= 64
+    if (n > br.cnt) { n -= br.cnt; br.buf = 0; br.cnt = 0; if (n >= 32u) { br.next_dw++; n -= 32u; } pull(); }
+    br.buf >>= n; br.cnt -= n;
+  };
+  auto read24 = [&](uint32_t n) -> uint32_t { need32(); const uint32_t v = (uint32_t)br.buf & ((1u << n) - 1u); br.buf >>= n; br.cnt -= n; return v; };
+  auto symbol = [&](uint32_t tree) -> uint32_t {  // read_symbol<true>
+    need32();
+    const uint32_t bits = (uint32_t)br.buf;
+    uint32_t e = rfl(lds_ld16(LDS_FIXED + tree + ((bits & 0xFFu) << 1)));
+    uint32_t len = e & 15u;
+    if (len > ROOT_BITS) {
+      const uint32_t idx = (e >> 4) + ((bits >> ROOT_BITS) & mask_bits(len - ROOT_BITS));
+      e = rfl(lds_ld16(LDS_FIXED + tree + (idx << 1)));
+      len = ROOT_BITS + (e & 15u);
+    }
+    br.buf >>= len; br.cnt -= len;
+    return e >> 4;
+  };
+  uint32_t p1 = LEAN_LD(L_P1), p2 = LEAN_LD(L_P2);
+  bool ctx_regs = LEAN_LD(L_CTX_REGS) != 0u;  // else: the tail of the short copy in flight (pend_n != 0), or memory
+  const uint32_t trivial = LEAN_LD(L_TRIVIAL), ctx_lut = LEAN_LD(L_CTX_LUT);
+  const uint32_t lut0v = lds_ld32(ctx_lut + 4u * lane), lut1v = lds_ld32(ctx_lut + 256u + 4u * lane);
+  uint32_t pend_n = 0; uint64_t pend_pos = 0;  // short copy whose bytes are on their way into v124 (see PEND_REGS)
+  uint32_t stage = LS_BEGIN;
+  int32_t insert_len = 0, copy_len = 0, distance_code = 0;
+  uint32_t distance_context = 0;
+
+  const uint32_t xb = hc_ld(HC_EXT_BASE), xring = xb + SPX_CTL_BYTES;
+  const uint32_t origin_bits = LEAN_LD(L_SP_ORIGIN) << 5;
+  uint32_t front_c = 0;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 rec_v = {0u, 0u};
+  uint32_t my_epoch = sp_ld(xb, XW_EPOCH);
+  {
+    // the prefix codes the records are parsed with: new ones (the first time, after a block switch) start a new epoch
+    const bool same = my_epoch != 0u && sp_ld(xb, XW_CMD_TREE) == LDS_FIXED + cmd_tree && sp_ld(xb, XW_DT0) == LDS_FIXED + dt0 && sp_ld(xb, XW_DT0 + 1) == LDS_FIXED + dt1 &&
+                      sp_ld(xb, XW_DT0 + 2) == LDS_FIXED + dt2 && sp_ld(xb, XW_DT0 + 3) == LDS_FIXED + dt3;
+    sp_st(xb, XW_POS, br.next_dw * 32u - br.cnt - origin_bits);
+    if (!same) {
+      sp_st(xb, XW_CMD_TREE, LDS_FIXED + cmd_tree); sp_st(xb, XW_DT0, LDS_FIXED + dt0); sp_st(xb, XW_DT0 + 1, LDS_FIXED + dt1);
+      sp_st(xb, XW_DT0 + 2, LDS_FIXED + dt2); sp_st(xb, XW_DT0 + 3, LDS_FIXED + dt3);
+      sp_st(xb, XW_POSTFIX, postfix_bits); sp_st(xb, XW_NUM_DIRECT, num_direct);
+      my_epoch++;
+      lds_release();
+      sp_st(xb, XW_EPOCH, my_epoch);
+    }
+  }
+  // the record at the reader's position, once wave 2 has written it (rel: stream bits from the ring's origin)
+  uint32_t pos_said = br.next_dw * 32u - br.cnt - origin_bits;
+  auto request = [&]() -> bool {
+    const uint32_t rel = br.next_dw * 32u - br.cnt - origin_bits;
+    if (rel - pos_said >= 128u) { sp_st(xb, XW_POS, rel); pos_said = rel; }  // (wave 2 stays less than a lap ahead of what it was told)
+    if (rel >= 0x40000000u) return false;
+    if (rel >= front_c) {
+      const uint64_t f = *reinterpret_cast<volatile __attribute__((address_space(3))) uint64_t*>(&g_smem[xb + 4u * XW_FRONT]);
+      front_c = rfl((uint32_t)(f >> 32)) == my_epoch ? rfl((uint32_t)f) : 0u;
+      if (rel >= front_c) return false;
+    }
+    rec_v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(&g_smem[xring + ((rel & (SPX_POS - 1u)) << 3)]);
+    return true;
+  };
+  // the copy in flight goes to memory (its bytes have arrived)
+  auto flush = [&]() {
+    if (pend_n) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pend_store8(out + pend_pos, pend_n, lane); pend_n = 0; }
+  };
+  bool rec_ok = request();
+  static const bool no_run_asm = false;
+
+  for (;;) {
+    if (bl1 == 0 || br.next_dw >= safe_dw) break;
+    if (br.next_dw >= win_end) { br.rebase(); win_end = br.chunk_base + 50u; }  // (the only place the window moves: between two commands)
+    if (rec_ok && !no_run_asm && P < 0xFFF00000ull && front_c <= 0x40000000u) {
+      // ---- a run of commands without literals (see LEAN_REC_RUN_ASM) ----
+      uint32_t ok = 1u, rx = rec_v.x, ry = rec_v.y, P32 = rfl((uint32_t)P), pp32 = rfl((uint32_t)pend_pos);
+      const uint32_t lim = rfl(safe_dw < win_end ? safe_dw : win_end), ncmd0 = ncmd;  // (rfl: scalar registers for the "s" operands)
+      asm volatile(LEAN_REC_RUN_ASM
+          : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [bl1] "+s"(bl1), [bl2] "+s"(bl2), [ncmd] "+s"(ncmd), [mlen] "+s"(mlen),
+            [d0] "+s"(d0), [d1] "+s"(d1), [d2] "+s"(d2), [d3] "+s"(d3), [P] "+s"(P32), [quota] "+s"(quota), [pn] "+s"(pend_n), [pp] "+s"(pp32),
+            [ok] "+s"(ok), [rx] "+v"(rx), [ry] "+v"(ry)
+          : [cur] "v"(br.cur), [lane] "v"(lane), [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
+            [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits), [front] "s"(rfl(front_c))
+          : "memory", "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "v124");
+      P = P32; pend_pos = pp32;
+      rec_v.x = rx; rec_v.y = ry; rec_ok = ok != 0u;
+      if (ncmd != ncmd0) ctx_regs = false;  // (the two bytes before P: the tail of the copy in flight)
+      if (bl1 == 0 || br.next_dw >= safe_dw) break;
+      if (br.next_dw >= win_end) continue;
+    }
+    for (uint32_t spins = 0; !rec_ok && spins < 8u; spins++) { if (spins) __builtin_amdgcn_s_sleep(4); rec_ok = request(); }  // (wave 2 is rarely behind)
+    if (!rec_ok) break;
+    const uint32_t rec_lo = rfl(rec_v.x), rec_hi = rfl(rec_v.y);
+    if (!(rec_lo & XR_VALID)) break;
+    const uint32_t n = rec_lo & 0xFFFFu, nb = (rec_lo >> 16) & 127u;
+    uint32_t lit_n = 0, lit_reg = 0;
+    int32_t dist;
+    uint32_t push;
+    if (rec_lo & XR_LITERALS) {
+      // ---- literals: the tree depends on the two bytes before (decode.rs:2463-2551) ----
+      const uint32_t ins = rec_hi;
+      if (ins > 16u || ins >= quota || ins > bl0) break;
+      advance(nb);
+      if (!ctx_regs) {
+        if (pend_n >= 2u) { p1 = pend_byte(pend_n - 1u); p2 = pend_byte(pend_n - 2u); }  // (the tail of the short copy in flight)
+        else { flush(); p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u; p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u; }
+        ctx_regs = true;
+      }
+      for (uint32_t i = 0; i < ins; i++) {
+        uint32_t tree = lit_tree;
+        if (!trivial) {
+          const uint32_t context = ((rdlane(lut0v, p1 >> 2) >> ((p1 & 3u) << 3)) | (rdlane(lut1v, p2 >> 2) >> ((p2 & 3u) << 3))) & 0xFFu;
+          tree = rdlane(ctx_tree_v, context);
+        }
+        const uint32_t lit = symbol(tree);
+        p2 = p1; p1 = lit;
+        lit_reg = (lane == i) ? lit : lit_reg;
+      }
+      lit_n = ins;
+      insert_len = (int32_t)ins; copy_len = (int32_t)n;
+      // ---- the distance behind them (ReadDistanceInternal, decode.rs:2066-2131) ----
+      if (rec_lo & XR_IMPLICIT) { dist = d0; push = 0u; distance_context = 1; distance_code = d0; }
+      else {
+        distance_context = (rec_lo >> XR_DCTX_SHIFT) & 3u;
+        distance_code = -1;
+        if (bl2 == 0) stage = LS_DISTANCE;
+        else {
+          const uint32_t dtree = distance_context == 0 ? dt0 : distance_context == 1 ? dt1 : distance_context == 2 ? dt2 : dt3;
+          const uint32_t code = symbol(dtree);
+          distance_context = 0;
+          bl2--;
+          if (code == 0u) { dist = d0; push = 0u; distance_context = 1; }
+          else if (code < 16u) {
+            const uint32_t sh = code << 1;
+            const uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
+            int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
+            const int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+            if (code & 1u) v += mag;
+            else { v -= mag; if (v <= 0) v = 0x7fffffff; }
+            dist = v; push = 1u;
+          } else if (dlut_ok && code < 64u) {
+            const uint32_t de = rdlane(dlut, code);
+            dist = (int32_t)((de >> 5) + read24(de & 31u)); push = 1u;
+          } else {
+            int32_t distval = (int32_t)code - (int32_t)num_direct;
+            int32_t dc = (int32_t)code;
+            if (distval >= 0) {
+              const int32_t postfix = distval & (int32_t)mask_bits(postfix_bits);
+              distval >>= postfix_bits;
+              const uint32_t nbits = ((uint32_t)distval >> 1) + 1;
+              const uint32_t bits = read24(nbits);
+              const int64_t offset = (int64_t)(int32_t)((((uint32_t)(distval & 1) + 2u) << nbits) - 4u);
+              dc = (int32_t)(((offset + (int64_t)bits) << postfix_bits) + postfix + (int64_t)num_direct);
+            }
+            dist = (int32_t)((uint32_t)dc - 16u + 1u); push = 1u;
+          }
+          distance_code = dist;
+        }
+      }
+      bl1--; ncmd++;
+      mlen -= (int32_t)ins;
+      // the literals go out with (in front of) the copy in flight: one store each
+      flush();
+      if (lane < lit_n) out[P + lane] = (uint8_t)lit_reg;
+      P += ins; bl0 -= ins; quota -= ins;
+      if (stage != LS_BEGIN) break;
+      // anything but the plain copy: the checked stages finish the command (nothing of the ring or the counts is touched yet)
+      const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
+      if (dist <= 0 || (uint32_t)dist > max_distance || n > 64u || (uint32_t)dist < n || n >= quota) { stage = LS_POST_DISTANCE; break; }
+    } else {
+      // ---- a command without literals: all of it is in the record ----
+      if (rec_lo & XR_IMPLICIT) { dist = d0; push = 0u; }
+      else {
+        if (bl2 == 0) break;
+        push = 1u;
+        if (!(rec_lo & XR_SHORT)) dist = (int32_t)rec_hi;
+        else if (rec_hi == 0u) { dist = d0; push = 0u; }
+        else {  // TakeDistanceFromRingBuffer, decode.rs:2017-2049
+          const uint32_t sh = rec_hi << 1;
+          const uint32_t back = 3u - ((0xaaafff1bu >> sh) & 3u);
+          int32_t v = back == 0 ? d0 : back == 1 ? d1 : back == 2 ? d2 : d3;
+          const int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+          if (rec_hi & 1u) v += mag;
+          else { v -= mag; if (v <= 0) v = 0x7fffffff; }
+          dist = v;
+        }
+      }
+      const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
+      if (dist <= 0 || (uint32_t)dist > max_distance || n > 64u || (uint32_t)dist < n || n >= quota) break;  // (untouched: the checked stages take it whole)
+      if (!(rec_lo & XR_IMPLICIT)) bl2--;
+      bl1--; ncmd++;
+      advance(nb);
+      flush();
+    }
+    // ---- the plain copy: its load is issued now, its store when the next command gets here (its source may be what this one writes) ----
+    if (push) { d3 = d2; d2 = d1; d1 = d0; d0 = dist; }
+    mlen -= (int32_t)n;
+    pend_load8(out + P - (uint32_t)dist, n, lane);
+    pend_n = n; pend_pos = P;
+    ctx_regs = false;
+    P += n; quota -= n;
+    need32();
+    rec_ok = request();
+  }
+  if (!ctx_regs && pend_n >= 2u) { p1 = pend_byte(pend_n - 1u); p2 = pend_byte(pend_n - 2u); ctx_regs = true; }
+  flush();
+  sp_st(xb, XW_POS, br.next_dw * 32u - br.cnt - origin_bits);
+  lds_st32(LDS_LEANWIN + 4u * lane, br.cur);
+  if (lane == 0) {
+    LEAN_ST(L_CHUNK_BASE, br.chunk_base);
+    LEAN_ST(L_P1, p1); LEAN_ST(L_P2, p2); LEAN_ST(L_CTX_REGS, ctx_regs ? 1u : 0u);
+    LEAN_ST(L_BUF_LO, (uint32_t)br.buf); LEAN_ST(L_BUF_HI, (uint32_t)(br.buf >> 32)); LEAN_ST(L_CNT, br.cnt); LEAN_ST(L_NEXT_DW, br.next_dw);
+    LEAN_ST(L_ISSUED, br.issued_half); LEAN_ST(L_P_LO, (uint32_t)P); LEAN_ST(L_P_HI, (uint32_t)(P >> 32)); LEAN_ST(L_QUOTA, quota);
+    LEAN_ST(L_MLEN, mlen); LEAN_ST(L_BL0, bl0); LEAN_ST(L_BL1, bl1); LEAN_ST(L_BL2, bl2);
+    LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
+    LEAN_ST(L_INSERT, insert_len); LEAN_ST(L_COPY, copy_len); LEAN_ST(L_DCODE, distance_code); LEAN_ST(L_DCTX, distance_context);
+    LEAN_ST(L_LITS_LEFT, 0u);
+  }
+  lds_sync();
+  return rfl(stage);
+}
+
 // ===================================== split lean loop: the parser =====================================
 // lean_commands<false> without the part that moves bytes (see "parse / copy split" above): the same stages, the same
 // hand-over to process_commands (L_STAGE ...), but a command that stays clear of every limit becomes a record for the
 // copier wave.  Returns with the ring drained: whatever the records produced is in memory.
-enum { L_SP_HEAD = L_COUNT, L_SP_LIT = L_COUNT + 1, L_SP_ORIGIN = L_COUNT + 2 /* dword the record ring's positions count from */,
-       L_SP_REC = L_COUNT + 3 /* command records (rec_wave) in use */, L_SP_COUNT = L_COUNT + 4 };
-static_assert(L_SP_COUNT * 4 <= 192, "LDS_LEAN too small");
 #define SP_CTX_REG "v125"
 __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_commands(uint32_t lut_vgpr, uint32_t ctx_tree_v) {
   const uint32_t lane = lane_id();
@@ -2602,29 +3012,34 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
   const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
   uint32_t scan_fails = 0;
-  // ---- parse / copy split: in a block with helper waves, wave 1 executes what this wave parses of a context-modelled metablock
-  // (copier_wave, lean_split_commands).  It stays engaged, idle while the checked stages run, until the metablock is done.
-  bool split_on = false;
-  if (LDS_ONLY && !CTX_NEVER && hc_ld(HC_NW_ALL) >= 4u && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS && mlen >= (int32_t)SP_MIN_MLEN && (g_engine_mode & 2u) == 0u) {
-    const uint32_t ctl = sp_ctl_base();
-    lds_sync();
-    if (lane < (uint32_t)CW_WORDS)
-      lds_st32(ctl + 4u * lane, lane == (uint32_t)CW_OUT_LO ? (uint32_t)(uintptr_t)out : lane == (uint32_t)CW_OUT_HI ? (uint32_t)((uint64_t)(uintptr_t)out >> 32) : 0u);
-    // wave 2 parses command records ahead of this wave (rec_wave) where the launch left room for their ring (no large window:
-    // a record's distance has at most 24 extra bits); positions count from the dword the reader is in now
+  // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
+  // ahead of this wave (rec_wave; the lean loop takes commands out of them); on request (BROTLI_AMD_ENGINE=split) wave 1 executes
+  // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
+  // metablock is done.
+  bool split_on = false, helpers_on = false;
+  uint32_t rec_base = 0;
+  if (LDS_ONLY && !CTX_NEVER && hc_ld(HC_NW_ALL) >= 4u && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS && mlen >= (int32_t)SP_MIN_MLEN && (g_engine_mode & 6u) != 6u) {
+    split_on = (g_engine_mode & 2u) == 0u;
+    // the records' ring: what is left of the LDS arena now that the tables of this metablock are built (no large window: a
+    // record's distance has at most 24 extra bits); positions count from the dword the reader is in now
     const uint32_t free_at = (a.top + 15u) & ~15u;
-    const uint32_t xb = a.lds_limit >= free_at + SPX_BYTES ? LDS_FIXED + free_at : 0u;  // (the tables of this metablock are built: what is left of the LDS arena is free)
-    hc_st(HC_EXT_BASE, xb);
     const uint32_t origin_dw = (br.next_dw - ((br.cnt + 31u) >> 5)) & ~1u;
-    const bool rec_on = xb != 0u && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u;
-    if (xb != 0u && lane < (uint32_t)XW_WORDS)
-      lds_st32(xb + 4u * lane, lane == (uint32_t)XW_ORIGIN_DW ? origin_dw : lane == (uint32_t)XW_LIMIT && rec_on ? ((br.end_dw - origin_dw - 8u) << 5) & ~63u : 0u);
-    if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); LEAN_ST(L_SP_ORIGIN, origin_dw); LEAN_ST(L_SP_REC, rec_on ? 1u : 0u); }
-    hc_st(HC_KIND, (uint32_t)HK_SPLIT);
-    lds_release();
-    hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
-    split_on = true;
+    if ((g_engine_mode & 4u) == 0u && a.lds_limit >= free_at + SPX_BYTES && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u) rec_base = LDS_FIXED + free_at;
+    if (split_on || rec_base != 0u) {
+      helpers_on = true;
+      lds_sync();
+      hc_st(HC_EXT_BASE, rec_base);
+      if (rec_base != 0u && lane < (uint32_t)XW_WORDS)
+        lds_st32(rec_base + 4u * lane, lane == (uint32_t)XW_ORIGIN_DW ? origin_dw : lane == (uint32_t)XW_LIMIT ? ((br.end_dw - origin_dw - 8u) << 5) & ~63u : 0u);
+      if (split_on && lane < (uint32_t)CW_WORDS)
+        lds_st32(sp_ctl_base() + 4u * lane, lane == (uint32_t)CW_OUT_LO ? (uint32_t)(uintptr_t)out : lane == (uint32_t)CW_OUT_HI ? (uint32_t)((uint64_t)(uintptr_t)out >> 32) : 0u);
+      if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); LEAN_ST(L_SP_ORIGIN, origin_dw); LEAN_ST(L_SP_REC, rec_base != 0u ? 1u : 0u); }
+      hc_st(HC_KIND, (uint32_t)HK_SPLIT);
+      lds_release();
+      hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
+    }
   }
+  if (LDS_ONLY && !CTX_NEVER && !helpers_on && lane == 0) LEAN_ST(L_SP_REC, 0u);
   uint32_t force_checked = 0;  // commands that go through the checked stages before the engine (or the lean loop) is tried again:
                                // the command the engine stopped at, more of them after invocations that got nowhere
 
@@ -2718,7 +3133,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         if (hc_ld(HC_FAILED) != 0u) STOP(E_UNREACHABLE);    // the copier did not answer (never seen)
         engine_commands += LEAN_LD(L_NCMD_LO);
       } else {
-        stage = rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+        stage = !CTX_NEVER && rec_base != 0u ? rfl(lean_rec_commands(ctx_tree_v)) : rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+        if (!CTX_NEVER && rec_base != 0u) engine_commands += LEAN_LD(L_NCMD_LO);
       }
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
@@ -3199,12 +3615,11 @@ command_done:
 done:
   FLUSH_LITERALS();
   FLUSH_PENDING();
-  if (split_on) {  // the copier goes back to sleep (HC_KIND stays: a helper that looks late must find nothing to do)
+  if (helpers_on) {  // the helpers go back to sleep (HC_KIND stays: a helper that looks late must find nothing to do)
     const uint32_t ctl = sp_ctl_base();
-    sp_st(ctl, CW_STOP, 1u);
-    const uint32_t xb = hc_ld(HC_EXT_BASE);
-    if (xb != 0u) sp_st(xb, XW_STOP, 1u);
-    for (uint32_t spins = 0; sp_ld(ctl, CW_STOP) != 2u || (xb != 0u && sp_ld(xb, XW_STOP) != 2u); spins++) {
+    if (split_on) sp_st(ctl, CW_STOP, 1u);
+    if (rec_base != 0u) sp_st(rec_base, XW_STOP, 1u);
+    for (uint32_t spins = 0; (split_on && sp_ld(ctl, CW_STOP) != 2u) || (rec_base != 0u && sp_ld(rec_base, XW_STOP) != 2u); spins++) {
       if (spins > SP_SPIN_CAP) { hc_st(HC_KIND, (uint32_t)HK_NO_ROUNDS); result = E_UNREACHABLE; break; }
       __builtin_amdgcn_s_sleep(2);
     }
@@ -3405,6 +3820,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
     s.nbt0 = s.nbt1 = s.nbt2 = 1;
     s.ar.top = 0;
     s.ar.cold = s.ar_end;
+    const uint32_t counted_before = s.num_metablocks;  // (what is counted from here on lies behind the resume point: see E_RETRY_ARENA below)
     {
       ColdScope c(s);
       BitReader& br = c.br;
@@ -3499,7 +3915,14 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
         s.prof[5] = (s.prof[5] & 0xFFFFFu) + ((__builtin_amdgcn_s_memtime() - run_t0) >> 8);
         TRY(run_e);
 #else
-        { const BrotliAmdResume* const m_ = mid; mid = nullptr; TRY(run_commands(s, m_, s.P, st)); }
+        {
+          const BrotliAmdResume* const m_ = mid; mid = nullptr;
+          const int run_e = run_commands(s, m_, s.P, st);
+          // a pass that stops in front of this metablock goes on, next time, from the resume point -- which lies in front of a run of
+          // metadata blocks that came before it: the next pass counts those again (num_metablocks was inflated)
+          if (run_e == E_RETRY_ARENA) s.num_metablocks = counted_before;
+          TRY(run_e);
+        }
 #endif
       }
     }
@@ -3753,8 +4176,9 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   {  // BROTLI_AMD_ENGINE=scan: the round-2 command engine only (A/B tests); the symbol is per device
     static const char* const eng = getenv("BROTLI_AMD_ENGINE");
     if (eng != nullptr) {
-      // bit 0: the scan engine only; bit 1: no parse / copy split of context-modelled metablocks (the default until it pays: "split" turns it on)
-      const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : 2u;
+      // bit 0: the scan engine only; bit 1: no copier wave for context-modelled metablocks (the default: it does not pay, see DESIGN;
+      // "split" turns it on); bit 2: no command records ("norec")
+      const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : 2u;
       hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
       if (e2 != hipSuccess) return e2;
     }

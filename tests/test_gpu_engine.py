@@ -36,7 +36,7 @@ def _check_against_oracle(pkg, datas, caps, flags=1, what=""):
         r = results[i]
         ok = (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp)
         if ok and info.result == 1:
-            ok = r.consumed == info.consumed and r.num_commands == info.num_commands
+            ok = r.consumed == info.consumed and r.num_commands == info.num_commands and r.num_metablocks == info.num_metablocks
         if not ok:
             bad.append((i, what, (r.result, r.error_code, r.decoded_size), (info.result, info.error_code, info.decoded_size), r.consumed, info.consumed, len(d), cap))
     assert not bad, (len(bad), bad[:10])
@@ -322,6 +322,54 @@ def test_the_engines_and_the_one_wave_path_agree(pkg):
     assert strip(rows["path"]) == strip(rows["scan"]) == strip(rows["none"])
     assert all(r[5] == 0 for r in rows["none"]), rows["none"]
     assert all(r[5] >= 0.9 * r[4] for r in rows["path"][:2]) and all(r[5] >= 0.9 * r[4] for r in rows["scan"][:2]), (rows["path"], rows["scan"])
+
+
+_CTX_SCRIPT = r"""
+import importlib.util, json, os, sys, hashlib
+ROOT = sys.argv[1]
+spec = importlib.util.spec_from_file_location("rust_brotli_decompressor_amd", os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec); sys.modules["rust_brotli_decompressor_amd"] = pkg; spec.loader.exec_module(pkg)
+gold = os.path.join(ROOT, "tests", "golden", "testdata")
+names = ["alice29.txt.compressed", "asyoulik.txt.compressed", "lcet10.txt.compressed", "plrabn12.txt.compressed"]
+datas = [open(os.path.join(gold, n), "rb").read() for n in names]
+caps = [1 << 20] * 4
+datas.append(datas[0][: len(datas[0]) // 2]); caps.append(1 << 20)                      # truncated
+bad = bytearray(datas[1]); bad[len(bad) // 3] ^= 4; datas.append(bytes(bad)); caps.append(1 << 20)  # damaged
+datas.append(datas[2]); caps.append(100000)                                                # output buffer too small
+datas = datas * int(sys.argv[2]); caps = caps * int(sys.argv[2])
+b = pkg.Batch(len(datas))
+res, outs = b.decode_host(datas, caps, 1)
+b.close()
+print(json.dumps([[r.result, r.error_code, r.decoded_size, r.consumed, r.num_commands, r.engine_commands, hashlib.sha256(o).hexdigest()] for r, o in zip(res, outs)]))
+"""
+
+
+@pytest.mark.parametrize("copies", [1, 160])
+def test_context_modelled_streams_with_and_without_the_helper_waves(pkg, copies):
+    """Metablocks whose literals depend on context (the reference's text fixtures: whole, truncated, damaged, output buffer too
+    small), in blocks of sixteen waves (7 streams) and of four (1120 streams), three times in fresh processes: default (wave 2
+    parses command records ahead of the decoding wave: rec_wave / lean_rec_commands), BROTLI_AMD_ENGINE=split (wave 1 also
+    executes what the decoding wave parses: copier_wave / lean_split_commands), BROTLI_AMD_ENGINE=norec (the decoding wave
+    alone).  Same status words and bytes, equal to the oracle's; `engine_commands` says which path ran."""
+    import json
+    import subprocess
+    rows = {}
+    for name, env in (("records", {}), ("split", {"BROTLI_AMD_ENGINE": "split"}), ("alone", {"BROTLI_AMD_ENGINE": "norec"})):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", _CTX_SCRIPT, ROOT, str(copies)], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    strip = lambda rs: [r[:5] + r[6:] for r in rs]  # everything but engine_commands
+    assert strip(rows["records"]) == strip(rows["split"]) == strip(rows["alone"])
+    gold = os.path.join(ROOT, "tests", "golden", "testdata")
+    names = ["alice29.txt.compressed", "asyoulik.txt.compressed", "lcet10.txt.compressed", "plrabn12.txt.compressed"]
+    for i, n in enumerate(names):
+        info, exp = oracle.decode(open(os.path.join(gold, n), "rb").read(), 1 << 20, 1)
+        for r in rows["records"][i::7]:
+            assert r[:5] == [info.result, info.error_code, info.decoded_size, info.consumed, info.num_commands] and r[6] == hashlib.sha256(exp).hexdigest(), (n, r)
+    assert all(r[5] == 0 for r in rows["alone"]), rows["alone"][:7]
+    for mode in ("records", "split"):
+        assert all(r[5] >= 0.9 * r[4] for i, r in enumerate(rows[mode]) if i % 7 < 4), (mode, rows[mode][:7])
 
 
 def test_batches_and_one_shot_calls_from_several_threads(pkg):

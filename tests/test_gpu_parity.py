@@ -32,8 +32,8 @@ def _check_against_oracle(pkg, datas, caps, flags=1, what=""):
         got = (r.result, r.error_code, r.decoded_size, outs[i])
         want = (info.result, info.error_code, info.decoded_size, exp)
         ok = got == want
-        if ok and info.result == 1:
-            ok = r.consumed == info.consumed
+        if ok and info.result == 1:  # (num_metablocks: also across passes with larger arenas, behind runs of metadata blocks)
+            ok = r.consumed == info.consumed and r.num_metablocks == info.num_metablocks and r.num_commands == info.num_commands
         if not ok:
             bad.append((i, what, got[:3], want[:3], r.consumed, info.consumed, len(d), cap))
     assert not bad, (len(bad), bad[:10])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of engine modes of one build on the same GPU box: tools/ab_env.sh <workload> <steps> <mode>...   (mode: default | scan | split)
+# A/B of engine modes of one build on the same GPU box: tools/ab_env.sh <workload> <steps> <mode>...   (mode: default | scan | split | norec)
 WL=$1; STEPS=$2; shift 2
 for round in 1 2; do
   for M in "$@"; do
