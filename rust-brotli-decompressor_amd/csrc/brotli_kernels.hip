@@ -1202,7 +1202,8 @@ constexpr uint32_t SPX_POS = 1024u;                   // ring size in stream bit
 constexpr uint32_t SPX_CTL_BYTES = 256u;
 constexpr uint32_t SPX_BYTES = SPX_CTL_BYTES + SPX_POS * 8u;
 enum { XW_FRONT = 0 /* u64: positions below are written (low), for parameter epoch (high) */, XW_POS = 2 /* the parser's position (lags) */,
-       XW_EPOCH = 3, XW_STOP = 4, XW_ORIGIN_DW = 5, XW_LIMIT = 6, XW_CMD_TREE = 7, XW_DT0 = 8, XW_POSTFIX = 12, XW_NUM_DIRECT = 13, XW_WORDS = 14 };
+       XW_EPOCH = 3, XW_STOP = 4, XW_ORIGIN_DW = 5, XW_LIMIT = 6, XW_CMD_TREE = 7, XW_DT0 = 8, XW_POSTFIX = 12, XW_NUM_DIRECT = 13,
+       XW_DICT_LO = 14, XW_DICT_HI = 15 /* the static dictionary (device address) */, XW_WORDS = 16 };
 enum { XR_VALID = 1u << 23, XR_LITERALS = 1u << 24, XR_IMPLICIT = 1u << 25, XR_DCTX_SHIFT = 26, XR_SHORT = 1u << 28 };
 __device__ __noinline__ void rec_wave();
 
@@ -2422,8 +2423,9 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     if (!(rec_lo & XR_VALID)) break;
     const uint32_t n = rec_lo & 0xFFFFu, nb = (rec_lo >> 16) & 127u;
     uint32_t lit_n = 0, lit_reg = 0;
-    int32_t dist;
-    uint32_t push;
+    int32_t dist = 0;
+    uint32_t push = 0;
+    bool committed = false;  // head and literals taken (a command with literals), or nothing yet
     if (rec_lo & XR_LITERALS) {
       // ---- literals: the tree depends on the two bytes before (decode.rs:2463-2551) ----
       const uint32_t ins = rec_hi;
@@ -2492,9 +2494,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
       if (lane < lit_n) out[P + lane] = (uint8_t)lit_reg;
       P += ins; bl0 -= ins; quota -= ins;
       if (stage != LS_BEGIN) break;
-      // anything but the plain copy: the checked stages finish the command (nothing of the ring or the counts is touched yet)
-      const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
-      if (dist <= 0 || (uint32_t)dist > max_distance || n > 64u || (uint32_t)dist < n || n >= quota) { stage = LS_POST_DISTANCE; break; }
+      committed = true;
     } else {
       // ---- a command without literals: all of it is in the record ----
       if (rec_lo & XR_IMPLICIT) { dist = d0; push = 0u; }
@@ -2513,20 +2513,50 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
           dist = v;
         }
       }
-      const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
-      if (dist <= 0 || (uint32_t)dist > max_distance || n > 64u || (uint32_t)dist < n || n >= quota) break;  // (untouched: the checked stages take it whole)
+    }
+    // ---- the plain copy (a short LZ77 reference that does not repeat itself, clear of every limit), or a word of the static dictionary
+    // that is (decode.rs:2593-2640); anything else goes to the checked stages -- whole, if nothing of it has been taken yet, else they
+    // finish it from the distance on (the ring and the copy's counts are untouched) ----
+    const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
+    const bool plain = dist > 0 && (uint32_t)dist <= max_distance && n <= 64u && (uint32_t)dist >= n && n < quota;
+    bool word = false;
+    WordShape w = {};
+    uint32_t word_offset = 0;
+    if (!plain) {
+      if ((uint32_t)dist > max_distance && dist > 0 && dist <= 0x7FFFFFFC && n >= 4u && n <= 24u) {
+        const uint32_t shift = kDictSizeBitsByLength[n];
+        const uint32_t word_id = (uint32_t)dist - max_distance - 1u;
+        const uint32_t transform_idx = word_id >> shift;
+        if (transform_idx < (uint32_t)BROTLI_NUM_TRANSFORMS) {
+          word_offset = kDictOffsetsByLength[n] + (word_id & mask_bits(shift)) * n;
+          w = word_shape(n, transform_idx);
+          word = w.total != 0u && w.total < quota && (int32_t)w.total <= mlen;
+        }
+      }
+      if (!word) { if (committed) stage = LS_POST_DISTANCE; break; }
+    }
+    if (!committed) {
       if (!(rec_lo & XR_IMPLICIT)) bl2--;
       bl1--; ncmd++;
       advance(nb);
       flush();
     }
-    // ---- the plain copy: its load is issued now, its store when the next command gets here (its source may be what this one writes) ----
-    if (push) { d3 = d2; d2 = d1; d1 = d0; d0 = dist; }
-    mlen -= (int32_t)n;
-    pend_load8(out + P - (uint32_t)dist, n, lane);
-    pend_n = n; pend_pos = P;
-    ctx_regs = false;
-    P += n; quota -= n;
+    if (word) {  // (the ring is not touched: decode.rs:2643-2644)
+      gcu8* const dict = (gcu8*)(uintptr_t)((uint64_t)sp_ld(xb, XW_DICT_LO) | ((uint64_t)sp_ld(xb, XW_DICT_HI) << 32));
+      const uint32_t ob = dictionary_word_bytes(dict, word_offset, w);
+      if (lane < w.total) out[P + lane] = (uint8_t)ob;
+      if (w.total >= 2u) { p1 = rdlane(ob, w.total - 1u); p2 = rdlane(ob, w.total - 2u); ctx_regs = true; }
+      else if (ctx_regs) { p2 = p1; p1 = rdlane(ob, 0); }  // (else: both come out of memory when a literal asks for them)
+      mlen -= (int32_t)w.total;
+      P += w.total; quota -= w.total;
+    } else {  // its load is issued now, its store when the next command gets here (its source may be what this one writes)
+      if (push) { d3 = d2; d2 = d1; d1 = d0; d0 = dist; }
+      mlen -= (int32_t)n;
+      pend_load8(out + P - (uint32_t)dist, n, lane);
+      pend_n = n; pend_pos = P;
+      ctx_regs = false;
+      P += n; quota -= n;
+    }
     need32();
     rec_ok = request();
   }
@@ -3030,7 +3060,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       lds_sync();
       hc_st(HC_EXT_BASE, rec_base);
       if (rec_base != 0u && lane < (uint32_t)XW_WORDS)
-        lds_st32(rec_base + 4u * lane, lane == (uint32_t)XW_ORIGIN_DW ? origin_dw : lane == (uint32_t)XW_LIMIT ? ((br.end_dw - origin_dw - 8u) << 5) & ~63u : 0u);
+        lds_st32(rec_base + 4u * lane, lane == (uint32_t)XW_ORIGIN_DW ? origin_dw : lane == (uint32_t)XW_LIMIT ? ((br.end_dw - origin_dw - 8u) << 5) & ~63u :
+                                       lane == (uint32_t)XW_DICT_LO ? (uint32_t)(uintptr_t)dict : lane == (uint32_t)XW_DICT_HI ? (uint32_t)((uint64_t)(uintptr_t)dict >> 32) : 0u);
       if (split_on && lane < (uint32_t)CW_WORDS)
         lds_st32(sp_ctl_base() + 4u * lane, lane == (uint32_t)CW_OUT_LO ? (uint32_t)(uintptr_t)out : lane == (uint32_t)CW_OUT_HI ? (uint32_t)((uint64_t)(uintptr_t)out >> 32) : 0u);
       if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); LEAN_ST(L_SP_ORIGIN, origin_dw); LEAN_ST(L_SP_REC, rec_base != 0u ? 1u : 0u); }
