@@ -1175,7 +1175,7 @@ __device__ __forceinline__ uint32_t sp_ctl_base() { return hc_ld(HC_BASE) + 3u *
 __device__ __forceinline__ uint32_t sp_ld(uint32_t ctl, uint32_t k) { return rfl(*reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * k])); }
 __device__ __forceinline__ void sp_st(uint32_t ctl, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[ctl + 4u * k]) = v; }
 #ifdef BROTLI_AMD_PROFILE_SPLIT
-__device__ unsigned long long g_split_prof[24];
+__device__ unsigned long long g_split_prof[40];
 #define SPLIT_PROF(k, t0) do { if (blockIdx.x == 0 && lane_id() == 0) g_split_prof[k] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #define SPLIT_COUNT(k, v) do { if (blockIdx.x == 0 && lane_id() == 0) g_split_prof[k] += (v); } while (0)
 #define SPLIT_T() __builtin_amdgcn_s_memtime()
@@ -2397,9 +2397,13 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
   bool rec_ok = request();
   static const bool no_run_asm = false;
 
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  uint64_t lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lap_t = __builtin_amdgcn_s_memtime(); const uint64_t lap_t0 = lap_t; uint32_t n_run = 0, n_lit = 0, n_nolit = 0, n_word = 0;
+#endif
   for (;;) {
     if (bl1 == 0 || br.next_dw >= safe_dw) break;
     if (br.next_dw >= win_end) { br.rebase(); win_end = br.chunk_base + 50u; }  // (the only place the window moves: between two commands)
+    SPLIT_LAP(0);
     if (rec_ok && !no_run_asm && P < 0xFFF00000ull && front_c <= 0x40000000u) {
       // ---- a run of commands without literals (see LEAN_REC_RUN_ASM) ----
       uint32_t ok = 1u, rx = rec_v.x, ry = rec_v.y, P32 = rfl((uint32_t)P), pp32 = rfl((uint32_t)pend_pos);
@@ -2411,6 +2415,10 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
           : [cur] "v"(br.cur), [lane] "v"(lane), [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
             [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits), [front] "s"(rfl(front_c))
           : "memory", "vcc", "scc", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "v124");
+      SPLIT_LAP(1);
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+      n_run += ncmd - ncmd0;
+#endif
       P = P32; pend_pos = pp32;
       rec_v.x = rx; rec_v.y = ry; rec_ok = ok != 0u;
       if (ncmd != ncmd0) ctx_regs = false;  // (the two bytes before P: the tail of the copy in flight)
@@ -2436,6 +2444,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
         else { flush(); p1 = P >= 1 ? (uint32_t)rfl(out[P - 1]) : 0u; p2 = P >= 2 ? (uint32_t)rfl(out[P - 2]) : 0u; }
         ctx_regs = true;
       }
+      SPLIT_LAP(2);
       for (uint32_t i = 0; i < ins; i++) {
         uint32_t tree = lit_tree;
         if (!trivial) {
@@ -2446,6 +2455,10 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
         p2 = p1; p1 = lit;
         lit_reg = (lane == i) ? lit : lit_reg;
       }
+      SPLIT_LAP(3);
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+      n_lit++;
+#endif
       lit_n = ins;
       insert_len = (int32_t)ins; copy_len = (int32_t)n;
       // ---- the distance behind them (ReadDistanceInternal, decode.rs:2066-2131) ----
@@ -2487,6 +2500,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
           distance_code = dist;
         }
       }
+      SPLIT_LAP(4);
       bl1--; ncmd++;
       mlen -= (int32_t)ins;
       // the literals go out with (in front of) the copy in flight: one store each
@@ -2517,6 +2531,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     // ---- the plain copy (a short LZ77 reference that does not repeat itself, clear of every limit), or a word of the static dictionary
     // that is (decode.rs:2593-2640); anything else goes to the checked stages -- whole, if nothing of it has been taken yet, else they
     // finish it from the distance on (the ring and the copy's counts are untouched) ----
+    SPLIT_LAP(5);
     const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
     const bool plain = dist > 0 && (uint32_t)dist <= max_distance && n <= 64u && (uint32_t)dist >= n && n < quota;
     bool word = false;
@@ -2557,9 +2572,16 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
       ctx_regs = false;
       P += n; quota -= n;
     }
+    SPLIT_LAP(6);
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+    if (word) n_word++; else if (!committed) n_nolit++;
+#endif
     need32();
     rec_ok = request();
   }
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 7; k++) g_split_prof[24 + k] += lap_acc[k]; g_split_prof[32] += n_run; g_split_prof[33] += n_lit; g_split_prof[34] += n_nolit; g_split_prof[35] += n_word; g_split_prof[36] += ncmd; g_split_prof[37] += 1; g_split_prof[38] += __builtin_amdgcn_s_memtime() - lap_t0; }
+#endif
   if (!ctx_regs && pend_n >= 2u) { p1 = pend_byte(pend_n - 1u); p2 = pend_byte(pend_n - 2u); ctx_regs = true; }
   flush();
   sp_st(xb, XW_POS, br.next_dw * 32u - br.cnt - origin_bits);
@@ -4155,6 +4177,13 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("split parser ticks per command: head %llu, literals %llu, distance %llu, next root + record request + checks %llu, post %llu, context fetch + tail %llu, loop top %llu\n",
            g_split_prof[16] / g_split_prof[11], g_split_prof[17] / g_split_prof[11], g_split_prof[18] / g_split_prof[11], g_split_prof[19] / g_split_prof[11],
            g_split_prof[20] / g_split_prof[11], g_split_prof[21] / g_split_prof[11], 0ull);
+#endif
+#ifdef BROTLI_AMD_PROFILE_SPLIT
+  if (blockIdx.x == 0 && lane_id() == 0 && g_split_prof[37] != 0)
+    printf("record loop: %llu calls, %llu commands (%llu in hand-written runs, %llu with literals, %llu without by the compiled path, %llu words), %llu ticks in the loop; ticks: top %llu, runs %llu, "
+           "head + context bytes %llu, literals %llu, distance %llu, counts + literal store %llu, copy / word + next record %llu\n",
+           g_split_prof[37], g_split_prof[36], g_split_prof[32], g_split_prof[33], g_split_prof[34], g_split_prof[35], g_split_prof[38],
+           g_split_prof[24], g_split_prof[25], g_split_prof[26], g_split_prof[27], g_split_prof[28], g_split_prof[29], g_split_prof[30]);
 #endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
   if (blockIdx.x == 0 && lane_id() == 0)
