@@ -2242,6 +2242,30 @@ __device__ __noinline__ void rec_wave() {
   "5:\n\t" \
   "s_lshr_b64 %[buf], %[buf], s95\n\t" \
   "s_sub_u32 %[cnt], %[cnt], s95\n\t" \
+  "s_cmp_ge_u32 %[cnt], 32\n\t"                 /* at least 32 bits in the buffer */ \
+  "s_cbranch_scc1 7f\n\t" \
+  "s_sub_u32 s96, %[ndw], %[cb]\n\t" \
+  "s_mov_b32 s97, 0\n\t" \
+  "v_readlane_b32 s96, %[cur], s96\n\t" \
+  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
+  "s_lshl_b64 s[96:97], s[96:97], %[cnt]\n\t" \
+  "s_add_u32 %[cnt], %[cnt], 32\n\t" \
+  "s_or_b64 %[buf], %[buf], s[96:97]\n" \
+  "7:\n\t"                                      /* the next command's record, if wave 2 has written it: asked for before the memory pipe is waited for */ \
+  "s_lshl_b32 s95, %[ndw], 5\n\t" \
+  "s_sub_u32 s95, s95, %[cnt]\n\t" \
+  "s_sub_u32 s95, s95, %[org]\n\t" \
+  "s_mov_b32 %[ok], 0\n\t" \
+  "s_cmp_ge_u32 s95, %[front]\n\t" \
+  "s_cbranch_scc1 8f\n\t" \
+  "s_and_b32 s95, s95, 0x3ff\n\t" \
+  "s_lshl_b32 s95, s95, 3\n\t" \
+  "s_add_u32 s95, s95, %[xring]\n\t" \
+  "v_mov_b32 %[rx], s95\n\t" \
+  "s_mov_b32 %[ok], 1\n\t" \
+  "ds_read_b32 %[ry], %[rx] offset:4\n\t" \
+  "ds_read_b32 %[rx], %[rx]\n" \
+  "8:\n\t" \
   "s_cmp_eq_u32 %[pn], 0\n\t"                   /* the copy in flight goes to memory */ \
   "s_cbranch_scc1 6f\n\t" \
   "s_add_u32 s96, %[outlo], %[pp]\n\t" \
@@ -2264,29 +2288,6 @@ __device__ __noinline__ void rec_wave() {
   "s_mov_b32 %[pp], %[P]\n\t" \
   "s_add_u32 %[P], %[P], s92\n\t" \
   "s_sub_u32 %[quota], %[quota], s92\n\t" \
-  "s_cmp_ge_u32 %[cnt], 32\n\t"                 /* at least 32 bits in the buffer */ \
-  "s_cbranch_scc1 7f\n\t" \
-  "s_sub_u32 s96, %[ndw], %[cb]\n\t" \
-  "s_mov_b32 s97, 0\n\t" \
-  "v_readlane_b32 s96, %[cur], s96\n\t" \
-  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
-  "s_lshl_b64 s[96:97], s[96:97], %[cnt]\n\t" \
-  "s_add_u32 %[cnt], %[cnt], 32\n\t" \
-  "s_or_b64 %[buf], %[buf], s[96:97]\n" \
-  "7:\n\t"                                      /* the next command's record, if wave 2 has written it */ \
-  "s_lshl_b32 s95, %[ndw], 5\n\t" \
-  "s_sub_u32 s95, s95, %[cnt]\n\t" \
-  "s_sub_u32 s95, s95, %[org]\n\t" \
-  "s_mov_b32 %[ok], 0\n\t" \
-  "s_cmp_ge_u32 s95, %[front]\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_and_b32 s95, s95, 0x3ff\n\t" \
-  "s_lshl_b32 s95, s95, 3\n\t" \
-  "s_add_u32 s95, s95, %[xring]\n\t" \
-  "v_mov_b32 %[rx], s95\n\t" \
-  "s_mov_b32 %[ok], 1\n\t" \
-  "ds_read_b32 %[ry], %[rx] offset:4\n\t" \
-  "ds_read_b32 %[rx], %[rx]\n\t" \
   "s_branch 1b\n" \
   "9:\n\t" \
   "s_waitcnt lgkmcnt(0)\n"

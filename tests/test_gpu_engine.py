@@ -324,6 +324,32 @@ def test_the_engines_and_the_one_wave_path_agree(pkg):
     assert all(r[5] >= 0.9 * r[4] for r in rows["path"][:2]) and all(r[5] >= 0.9 * r[4] for r in rows["scan"][:2]), (rows["path"], rows["scan"])
 
 
+def test_large_window_streams_fall_back_to_the_one_wave_path(pkg):
+    """The engines and the command records are for streams without the large-window extension (their distance parse allows 24
+    extra bits: decode.rs:152-187 vs 2066-2131).  A large-window stream of the metric's make-up, and one of text, must come out
+    right through the one-wave path -- and say so: engine_commands == 0."""
+    ref = _enc()
+    sys.path.insert(0, ROOT)
+    import workloads as w
+    raw = w.long_backref_stream(77, 1 << 20)
+    text = oracle.decode(open(os.path.join(ROOT, "tests", "golden", "testdata", "alice29.txt.compressed"), "rb").read(), 1 << 20, 1)[1]
+    datas, raws = [], []
+    for r in (raw, text):
+        datas.append(ref.encode_stream([r], {ref.PARAM_QUALITY: 5, ref.PARAM_LARGE_WINDOW: 1, ref.PARAM_LGWIN: 26})); raws.append(r)
+    batch = pkg.Batch(len(datas))
+    results, outs = batch.decode_host(datas, [len(r) for r in raws], 1)
+    batch.close()
+    for d, r, res, out in zip(datas, raws, results, outs):
+        info, exp = oracle.decode(d, len(r), 1)
+        assert exp == r and (res.result, res.error_code, res.decoded_size, res.num_commands) == (1, 1, len(r), info.num_commands) and out == r
+        assert res.engine_commands == 0, res.engine_commands
+    # (without the flag the same streams are refused, as the reference's plain instances refuse them: ffi/mod.rs:127)
+    batch = pkg.Batch(len(datas))
+    results, _ = batch.decode_host(datas, [len(r) for r in raws], 0)
+    batch.close()
+    assert all((res.result, res.error_code) == (0, -13) for res in results)
+
+
 _CTX_SCRIPT = r"""
 import importlib.util, json, os, sys, hashlib
 ROOT = sys.argv[1]
