@@ -4213,10 +4213,10 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("\npath engine per region: %llu path positions, %llu closure states in %llu.%llu rounds, %llu.%llu sync rounds, %llu anchors; states by hand %llu in all (%llu records met that said so); records that hit the hop cap %llu, the closure cap %llu\n",
            g_path_prof[22] / g_path_prof[20], g_path_prof[24] / g_path_prof[20], g_path_prof[23] / g_path_prof[20], (g_path_prof[23] * 10 / g_path_prof[20]) % 10,
            g_path_prof[21] / g_path_prof[20], (g_path_prof[21] * 10 / g_path_prof[20]) % 10, g_path_prof[27] / g_path_prof[20], g_path_prof[25], g_path_prof[31], g_path_prof[29], g_path_prof[30]);
+    printf("\npath engine resolve alone: %llu per region (the figure called resolve above is then the lane-per-command stores behind it)\n", g_path_prof[11] / g_path_prof[20]);
     printf("\npath engine dependent copies: %llu per region, the last wave's ticks in them %llu per region\n", g_path_prof[35] / g_path_prof[20], g_path_prof[34] / g_path_prof[20]);
     printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);
-    printf("\npath engine closure: block rounds %llu (%llu ticks each), wave-0 tails %llu (%llu ticks each), uncapped passes %llu (%llu ticks each)\n", g_path_prof[14], g_path_prof[11] / (g_path_prof[14] + 1), g_path_prof[15], g_path_prof[12] / (g_path_prof[15] + 1), g_path_prof[16], g_path_prof[13] / (g_path_prof[16] + 1));
   }
 #endif
   // no more streams: the helper waves may go

@@ -37,8 +37,15 @@
 constexpr uint32_t PE_RBL = 32768;                // stream bits per region (local bit 0 = the dword the entry lies in)
 constexpr uint32_t PE_CHUNKS = PE_RBL / 32;       // one lane per chunk of 32 bits: the whole block
 constexpr uint32_t PE_RANKS = 6656;               // path positions of a region at most (the region is cut where they run out)
-constexpr uint32_t PE_WCAP = 8192;                // closure states at most (records that would need more say BYHAND)
+#ifndef BROTLI_AMD_PE_WCAP
+#define BROTLI_AMD_PE_WCAP 8192
+#endif
+constexpr uint32_t PE_WCAP = BROTLI_AMD_PE_WCAP;  // closure states at most (records that would need more say BYHAND)
 constexpr uint32_t PE_STATES = PE_RANKS + PE_WCAP;
+#ifndef BROTLI_AMD_PE_GROW_BELOW
+#define BROTLI_AMD_PE_GROW_BELOW (PE_WCAP / 4u)
+#endif
+constexpr uint32_t PE_GROW_BELOW = BROTLI_AMD_PE_GROW_BELOW;  // closure states below which a region that had been halved takes twice the bits again
 constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluation takes; a run that needs more goes on in the lane's next evaluation
 constexpr uint32_t PE_SYNC_ROUNDS = SC_WAVES + 1;  // rounds between waves the chunk entries get to settle: enough for any code
 constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
@@ -64,7 +71,8 @@ constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes pe
 constexpr uint32_t PE_BLIST = PE_NEXT + 2 * PE_CMDS;                // u16 per command with a long copy from in front of the region or a long literal run: its index
 constexpr uint32_t PE_RS = PE_NEXT + 4 * PE_CMDS;                   // 64 bytes per batch of the resolve: its sums, the ring it ends with, its list counts
 constexpr uint32_t PE_DLIST = PE_NEXT;                            // u16 per copy that reads the region's own output: its command (the records are dead by then)
-constexpr uint32_t PE_LIST = PE_WST + PE_WCAP * 2;                // u16 per listed command (+ 1): its state as bit | kind << 15
+constexpr uint32_t PE_WSTB = PE_WCAP * 2 > PE_CMDS * 16 ? PE_WCAP * 2 : PE_CMDS * 16;  // (bytes of that room: its larger tenant)
+constexpr uint32_t PE_LIST = PE_WST + PE_WSTB;                    // u16 per listed command (+ 1): its state as bit | kind << 15
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
 constexpr uint32_t PE_TAILQ = PE_LIST;                              // u16 per state the bulk of the records left for the thin end (list and anchors are not in use then)
 constexpr uint32_t PE_TAILCAP = 1024;
@@ -78,13 +86,13 @@ constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see 
 constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
 constexpr uint32_t PE_BYTES = PE_ANCH + 128 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
-static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_CMDS * 16 <= PE_WCAP * 2 && PE_CMDS * 4 <= PE_CHUNKS * 4, "overlays");
+static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_WCAP * 2 <= PE_WSTB && PE_CMDS * 4 <= PE_CHUNKS * 4 && PE_STATES % 8 == 0, "overlays");
 static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0, "alignment");
 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */ };
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -266,6 +274,44 @@ __device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[
     // there, and a lane without a state, or whose run starts beyond them, has nothing to hop)
     uint32_t m[NS]; bool part[NS];
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = ok[t] && y[t] < c.Lp; m[t] = part[t] ? n[t] : 0u; }
+#ifndef BROTLI_AMD_PE_NO_HOP_ASM
+    if constexpr (NS <= 2u) {
+      // The same loop by hand.  A state that has stopped hopping -- no literals left, or on the path -- stays stopped, so the
+      // lanes still hopping are an execution mask that only ever narrows: v_cmpx drops the lanes, the step itself is an
+      // add and a decrement (four vector instructions a hop and state; the compiled form below takes ten).
+      const uint32_t jb = pb + PE_J1F;
+      uint32_t ya0 = y[0] + jb, ya1 = y[NS - 1u] + jb, m0 = m[0], m1 = m[NS - 1u], f0, f1;
+      uint64_t e0, e1, ea;
+#define PE_HOP1 \
+      "s_mov_b64 exec, %[e0]\n\tds_read_u8 %[f0], %[y0]\n\ts_waitcnt lgkmcnt(0)\n\tv_cmpx_gt_u32 vcc, %[c80], %[f0]\n\tv_add_u32 %[y0], %[y0], %[f0]\n\t" \
+      "v_subrev_u32 %[m0], 1, %[m0]\n\tv_cmpx_ne_u32 vcc, 0, %[m0]\n\ts_mov_b64 %[e0], exec\n\ts_cmp_eq_u64 %[e0], 0\n\ts_cbranch_scc1 .Lpe_hop_done_%=\n\t"
+#define PE_HOP2 \
+      "s_mov_b64 exec, %[e0]\n\tds_read_u8 %[f0], %[y0]\n\ts_mov_b64 exec, %[e1]\n\tds_read_u8 %[f1], %[y1]\n\ts_mov_b64 exec, %[e0]\n\ts_waitcnt lgkmcnt(1)\n\t" \
+      "v_cmpx_gt_u32 vcc, %[c80], %[f0]\n\tv_add_u32 %[y0], %[y0], %[f0]\n\tv_subrev_u32 %[m0], 1, %[m0]\n\tv_cmpx_ne_u32 vcc, 0, %[m0]\n\ts_mov_b64 %[e0], exec\n\t" \
+      "s_mov_b64 exec, %[e1]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+      "v_cmpx_gt_u32 vcc, %[c80], %[f1]\n\tv_add_u32 %[y1], %[y1], %[f1]\n\tv_subrev_u32 %[m1], 1, %[m1]\n\tv_cmpx_ne_u32 vcc, 0, %[m1]\n\ts_mov_b64 %[e1], exec\n\t" \
+      "s_or_b64 %[ea], %[e0], %[e1]\n\ts_cbranch_scc0 .Lpe_hop_done_%=\n\t"
+      if constexpr (NS == 1u) {
+        asm volatile("s_mov_b64 %[ea], exec\n\tv_cmp_ne_u32 %[e0], 0, %[m0]\n\ts_cmp_eq_u64 %[e0], 0\n\ts_cbranch_scc1 .Lpe_hop_done_%=\n\t"
+                     PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1
+                     ".Lpe_hop_done_%=:\n\ts_mov_b64 exec, %[ea]"
+                     : [y0] "+v"(ya0), [m0] "+v"(m0), [f0] "=&v"(f0), [e0] "=&s"(e0), [ea] "=&s"(ea)
+                     : [c80] "v"(0x80u) : "vcc", "scc", "memory");
+        (void)ya1; (void)m1; (void)f1; (void)e1;
+        y[0] = ya0 - jb; m[0] = m0;
+      } else {
+        uint64_t sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\tv_cmp_ne_u32 %[e0], 0, %[m0]\n\tv_cmp_ne_u32 %[e1], 0, %[m1]\n\ts_or_b64 %[ea], %[e0], %[e1]\n\ts_cbranch_scc0 .Lpe_hop_done_%=\n\t"
+                     PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2
+                     ".Lpe_hop_done_%=:\n\ts_mov_b64 exec, %[sv]"
+                     : [y0] "+v"(ya0), [m0] "+v"(m0), [f0] "=&v"(f0), [y1] "+v"(ya1), [m1] "+v"(m1), [f1] "=&v"(f1), [e0] "=&s"(e0), [e1] "=&s"(e1), [ea] "=&s"(ea), [sv] "=&s"(sv)
+                     : [c80] "v"(0x80u) : "vcc", "scc", "memory");
+        y[0] = ya0 - jb; m[0] = m0; y[NS - 1u] = ya1 - jb; m[NS - 1u] = m1;
+      }
+#undef PE_HOP1
+#undef PE_HOP2
+    } else
+#endif
     for (uint32_t h = 0; h < PE_HOPCAP; h++) {
       uint32_t f[NS]; bool any = false;
       _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) f[t] = lds_ld8(pb + PE_J1F + (m[t] != 0u ? y[t] : 0u));
@@ -400,7 +446,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t avail = in_limit - (lbdw << 5);
       const bool go = st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
       pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, st.b & 31u); pe_ctl_st(pb, PEC_L, avail < st.rbl ? avail : st.rbl);
-      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
+      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS); pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
       pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
       pe_ctl_st(pb, PEC_P0_LO, (uint32_t)st.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(st.P >> 32));
       pe_ctl_st(pb, PEC_MODE, st.run_on); pe_ctl_st(pb, PEC_ENT, st.b & 31u);
@@ -466,16 +512,19 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const u32x4 bq = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_J1F + cbase + 16u]);
       jw[0] = a.x; jw[1] = a.y; jw[2] = a.z; jw[3] = a.w; jw[4] = bq.x; jw[5] = bq.y; jw[6] = bq.z; jw[7] = bq.w;
     }
-    uint32_t xt[4] = {0u, 0u, 0u, 0u};
-    _Pragma("unroll") for (int y = 31; y >= 0; y--) {
-      const uint32_t len = (jw[y >> 2] >> ((y & 3) * 8)) & 15u;
-      const uint32_t t = (uint32_t)y + len;
-      // (t < 32: the exit is the one of bit t, which is already there)
-      const uint32_t tc = t & 31u;
-      const uint32_t dsel = tc < 8u ? xt[0] : tc < 16u ? xt[1] : tc < 24u ? xt[2] : xt[3];
-      const uint32_t ex_t = (dsel >> ((tc & 7u) * 4u)) & 15u;
-      const uint32_t exy = t >= 32u ? t - 32u : ex_t;
-      xt[y >> 3] |= exy << ((y & 7) * 4);
+    // (a window of sixteen nibbles slides down the chunk: nibble j = the exit of bit y + 1 + j, for the bits of the next
+    // chunk what they are -- j bits into it; a code word is at most fifteen bits long, so the exit of bit y is one nibble of
+    // the window, and the window behind bit y is the table's half)
+    uint32_t xt[4];
+    {
+      uint64_t win = 0xFEDCBA9876543210ull;
+      _Pragma("unroll") for (int y = 31; y >= 0; y--) {
+        const uint32_t len = (jw[y >> 2] >> ((y & 3) * 8)) & 15u;
+        const uint32_t exy = (uint32_t)(win >> (((len - 1u) & 15u) << 2)) & 15u;
+        win = (win << 4) | exy;
+        if (y == 16) { xt[2] = (uint32_t)win; xt[3] = (uint32_t)(win >> 32); }
+      }
+      xt[0] = (uint32_t)win; xt[1] = (uint32_t)(win >> 32);
     }
     auto exit_of = [&](uint32_t e) -> uint32_t {
       const uint32_t dsel = e < 8u ? xt[0] : e < 16u ? xt[1] : e < 24u ? xt[2] : xt[3];
@@ -727,7 +776,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     __syncthreads();
     PE_COUNT(24, pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP);
     const uint32_t wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
-    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pb, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_WCAP / 4u && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pb, PEC_STATE + 8, rbl); }
+    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pb, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_GROW_BELOW && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pb, PEC_STATE + 8, rbl); }
     PE_PROF(4);
     // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
     for (uint32_t i0 = T; i0 < PE_RANKS + wn; i0 += 4u * 64u * SC_WAVES) {
@@ -746,20 +795,27 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     }
     __syncthreads();
     PE_PROF(5);
-    // ---- the walk (wave 0): the stream's states in order, LIST[k] = bit | kind << 15 of the state command k starts from ----
+    // ---- the walk (wave 0) and, behind it, the details (the other waves): the stream's states in order, LIST[k] = bit | kind << 15
+    // of the state command k starts from.  Wave 0 follows the stream eight commands a hop (NEXT8 knows the way wherever the next
+    // eight records are ordinary ones: everywhere but at the region's end) and publishes every anchor as it finds it; then
+    // command by command up to the first record that is no way on (END: the run leaves the region; BYHAND: the closure ran
+    // out of room -- the next region starts there).  Wave w + 1 takes batch w -- commands 64 w .. 64 w + 63 -- as soon as the nine
+    // anchors that span it are there (or the walk is over): lane = command, the state it starts from by following the anchor's
+    // records, then its fields parsed once more, its distance from the state after.  The fields stay in the lane's registers:
+    // the resolve below is by the same wave.
+    const uint32_t bw = (me + SC_WAVES - 1u) & (SC_WAVES - 1u);  // this wave's batch (wave 0, which walks, gets the last one)
+    uint32_t dr0 = 0, dr1 = 0, dr2 = 0, dr3 = 0;
     if (me == 0) {
-      // first the hops of eight commands (NEXT8 knows the way wherever the next eight records are ordinary ones: everywhere but
-      // at the region's end), the anchors in two registers; then command by command up to the first record that is no way on
-      // (END: the run leaves the region; BYHAND: the closure ran out of room -- the next region starts there)
-      uint32_t id = PE_RANKS, na = 0, av0 = 0, av1 = 0;
+      uint32_t id = PE_RANKS, na = 0;
       for (;;) {
         const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
         if (n8 >= PEN_FIRST_SPECIAL || na >= 120u) break;
-        if (na < 64u) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(av0) : "s"(id), "s"(na) : "m0");
-        else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(av1) : "s"(id), "s"(na - 64u) : "m0");
+        if (lane == 0) {
+          *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + (na << 2)]) = id;
+          *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NAPUB]) = na + 1u;
+        }
         na++; id = n8;
       }
-      lds_st32(pb + PE_ANCH + (lane << 2), av0); lds_st32(pb + PE_ANCH + ((64u + lane) << 2), av1);
       uint32_t m = 8u * na, desc;
       for (;;) {
         if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
@@ -773,45 +829,56 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // the last command needs its distance: 64 bits at the closing state
       if (m != 0u && (desc >> 15) == 0u && (desc & 0x7FFFu) + 64u > c.L) m--;
       pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
+      lds_sync();
+      pe_ctl_st(pb, PEC_WDONE, 1u);
       PE_COUNT(26, m); PE_COUNT(27, na);
     }
-    __syncthreads();
     PE_PROF(6);
+    {
+      const uint32_t k0 = bw << 6;
+      uint32_t na_k, m_k;
+      for (;;) {
+        const uint32_t done = pe_ctl_ld(pb, PEC_WDONE), pub = pe_ctl_ld(pb, PEC_NAPUB);
+        if (done != 0u) { lds_sync(); na_k = pe_ctl_ld(pb, PEC_NA); m_k = pe_ctl_ld(pb, PEC_M); break; }
+        if (pub >= (k0 >> 3) + 9u) { na_k = pub; m_k = PE_CMDS + 64u; break; }  // (nine anchors on: the batch is whole whatever comes behind)
+        __builtin_amdgcn_s_sleep(6);
+      }
+      lds_sync();
+      if (k0 <= m_k) {
+        // the state command kk starts from: behind an anchor by the records, else what the walk listed
+        auto state_of = [&](const uint32_t kk) -> uint32_t {
+          if (kk >= 8u * na_k) return lds_ld16(pb + PE_LIST + ((kk < PE_CMDS + 8u ? kk : 0u) << 1));
+          uint32_t st = *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + ((kk >> 3) << 2)]);
+          for (uint32_t h = 0; h < (kk & 7u); h++) st = lds_ld16(pb + PE_NEXT + (st << 1));
+          return st < PE_RANKS ? lds_ld16(pb + PE_POR + (st << 1)) : lds_ld16(pb + PE_WST + ((st - PE_RANKS) << 1));
+        };
+        const uint32_t k = k0 + lane;
+        const bool on = k < m_k;
+        const uint32_t s0 = state_of(k <= m_k ? k : 0u);
+        const uint32_t s_last = state_of(k0 + 64u <= m_k ? k0 + 64u : 0u);
+        uint32_t s1 = bperm(((lane + 1u) & 63u) << 2, s0);
+        s1 = lane == 63u ? s_last : s1;
+        if (k <= m_k && k < 8u * na_k) lds_st16(pb + PE_LIST + (k << 1), s0);  // (the resolve reads where the stream goes on out of the list)
+        if (k0 < m_k) {
+          const PeParse pr = pe_eval<false, false>(c, s0 & 0x7FFFu, s0 >> 15, on);
+          uint32_t kind = SCK_IMPLICIT, val = 0;
+          if (__ballot(on && (s1 >> 15) == 0u) != 0ull) {
+            uint32_t lo, hi;
+            pe_bits64(pb, on ? (s1 & 0x7FFFu) : 0u, lo, hi);
+            const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
+            if ((s1 >> 15) == 0u) { kind = d.kind; val = d.val; }
+          }
+          // a command the fields do not hold goes to the checked loop (bit 30 of w0: the resolve stops in front of it)
+          const bool odd = pr.u > 255u || pr.insert >= 0x10000u || val >= (1u << 30) || pr.code >= 2u;
+          if (on) {
+            dr0 = pr.x | ((pr.u & 255u) << 15) | (odd ? 1u << 30 : 0u); dr1 = (pr.insert & 0xFFFFu) | (pr.ry << 16);
+            dr2 = pr.copy; dr3 = (kind << 30) | (val & 0x3FFFFFFFu);
+          }
+        }
+      }
+    }
+    __syncthreads();
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
-    {  // the commands behind an anchor: thread 8 a + j follows anchor a's state j records on
-      const uint32_t na = pe_ctl_ld(pb, PEC_NA);
-      if (T < na * 8u) {
-        const uint32_t j = T & 7u;
-        uint32_t st = lds_ld32(pb + PE_ANCH + ((T >> 3) << 2));
-        for (uint32_t h = 0; h < j; h++) st = lds_ld16(pb + PE_NEXT + (st << 1));
-        const uint32_t dsc = st < PE_RANKS ? lds_ld16(pb + PE_POR + (st << 1)) : lds_ld16(pb + PE_WST + ((st - PE_RANKS) << 1));
-        lds_st16(pb + PE_LIST + (T << 1), dsc);
-      }
-    }
-    __syncthreads();
-    // ---- details: lane = command; its fields from the state it starts from, its distance from the state after ----
-    // (the records overlay the closure's states, which nothing reads any more: the walk's list holds bit and kind)
-    for (uint32_t k0 = 64u * me; k0 < m; k0 += 64u * SC_WAVES) {
-      const uint32_t k = k0 + lane;
-      const bool on = k < m;
-      const uint32_t s0 = on ? lds_ld16(pb + PE_LIST + (k << 1)) : 0u, s1 = on ? lds_ld16(pb + PE_LIST + ((k + 1u) << 1)) : 0u;
-      const PeParse pr = pe_eval<false, false>(c, s0 & 0x7FFFu, s0 >> 15, on);
-      uint32_t kind = SCK_IMPLICIT, val = 0;
-      if (__ballot(on && (s1 >> 15) == 0u) != 0ull) {
-        uint32_t lo, hi;
-        pe_bits64(pb, on ? (s1 & 0x7FFFu) : 0u, lo, hi);
-        const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
-        if ((s1 >> 15) == 0u) { kind = d.kind; val = d.val; }
-      }
-      // a command the fields do not hold goes to the checked loop (bit 30 of w0: the resolve stops in front of it)
-      const bool odd = pr.u > 255u || pr.insert >= 0x10000u || val >= (1u << 30) || pr.code >= 2u;
-      if (on) {
-        const uint32_t ra = pb + PE_REC + (k << 4);
-        lds_st32(ra, pr.x | ((pr.u & 255u) << 15) | (odd ? 1u << 30 : 0u)); lds_st32(ra + 4u, (pr.insert & 0xFFFFu) | (pr.ry << 16));
-        lds_st32(ra + 8u, pr.copy); lds_st32(ra + 12u, (kind << 30) | (val & 0x3FFFFFFFu));
-      }
-    }
-    __syncthreads();
     PE_PROF(7);
     // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
     // of it -- the sums (literals, commands, distances, output bytes) and the distance ring (decode.rs:2017-2049) -- goes
@@ -823,12 +890,12 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     uint32_t my_exec = 0;  // commands of this wave's batch that are executed
     {
       const PeStream st = pe_st_load(pb);
-      const bool mine = me < nb;
-      const uint32_t k0 = me << 6;
+      const bool mine = bw < nb;
+      const uint32_t k0 = bw << 6;
       const uint32_t K = mine ? (m - k0 < 64u ? m - k0 : 64u) : 0u;
       const bool active = lane < K;
       const uint32_t ra = pb + PE_REC + ((mine ? k0 + (active ? lane : 0u) : 0u) << 4);
-      const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), r2 = lds_ld32(ra + 8u), r3 = lds_ld32(ra + 12u);
+      const uint32_t r0 = dr0, r1 = dr1, r2 = dr2, r3 = dr3;  // (the details above: this wave's batch, in its registers)
       const uint32_t ins = active ? r1 & 0xFFFFu : 0u, copy = active ? r2 : 0u;
       const uint32_t kind = active ? r3 >> 30 : (uint32_t)SCK_NONE, val = r3 & 0x3FFFFFFFu;
       const bool odd = ((r0 >> 30) & 1u) != 0u;
@@ -867,7 +934,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
       }
       // the batch's sums and the ring it ends with (all its pushes: a batch that stops short is the last one that counts)
-      const uint32_t rs = pb + PE_RS + (me << 6);
+      const uint32_t rs = pb + PE_RS + (bw << 6);
       if (mine) {
         const uint32_t tperm = bperm(perm << 2, dtag), vperm = bperm(perm << 2, (uint32_t)dval);  // lane r: the r-th push
         if (lane == 0) {
@@ -884,7 +951,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
       int32_t d0 = st.d0, d1 = st.d1, d2 = st.d2, d3 = st.d3;
-      for (uint32_t j = 0; j < me && mine; j++) {
+      for (uint32_t j = 0; j < bw && mine; j++) {
         const uint32_t rj = pb + PE_RS + (j << 6);
         const uint32_t w = lds_ld32(rj + (lane < 12u ? lane << 2 : 0u));   // (one read: lane k word k)
         c_lit += rdlane(w, 0); const uint32_t t1 = rdlane(w, 1); c_cmd += t1 & 0xFFFFu; c_dst += t1 >> 16; c_out += rdlane(w, 2);
@@ -921,7 +988,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         // (every batch in front of one that executes anything went through whole: its counts are its lists' lengths)
         uint32_t c_dep = 0, c_big = 0;
         {
-          const uint32_t w = lane < me ? lds_ld32(pb + PE_RS + (lane << 6) + 48u) : 0u;
+          const uint32_t w = lane < bw ? lds_ld32(pb + PE_RS + (lane << 6) + 48u) : 0u;
           const uint32_t sum = sc_scan(w);  // (two 16-bit sums side by side: at most 1024 each)
           const uint32_t tot = rdlane(sum, 63);
           c_dep = tot & 0xFFFFu; c_big = tot >> 16;
@@ -930,7 +997,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         if (lane < my_exec) {
           if (dep != 0u) lds_st16(pb + PE_DLIST + ((c_dep + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm2, 0u))) << 1), k0 + lane);
           if (bigc) lds_st16(pb + PE_BLIST + ((c_big + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm2, 0u))) << 1), k0 + lane);
-          lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 12u, (uint32_t)dist);
+          lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 4u, r1); lds_st32(ra + 8u, r2); lds_st32(ra + 12u, (uint32_t)dist);
           lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
         }
         // the batch the engine's part ends in leaves the stream's state: sums up to there, the ring behind its executed pushes
@@ -978,20 +1045,46 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         pe_st_store(pb, sn);
       }
     }
+    PE_PROF(11);
     // ---- execute ----
     {
       gu8* const o = out + P0;
       // (a) lane = command: the literals in front of the path, decoded again one after the other; the literals on the path out
-      // of lit[], four bytes a step; the command's copy where it is short and its source lies in front of the region's
-      // output (one 16-byte load, stores in pieces)
-      // (every wave the batch it resolved)
+      // of lit[], four bytes a step; the command's
+      // copy where it is short and its source lies in front of the region's output (one 16-byte load, stores in pieces).
+      // Every wave the batch it resolved -- and, where the region has at most eight batches, the path's literals of batch b by
+      // wave b + 9 (whose own batch does not exist) at the same time: the records and offsets are in LDS behind the barrier above.
+      const uint32_t kp_all = pe_ctl_ld(pb, PEC_KP);
+#ifdef BROTLI_AMD_PE_NO_EXEC_SPLIT
+      const bool exec_split = false;
+#else
+      const bool exec_split = nb <= 8u;
+#endif
+      auto path_literals = [&](const uint32_t b, const uint32_t cnt) {
+        const uint32_t k = (b << 6) + lane;
+        const bool on = lane < cnt;
+        const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
+        const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u);
+        const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
+        const uint32_t ins = on ? r1 & 0xFFFFu : 0u, ry = r1 >> 16;
+        uint32_t u = (r0 >> 15) & 255u;
+        u = u < ins ? u : ins;
+        gu8* dst = o + off + u;
+        uint32_t n = ins - u; n = n <= PE_LANE_LITS ? n : 0u;   // (longer runs: a wave of their own, below)
+        uint32_t la = pb + PE_LIT + ry;
+        while (__ballot(n != 0u) != 0ull) {
+          const uint32_t b0 = lds_ld8(la), b1 = lds_ld8(la + 1u), b2 = lds_ld8(la + 2u), b3 = lds_ld8(la + 3u);
+          if (n >= 4u) { *reinterpret_cast<gu32*>(dst) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); dst += 4; la += 4u; n -= 4u; }
+          else if (n != 0u) { dst[0] = (uint8_t)b0; if (n > 1u) dst[1] = (uint8_t)b1; if (n > 2u) dst[2] = (uint8_t)b2; n = 0u; }
+        }
+      };
       if (my_exec != 0u) {
-        const uint32_t k = (me << 6) + lane;
+        const uint32_t k = (bw << 6) + lane;
         const bool on = lane < my_exec;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
         const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
         const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
-        const uint32_t ins = on ? r1 & 0xFFFFu : 0u, ry = r1 >> 16;
+        const uint32_t ins = on ? r1 & 0xFFFFu : 0u;
         uint32_t u = (r0 >> 15) & 255u;
         u = u < ins ? u : ins;
         // (the region's quota check leaves SC_MIN_QUOTA bytes of room behind P0: sixteen bytes from a source in front of it are inside the buffer)
@@ -1001,17 +1094,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         if (shortcopy) cv = *reinterpret_cast<gu32x4*>(cdst - dist);
         uint32_t y = r0 & 0x7FFFu;
         gu8* dst = o + off;
-        uint32_t n = ins - u; n = n <= PE_LANE_LITS ? n : 0u;   // (longer runs: a wave of their own, below)
         while (__ballot(u != 0u) != 0ull) {
           uint32_t sy, ln;
           sc_lookup(c.lit_tree, pe_bits32(pb, u != 0u ? y : 0u), sy, ln);
           if (u != 0u) { *dst = (uint8_t)sy; dst++; y += ln; u--; }
-        }
-        uint32_t la = pb + PE_LIT + ry;
-        while (__ballot(n != 0u) != 0ull) {
-          const uint32_t b0 = lds_ld8(la), b1 = lds_ld8(la + 1u), b2 = lds_ld8(la + 2u), b3 = lds_ld8(la + 3u);
-          if (n >= 4u) { *reinterpret_cast<gu32*>(dst) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); dst += 4; la += 4u; n -= 4u; }
-          else if (n != 0u) { dst[0] = (uint8_t)b0; if (n > 1u) dst[1] = (uint8_t)b1; if (n > 2u) dst[2] = (uint8_t)b2; n = 0u; }
         }
         if (shortcopy) {
           uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
@@ -1025,6 +1111,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             }
           }
         }
+        if (!exec_split || bw >= 7u) path_literals(bw, my_exec);
+      } else if (exec_split && bw >= 8u && bw < 15u) {
+        const uint32_t b = bw - 8u;
+        const uint32_t cnt = kp_all <= (b << 6) ? 0u : (kp_all - (b << 6) < 64u ? kp_all - (b << 6) : 64u);
+        if (cnt != 0u) path_literals(b, cnt);
       }
       __syncthreads();
       PE_PROF(8);
