@@ -4214,6 +4214,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
            g_path_prof[22] / g_path_prof[20], g_path_prof[24] / g_path_prof[20], g_path_prof[23] / g_path_prof[20], (g_path_prof[23] * 10 / g_path_prof[20]) % 10,
            g_path_prof[21] / g_path_prof[20], (g_path_prof[21] * 10 / g_path_prof[20]) % 10, g_path_prof[27] / g_path_prof[20], g_path_prof[25], g_path_prof[31], g_path_prof[29], g_path_prof[30]);
     printf("\npath engine resolve alone: %llu per region (the figure called resolve above is then the lane-per-command stores behind it)\n", g_path_prof[11] / g_path_prof[20]);
+    printf("\npath engine per region: %llu items that get a wave (long copies from in front of the region, long literal runs), %llu copies that read the region's own output\n", g_path_prof[12] / g_path_prof[20], g_path_prof[13] / g_path_prof[20]);
     printf("\npath engine dependent copies: %llu per region, the last wave's ticks in them %llu per region\n", g_path_prof[35] / g_path_prof[20], g_path_prof[34] / g_path_prof[20]);
     printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);

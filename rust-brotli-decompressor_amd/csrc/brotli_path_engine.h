@@ -50,6 +50,11 @@ constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluat
 constexpr uint32_t PE_SYNC_ROUNDS = SC_WAVES + 1;  // rounds between waves the chunk entries get to settle: enough for any code
 constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
 constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this long are stored by their command's lane, four bytes a step
+#ifndef BROTLI_AMD_PE_LANE_COPY
+#define BROTLI_AMD_PE_LANE_COPY 16
+#endif
+constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this long from in front of the region are done by their command's lane (16-byte loads, 16 .. 64)
+static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
 constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own: the path's literals are the run's
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
 static_assert(PE_CHUNKS == 64u * SC_WAVES, "one chunk per lane of the block");
@@ -59,6 +64,12 @@ constexpr uint32_t PE_CTL = 0;                                    // 1024: contr
 constexpr uint32_t PE_IN = 1024;                                   // the region's input: PE_RBL / 32 + 6 dwords
 constexpr uint32_t PE_J1F = PE_IN + (PE_RBL / 32 + 8) * 4;        // code length at every bit, bit 7: on the path; later NEXT8
 constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per state: the state eight commands on
+constexpr uint32_t PE_STG = PE_J1F;                               // the region's output while it is put together (execute), where it fits: see PE_STG_CAP
+#ifndef BROTLI_AMD_PE_STG_CAP
+#define BROTLI_AMD_PE_STG_CAP 32768
+#endif
+constexpr uint32_t PE_STG_CAP = BROTLI_AMD_PE_STG_CAP;            // output bytes of a region that is put together in LDS and written out in one piece (0: never)
+static_assert(PE_STG_CAP <= PE_RBL, "the stage lives in J1's room");
 constexpr uint32_t PE_PM = PE_J1F + PE_RBL + 64;                  // u32 per chunk: which of its bits are on the path; later OFF
 constexpr uint32_t PE_OFF = PE_PM;                                // u32 per listed command: where its output starts (from the region's)
 constexpr uint32_t PE_CB = PE_PM + PE_CHUNKS * 4;                 // u16 per chunk: path positions in front of it
@@ -92,7 +103,8 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */ };
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
+       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -978,7 +990,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // a copy whose source reaches into the region's own output is done afterwards (bit 31 of w0); long items get a wave
       const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
       uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
-      const bool bigc = (copy > 16u && dep == 0u) || ins - uu > PE_LANE_LITS;
+      const bool bigc = (copy > PE_LANE_COPY && dep == 0u) || ins - uu > PE_LANE_LITS;
       const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc);
       if (mine && lane == 0) lds_st32(rs + 48u, (uint32_t)__popcll(dmk) | ((uint32_t)__popcll(bmk) << 16));
       __syncthreads();
@@ -1020,9 +1032,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           sn.d0 = e0; sn.d1 = e1; sn.d2 = e2; sn.d3 = e3;
           pe_st_store(pb, sn);
           pe_ctl_st(pb, PEC_ANYDEP, c_dep + (uint32_t)__popcll(dm2)); pe_ctl_st(pb, PEC_NBIG, c_big + (uint32_t)__popcll(bm2));
+          pe_ctl_st(pb, PEC_OUTTOT, out_tot); pe_ctl_st(pb, PEC_STAGED, (PE_STG_CAP != 0u && out_tot <= PE_STG_CAP) ? 1u : 0u);
         }
       }
-      if (kp_total == 0u && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); }  // (nothing executed: the state stays)
+      if (kp_total == 0u && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); }  // (nothing executed: the state stays)
       __syncthreads();
       if (me == 0) {
         // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
@@ -1054,6 +1067,24 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // copy where it is short and its source lies in front of the region's output (one 16-byte load, stores in pieces).
       // Every wave the batch it resolved -- and, where the region has at most eight batches, the path's literals of batch b by
       // wave b + 9 (whose own batch does not exist) at the same time: the records and offsets are in LDS behind the barrier above.
+      // Where the region's whole output fits J1's room (nobody reads J1 or NEXT8 any more), it is put together THERE and written
+      // out in one piece at the end: the stores of (a) are a few bytes each at addresses all over the place, and the copies
+      // of (c) wait for each other -- through LDS both cost a fraction of what they cost through memory.
+      const bool staged = pe_ctl_ld(pb, PEC_STAGED) != 0u;
+      const uint32_t sg = pb + PE_STG;
+      // (a wave's LZ77 copy into the stage, decode.rs:2641-2720: byte q comes from byte q mod distance of the `distance` bytes
+      // in front of the destination, which lie in the stage or, in front of the region, in memory)
+      auto stage_copy = [&](const uint32_t dpos, const uint32_t n, const uint32_t dist) {
+        uint32_t mm = dist >= 64u ? lane : lane % dist; const uint32_t step = dist > 64u ? 64u : 64u % dist;
+        for (uint32_t q = 0; q < n; q += 64u) {
+          if (q + lane < n) {
+            const int32_t sp = (int32_t)dpos - (int32_t)dist + (int32_t)(dist >= n ? q + lane : mm);
+            const uint32_t t = sp < 0 ? (uint32_t)*(o + (int64_t)sp) : lds_ld8(sg + (uint32_t)sp);
+            lds_st8(sg + dpos + q + lane, t);
+          }
+          mm += step; if (mm >= dist) mm -= dist;
+        }
+      };
       const uint32_t kp_all = pe_ctl_ld(pb, PEC_KP);
 #ifdef BROTLI_AMD_PE_NO_EXEC_SPLIT
       const bool exec_split = false;
@@ -1072,6 +1103,16 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         gu8* dst = o + off + u;
         uint32_t n = ins - u; n = n <= PE_LANE_LITS ? n : 0u;   // (longer runs: a wave of their own, below)
         uint32_t la = pb + PE_LIT + ry;
+        if (staged) {
+          uint32_t dx = sg + off + u;
+          while (__ballot(n != 0u) != 0ull) {
+            const uint32_t b0 = lds_ld8(la), b1 = lds_ld8(la + 1u), b2 = lds_ld8(la + 2u), b3 = lds_ld8(la + 3u);
+            if (n != 0u) { lds_st8(dx, b0); if (n > 1u) lds_st8(dx + 1u, b1); if (n > 2u) lds_st8(dx + 2u, b2); if (n > 3u) lds_st8(dx + 3u, b3); }
+            const uint32_t adv = n < 4u ? n : 4u;
+            dx += adv; la += adv; n -= adv;
+          }
+          return;
+        }
         while (__ballot(n != 0u) != 0ull) {
           const uint32_t b0 = lds_ld8(la), b1 = lds_ld8(la + 1u), b2 = lds_ld8(la + 2u), b3 = lds_ld8(la + 3u);
           if (n >= 4u) { *reinterpret_cast<gu32*>(dst) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24); dst += 4; la += 4u; n -= 4u; }
@@ -1088,26 +1129,40 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         uint32_t u = (r0 >> 15) & 255u;
         u = u < ins ? u : ins;
         // (the region's quota check leaves SC_MIN_QUOTA bytes of room behind P0: sixteen bytes from a source in front of it are inside the buffer)
-        const bool shortcopy = on && (r0 >> 31) == 0u && cn != 0u && cn <= 16u;
+        const bool shortcopy = on && (r0 >> 31) == 0u && cn != 0u && cn <= PE_LANE_COPY;
         gu8* const cdst = o + off + ins;
-        u32x4 cv = {0u, 0u, 0u, 0u};
-        if (shortcopy) cv = *reinterpret_cast<gu32x4*>(cdst - dist);
+        u32x4 cv[PE_LANE_COPY / 16u];
+        _Pragma("unroll") for (uint32_t g = 0; g < PE_LANE_COPY / 16u; g++) {
+          cv[g] = u32x4{0u, 0u, 0u, 0u};
+          if (shortcopy && cn > 16u * g) cv[g] = *reinterpret_cast<gu32x4*>(cdst - dist + 16u * g);
+        }
         uint32_t y = r0 & 0x7FFFu;
         gu8* dst = o + off;
+        uint32_t dx = sg + off;
         while (__ballot(u != 0u) != 0ull) {
           uint32_t sy, ln;
           sc_lookup(c.lit_tree, pe_bits32(pb, u != 0u ? y : 0u), sy, ln);
-          if (u != 0u) { *dst = (uint8_t)sy; dst++; y += ln; u--; }
+          if (u != 0u) { if (staged) lds_st8(dx, sy); else *dst = (uint8_t)sy; dst++; dx++; y += ln; u--; }
         }
-        if (shortcopy) {
-          uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
-          _Pragma("unroll") for (uint32_t q = 0; q < 4u; q++) {
-            if (cn >= 4u * q + 4u) *reinterpret_cast<gu32*>(cdst + 4u * q) = w[q];
-            else if (cn > 4u * q) {
-              const uint32_t rest = cn - 4u * q;
-              cdst[4u * q] = (uint8_t)w[q];
-              if (rest > 1u) cdst[4u * q + 1u] = (uint8_t)(w[q] >> 8);
-              if (rest > 2u) cdst[4u * q + 2u] = (uint8_t)(w[q] >> 16);
+        if (staged) {
+          // the short copy's bytes into the stage, one at a time out of the sixteen loaded
+          uint32_t w0 = cv[0].x, w1 = cv[0].y, w2 = cv[0].z, w3 = cv[0].w, left = shortcopy ? cn : 0u, cx = sg + off + ins;
+          while (__ballot(left != 0u) != 0ull) {
+            if (left != 0u) { lds_st8(cx, w0 & 0xFFu); cx++; left--; }
+            w0 = __builtin_amdgcn_alignbit(w1, w0, 8); w1 = __builtin_amdgcn_alignbit(w2, w1, 8); w2 = __builtin_amdgcn_alignbit(w3, w2, 8); w3 >>= 8;
+          }
+        } else if (shortcopy) {
+          _Pragma("unroll") for (uint32_t g = 0; g < PE_LANE_COPY / 16u; g++) {
+            const uint32_t w[4] = {cv[g].x, cv[g].y, cv[g].z, cv[g].w};
+            _Pragma("unroll") for (uint32_t q4 = 0; q4 < 4u; q4++) {
+              const uint32_t q = 4u * g + q4;
+              if (cn >= 4u * q + 4u) *reinterpret_cast<gu32*>(cdst + 4u * q) = w[q4];
+              else if (cn > 4u * q) {
+                const uint32_t rest = cn - 4u * q;
+                cdst[4u * q] = (uint8_t)w[q4];
+                if (rest > 1u) cdst[4u * q + 1u] = (uint8_t)(w[q4] >> 8);
+                if (rest > 2u) cdst[4u * q + 2u] = (uint8_t)(w[q4] >> 16);
+              }
             }
           }
         }
@@ -1130,6 +1185,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // of the region's output
       {
         const uint32_t nbig = pe_ctl_ld(pb, PEC_NBIG);
+        PE_COUNT(12, nbig);
         for (uint32_t j = me; j < nbig; j += SC_WAVES) {
           const uint32_t k = rfl(lds_ld16(pb + PE_BLIST + (j << 1)));
           const uint32_t ra = pb + PE_REC + (k << 4);
@@ -1141,9 +1197,13 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           if (n > PE_LANE_LITS) {
             gu8* const lp = o + off + u;
             const uint32_t la = pb + PE_LIT + ry;
-            for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
+            if (staged) { for (uint32_t i = lane; i < n; i += 64u) lds_st8(sg + off + u + i, lds_ld8(la + i)); }
+            else for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
           }
-          if (cn > 16u && (r0 >> 31) == 0u) {
+          if (cn > PE_LANE_COPY && (r0 >> 31) == 0u && staged) {
+            gu8* const src = o + off + ins - dist;   // (all of it in front of the region)
+            for (uint32_t q = lane; q < cn; q += 64u) lds_st8(sg + off + ins + q, src[q]);
+          } else if (cn > PE_LANE_COPY && (r0 >> 31) == 0u) {
             gu8* const dst = o + off + ins; gu8* const src = dst - dist;
             if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
             else {
@@ -1156,9 +1216,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
       }
       PE_PROF(9);
-      // (c) copies that read the region's own output: one after the other (a wave's stores are visible to its later loads)
+      // (c) copies that read the region's own output.
       const uint32_t ndep = pe_ctl_ld(pb, PEC_ANYDEP);
-      if (ndep != 0u) {
+      PE_COUNT(13, ndep);
+      // The general way: one after the other where they build on each other (a wave's stores are visible to its later loads).
+      auto dependent_copies_in_order = [&]() {
         // Which of them only read what (a) and (b) wrote -- literals and copies from in front of the region?  Those whose
         // source does not touch the destination of an earlier dependent copy (destinations lie in command order: a binary
         // search), and that do not overlap themselves.  They go side by side, one wave each (bit 29 of w0); the rest in order.
@@ -1195,6 +1257,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           const uint32_t r0 = rfl(lds_ld32(ra));
           if (((r0 >> 29) & 1u) == 0u) continue;
           const uint32_t cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
+          if (staged) { stage_copy(rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (rfl(lds_ld32(ra + 4u)) & 0xFFFFu), cn, dist); continue; }
           gu8* const dst = o + rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (rfl(lds_ld32(ra + 4u)) & 0xFFFFu); gu8* const src = dst - dist;
           if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
           else {
@@ -1222,6 +1285,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
               dep_n++;
 #endif
               const uint32_t n = rdlane(xn, kk), dist = rdlane(xd, kk), dpos = rdlane(xo, kk) + (rdlane(x1, kk) & 0xFFFFu);
+              if (staged) { stage_copy(dpos, n, dist); continue; }
               gu8* const dst = o + dpos; gu8* const src = dst - dist;
               if (dist < n) {
                 // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
@@ -1243,6 +1307,21 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (blockIdx.x == 0 && lane == 0) { atomicAdd(&g_path_prof[34], (unsigned long long)(__builtin_amdgcn_s_memtime() - dep_t0)); atomicAdd(&g_path_prof[35], (unsigned long long)dep_n); }
 #endif
+        }
+      
+      };
+      if (ndep != 0u) dependent_copies_in_order();
+      if (staged) {
+        // the region's output, out of the stage in one piece: sixteen bytes a thread and step
+        __syncthreads();
+        const uint32_t tot = pe_ctl_ld(pb, PEC_OUTTOT);
+        for (uint32_t x = T << 4; x < tot; x += 16u * 64u * SC_WAVES) {
+          const u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[sg + x]);
+          if (x + 16u <= tot) *reinterpret_cast<gu32x4*>(o + x) = v;
+          else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            _Pragma("unroll") for (uint32_t q = 0; q < 16u; q++) if (x + q < tot) o[x + q] = (uint8_t)(w[q >> 2] >> ((q & 3u) * 8u));
+          }
         }
       }
       PE_PROF(10);
