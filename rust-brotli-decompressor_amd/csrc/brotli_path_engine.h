@@ -63,7 +63,12 @@ static_assert(PE_CHUNKS == 64u * SC_WAVES, "one chunk per lane of the block");
 constexpr uint32_t PE_CTL = 0;                                    // 1024: control words (the first 32 as the scan engine's), the stream's state
 constexpr uint32_t PE_IN = 1024;                                   // the region's input: PE_RBL / 32 + 6 dwords
 constexpr uint32_t PE_J1F = PE_IN + (PE_RBL / 32 + 8) * 4;        // code length at every bit, bit 7: on the path; later NEXT8
-constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per state: the state eight commands on
+constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per state: the state PE_JUMP commands on
+#ifndef BROTLI_AMD_PE_JUMP_LOG
+#define BROTLI_AMD_PE_JUMP_LOG 3
+#endif
+constexpr uint32_t PE_JUMP_LOG = BROTLI_AMD_PE_JUMP_LOG, PE_JUMP = 1u << PE_JUMP_LOG;  // commands a hop of the walk (8 or 16)
+static_assert(PE_JUMP_LOG == 3 || PE_JUMP_LOG == 4, "the walk's hop");
 constexpr uint32_t PE_STG = PE_J1F;                               // the region's output while it is put together (execute), where it fits: see PE_STG_CAP
 #ifndef BROTLI_AMD_PE_STG_CAP
 #define BROTLI_AMD_PE_STG_CAP 32768
@@ -336,11 +341,12 @@ __device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if (part[t]) n[t] = m[t];
   } else
   for (;;) {
-    uint32_t f[NS], yc[NS]; bool go[NS]; bool any = false;
+    uint32_t f[NS], yc[NS], xb[NS]; bool go[NS]; bool any = false;
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
       yc[t] = y[t] < c.Lp ? y[t] : 0u;
+      xb[t] = 0u;
       if (J1) f[t] = lds_ld8(pb + PE_J1F + yc[t]);
-      else f[t] = ((lds_ld32(pb + PE_PM + ((yc[t] >> 5) << 2)) >> (yc[t] & 31u)) & 1u) << 7;
+      else { f[t] = ((lds_ld32(pb + PE_PM + ((yc[t] >> 5) << 2)) >> (yc[t] & 31u)) & 1u) << 7; xb[t] = pe_bits32(pb, yc[t]); }  // (the code word's bits in the same round trip as the flag)
     }
     SC_STAGE();
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
@@ -351,7 +357,7 @@ __device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
       uint32_t len;
       if (J1) len = f[t] & 15u;
-      else { uint32_t sy; sc_lookup(c.lit_tree, pe_bits32(pb, yc[t]), sy, len); }
+      else { uint32_t sy; sc_lookup(c.lit_tree, xb[t], sy, len); }
       if (go[t]) { y[t] += len; n[t]--; hops[t]++; }
     }
   }
@@ -806,6 +812,27 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
     }
     __syncthreads();
+    if (PE_JUMP_LOG == 4) {
+      // ... and from it the state sixteen commands on, in place: every thread its own states' (one in 1024), read before the
+      // barrier, written behind it
+      constexpr uint32_t PER = (PE_STATES + 64u * SC_WAVES - 1u) / (64u * SC_WAVES);
+      uint32_t b2[PER];
+      _Pragma("unroll") for (uint32_t t = 0; t < PER; t++) {
+        const uint32_t i = T + t * 64u * SC_WAVES;
+        const bool valid = i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn);
+        b2[t] = valid ? lds_ld16(pb + PE_N8 + (i << 1)) : (uint32_t)PEN_NONE;
+      }
+      _Pragma("unroll") for (uint32_t t = 0; t < PER; t++) {
+        const uint32_t w2 = lds_ld16(pb + PE_N8 + ((b2[t] < PEN_FIRST_SPECIAL ? b2[t] : 0u) << 1));
+        b2[t] = b2[t] < PEN_FIRST_SPECIAL ? w2 : (uint32_t)PEN_NONE;
+      }
+      __syncthreads();
+      _Pragma("unroll") for (uint32_t t = 0; t < PER; t++) {
+        const uint32_t i = T + t * 64u * SC_WAVES;
+        if (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) lds_st16(pb + PE_N8 + (i << 1), b2[t] < PEN_FIRST_SPECIAL ? b2[t] : (uint32_t)PEN_NONE);
+      }
+      __syncthreads();
+    }
     PE_PROF(5);
     // ---- the walk (wave 0) and, behind it, the details (the other waves): the stream's states in order, LIST[k] = bit | kind << 15
     // of the state command k starts from.  Wave 0 follows the stream eight commands a hop (NEXT8 knows the way wherever the next
@@ -821,14 +848,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       uint32_t id = PE_RANKS, na = 0;
       for (;;) {
         const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
-        if (n8 >= PEN_FIRST_SPECIAL || na >= 120u) break;
+        if (n8 >= PEN_FIRST_SPECIAL || na >= 960u / PE_JUMP) break;
         if (lane == 0) {
           *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + (na << 2)]) = id;
           *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NAPUB]) = na + 1u;
         }
         na++; id = n8;
       }
-      uint32_t m = 8u * na, desc;
+      uint32_t m = PE_JUMP * na, desc;
       for (;;) {
         if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
         const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
@@ -852,16 +879,16 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       for (;;) {
         const uint32_t done = pe_ctl_ld(pb, PEC_WDONE), pub = pe_ctl_ld(pb, PEC_NAPUB);
         if (done != 0u) { lds_sync(); na_k = pe_ctl_ld(pb, PEC_NA); m_k = pe_ctl_ld(pb, PEC_M); break; }
-        if (pub >= (k0 >> 3) + 9u) { na_k = pub; m_k = PE_CMDS + 64u; break; }  // (nine anchors on: the batch is whole whatever comes behind)
+        if (pub >= (k0 >> PE_JUMP_LOG) + 64u / PE_JUMP + 1u) { na_k = pub; m_k = PE_CMDS + 64u; break; }  // (the anchors that span it and one more: the batch is whole whatever comes behind)
         __builtin_amdgcn_s_sleep(6);
       }
       lds_sync();
       if (k0 <= m_k) {
         // the state command kk starts from: behind an anchor by the records, else what the walk listed
         auto state_of = [&](const uint32_t kk) -> uint32_t {
-          if (kk >= 8u * na_k) return lds_ld16(pb + PE_LIST + ((kk < PE_CMDS + 8u ? kk : 0u) << 1));
-          uint32_t st = *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + ((kk >> 3) << 2)]);
-          for (uint32_t h = 0; h < (kk & 7u); h++) st = lds_ld16(pb + PE_NEXT + (st << 1));
+          if (kk >= PE_JUMP * na_k) return lds_ld16(pb + PE_LIST + ((kk < PE_CMDS + 8u ? kk : 0u) << 1));
+          uint32_t st = *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + ((kk >> PE_JUMP_LOG) << 2)]);
+          for (uint32_t h = 0; h < (kk & (PE_JUMP - 1u)); h++) st = lds_ld16(pb + PE_NEXT + (st << 1));
           return st < PE_RANKS ? lds_ld16(pb + PE_POR + (st << 1)) : lds_ld16(pb + PE_WST + ((st - PE_RANKS) << 1));
         };
         const uint32_t k = k0 + lane;
@@ -870,7 +897,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         const uint32_t s_last = state_of(k0 + 64u <= m_k ? k0 + 64u : 0u);
         uint32_t s1 = bperm(((lane + 1u) & 63u) << 2, s0);
         s1 = lane == 63u ? s_last : s1;
-        if (k <= m_k && k < 8u * na_k) lds_st16(pb + PE_LIST + (k << 1), s0);  // (the resolve reads where the stream goes on out of the list)
+        if (k <= m_k && k < PE_JUMP * na_k) lds_st16(pb + PE_LIST + (k << 1), s0);  // (the resolve reads where the stream goes on out of the list)
         if (k0 < m_k) {
           const PeParse pr = pe_eval<false, false>(c, s0 & 0x7FFFu, s0 >> 15, on);
           uint32_t kind = SCK_IMPLICIT, val = 0;
@@ -1182,11 +1209,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         pre_ok = true;
       }
       // (b) the commands listed for it get a wave each: long literal runs out of lit[], long copies whose source lies in front
-      // of the region's output
+      // of the region's output.  A wave takes its items three at a time: the copies of up to 64 bytes are asked for side by
+      // side and stored when all three are there (their sources lie far back: a round trip to memory each).
       {
         const uint32_t nbig = pe_ctl_ld(pb, PEC_NBIG);
         PE_COUNT(12, nbig);
-        for (uint32_t j = me; j < nbig; j += SC_WAVES) {
+        auto big_item = [&](const uint32_t j, uint32_t& pt, uint32_t& pd, uint32_t& pn) {
+          pn = 0; pt = 0; pd = 0;
+          if (j >= nbig) return;
           const uint32_t k = rfl(lds_ld16(pb + PE_BLIST + (j << 1)));
           const uint32_t ra = pb + PE_REC + (k << 4);
           const uint32_t r0 = rfl(lds_ld32(ra)), r1 = rfl(lds_ld32(ra + 4u)), cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
@@ -1200,12 +1230,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             if (staged) { for (uint32_t i = lane; i < n; i += 64u) lds_st8(sg + off + u + i, lds_ld8(la + i)); }
             else for (uint32_t i = lane; i < n; i += 64u) lp[i] = (uint8_t)lds_ld8(la + i);
           }
-          if (cn > PE_LANE_COPY && (r0 >> 31) == 0u && staged) {
-            gu8* const src = o + off + ins - dist;   // (all of it in front of the region)
-            for (uint32_t q = lane; q < cn; q += 64u) lds_st8(sg + off + ins + q, src[q]);
-          } else if (cn > PE_LANE_COPY && (r0 >> 31) == 0u) {
-            gu8* const dst = o + off + ins; gu8* const src = dst - dist;
-            if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
+          if (cn > PE_LANE_COPY && (r0 >> 31) == 0u) {
+            gu8* const dst = o + off + ins; gu8* const src = dst - dist;   // (all of the source in front of the region)
+            if (cn <= 64u) { if (lane < cn) pt = src[lane]; pd = off + ins; pn = cn; }
+            else if (staged) { for (uint32_t q = lane; q < cn; q += 64u) lds_st8(sg + off + ins + q, src[q]); }
             else {
               const uint32_t n16 = cn >> 4;
               for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
@@ -1213,6 +1241,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
               if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
             }
           }
+        };
+        auto big_store = [&](const uint32_t pt, const uint32_t pd, const uint32_t pn) {
+          if (lane < pn) { if (staged) lds_st8(sg + pd + lane, pt); else o[pd + lane] = (uint8_t)pt; }
+        };
+        for (uint32_t j0 = me; j0 < nbig; j0 += 3u * SC_WAVES) {
+          uint32_t t0, d0, n0, t1, d1, n1, t2, d2, n2;
+          big_item(j0, t0, d0, n0); big_item(j0 + SC_WAVES, t1, d1, n1); big_item(j0 + 2u * SC_WAVES, t2, d2, n2);
+          big_store(t0, d0, n0); big_store(t1, d1, n1); big_store(t2, d2, n2);
         }
       }
       PE_PROF(9);
