@@ -92,6 +92,9 @@ constexpr uint32_t PE_LIST = PE_WST + PE_WSTB;                    // u16 per lis
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
 constexpr uint32_t PE_TAILQ = PE_LIST;                              // u16 per state the bulk of the records left for the thin end (list and anchors are not in use then)
 constexpr uint32_t PE_TAILCAP = 1024;
+#ifndef BROTLI_AMD_PE_POLL_SLEEP
+#define BROTLI_AMD_PE_POLL_SLEEP 6   // (x 64 clocks between two looks at what the walk has published)
+#endif
 #ifndef BROTLI_AMD_PE_TAIL_WAVES
 #define BROTLI_AMD_PE_TAIL_WAVES 16
 #endif
@@ -880,7 +883,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         const uint32_t done = pe_ctl_ld(pb, PEC_WDONE), pub = pe_ctl_ld(pb, PEC_NAPUB);
         if (done != 0u) { lds_sync(); na_k = pe_ctl_ld(pb, PEC_NA); m_k = pe_ctl_ld(pb, PEC_M); break; }
         if (pub >= (k0 >> PE_JUMP_LOG) + 64u / PE_JUMP + 1u) { na_k = pub; m_k = PE_CMDS + 64u; break; }  // (the anchors that span it and one more: the batch is whole whatever comes behind)
-        __builtin_amdgcn_s_sleep(6);
+        __builtin_amdgcn_s_sleep(BROTLI_AMD_PE_POLL_SLEEP);
       }
       lds_sync();
       if (k0 <= m_k) {
