@@ -93,7 +93,7 @@ constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anc
 constexpr uint32_t PE_TAILQ = PE_LIST;                              // u16 per state the bulk of the records left for the thin end (list and anchors are not in use then)
 constexpr uint32_t PE_TAILCAP = 1024;
 #ifndef BROTLI_AMD_PE_POLL_SLEEP
-#define BROTLI_AMD_PE_POLL_SLEEP 6   // (x 64 clocks between two looks at what the walk has published)
+#define BROTLI_AMD_PE_POLL_SLEEP 2   // (x 64 clocks between two looks at what the walk has published)
 #endif
 #ifndef BROTLI_AMD_PE_TAIL_WAVES
 #define BROTLI_AMD_PE_TAIL_WAVES 16

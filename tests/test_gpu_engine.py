@@ -159,6 +159,48 @@ def test_streams_that_stress_the_engines_hand_overs(pkg, seed):
     _check_against_oracle(pkg, datas, caps, 1, "hand-overs")
 
 
+def test_regions_put_together_in_lds(pkg):
+    """Round 3: a region whose output fits J1's room is put together in LDS and written out in one piece; copies that read the
+    region's own output go through LDS there (csrc/brotli_path_engine.h, execute).  Synthetic LZ77 data whose copies are short
+    and come from a few bytes to a few hundred bytes back -- overlapping themselves, reading each other's output, reaching
+    back over the region's first byte -- next to stretches of long copies from far back, whose regions do not fit the stage:
+    both kinds of region follow each other in one stream."""
+    import numpy as np
+    ref = _enc()
+    rng = np.random.Generator(np.random.PCG64(4711))
+    rnd = random.Random(4711)
+    pr = np.arange(1, 65, dtype=np.float64) ** -1.0
+    pr /= pr.sum()
+
+    def zipf(n):
+        return (rng.choice(64, size=n, p=pr) + 32).astype(np.uint8).tobytes()
+
+    raws = []
+    for near in (8, 40, 300, 5000):
+        out = bytearray(zipf(2000))
+        while len(out) < 700000:
+            k = rnd.random()
+            if k < 0.45:
+                out += zipf(rnd.choice([1, 2, 3, 5, 9, 17, 40, 70, 130]))
+            elif k < 0.95:  # a copy from close by (byte by byte: it may overlap itself)
+                d = rnd.randrange(1, min(len(out), near) + 1)
+                for _ in range(rnd.choice([3, 4, 5, 8, 15, 16, 17, 31, 33, 63, 64, 65, 200])):
+                    out.append(out[-d])
+            else:  # a stretch of long copies from far back
+                for _ in range(rnd.randrange(1, 6)):
+                    n = rnd.randrange(1000, 30000)
+                    o = rnd.randrange(0, max(1, len(out) - n))
+                    out += out[o:o + n]
+        raws.append(bytes(out))
+    datas, caps = [], []
+    for raw in raws:
+        for q, lgwin in ((5, 22), (rnd.choice([2, 4, 6, 9]), rnd.choice([18, 20, 24]))):
+            c = ref.encode(raw, q, lgwin)
+            d, cp = _variants(rnd, c, len(raw), damaged=3)
+            datas += d; caps += cp
+    _check_against_oracle(pkg, datas, caps, 1, "lds stage")
+
+
 def test_many_block_types(pkg):
     """literal, command and distance statistics that change every few KiB: the encoder answers with many block types and
     short blocks (block switches every few dozen commands: the engine's part ends at each of them)"""
