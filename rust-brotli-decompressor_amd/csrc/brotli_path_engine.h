@@ -507,12 +507,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       bool any2 = false;
       _Pragma("unroll") for (int j = 0; j < 8; j++) any2 = any2 || Lw[j] > ROOT_BITS;
       if (__ballot(any2) != 0ull) {
+        // (the eight second-level entries asked for side by side -- a lane that needs none reads the table's first entry --:
+        // one round trip, not one per bit; codes of more than eight bits are the rule in data of high entropy)
+        uint32_t e2[8];
         _Pragma("unroll") for (int j = 0; j < 8; j++) {
-          if (Lw[j] > ROOT_BITS) {
-            const uint32_t idx = (e[j] >> 4) + __builtin_amdgcn_ubfe(v >> j, ROOT_BITS, Lw[j] - ROOT_BITS);
-            Lw[j] = ROOT_BITS + (lds_ld16(c.lit_tree + (idx << 1)) & 15u);
-          }
+          const uint32_t idx = Lw[j] > ROOT_BITS ? (e[j] >> 4) + __builtin_amdgcn_ubfe(v >> j, ROOT_BITS, Lw[j] - ROOT_BITS) : 0u;
+          e2[j] = lds_ld16(c.lit_tree + (idx << 1));
         }
+        _Pragma("unroll") for (int j = 0; j < 8; j++) if (Lw[j] > ROOT_BITS) Lw[j] = ROOT_BITS + (e2[j] & 15u);
       }
       const uint32_t w0 = Lw[0] | (Lw[1] << 8) | (Lw[2] << 16) | (Lw[3] << 24), w1 = Lw[4] | (Lw[5] << 8) | (Lw[6] << 16) | (Lw[7] << 24);
       lds_st32(pb + PE_J1F + pos0, w0); lds_st32(pb + PE_J1F + pos0 + 4u, w1);
