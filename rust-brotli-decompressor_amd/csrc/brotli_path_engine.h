@@ -103,14 +103,7 @@ constexpr uint32_t PE_TAILCAP = 1024;
 #endif
 constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see the thin end of the records through
 constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
-#ifdef BROTLI_AMD_PE_NO_CMD_TABLE
-constexpr bool PE_CMD_TABLE = false;
-constexpr uint32_t PE_CT = PE_ANCH + 128 * 4, PE_BYTES = PE_CT;
-#else
-constexpr bool PE_CMD_TABLE = true;
-constexpr uint32_t PE_CT = PE_ANCH + 128 * 4;                     // u32 per command symbol: what the records want of it -- insert base | insert extra bits << 16 | copy extra bits << 21 | implicit distance << 26 (kCmdLut's row, src/prefix.rs:115-5755, as far as the records go)
-constexpr uint32_t PE_BYTES = PE_CT + 704 * 4;
-#endif
+constexpr uint32_t PE_BYTES = PE_ANCH + 128 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_WCAP * 2 <= PE_WSTB && PE_CMDS * 4 <= PE_CHUNKS * 4 && PE_STATES % 8 == 0, "overlays");
 static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0, "alignment");
@@ -276,16 +269,10 @@ __device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[
     }
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
       const uint32_t cmd = e[t] >> 4, cell = cmd >> 6;
-      if (PE_CMD_TABLE && !FULL) {
-        // (the records want the insert length and the command's bits, not the copy length: one table word a symbol)
-        const uint32_t tw = lds_ld32(pb + PE_CT + ((cmd < 704u ? cmd : 0u) << 2));
-        ie[t] = tw & 0x1FFFFFu; ce[t] = ((tw >> 21) & 31u) << 16; imp[t] = (tw >> 26) & 1u;
-      } else {
-        const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
-        const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
-        ie[t] = bperm(ins_code << 2, c.lut_vgpr); ce[t] = bperm((32u + copy_code) << 2, c.lut_vgpr);
-        imp[t] = cmd < 128u ? 1u : 0u;
-      }
+      const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
+      const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+      ie[t] = bperm(ins_code << 2, c.lut_vgpr); ce[t] = bperm((32u + copy_code) << 2, c.lut_vgpr);
+      imp[t] = cmd < 128u ? 1u : 0u;
     }
     SC_STAGE();
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
@@ -470,12 +457,6 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     st.rbl = PE_RBL;  // bits the next region takes: halved where the closure ran out of room, doubled back where it is small
     st.first = 1u;
     pe_st_store(pb, st);
-  }
-  if (PE_CMD_TABLE && T < 704u) {
-    const uint32_t cmd = T, cell = cmd >> 6;
-    const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u);
-    const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
-    lds_st32(pb + PE_CT + (cmd << 2), (uint32_t)kInsBase[ins_code] | ((uint32_t)kInsExtra[ins_code] << 16) | ((uint32_t)kCopyExtra[copy_code] << 21) | (cmd < 128u ? 1u << 26 : 0u));
   }
   uint32_t pre_a = 0, pre_b = 0; bool pre_ok = false;  // the next region's input dwords of this lane, once they are known
   for (;;) {
