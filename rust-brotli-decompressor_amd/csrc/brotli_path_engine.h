@@ -850,6 +850,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     const uint32_t bw = (me + SC_WAVES - 1u) & (SC_WAVES - 1u);  // this wave's batch (wave 0, which walks, gets the last one)
     uint32_t dr0 = 0, dr1 = 0, dr2 = 0, dr3 = 0;
     if (me == 0) {
+      __builtin_amdgcn_s_setprio(3);  // (the walk is the one chain everybody waits for: first in line on its SIMD)
       uint32_t id = PE_RANKS, na = 0;
       for (;;) {
         const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
@@ -875,6 +876,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
       lds_sync();
       pe_ctl_st(pb, PEC_WDONE, 1u);
+#ifdef BROTLI_AMD_DECODER_PRIO
+      __builtin_amdgcn_s_setprio(BROTLI_AMD_DECODER_PRIO);
+#else
+      __builtin_amdgcn_s_setprio(0);
+#endif
       PE_COUNT(26, m); PE_COUNT(27, na);
     }
     PE_PROF(6);
