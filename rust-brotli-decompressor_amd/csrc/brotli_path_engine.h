@@ -876,11 +876,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
       lds_sync();
       pe_ctl_st(pb, PEC_WDONE, 1u);
-#ifdef BROTLI_AMD_DECODER_PRIO
-      __builtin_amdgcn_s_setprio(BROTLI_AMD_DECODER_PRIO);
-#else
-      __builtin_amdgcn_s_setprio(0);
-#endif
+      __builtin_amdgcn_s_setprio(BROTLI_AMD_DECODER_PRIO);  // (back to the decoding wave's own)
       PE_COUNT(26, m); PE_COUNT(27, na);
     }
     PE_PROF(6);
