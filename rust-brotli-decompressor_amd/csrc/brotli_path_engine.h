@@ -103,16 +103,19 @@ constexpr uint32_t PE_TAILCAP = 1024;
 #endif
 constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see the thin end of the records through
 constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
-constexpr uint32_t PE_BYTES = PE_ANCH + 128 * 4;
+constexpr uint32_t PE_TD = PE_ANCH + 128 * 4;                    // u16 per entry of the distance code's table: the same two levels, a leaf's value = bits of the whole distance code (symbol + extra)
+constexpr uint32_t PE_TD_ENTRIES = 1024;                          // (920 is the most a distance alphabet without large window takes)
+constexpr uint32_t PE_TC = PE_TD + PE_TD_ENTRIES * 2;             // u32 per command symbol: insert base | insert extra bits << 15 | copy extra bits << 20 | implicit distance << 25
+constexpr uint32_t PE_BYTES = PE_TC + 704 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_WCAP * 2 <= PE_WSTB && PE_CMDS * 4 <= PE_CHUNKS * 4 && PE_STATES % 8 == 0, "overlays");
-static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0, "alignment");
+static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0 && PE_TD % 4 == 0 && PE_TC % 4 == 0, "alignment");
 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
        PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
-       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */ };
+       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -392,6 +395,140 @@ __device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[
     r[t].code = code; r[t].next = next;
   }
 }
+
+// The records' evaluation (two states a lane, side by side), written for the instruction count: the records are bound by the
+// SIMDs' issue rate (tools/ubench/valu_rate.hip: one instruction per four clocks and SIMD whatever its kind), so everything a
+// table can answer is a table -- PE_TD gives the bits of a whole distance code (ReadDistanceInternal, decode.rs:2066-2131:
+// symbol + extra bits) where the distance tree gives the symbol, PE_TC what ReadCommandInternal (decode.rs:2134-2189) takes
+// out of kCmdLut -- and a lane without a state evaluates bit 0 like everybody else instead of being masked out.
+// In: d[t] = bit | kind << 15 of state t (0 where the lane has none), on[t]; a run that ran out of hops last time goes on from
+// (ry[t], rn[t]) with rimp[t] (RES[t]).  Out: code[t] / next[t] as PeParse's; for code 3 ry / rn / rimp say where the run stands.
+template <uint32_t NS>
+__device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[NS], const bool (&on)[NS], const bool (&res)[NS], uint32_t (&ry)[NS], uint32_t (&rn)[NS], uint32_t (&rimp)[NS],
+                                            uint32_t (&code)[NS], uint32_t (&next)[NS]) {
+  static_assert(NS == 1u || NS == 2u, "one or two states a lane");
+  const uint32_t pb = c.pb;
+  uint32_t q[NS], p[NS], kd[NS], lo[NS], hi[NS]; bool ok[NS];
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    const uint32_t pos = d[t] & 0x7FFFu;
+    ok[t] = on[t] && pos + 128u <= c.L; q[t] = ok[t] ? pos : 0u; kd[t] = d[t] >> 15;
+    lo[t] = pe_bits32(pb, q[t]);
+  }
+  SC_STAGE();
+  {
+    // the distance code at the state's bit: its length (a state of kind I has none: the read is harmless)
+    uint32_t e[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = lds_ld16(pb + PE_TD + ((lo[t] & 0xFFu) << 1));
+    SC_STAGE();
+    if (__ballot((e[0] & 15u) > ROOT_BITS || (e[NS - 1u] & 15u) > ROOT_BITS) != 0ull) {
+      uint32_t e2[NS];
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+        const uint32_t Ld = e[t] & 15u;
+        const uint32_t idx = Ld > ROOT_BITS ? (e[t] >> 4) + __builtin_amdgcn_ubfe(lo[t], ROOT_BITS, Ld - ROOT_BITS) : (lo[t] & 0xFFu);
+        e2[t] = lds_ld16(pb + PE_TD + (idx << 1));
+      }
+      SC_STAGE();
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = e2[t];   // (a leaf of the first level is read again: the same entry)
+    }
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) p[t] = q[t] + (kd[t] == 0u ? e[t] >> 4 : 0u);
+  }
+  // the command's head
+  uint32_t y[NS], n[NS], imp[NS];
+  {
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) pe_bits64(pb, p[t], lo[t], hi[t]);
+    SC_STAGE();
+    uint32_t e[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = lds_ld16(c.cmd_tree + ((lo[t] & 0xFFu) << 1));
+    SC_STAGE();
+    if (__ballot((e[0] & 15u) > ROOT_BITS || (e[NS - 1u] & 15u) > ROOT_BITS) != 0ull) {
+      uint32_t e2[NS];
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+        const uint32_t Lh = e[t] & 15u;
+        const uint32_t idx = Lh > ROOT_BITS ? (e[t] >> 4) + __builtin_amdgcn_ubfe(lo[t], ROOT_BITS, Lh - ROOT_BITS) : (lo[t] & 0xFFu);
+        e2[t] = lds_ld16(c.cmd_tree + (idx << 1));
+      }
+      SC_STAGE();
+      _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if ((e[t] & 15u) > ROOT_BITS) e[t] = (e2[t] & ~15u) | ((e2[t] & 15u) + ROOT_BITS);   // (a code word is at most fifteen bits long)
+    }
+    uint32_t tc[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) tc[t] = lds_ld32(pb + PE_TC + ((e[t] >> 4) << 2));
+    SC_STAGE();
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+      const uint32_t Lh = e[t] & 15u, ib = (tc[t] >> 15) & 31u, cb = (tc[t] >> 20) & 31u;
+      const uint32_t xb = __builtin_amdgcn_alignbit(hi[t], lo[t], Lh);   // the bits behind the command symbol
+      const uint32_t ins = (tc[t] & 0x7FFFu) + __builtin_amdgcn_ubfe(xb, 0u, ib);
+      y[t] = p[t] + Lh + ib + cb; n[t] = ins; imp[t] = (tc[t] >> 25) & 1u;
+      if (res[t]) { y[t] = ry[t]; n[t] = rn[t]; imp[t] = rimp[t]; }
+    }
+  }
+  // the literal run, hop by hop through J1 until it is on the path (the bytes from Lp on carry the path flag: a run that
+  // reaches them stops by itself), at most PE_HOPCAP hops
+  {
+    uint32_t m[NS]; bool part[NS];
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = ok[t] && y[t] < c.Lp; m[t] = part[t] ? n[t] : 0u; }
+    const uint32_t jb = pb + PE_J1F;
+    uint32_t ya0 = y[0] + jb, ya1 = y[NS - 1u] + jb, m0 = m[0], m1 = m[NS - 1u], f0, f1;
+    uint64_t e0, e1, ea, sv;
+    // (a state that has stopped hopping -- no literals left, or on the path -- stays stopped: the lanes still hopping are an
+    // execution mask that only ever narrows; v_cmpx drops the lanes, the step itself is an add and a decrement)
+#define PE_HOP1 \
+      "s_mov_b64 exec, %[e0]\n\tds_read_u8 %[f0], %[y0]\n\ts_waitcnt lgkmcnt(0)\n\tv_cmpx_gt_u32 vcc, %[c80], %[f0]\n\tv_add_u32 %[y0], %[y0], %[f0]\n\t" \
+      "v_subrev_u32 %[m0], 1, %[m0]\n\tv_cmpx_ne_u32 vcc, 0, %[m0]\n\ts_mov_b64 %[e0], exec\n\ts_cmp_eq_u64 %[e0], 0\n\ts_cbranch_scc1 .Lpe_hopr_done_%=\n\t"
+#define PE_HOP2 \
+      "s_mov_b64 exec, %[e0]\n\tds_read_u8 %[f0], %[y0]\n\ts_mov_b64 exec, %[e1]\n\tds_read_u8 %[f1], %[y1]\n\ts_mov_b64 exec, %[e0]\n\ts_waitcnt lgkmcnt(1)\n\t" \
+      "v_cmpx_gt_u32 vcc, %[c80], %[f0]\n\tv_add_u32 %[y0], %[y0], %[f0]\n\tv_subrev_u32 %[m0], 1, %[m0]\n\tv_cmpx_ne_u32 vcc, 0, %[m0]\n\ts_mov_b64 %[e0], exec\n\t" \
+      "s_mov_b64 exec, %[e1]\n\ts_waitcnt lgkmcnt(0)\n\t" \
+      "v_cmpx_gt_u32 vcc, %[c80], %[f1]\n\tv_add_u32 %[y1], %[y1], %[f1]\n\tv_subrev_u32 %[m1], 1, %[m1]\n\tv_cmpx_ne_u32 vcc, 0, %[m1]\n\ts_mov_b64 %[e1], exec\n\t" \
+      "s_or_b64 %[ea], %[e0], %[e1]\n\ts_cbranch_scc0 .Lpe_hopr_done_%=\n\t"
+    if constexpr (NS == 1u) {
+      asm volatile("s_mov_b64 %[sv], exec\n\tv_cmp_ne_u32 %[e0], 0, %[m0]\n\ts_cmp_eq_u64 %[e0], 0\n\ts_cbranch_scc1 .Lpe_hopr_done_%=\n\t"
+                   PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1
+                   ".Lpe_hopr_done_%=:\n\ts_mov_b64 exec, %[sv]"
+                   : [y0] "+v"(ya0), [m0] "+v"(m0), [f0] "=&v"(f0), [e0] "=&s"(e0), [sv] "=&s"(sv)
+                   : [c80] "v"(0x80u) : "vcc", "scc", "memory");
+      (void)ya1; (void)m1; (void)f1; (void)e1; (void)ea;
+      y[0] = ya0 - jb;
+      if (part[0]) n[0] = m0;
+    } else {
+      asm volatile("s_mov_b64 %[sv], exec\n\tv_cmp_ne_u32 %[e0], 0, %[m0]\n\tv_cmp_ne_u32 %[e1], 0, %[m1]\n\ts_or_b64 %[ea], %[e0], %[e1]\n\ts_cbranch_scc0 .Lpe_hopr_done_%=\n\t"
+                   PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2
+                   ".Lpe_hopr_done_%=:\n\ts_mov_b64 exec, %[sv]"
+                   : [y0] "+v"(ya0), [m0] "+v"(m0), [f0] "=&v"(f0), [y1] "+v"(ya1), [m1] "+v"(m1), [f1] "=&v"(f1), [e0] "=&s"(e0), [e1] "=&s"(e1), [ea] "=&s"(ea), [sv] "=&s"(sv)
+                   : [c80] "v"(0x80u) : "vcc", "scc", "memory");
+      y[0] = ya0 - jb; y[NS - 1u] = ya1 - jb;
+      if (part[0]) n[0] = m0;
+      if (part[NS - 1u]) n[NS - 1u] = m1;
+    }
+#undef PE_HOP1
+#undef PE_HOP2
+  }
+  uint32_t pmw[NS], cbw[NS], yc[NS]; bool inside[NS];
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    inside[t] = y[t] < c.Lp; yc[t] = inside[t] ? y[t] : 0u;
+    pmw[t] = lds_ld32(pb + PE_PM + ((yc[t] >> 5) << 2)); cbw[t] = lds_ld16(pb + PE_CB + ((yc[t] >> 5) << 1));
+  }
+  SC_STAGE();
+  uint32_t rk[NS], q2[NS]; bool onp[NS];
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    onp[t] = ((pmw[t] >> (yc[t] & 31u)) & 1u) != 0u;
+    rk[t] = cbw[t] + (uint32_t)__builtin_popcount(pmw[t] & ((1u << (yc[t] & 31u)) - 1u));
+    const uint32_t rr = rk[t] + n[t];
+    q2[t] = lds_ld16(pb + PE_POR + ((rr < c.Rn ? rr : 0u) << 1));
+  }
+  SC_STAGE();
+  _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
+    uint32_t cd, nx;
+    if (!ok[t] || !inside[t]) { cd = 2u; nx = 0u; }
+    else if (n[t] != 0u) {
+      if (!onp[t]) { cd = 3u; nx = 0u; }
+      else if (rk[t] + n[t] >= c.Rn) { cd = 2u; nx = 0u; }
+      else if (imp[t]) { cd = 1u; nx = q2[t] | 0x8000u; }
+      else { cd = 0u; nx = rk[t] + n[t]; }
+    } else if (!imp[t] && onp[t]) { cd = 0u; nx = rk[t]; }
+    else { cd = 1u; nx = y[t] | (imp[t] ? 0x8000u : 0u); }
+    code[t] = cd; next[t] = nx; ry[t] = y[t]; rn[t] = n[t]; rimp[t] = imp[t];
+  }
+}
 template <bool CAPPED, bool J1>
 __device__ __forceinline__ PeParse pe_eval(const PeCtx& c, uint32_t pos, uint32_t kind, bool on) {
   const uint32_t pos_[1] = {pos}, kind_[1] = {kind}; const bool on_[1] = {on};
@@ -458,6 +595,33 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     st.first = 1u;
     pe_st_store(pb, st);
   }
+  // ---- the records' tables (see pe_eval_rec) ----
+  for (uint32_t i = T; i < 704u; i += 64u * SC_WAVES) {
+    const uint32_t cell = i >> 6;
+    const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((i >> 3) & 7u);
+    const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (i & 7u);
+    lds_st32(pb + PE_TC + (i << 2), (uint32_t)kInsBase[ins_code] | ((uint32_t)kInsExtra[ins_code] << 15) | ((uint32_t)kCopyExtra[copy_code] << 20) | (i < 128u ? 1u << 25 : 0u));
+  }
+  if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TDN, 256u);
+  __syncthreads();
+  if (T < 256u) {
+    const uint32_t e = lds_ld16(c.dtree + (T << 1)), Ld = e & 15u;
+    if (Ld > ROOT_BITS) __hip_atomic_fetch_max(reinterpret_cast<pe_lds_u32*>(&g_smem[pb + PE_CTL + 4u * PEC_TDN]), (e >> 4) + (1u << (Ld - ROOT_BITS)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  const uint32_t td_n = pe_ctl_ld(pb, PEC_TDN);
+  for (uint32_t i = T; i < td_n && i < PE_TD_ENTRIES; i += 64u * SC_WAVES) {
+    uint32_t e = lds_ld16(c.dtree + (i << 1));
+    const uint32_t l4 = e & 15u;
+    if (i >= 256u || l4 <= ROOT_BITS) {   // a leaf: the symbol's bits and its extra bits (decode.rs:2099-2128)
+      const uint32_t code = e >> 4, Lw = l4 + (i >= 256u ? ROOT_BITS : 0u);
+      const int32_t dv = (int32_t)code - (int32_t)c.num_direct;
+      const uint32_t nb = (code >= 16u && dv >= 0) ? (((uint32_t)dv >> c.postfix_bits) >> 1) + 1u : 0u;
+      e = l4 | ((Lw + nb) << 4);
+    }
+    lds_st16(pb + PE_TD + (i << 1), e);
+  }
+  const bool td_ok = td_n <= PE_TD_ENTRIES;   // (a table that does not fit: the engine leaves the metablock to the one-wave loop)
   uint32_t pre_a = 0, pre_b = 0; bool pre_ok = false;  // the next region's input dwords of this lane, once they are known
   for (;;) {
     // ================= the region =================
@@ -465,7 +629,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const PeStream st = pe_st_load(pb);
       const uint32_t lbdw = st.b >> 5;
       const uint32_t avail = in_limit - (lbdw << 5);
-      const bool go = st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
+      const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
       pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, st.b & 31u); pe_ctl_st(pb, PEC_L, avail < st.rbl ? avail : st.rbl);
       pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS); pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
       pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
@@ -498,6 +662,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       pe_st_store(pb, st);
     }
     // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
+#if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 1
+    for (int rep_ = 0; rep_ < 2; rep_++)
+#endif
     for (uint32_t g = T; g < PE_RBL / 8u; g += 64u * SC_WAVES) {
       const uint32_t pos0 = g << 3;
       const uint32_t v = pe_bits32(pb, pos0);
@@ -701,12 +868,19 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // list --, and the thin end of it with ONE state a lane (half the instructions a pass: what is left are chains, a pass
     // is one link of each), the waves taking the list's states the way the bulk took path positions.  (Measured: handing
     // over below 80 busy slots of 128, all sixteen waves in the second phase: 7.64 ms against 7.92 with 32 / four waves.)
-    auto records_loop = [&](auto nsl_, const uint32_t phase, const uint32_t tail_n) {
+    // ---- records: a persistent loop.  Source 0: every path position as kind E (a shared counter hands them out); a lane
+    // whose record leads to a state that is not a path state (the run ended before it met the path, or the command has an implicit
+    // distance) appends that state to the closure and evaluates it itself next; a lane whose run used up its hops goes on with it
+    // next time.  Two states a lane until the counter is exhausted and a wave has less than PE_TAIL_AT of its slots busy -- what it
+    // still holds (chains of states that are not path states) goes on the list.  Source 1: the list, one state a lane (half the
+    // instructions a pass: what is left are chains, a pass is one link of each).  (Tried in round 4: a first pass over the path
+    // positions without the bookkeeping, the closure in a second one -- slower, 8.1 against 7.2 ms: the closure's chains are deep
+    // and thin, and only side by side with fresh path positions do they find the lanes busy.)
+    auto records_loop = [&](auto nsl_, const uint32_t source, const uint32_t limit) {
       constexpr uint32_t NSL = decltype(nsl_)::value;
-      uint32_t sid[NSL], sps[NSL], skd[NSL]; bool has[NSL];
-      PeResume rs[NSL];
-      _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { sid[t] = 0u; sps[t] = 0u; skd[t] = 0u; has[t] = false; rs[t].on = false; rs[t].y = 0u; rs[t].n = 0u; rs[t].implicit = 0u; }
-      if (phase == 0u && T == 0u) { has[0] = true; sid[0] = PE_RANKS; sps[0] = le; skd[0] = 1u; }  // the closure's first state: a command starts at the entry
+      uint32_t sid[NSL], dsc[NSL], ry[NSL], rn[NSL], rimp[NSL]; bool has[NSL], res[NSL];
+      _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { sid[t] = 0u; dsc[t] = 0u; ry[t] = 0u; rn[t] = 0u; rimp[t] = 0u; has[t] = false; res[t] = false; }
+      if (source == 0u && T == 0u) { has[0] = true; sid[0] = PE_RANKS; dsc[0] = le | 0x8000u; }  // the closure's first state: a command starts at the entry
       uint32_t iters = 0; (void)iters;
       bool dry = false;  // the source has nothing more for this wave
       for (;;) {
@@ -714,30 +888,25 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           uint64_t nm[NSL]; uint32_t want = 0;
           _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { nm[t] = __ballot(!has[t]); want += (uint32_t)__popcll(nm[t]); }
           if (want != 0u && !dry) {
-            const uint32_t limit = phase == 0u ? c.Rn : tail_n;
             uint32_t base = 0;
-            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * (phase == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), want);
+            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * (source == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), want);
             base = rfl(base);
             if (base + want > limit) dry = true;
-            uint32_t idv[NSL]; bool take[NSL];
             _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
               const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm[t], 0u));
               base += (uint32_t)__popcll(nm[t]);
-              take[t] = !has[t] && rr < limit;
-              idv[t] = rr;
-              if (phase != 0u) idv[t] = take[t] ? lds_ld16(pb + PE_TAILQ + (rr << 1)) : (uint32_t)PEN_NONE;
-            }
-            _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
-              take[t] = take[t] && idv[t] < PEN_FIRST_SPECIAL;
-              const uint32_t idc = take[t] ? idv[t] : 0u;
-              const uint32_t stv = idc < PE_RANKS ? lds_ld16(pb + PE_POR + (idc << 1)) : lds_ld16(pb + PE_WST + ((idc - PE_RANKS) << 1));
-              if (take[t]) { has[t] = true; sid[t] = idc; sps[t] = stv & 0x7FFFu; skd[t] = stv >> 15; rs[t].on = false; }
+              bool take = !has[t] && rr < limit;
+              uint32_t idv = rr;
+              if (source == 1u) { idv = lds_ld16(pb + PE_TAILQ + ((take ? rr : 0u) << 1)); take = take && idv < PEN_FIRST_SPECIAL; }
+              const uint32_t idc = take ? idv : 0u;
+              const uint32_t stv = lds_ld16(pb + (idc < PE_RANKS ? PE_POR + (idc << 1) : PE_WST + ((idc - PE_RANKS) << 1)));
+              if (take) { has[t] = true; sid[t] = idc; dsc[t] = stv; res[t] = false; }
             }
           }
         }
         const uint64_t h0 = __ballot(has[0]), h1 = NSL > 1u ? __ballot(has[NSL - 1u]) : 0ull;
         if ((h0 | h1) == 0ull) break;
-        if (phase == 0u && dry && (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1) < PE_TAIL_AT) {
+        if (source == 0u && dry && (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1) < PE_TAIL_AT) {
           // the thin end: what this wave still holds goes on the list
           const uint32_t cnt = (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1);
           uint32_t base = 0;
@@ -746,6 +915,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           if (base + cnt <= PE_TAILCAP) {
             const uint32_t i0 = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(h0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h0, 0u));
             const uint32_t i1 = base + (uint32_t)__popcll(h0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(h1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h1, 0u));
+            // (a run that stands in the middle of its hops starts over on the list's side: the list holds states)
             if (has[0]) lds_st16(pb + PE_TAILQ + (i0 << 1), sid[0]);
             if (NSL > 1u && has[NSL - 1u]) lds_st16(pb + PE_TAILQ + (i1 << 1), sid[NSL - 1u]);
             break;
@@ -753,12 +923,16 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           // (the list is full: this wave sees its states through itself; its claim on the list holds no states -- marked so)
           for (uint32_t i = base + lane; i < base + cnt && i < PE_TAILCAP; i += 64u) lds_st16(pb + PE_TAILQ + (i << 1), PEN_NONE);
         }
-        PeParse pr[NSL];
-        pe_eval_n<NSL, true, true, true, false>(c, sps, skd, has, pr, rs);
+        uint32_t code[NSL], nxt[NSL];
+        {
+          uint32_t dd[NSL];
+          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) dd[t] = has[t] ? dsc[t] : 0u;
+          pe_eval_rec<NSL>(c, dd, has, res, ry, rn, rimp, code, nxt);
+        }
         iters++;
         {
           bool app[NSL]; uint64_t am[NSL]; uint32_t slot[NSL]; uint32_t wantw = 0;
-          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { app[t] = has[t] && pr[t].code == 1u; am[t] = __ballot(app[t]); wantw += (uint32_t)__popcll(am[t]); slot[t] = 0; }
+          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { app[t] = has[t] && code[t] == 1u; am[t] = __ballot(app[t]); wantw += (uint32_t)__popcll(am[t]); slot[t] = 0; }
           if (wantw != 0u) {  // (appending closure states: one LDS atomic per wave and pass)
             uint32_t base = 0;
             if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, wantw);
@@ -769,28 +943,25 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             }
           }
           _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
-            if (has[t]) {
-              if (pr[t].code == 3u) { rs[t].on = true; rs[t].y = pr[t].hy; rs[t].n = pr[t].hn; rs[t].implicit = pr[t].implicit; }  // more hops next time
-              else {
-                uint32_t nx = pr[t].code == 0u ? pr[t].next : pr[t].code == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
-                bool goes_on = false;
-                if (app[t] && slot[t] < PE_WCAP) { lds_st16(pb + PE_WST + (slot[t] << 1), pr[t].next); nx = PE_RANKS + slot[t]; goes_on = true; }
-                PE_LANECOUNT(30, app[t] && slot[t] >= PE_WCAP);
-                lds_st16(pb + PE_NEXT + (sid[t] << 1), nx);
-                rs[t].on = false;
-                if (goes_on) { sid[t] = PE_RANKS + slot[t]; sps[t] = pr[t].next & 0x7FFFu; skd[t] = pr[t].next >> 15; }
-                else has[t] = false;
-              }
-            }
+            const bool fin = has[t] && code[t] != 3u;                  // the record is there (code 3: more hops next time, from ry / rn)
+            const bool goes_on = app[t] && slot[t] < PE_WCAP;           // ... and leads to a state that is not a path state: this lane's next
+            PE_LANECOUNT(30, app[t] && slot[t] >= PE_WCAP);
+            const uint32_t nx = goes_on ? PE_RANKS + slot[t] : code[t] == 0u ? nxt[t] : code[t] == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
+            if (goes_on) lds_st16(pb + PE_WST + (slot[t] << 1), nxt[t]);
+            if (fin) lds_st16(pb + PE_NEXT + (sid[t] << 1), nx);
+            res[t] = has[t] && code[t] == 3u;
+            has[t] = res[t] || goes_on;
+            sid[t] = goes_on ? PE_RANKS + slot[t] : sid[t];
+            dsc[t] = goes_on ? nxt[t] : dsc[t];
           }
         }
       }
-      PE_COUNT(23 - 12 * phase, iters);
+      PE_COUNT(23 - 12 * source, iters);
     };
 #ifndef BROTLI_AMD_PE_BULK_NS
 #define BROTLI_AMD_PE_BULK_NS 2
 #endif
-    records_loop(std::integral_constant<uint32_t, BROTLI_AMD_PE_BULK_NS>{}, 0u, 0u);
+    records_loop(std::integral_constant<uint32_t, BROTLI_AMD_PE_BULK_NS>{}, 0u, c.Rn);
     __syncthreads();
     {
       const uint32_t tail_n = pe_ctl_ld(pb, PEC_TAILN) < PE_TAILCAP ? pe_ctl_ld(pb, PEC_TAILN) : PE_TAILCAP;
@@ -802,6 +973,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pb, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_GROW_BELOW && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pb, PEC_STATE + 8, rbl); }
     PE_PROF(4);
     // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
+#if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 4
+    for (int rep_ = 0; rep_ < 2; rep_++)
+#endif
     for (uint32_t i0 = T; i0 < PE_RANKS + wn; i0 += 4u * 64u * SC_WAVES) {
       uint32_t a[4];
       _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) { const uint32_t i = i0 + t * 64u * SC_WAVES; a[t] = (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) ? i : (uint32_t)PEN_NONE; }
