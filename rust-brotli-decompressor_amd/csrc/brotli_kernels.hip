@@ -4224,6 +4224,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("\npath engine dependent copies: %llu per region, the last wave's ticks in them %llu per region\n", g_path_prof[35] / g_path_prof[20], g_path_prof[34] / g_path_prof[20]);
     printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);
+    { unsigned long long eng = 0; for (int k = 0; k <= 11; k++) eng += g_path_prof[k]; eng += g_path_prof[17] + g_path_prof[18];
+      printf("\nkernel ticks of block 0 in this launch: %llu; the path engine's regions so far (all launches): %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0), eng); }
   }
 #endif
   // no more streams: the helper waves may go

@@ -82,7 +82,8 @@ constexpr uint32_t PE_EX = PE_CB + PE_CHUNKS * 2 + 16;            // 2 x u8 per 
 constexpr uint32_t PE_POR = PE_EX + 2 * PE_CHUNKS + 16;           // u16 per rank: its bit
 constexpr uint32_t PE_LIT = PE_POR + PE_RANKS * 2;                // u8 per rank: its literal
 constexpr uint32_t PE_NEXT = PE_LIT + PE_RANKS;                   // u16 per state: the state its command's literals end in
-constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2;              // u16 per closure state: bit | kind << 15; later the commands' records
+constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2 + 16;         // u16 per closure state: bit | kind << 15; later the commands' records.  (The word in between, NEXT[PE_STATES], says PEN_NONE:
+                                                                  // NEXT8's hops clamp their index to it instead of asking whether the state they stand on is one)
 constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes per listed command
 constexpr uint32_t PE_BLIST = PE_NEXT + 2 * PE_CMDS;                // u16 per command with a long copy from in front of the region or a long literal run: its index
 constexpr uint32_t PE_RS = PE_NEXT + 4 * PE_CMDS;                   // 64 bytes per batch of the resolve: its sums, the ring it ends with, its list counts
@@ -115,7 +116,7 @@ enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SP
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
        PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
-       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */ };
+       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */, PEC_SCRATCH = 130 /* stores that are not meant land here */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 __device__ unsigned long long g_path_prof[40];
@@ -133,6 +134,14 @@ __device__ __forceinline__ uint32_t pe_ctl_ld(uint32_t pb, uint32_t k) { return 
 __device__ __forceinline__ void pe_ctl_st(uint32_t pb, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * k]) = v; }
 __device__ __forceinline__ uint32_t pe_atomic_add(uint32_t addr, uint32_t v) {
   return __hip_atomic_fetch_add(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// ... by lane 0 alone, the old value in every lane's hands (uniform): the compiler's own form of an atomic inside `if (lane == 0)`
+// counts the active lanes and multiplies first -- twenty instructions where these six do
+__device__ __forceinline__ uint32_t pe_atomic_add_uniform(uint32_t addr, uint32_t v) {
+  uint32_t r; uint64_t sv;
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %[r], %[a], %[v]\n\ts_mov_b64 exec, %[sv]\n\ts_waitcnt lgkmcnt(0)"
+               : [r] "=&v"(r), [sv] "=&s"(sv) : [a] "v"(addr), [v] "v"(v) : "memory");
+  return rfl(r);
 }
 __device__ __forceinline__ uint32_t pe_atomic_min(uint32_t addr, uint32_t v) {
   return __hip_atomic_fetch_min(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -517,16 +526,11 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
   }
   SC_STAGE();
   _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
-    uint32_t cd, nx;
-    if (!ok[t] || !inside[t]) { cd = 2u; nx = 0u; }
-    else if (n[t] != 0u) {
-      if (!onp[t]) { cd = 3u; nx = 0u; }
-      else if (rk[t] + n[t] >= c.Rn) { cd = 2u; nx = 0u; }
-      else if (imp[t]) { cd = 1u; nx = q2[t] | 0x8000u; }
-      else { cd = 0u; nx = rk[t] + n[t]; }
-    } else if (!imp[t] && onp[t]) { cd = 0u; nx = rk[t]; }
-    else { cd = 1u; nx = y[t] | (imp[t] ? 0x8000u : 0u); }
-    code[t] = cd; next[t] = nx; ry[t] = y[t]; rn[t] = n[t]; rimp[t] = imp[t];
+    // (flat on purpose: nested branches become execution-mask juggling, these are six selects)
+    const bool live = ok[t] && inside[t], more = n[t] != 0u && !onp[t], over = onp[t] && rk[t] + n[t] >= c.Rn, plain = onp[t] && imp[t] == 0u;
+    code[t] = !live ? 2u : more ? 3u : over ? 2u : plain ? 0u : 1u;
+    next[t] = plain ? rk[t] + n[t] : (onp[t] ? q2[t] : y[t]) | (imp[t] << 15);
+    ry[t] = y[t]; rn[t] = n[t]; rimp[t] = imp[t];
   }
 }
 template <bool CAPPED, bool J1>
@@ -808,6 +812,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
     }
     if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry (lane 0 evaluates it)
+    if (T == 1u) lds_st16(pb + PE_NEXT + (PE_STATES << 1), PEN_NONE);  // (NEXT8's sentinel)
     {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u, cut = tmin << 5;
       c.Lp = lim < cut ? lim : cut;
@@ -888,9 +893,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           uint64_t nm[NSL]; uint32_t want = 0;
           _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { nm[t] = __ballot(!has[t]); want += (uint32_t)__popcll(nm[t]); }
           if (want != 0u && !dry) {
-            uint32_t base = 0;
-            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * (source == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), want);
-            base = rfl(base);
+            uint32_t base = pe_atomic_add_uniform(pb + PE_CTL + 4u * (source == 0u ? (uint32_t)PEC_NEXTRANK : (uint32_t)PEC_TAILNEXT), want);
             if (base + want > limit) dry = true;
             _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
               const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm[t], 0u));
@@ -900,7 +903,8 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
               if (source == 1u) { idv = lds_ld16(pb + PE_TAILQ + ((take ? rr : 0u) << 1)); take = take && idv < PEN_FIRST_SPECIAL; }
               const uint32_t idc = take ? idv : 0u;
               const uint32_t stv = lds_ld16(pb + (idc < PE_RANKS ? PE_POR + (idc << 1) : PE_WST + ((idc - PE_RANKS) << 1)));
-              if (take) { has[t] = true; sid[t] = idc; dsc[t] = stv; res[t] = false; }
+              has[t] = has[t] || take; res[t] = res[t] && !take;
+              sid[t] = take ? idc : sid[t]; dsc[t] = take ? stv : dsc[t];
             }
           }
         }
@@ -934,9 +938,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           bool app[NSL]; uint64_t am[NSL]; uint32_t slot[NSL]; uint32_t wantw = 0;
           _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { app[t] = has[t] && code[t] == 1u; am[t] = __ballot(app[t]); wantw += (uint32_t)__popcll(am[t]); slot[t] = 0; }
           if (wantw != 0u) {  // (appending closure states: one LDS atomic per wave and pass)
-            uint32_t base = 0;
-            if (lane == 0) base = pe_atomic_add(pb + PE_CTL + 4u * PEC_WN, wantw);
-            base = rfl(base);
+            uint32_t base = pe_atomic_add_uniform(pb + PE_CTL + 4u * PEC_WN, wantw);
             _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
               slot[t] = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(am[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am[t], 0u));
               base += (uint32_t)__popcll(am[t]);
@@ -947,8 +949,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             const bool goes_on = app[t] && slot[t] < PE_WCAP;           // ... and leads to a state that is not a path state: this lane's next
             PE_LANECOUNT(30, app[t] && slot[t] >= PE_WCAP);
             const uint32_t nx = goes_on ? PE_RANKS + slot[t] : code[t] == 0u ? nxt[t] : code[t] == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
-            if (goes_on) lds_st16(pb + PE_WST + (slot[t] << 1), nxt[t]);
-            if (fin) lds_st16(pb + PE_NEXT + (sid[t] << 1), nx);
+            // (no masks: a lane with nothing to store writes the scratch word)
+            lds_st16(goes_on ? pb + PE_WST + (slot[t] << 1) : pb + PE_CTL + 4u * PEC_SCRATCH, nxt[t]);
+            lds_st16(fin ? pb + PE_NEXT + (sid[t] << 1) : pb + PE_CTL + 4u * PEC_SCRATCH, nx);
             res[t] = has[t] && code[t] == 3u;
             has[t] = res[t] || goes_on;
             sid[t] = goes_on ? PE_RANKS + slot[t] : sid[t];
@@ -976,19 +979,26 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 4
     for (int rep_ = 0; rep_ < 2; rep_++)
 #endif
-    for (uint32_t i0 = T; i0 < PE_RANKS + wn; i0 += 4u * 64u * SC_WAVES) {
-      uint32_t a[4];
-      _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) { const uint32_t i = i0 + t * 64u * SC_WAVES; a[t] = (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) ? i : (uint32_t)PEN_NONE; }
+    // (twelve states a lane side by side -- a region's states in one go, as a rule --: the phase is eight dependent LDS round
+    // trips whatever the number of states a lane carries through them)
+    for (uint32_t j0 = T; j0 < c.Rn + wn; j0 += 12u * 64u * SC_WAVES) {
+      constexpr uint32_t NW = 12u;
+      uint32_t a[NW], ix[NW];
+      _Pragma("unroll") for (uint32_t t = 0; t < NW; t++) {
+        const uint32_t j = j0 + t * 64u * SC_WAVES;
+        ix[t] = j < c.Rn ? j : j < c.Rn + wn ? PE_RANKS + (j - c.Rn) : PE_STATES;   // the path states, then the closure's
+        a[t] = ix[t];
+      }
       _Pragma("unroll") for (int h = 0; h < 8; h++) {
-        uint32_t v[4];
-        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) v[t] = lds_ld16(pb + PE_NEXT + ((a[t] < PEN_FIRST_SPECIAL ? a[t] : 0u) << 1));
-        _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) a[t] = a[t] < PEN_FIRST_SPECIAL ? v[t] : (uint32_t)PEN_NONE;
+        // (a record that is no way on -- END, BYHAND -- is a number beyond the states: clamped, it reads the word behind the table,
+        // which says NONE, and stays there)
+        uint32_t v[NW];
+        _Pragma("unroll") for (uint32_t t = 0; t < NW; t++) v[t] = lds_ld16(pb + PE_NEXT + ((a[t] < PE_STATES ? a[t] : PE_STATES) << 1));
+        _Pragma("unroll") for (uint32_t t = 0; t < NW; t++) a[t] = v[t];
       }
       // (written behind a barrier: J1's room is read by nobody any more, the records are complete)
-      _Pragma("unroll") for (uint32_t t = 0; t < 4u; t++) {
-        const uint32_t i = i0 + t * 64u * SC_WAVES;
-        if (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) lds_st16(pb + PE_N8 + (i << 1), a[t] < PEN_FIRST_SPECIAL ? a[t] : (uint32_t)PEN_NONE);
-      }
+      _Pragma("unroll") for (uint32_t t = 0; t < NW; t++)
+        if (ix[t] < PE_STATES) lds_st16(pb + PE_N8 + (ix[t] << 1), a[t] < PEN_FIRST_SPECIAL ? a[t] : (uint32_t)PEN_NONE);
     }
     __syncthreads();
     if (PE_JUMP_LOG == 4) {
