@@ -975,7 +975,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
        HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */,
        HC_EXT_BASE = 13 /* LDS base of the command-record ring of the parse / copy split (SPX_BYTES, in the free tail of the table arena); 0 = this metablock has none */ };
-enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6 };  // HC_KIND
+enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6, HK_PATH2 = 7 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
        // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
@@ -1144,7 +1144,8 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
 }
 
 __device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
-__device__ __noinline__ uint32_t path_engine(const uint32_t me_);
+namespace pe16 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }   // one engine of sixteen waves
+namespace pe8 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }    // two engines of eight, regions in turns
 // which command engine blocks of sixteen waves use: 0 = the path engine where it applies (brotli_path_engine.h), 1 = the scan
 // engine only (experiments, A/B tests: BROTLI_AMD_ENGINE=scan)
 __device__ uint32_t g_engine_mode = 2;
@@ -1315,7 +1316,8 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     lds_acquire();
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
-    if (kind == HK_PATH) { path_engine(me); continue; }
+    if (kind == HK_PATH) { pe16::path_engine(me); continue; }
+    if (kind == HK_PATH2) { pe8::path_engine(me); continue; }
     if (kind == HK_SPLIT) {  // a context-modelled metablock: wave 1 copies (if asked to), wave 2 parses command records; the others go back to sleep
       if (rfl(me) == 1u && (g_engine_mode & 2u) == 0u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave();
       continue;
@@ -1784,7 +1786,25 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 }
 
 #include "brotli_scan_engine.h"
+#define PE_CFG_NS pe16
+#define PE_CFG_WAVES 16
+#define PE_CFG_RBL 32768
+#define PE_CFG_PIPE 0
 #include "brotli_path_engine.h"
+#undef PE_CFG_NS
+#undef PE_CFG_WAVES
+#undef PE_CFG_RBL
+#undef PE_CFG_PIPE
+#define PE_CFG_NS pe8
+#define PE_CFG_WAVES 8
+#define PE_CFG_RBL 16384
+#define PE_CFG_PIPE 1
+#include "brotli_path_engine.h"
+#undef PE_CFG_NS
+#undef PE_CFG_WAVES
+#undef PE_CFG_RBL
+#undef PE_CFG_PIPE
+using pe16::PE_MIN_INPUT;
 
 // The pending copy of the lean loop lives in registers the compiler does not know about: v[120:123] (16 bytes per lane)
 // and v124 (one byte per lane), named in inline asm only.  As C++ variables they were shuffled through other registers
@@ -3068,6 +3088,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
   const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
   uint32_t scan_fails = 0;
+  bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
   // ahead of this wave (rec_wave; the lean loop takes commands out of them); on request (BROTLI_AMD_ENGINE=split) wave 1 executes
   // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
@@ -3125,16 +3146,19 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         sc_ctl_st(sb, SCC_DT0, LDS_FIXED + dt0); sc_ctl_st(sb, SCC_DT0 + 1, LDS_FIXED + dt1); sc_ctl_st(sb, SCC_DT0 + 2, LDS_FIXED + dt2); sc_ctl_st(sb, SCC_DT0 + 3, LDS_FIXED + dt3);
         sc_ctl_st(sb, SCC_POSTFIX, postfix_bits); sc_ctl_st(sb, SCC_NUM_DIRECT, num_direct);
         sc_ctl_st(sb, SCC_OUT_LO, (uint32_t)(uintptr_t)out); sc_ctl_st(sb, SCC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
-        hc_st(HC_KIND, use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
+        const bool use_pipe = use_path && (g_engine_mode & 8u) != 0u && !prefer_one_engine;   // (two engines of eight waves, regions in turns: BROTLI_AMD_ENGINE=path2 -- measured slower than one of sixteen, see DESIGN)
+        hc_st(HC_KIND, use_pipe ? (uint32_t)HK_PATH2 : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
-        const uint32_t took = use_path ? rfl(path_engine(0)) : rfl(scan_engine(0));
+        const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+        prefer_one_engine = false;
         engine_commands += took;
         {  // the literal rounds' mailbox words lie in the engine's rings: back to their idle state
           const uint32_t hb_ = hc_ld(HC_BASE);
           for (uint32_t t = lane; t < SC_WAVES * 16u; t += 64u) lds_st32(hb_ + (t >> 4) * HL_SLOT + HL_CTL + 4u * (t & 15u), 0u);
         }
-        const uint32_t form = LEAN_LD(L_SC_POS_HI);
+        const uint32_t form_raw = LEAN_LD(L_SC_POS_HI), form = form_raw & 0xFFu;
+        const bool declined = (form_raw >> 8) != 0u;   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
         br.seek(pos);
@@ -3147,7 +3171,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         lit_pos = P;
         force_checked = form == SCX_BEGIN ? 1u : 0u;  // (the command the engine stopped IN FRONT OF goes through the checked stages; one it stopped inside is on its way through them already)
         // (an invocation that got nowhere -- few commands AND few bytes: a long literal run is one command -- makes the next ones rarer)
-        if (took < 64u && P - P_before < 4096u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
+        if (declined) { prefer_one_engine = true; force_checked = 0u; }
+        else if (took < 64u && P - P_before < 4096u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
         insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
         distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
         lds_sync();
@@ -4224,7 +4249,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("\npath engine dependent copies: %llu per region, the last wave's ticks in them %llu per region\n", g_path_prof[35] / g_path_prof[20], g_path_prof[34] / g_path_prof[20]);
     printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);
-    { unsigned long long eng = 0; for (int k = 0; k <= 11; k++) eng += g_path_prof[k]; eng += g_path_prof[17] + g_path_prof[18];
+    printf("\npath engine, two engines (engine 0's wave 0, ticks per region): waiting for the window %llu, for the stream %llu, for the region before's output %llu\n", g_path_prof[15] / g_path_prof[20], g_path_prof[16] / g_path_prof[20], g_path_prof[14] / g_path_prof[20]);
+    { unsigned long long eng = 0; for (int k = 0; k <= 11; k++) eng += g_path_prof[k]; eng += g_path_prof[14] + g_path_prof[15] + g_path_prof[16]; eng += g_path_prof[17] + g_path_prof[18];
       printf("\nkernel ticks of block 0 in this launch: %llu; the path engine's regions so far (all launches): %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0), eng); }
   }
 #endif
@@ -4248,7 +4274,8 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
     if (eng != nullptr) {
       // bit 0: the scan engine only; bit 1: no copier wave for context-modelled metablocks (the default: it does not pay, see DESIGN;
       // "split" turns it on); bit 2: no command records ("norec")
-      const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : 2u;
+      // bit 3: the path engine as two engines of eight waves that take the stream's regions in turns ("path2"; experiment)
+      const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : 2u;
       hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
       if (e2 != hipSuccess) return e2;
     }

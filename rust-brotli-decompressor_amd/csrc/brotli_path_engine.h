@@ -32,23 +32,25 @@
 //
 // Nothing depends on a guess: a record is the exact parse of its state or a marker (END: the parse leaves the region;
 // BYHAND: a cap was hit), and the walk starts at the stream's real position.
-#pragma once
+// (no include guard: brotli_kernels.hip includes this file once per configuration -- PE_CFG_NS the namespace, PE_CFG_WAVES the
+// waves of one engine, PE_CFG_RBL its region in stream bits, PE_CFG_PIPE whether two engines of a block take turns)
+#if !defined(PE_CFG_NS) || !defined(PE_CFG_WAVES) || !defined(PE_CFG_RBL) || !defined(PE_CFG_PIPE)
+#error "brotli_path_engine.h: configuration macros missing"
+#endif
+namespace PE_CFG_NS {
+constexpr uint32_t GW = PE_CFG_WAVES;             // waves of one engine
+constexpr bool PIPE = PE_CFG_PIPE != 0;           // two engines of GW waves a block, taking the stream's regions in turns
+static_assert(PIPE ? 2u * GW == SC_WAVES : GW == SC_WAVES, "engines and waves of a block");
 
-constexpr uint32_t PE_RBL = 32768;                // stream bits per region (local bit 0 = the dword the entry lies in)
+constexpr uint32_t PE_RBL = PE_CFG_RBL;           // stream bits per region (local bit 0 = the first bit of the region's first dword)
 constexpr uint32_t PE_CHUNKS = PE_RBL / 32;       // one lane per chunk of 32 bits: the whole block
-constexpr uint32_t PE_RANKS = 6656;               // path positions of a region at most (the region is cut where they run out)
-#ifndef BROTLI_AMD_PE_WCAP
-#define BROTLI_AMD_PE_WCAP 8192
-#endif
-constexpr uint32_t PE_WCAP = BROTLI_AMD_PE_WCAP;  // closure states at most (records that would need more say BYHAND)
+constexpr uint32_t PE_RANKS = PE_RBL / 64u * 13u;  // path positions of a region at most (the region is cut where they run out): 6656 of 32 Kbit
+constexpr uint32_t PE_WCAP = PE_RBL / 4u;         // closure states at most (records that would need more say BYHAND)
 constexpr uint32_t PE_STATES = PE_RANKS + PE_WCAP;
-#ifndef BROTLI_AMD_PE_GROW_BELOW
-#define BROTLI_AMD_PE_GROW_BELOW (PE_WCAP / 4u)
-#endif
-constexpr uint32_t PE_GROW_BELOW = BROTLI_AMD_PE_GROW_BELOW;  // closure states below which a region that had been halved takes twice the bits again
+constexpr uint32_t PE_GROW_BELOW = PE_WCAP / 4u;  // closure states below which a region that had been halved takes twice the bits again
 constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluation takes; a run that needs more goes on in the lane's next evaluation
-constexpr uint32_t PE_SYNC_ROUNDS = SC_WAVES + 1;  // rounds between waves the chunk entries get to settle: enough for any code
-constexpr uint32_t PE_CMDS = 1024;                // commands one region's walk lists at most
+constexpr uint32_t PE_SYNC_ROUNDS = GW + 1;  // rounds between waves the chunk entries get to settle: enough for any code
+constexpr uint32_t PE_CMDS = PE_RBL / 32u;          // commands one region's walk lists at most
 constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this long are stored by their command's lane, four bytes a step
 #ifndef BROTLI_AMD_PE_LANE_COPY
 #define BROTLI_AMD_PE_LANE_COPY 16
@@ -57,7 +59,11 @@ constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this
 static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
 constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own: the path's literals are the run's
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
-static_assert(PE_CHUNKS == 64u * SC_WAVES, "one chunk per lane of the block");
+constexpr uint32_t PE_PIPE_MARGIN = 1024;          // two engines: a region's tables start this many bits in front of where the stream is expected to enter it
+constexpr uint32_t PE_PIPE_USEFUL = 4096;          // ... and are used if the stream enters them with at least this many bits to go
+constexpr uint32_t PE_PIPE_HAND = 48;              // ... and the walk evaluates this many states itself before the stream is on the path (commands without literals, one after the other)
+constexpr uint32_t PE_PIPE_DECLINE = 2500;         // ... and a literal run from here on is the one-engine form's (its regions hold 6656 path positions, these half)
+static_assert(PE_CHUNKS == 64u * GW, "one chunk per lane of the block");
 
 // LDS layout, offsets from the engine's base (the scan engine's: the two never run at the same time)
 constexpr uint32_t PE_CTL = 0;                                    // 1024: control words (the first 32 as the scan engine's), the stream's state
@@ -70,16 +76,13 @@ constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per sta
 constexpr uint32_t PE_JUMP_LOG = BROTLI_AMD_PE_JUMP_LOG, PE_JUMP = 1u << PE_JUMP_LOG;  // commands a hop of the walk (8 or 16)
 static_assert(PE_JUMP_LOG == 3 || PE_JUMP_LOG == 4, "the walk's hop");
 constexpr uint32_t PE_STG = PE_J1F;                               // the region's output while it is put together (execute), where it fits: see PE_STG_CAP
-#ifndef BROTLI_AMD_PE_STG_CAP
-#define BROTLI_AMD_PE_STG_CAP 32768
-#endif
-constexpr uint32_t PE_STG_CAP = BROTLI_AMD_PE_STG_CAP;            // output bytes of a region that is put together in LDS and written out in one piece (0: never)
+constexpr uint32_t PE_STG_CAP = PE_RBL;            // output bytes of a region that is put together in LDS and written out in one piece (0: never)
 static_assert(PE_STG_CAP <= PE_RBL, "the stage lives in J1's room");
 constexpr uint32_t PE_PM = PE_J1F + PE_RBL + 64;                  // u32 per chunk: which of its bits are on the path; later OFF
 constexpr uint32_t PE_OFF = PE_PM;                                // u32 per listed command: where its output starts (from the region's)
 constexpr uint32_t PE_CB = PE_PM + PE_CHUNKS * 4;                 // u16 per chunk: path positions in front of it
-constexpr uint32_t PE_EX = PE_CB + PE_CHUNKS * 2 + 16;            // 2 x u8 per chunk: where the chain leaves it (two buffers)
-constexpr uint32_t PE_POR = PE_EX + 2 * PE_CHUNKS + 16;           // u16 per rank: its bit
+constexpr uint32_t PE_EX = PE_CB + PE_CHUNKS * 2 + 16;            // u8 per wave: where the chain leaves its last chunk (two buffers of 64)
+constexpr uint32_t PE_POR = PE_EX + 2 * 64 + 32;                   // u16 per rank: its bit   (PE_EX: two buffers of a byte per wave)
 constexpr uint32_t PE_LIT = PE_POR + PE_RANKS * 2;                // u8 per rank: its literal
 constexpr uint32_t PE_NEXT = PE_LIT + PE_RANKS;                   // u16 per state: the state its command's literals end in
 constexpr uint32_t PE_WST = PE_NEXT + PE_STATES * 2 + 16;         // u16 per closure state: bit | kind << 15; later the commands' records.  (The word in between, NEXT[PE_STATES], says PEN_NONE:
@@ -92,34 +95,48 @@ constexpr uint32_t PE_WSTB = PE_WCAP * 2 > PE_CMDS * 16 ? PE_WCAP * 2 : PE_CMDS 
 constexpr uint32_t PE_LIST = PE_WST + PE_WSTB;                    // u16 per listed command (+ 1): its state as bit | kind << 15
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
 constexpr uint32_t PE_TAILQ = PE_LIST;                              // u16 per state the bulk of the records left for the thin end (list and anchors are not in use then)
-constexpr uint32_t PE_TAILCAP = 1024;
+constexpr uint32_t PE_TAILCAP = PE_CMDS;
 #ifndef BROTLI_AMD_PE_POLL_SLEEP
 #define BROTLI_AMD_PE_POLL_SLEEP 2   // (x 64 clocks between two looks at what the walk has published)
 #endif
 #ifndef BROTLI_AMD_PE_TAIL_WAVES
-#define BROTLI_AMD_PE_TAIL_WAVES 16
+#define BROTLI_AMD_PE_TAIL_WAVES 16   /* (all of an engine's, whatever their number) */
 #endif
 #ifndef BROTLI_AMD_PE_TAIL_AT
 #define BROTLI_AMD_PE_TAIL_AT 80
 #endif
 constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see the thin end of the records through
 constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
-constexpr uint32_t PE_TD = PE_ANCH + 128 * 4;                    // u16 per entry of the distance code's table: the same two levels, a leaf's value = bits of the whole distance code (symbol + extra)
+constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine's tables
+// What the engines of a block share: the invocation's parameters, the stream's state, the records' two tables.  One engine: at the
+// end of its tables (the control words are its own); two engines: in front of theirs, with a block of control words of its own.
 constexpr uint32_t PE_TD_ENTRIES = 1024;                          // (920 is the most a distance alphabet without large window takes)
+constexpr uint32_t PE_SHARED_CTL = PIPE ? 1024u : 0u;             // the shared control words (two engines)
+constexpr uint32_t PE_TD = PIPE ? PE_SHARED_CTL : PE_SET_BYTES;   // u16 per entry of the distance code's table: the same two levels, a leaf's value = bits of the whole distance code (symbol + extra)
 constexpr uint32_t PE_TC = PE_TD + PE_TD_ENTRIES * 2;             // u32 per command symbol: insert base | insert extra bits << 15 | copy extra bits << 20 | implicit distance << 25
-constexpr uint32_t PE_BYTES = PE_TC + 704 * 4;
+constexpr uint32_t PE_SET0 = PIPE ? PE_TC + 704 * 4 : 0u;         // the first engine's tables
+constexpr uint32_t PE_BYTES = PIPE ? PE_SET0 + 2u * PE_SET_BYTES : PE_TC + 704 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_WCAP * 2 <= PE_WSTB && PE_CMDS * 4 <= PE_CHUNKS * 4 && PE_STATES % 8 == 0, "overlays");
-static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0 && PE_TD % 4 == 0 && PE_TC % 4 == 0, "alignment");
+static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0 && PE_TD % 4 == 0 && PE_TC % 4 == 0 && PE_SET0 % 16 == 0 && PE_SET_BYTES % 16 == 0, "alignment");
 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
        PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
-       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */, PEC_SCRATCH = 130 /* stores that are not meant land here */ };
+       PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */, PEC_SCRATCH = 130 /* stores that are not meant land here */, PEC_GBAR = 131 /* the engine's barrier: arrivals so far */,
+       // two engines (words of the shared block): what they tell each other
+       PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
+       PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
+       PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
+#ifndef BROTLI_AMD_PATH_PROF_DEFINED
+#define BROTLI_AMD_PATH_PROF_DEFINED
+}  // namespace
 __device__ unsigned long long g_path_prof[40];
+namespace PE_CFG_NS {
+#endif
 #define PE_PROF(k) do { if (me == 0) { uint64_t _t = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0) pp_acc[k] += _t - pp_t; pp_t = _t; } } while (0)
 #define PE_COUNT(k, v) do { if (me == 0 && blockIdx.x == 0) pp_acc[k] += (v); } while (0)
 #define PE_LANECOUNT(k, cond) do { if (blockIdx.x == 0 && (cond)) atomicAdd(&g_path_prof[k], 1ull); } while (0)
@@ -190,7 +207,7 @@ __device__ __forceinline__ void pe_st_store(uint32_t pb, const PeStream& st) {
 
 // What every phase needs to know about the region (uniform)
 struct PeCtx {
-  uint32_t pb, lit_tree, cmd_tree, dtree, postfix_bits, num_direct, lut_vgpr;
+  uint32_t pb, td, tc, lit_tree, cmd_tree, dtree, postfix_bits, num_direct, lut_vgpr;   // (pb: the engine's tables; td, tc: the records' tables)
   uint32_t L;    // bits of the region that may be parsed (a record needs 128 in front of it)
   uint32_t Lp;   // the path ends in front of this bit
   uint32_t Rn;   // path positions
@@ -427,14 +444,14 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
   {
     // the distance code at the state's bit: its length (a state of kind I has none: the read is harmless)
     uint32_t e[NS];
-    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = lds_ld16(pb + PE_TD + ((lo[t] & 0xFFu) << 1));
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = lds_ld16(c.td + ((lo[t] & 0xFFu) << 1));
     SC_STAGE();
     if (__ballot((e[0] & 15u) > ROOT_BITS || (e[NS - 1u] & 15u) > ROOT_BITS) != 0ull) {
       uint32_t e2[NS];
       _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
         const uint32_t Ld = e[t] & 15u;
         const uint32_t idx = Ld > ROOT_BITS ? (e[t] >> 4) + __builtin_amdgcn_ubfe(lo[t], ROOT_BITS, Ld - ROOT_BITS) : (lo[t] & 0xFFu);
-        e2[t] = lds_ld16(pb + PE_TD + (idx << 1));
+        e2[t] = lds_ld16(c.td + (idx << 1));
       }
       SC_STAGE();
       _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) e[t] = e2[t];   // (a leaf of the first level is read again: the same entry)
@@ -460,7 +477,7 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
       _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) if ((e[t] & 15u) > ROOT_BITS) e[t] = (e2[t] & ~15u) | ((e2[t] & 15u) + ROOT_BITS);   // (a code word is at most fifteen bits long)
     }
     uint32_t tc[NS];
-    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) tc[t] = lds_ld32(pb + PE_TC + ((e[t] >> 4) << 2));
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) tc[t] = lds_ld32(c.tc + ((e[t] >> 4) << 2));
     SC_STAGE();
     _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
       const uint32_t Lh = e[t] & 15u, ib = (tc[t] >> 15) & 31u, cb = (tc[t] >> 20) & 31u;
@@ -560,23 +577,46 @@ __device__ __forceinline__ PeParse pe_eval(const PeCtx& c, uint32_t pos, uint32_
     } } while (0)
 #endif
 
+// The barrier of one engine's waves.  One engine a block: the hardware's.  Two: a counter in the engine's control words that
+// only ever grows -- a wave adds one and waits until all GW have (s_barrier knows the block's waves only, and the other engine is
+// somewhere else in its region).  A wave that waits unreasonably long stops the kernel rather than the machine.
+#if PE_CFG_PIPE
+__device__ __forceinline__ void pe_spin_check(uint32_t& spins) { if (++spins > (1u << 24)) __builtin_trap(); }
+#define PE_SPIN_CHECK(s_) pe_spin_check(s_)
+__device__ __forceinline__ void pe_gbar(const uint32_t pb, uint32_t& target) {
+  target += GW;
+  const uint32_t old = pe_atomic_add_uniform(pb + PE_CTL + 4u * PEC_GBAR, 1u);   // (waits for this wave's LDS traffic: lgkmcnt(0))
+  if (old + 1u != target) { uint32_t spins = 0; while ((int32_t)(pe_ctl_ld(pb, PEC_GBAR) - target) < 0) { __builtin_amdgcn_s_sleep(1); pe_spin_check(spins); } }
+}
+#define PE_BAR() pe_gbar(pb, gb_target)
+#else
+#define PE_BAR() __syncthreads()
+#define PE_SPIN_CHECK(s_) do { } while (0)
+#endif
+
 // One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
 // Returns (wave 0) the number of commands it took; exit form and state in LDS_LEAN as the scan engine leaves them.
 __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   const uint32_t lane = lane_id();
-  const uint32_t me = rfl(me_);
-  const uint32_t T = threadIdx.x;
-  const uint32_t pb = hc_ld(HC_SCAN_BASE);
+  const uint32_t eng = PIPE ? rfl(me_) / GW : 0u;                 // the engine this wave belongs to
+  const uint32_t me = PIPE ? rfl(me_) % GW : rfl(me_);            // ... and its number in it
+  const uint32_t T = PIPE ? threadIdx.x % (64u * GW) : threadIdx.x;
+  const uint32_t pbs = hc_ld(HC_SCAN_BASE);                       // what the block's engines share
+  const uint32_t pb = pbs + PE_SET0 + eng * PE_SET_BYTES;         // this engine's tables
+  if (PIPE) {   // what the two engines tell each other starts from nothing
+    if (threadIdx.x < 8u) lds_st32(pbs + PE_CTL + 4u * (PEC_RESOLVED + threadIdx.x), 0u);
+    if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_GBAR, 0u);
+  }
   __syncthreads();  // the parameters are in place
 #ifdef BROTLI_AMD_PROFILE_SCAN
   uint64_t pp_acc[32] = {}; uint64_t pp_t = __builtin_amdgcn_s_memtime();
 #endif
   PeCtx c;
-  c.pb = pb;
-  c.lit_tree = pe_ctl_ld(pb, SCC_LIT_TREE); c.cmd_tree = pe_ctl_ld(pb, SCC_CMD_TREE); c.dtree = pe_ctl_ld(pb, SCC_DT0);
-  c.postfix_bits = pe_ctl_ld(pb, SCC_POSTFIX); c.num_direct = pe_ctl_ld(pb, SCC_NUM_DIRECT);
-  const uint32_t base_dw = pe_ctl_ld(pb, SCC_BASE_DW), in_limit = pe_ctl_ld(pb, SCC_IN_LIMIT);
-  gu8* const out = (gu8*)(uintptr_t)((uint64_t)pe_ctl_ld(pb, SCC_OUT_LO) | ((uint64_t)pe_ctl_ld(pb, SCC_OUT_HI) << 32));
+  c.pb = pb; c.td = pbs + PE_TD; c.tc = pbs + PE_TC;
+  c.lit_tree = pe_ctl_ld(pbs, SCC_LIT_TREE); c.cmd_tree = pe_ctl_ld(pbs, SCC_CMD_TREE); c.dtree = pe_ctl_ld(pbs, SCC_DT0);
+  c.postfix_bits = pe_ctl_ld(pbs, SCC_POSTFIX); c.num_direct = pe_ctl_ld(pbs, SCC_NUM_DIRECT);
+  const uint32_t base_dw = pe_ctl_ld(pbs, SCC_BASE_DW), in_limit = pe_ctl_ld(pbs, SCC_IN_LIMIT);
+  gu8* const out = (gu8*)(uintptr_t)((uint64_t)pe_ctl_ld(pbs, SCC_OUT_LO) | ((uint64_t)pe_ctl_ld(pbs, SCC_OUT_HI) << 32));
   gcu32* const in_dw = BitReader::base() + base_dw;
   const uint32_t limit_dw = (in_limit + 31u) >> 5;
   c.lut_vgpr = 0;
@@ -586,7 +626,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   // ---- wave 0: the stream's state (uniform), into its LDS words ----
   if (me == 0) {
     PeStream st;
-    st.b = pe_ctl_ld(pb, SCC_ENTRY);  // next command (bits from the engine's origin)
+    st.b = pe_ctl_ld(pbs, SCC_ENTRY);  // next command (bits from the engine's origin)
     st.P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
     st.quota = LEAN_LD(L_QUOTA); st.mlen = (int32_t)LEAN_LD(L_MLEN);
     st.bl0 = LEAN_LD(L_BL0); st.bl1 = LEAN_LD(L_BL1); st.bl2 = LEAN_LD(L_BL2);
@@ -597,24 +637,24 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     st.run_on = 0; st.run_rem = 0; st.run_copy = 0; st.run_implicit = 0; st.run_dctx = 0;
     st.rbl = PE_RBL;  // bits the next region takes: halved where the closure ran out of room, doubled back where it is small
     st.first = 1u;
-    pe_st_store(pb, st);
+    pe_st_store(pbs, st);
   }
   // ---- the records' tables (see pe_eval_rec) ----
-  for (uint32_t i = T; i < 704u; i += 64u * SC_WAVES) {
+  for (uint32_t i = threadIdx.x; i < 704u; i += 64u * SC_WAVES) {
     const uint32_t cell = i >> 6;
     const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((i >> 3) & 7u);
     const uint32_t copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (i & 7u);
-    lds_st32(pb + PE_TC + (i << 2), (uint32_t)kInsBase[ins_code] | ((uint32_t)kInsExtra[ins_code] << 15) | ((uint32_t)kCopyExtra[copy_code] << 20) | (i < 128u ? 1u << 25 : 0u));
+    lds_st32(c.tc + (i << 2), (uint32_t)kInsBase[ins_code] | ((uint32_t)kInsExtra[ins_code] << 15) | ((uint32_t)kCopyExtra[copy_code] << 20) | (i < 128u ? 1u << 25 : 0u));
   }
-  if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TDN, 256u);
+  if (threadIdx.x == 0u) lds_st32(pbs + PE_CTL + 4u * PEC_TDN, 256u);
   __syncthreads();
-  if (T < 256u) {
-    const uint32_t e = lds_ld16(c.dtree + (T << 1)), Ld = e & 15u;
-    if (Ld > ROOT_BITS) __hip_atomic_fetch_max(reinterpret_cast<pe_lds_u32*>(&g_smem[pb + PE_CTL + 4u * PEC_TDN]), (e >> 4) + (1u << (Ld - ROOT_BITS)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (threadIdx.x < 256u) {
+    const uint32_t e = lds_ld16(c.dtree + (threadIdx.x << 1)), Ld = e & 15u;
+    if (Ld > ROOT_BITS) __hip_atomic_fetch_max(reinterpret_cast<pe_lds_u32*>(&g_smem[pbs + PE_CTL + 4u * PEC_TDN]), (e >> 4) + (1u << (Ld - ROOT_BITS)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
-  const uint32_t td_n = pe_ctl_ld(pb, PEC_TDN);
-  for (uint32_t i = T; i < td_n && i < PE_TD_ENTRIES; i += 64u * SC_WAVES) {
+  const uint32_t td_n = pe_ctl_ld(pbs, PEC_TDN);
+  for (uint32_t i = threadIdx.x; i < td_n && i < PE_TD_ENTRIES; i += 64u * SC_WAVES) {
     uint32_t e = lds_ld16(c.dtree + (i << 1));
     const uint32_t l4 = e & 15u;
     if (i >= 256u || l4 <= ROOT_BITS) {   // a leaf: the symbol's bits and its extra bits (decode.rs:2099-2128)
@@ -623,53 +663,54 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t nb = (code >= 16u && dv >= 0) ? (((uint32_t)dv >> c.postfix_bits) >> 1) + 1u : 0u;
       e = l4 | ((Lw + nb) << 4);
     }
-    lds_st16(pb + PE_TD + (i << 1), e);
+    lds_st16(c.td + (i << 1), e);
   }
   const bool td_ok = td_n <= PE_TD_ENTRIES;   // (a table that does not fit: the engine leaves the metablock to the one-wave loop)
   uint32_t pre_a = 0, pre_b = 0; bool pre_ok = false;  // the next region's input dwords of this lane, once they are known
-  for (;;) {
-    // ================= the region =================
-    if (me == 0) {
-      const PeStream st = pe_st_load(pb);
-      const uint32_t lbdw = st.b >> 5;
-      const uint32_t avail = in_limit - (lbdw << 5);
-      const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
-      pe_ctl_st(pb, PEC_LBDW, lbdw); pe_ctl_st(pb, PEC_LE, st.b & 31u); pe_ctl_st(pb, PEC_L, avail < st.rbl ? avail : st.rbl);
-      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u); pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS); pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
-      pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
-      pe_ctl_st(pb, PEC_P0_LO, (uint32_t)st.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(st.P >> 32));
-      pe_ctl_st(pb, PEC_MODE, st.run_on); pe_ctl_st(pb, PEC_ENT, st.b & 31u);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the region before: its stores are in memory before anyone reads them as copy sources)
-    __syncthreads();
-    if (pe_ctl_ld(pb, PEC_GO) == 0u) break;
-    const uint32_t lbdw = pe_ctl_ld(pb, PEC_LBDW), le = pe_ctl_ld(pb, PEC_LE);
+  uint32_t lbdw = 0, le = 0, wn = 0; uint64_t P0 = 0;   // the region: its first dword, the entry's bit in it, its closure states, where its output starts
+  uint32_t gb_target = 0; (void)gb_target;               // (two engines: this engine's barriers so far, times GW)
+  uint32_t kseq = 0; (void)kseq;                         // (two engines: the number of the region this engine is at)
+  // What the region's tables start from (the engine's wave 0): the window and the counters of the phases.
+  auto setup_tables = [&](const uint32_t lbdw_, const uint32_t le_, const uint32_t bits, const uint32_t mode, const uint32_t ent_) {
+    pe_ctl_st(pb, PEC_LBDW, lbdw_); pe_ctl_st(pb, PEC_LE, le_); pe_ctl_st(pb, PEC_L, bits);
+    pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
+    pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
+    pe_ctl_st(pb, PEC_MODE, mode); pe_ctl_st(pb, PEC_ENT, ent_);
+  };
+  // ... and what the walk and what follows it start from: where the region's output begins, nothing published yet
+  auto setup_walk = [&](const uint64_t P_) {
+    pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
+    pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P_); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P_ >> 32));
+  };
+  // ================= the region's tables: input, J1, the path, the records, NEXT8 =================
+  // (0: there they are; 1: the region was one of a long literal run and is done, on to the next; 2: the invocation ends)
+  auto build = [&]() -> uint32_t {
+    lbdw = pe_ctl_ld(pb, PEC_LBDW); le = pe_ctl_ld(pb, PEC_LE);
     c.L = pe_ctl_ld(pb, PEC_L);
-    const uint64_t P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
     PE_COUNT(20, 1);
     // ---- input (asked for behind the resolve of the region before, where there was one) ----
-    if (!pre_ok) { pre_a = lbdw + T < limit_dw ? in_dw[lbdw + T] : 0u; pre_b = (T < 6u && lbdw + 1024u + T < limit_dw) ? in_dw[lbdw + 1024u + T] : 0u; }
+    if (!pre_ok) { pre_a = lbdw + T < limit_dw ? in_dw[lbdw + T] : 0u; pre_b = (T < 6u && lbdw + PE_CHUNKS + T < limit_dw) ? in_dw[lbdw + PE_CHUNKS + T] : 0u; }
     lds_st32(pb + PE_IN + (T << 2), pre_a);
-    if (T < 6u) lds_st32(pb + PE_IN + ((1024u + T) << 2), pre_b);
+    if (T < 6u) lds_st32(pb + PE_IN + ((PE_CHUNKS + T) << 2), pre_b);
     pre_ok = false;
-    __syncthreads();
+    PE_BAR();
     PE_PROF(0);
-    if (me == 0 && pe_ctl_ld(pb, PEC_STATE + 20) != 0u) {
+    if (!PIPE && me == 0 && pe_ctl_ld(pbs, PEC_STATE + 20) != 0u) {
       // the invocation's first region: is its first command one with a long literal run?  (later regions know from the resolve
       // of the region before)
-      PeStream st = pe_st_load(pb);
+      PeStream st = pe_st_load(pbs);
       st.first = 0u;
       if (c.L >= 256u) {
         PE_TRY_RUN(st, le);
         if (st.run_on != 0u) { pe_ctl_st(pb, PEC_MODE, 1u); pe_ctl_st(pb, PEC_ENT, st.b - (lbdw << 5)); }
       }
-      pe_st_store(pb, st);
+      pe_st_store(pbs, st);
     }
     // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
 #if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 1
     for (int rep_ = 0; rep_ < 2; rep_++)
 #endif
-    for (uint32_t g = T; g < PE_RBL / 8u; g += 64u * SC_WAVES) {
+    for (uint32_t g = T; g < PE_RBL / 8u; g += 64u * GW) {
       const uint32_t pos0 = g << 3;
       const uint32_t v = pe_bits32(pb, pos0);
       uint32_t e[8], Lw[8];
@@ -690,7 +731,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t w0 = Lw[0] | (Lw[1] << 8) | (Lw[2] << 16) | (Lw[3] << 24), w1 = Lw[4] | (Lw[5] << 8) | (Lw[6] << 16) | (Lw[7] << 24);
       lds_st32(pb + PE_J1F + pos0, w0); lds_st32(pb + PE_J1F + pos0 + 4u, w1);
     }
-    __syncthreads();
+    PE_BAR();
     PE_PROF(1);
     // ---- the path: chunk T's chain from its entry.  Inside a wave the entries settle through the lanes (a chunk's entry is
     // the exit of the chunk before: one cross-lane read a step, no barrier); between waves through LDS, a barrier a round.
@@ -740,14 +781,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       if (lane == 63u) lds_st8(pb + PE_EX + slot * 64u + me, ex);
       const uint32_t fw = pb + PE_CTL + 4u * (PEC_CHG + rounds % 3u);
       if (T == 0u) lds_st32(pb + PE_CTL + 4u * (PEC_CHG + (rounds + 1u) % 3u), 0u);
-      __syncthreads();
+      PE_BAR();
       const uint32_t ne = me == 0u ? 0u : rfl(lds_ld8(pb + PE_EX + slot * 64u + me - 1u));
       if (ne != wave_entry && lane == 0) lds_st32(fw, 1u);
       wave_entry = ne;
       rounds++;
-      __syncthreads();
+      PE_BAR();
       if (rfl(lds_ld32(fw)) == 0u) break;
-      if (rounds >= PE_SYNC_ROUNDS) { if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TMIN, 0u); __syncthreads(); break; }  // (cannot happen: see above; no path, no region)
+      if (rounds >= PE_SYNC_ROUNDS) { if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_TMIN, 0u); PE_BAR(); break; }  // (cannot happen: see above; no path, no region)
     }
     // the chunk's own path positions: the chain from its entry, out of the registers
     uint32_t pm = 0;
@@ -773,16 +814,16 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     uint32_t cnt = (uint32_t)__builtin_popcount(pm);
     uint32_t incl = sc_scan(cnt);
     if (lane == 63u) lds_st32(pb + PE_CTL + 4u * (PEC_WSUM + me), incl);
-    __syncthreads();
+    PE_BAR();
     uint32_t wbase = 0;
     {
-      const uint32_t ws = lane < SC_WAVES ? lds_ld32(pb + PE_CTL + 4u * (PEC_WSUM + lane)) : 0u;
+      const uint32_t ws = lane < GW ? lds_ld32(pb + PE_CTL + 4u * (PEC_WSUM + lane)) : 0u;
       const uint32_t wi = sc_scan(ws);
       wbase = rdlane(wi - ws, me);
     }
     uint32_t cb = wbase + incl - cnt;
     if (cb + cnt > PE_RANKS) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T);  // the ranks run out inside this chunk: the region ends in front of it
-    __syncthreads();
+    PE_BAR();
     const uint32_t tmin = pe_ctl_ld(pb, PEC_TMIN);
     if (T >= tmin) { pm = 0; cnt = 0; }
     if (T == tmin || (tmin == PE_CHUNKS && T == PE_CHUNKS - 1u)) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_RN]) = T == tmin ? cb : cb + cnt;
@@ -820,7 +861,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // sentinels: the sixteen bytes of J1 from Lp on carry the path flag, so that the records' hop loops stop there by themselves
     // (no path position lies there: nobody else writes them)
     if (T < 16u) lds_st8(pb + PE_J1F + c.Lp + T, lds_ld8(pb + PE_J1F + c.Lp + T) | 0x80u);
-    __syncthreads();
+    PE_BAR();
     c.Rn = pe_ctl_ld(pb, PEC_RN);
     PE_PROF(2);
     PE_COUNT(22, c.Rn);
@@ -829,39 +870,39 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // the region hold (one short of each limit: what happens AT a limit is the checked loop's), go out; the next region
       // starts behind them ----
       if (me == 0) {
-        const PeStream st = pe_st_load(pb);
+        const PeStream st = pe_st_load(pbs);
         uint32_t take = st.run_rem;
         const uint32_t cap1 = c.Rn != 0u ? c.Rn - 1u : 0u, cap2 = st.quota > 1u ? st.quota - 1u : 0u;
         take = take < cap1 ? take : cap1; take = take < st.bl0 ? take : st.bl0; take = take < cap2 ? take : cap2;
         pe_ctl_st(pb, PEC_TAKE, take);
       }
-      __syncthreads();
+      PE_BAR();
       const uint32_t take = pe_ctl_ld(pb, PEC_TAKE);
       {
         gu8* const o = out + P0;
-        for (uint32_t i = T << 2; i < take; i += 4u * 64u * SC_WAVES) {
+        for (uint32_t i = T << 2; i < take; i += 4u * 64u * GW) {
           const uint32_t v = lds_ld32(pb + PE_LIT + i);
           if (i + 4u <= take) *reinterpret_cast<gu32*>(o + i) = v;
           else { o[i] = (uint8_t)v; if (i + 1u < take) o[i + 1u] = (uint8_t)(v >> 8); if (i + 2u < take) o[i + 2u] = (uint8_t)(v >> 16); }
         }
       }
       if (me == 0) {
-        PeStream st = pe_st_load(pb);
+        PeStream st = pe_st_load(pbs);
         st.P += take; st.quota -= take; st.bl0 -= take; st.mlen -= (int32_t)take; st.run_rem -= take;
         const uint32_t np = take != 0u ? rfl(lds_ld16(pb + PE_POR + (take << 1))) : ent;
         st.b = (lbdw << 5) + np;
         pe_ctl_st(pb, PEC_CONT, (take != 0u && st.run_rem != 0u) ? 1u : 0u); pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
         PE_COUNT(19, take);
-        pe_st_store(pb, st);
+        pe_st_store(pbs, st);
       }
-      __syncthreads();
-      if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
+      PE_BAR();
+      if (pe_ctl_ld(pb, PEC_CONT) == 0u) return 2u;
       {
         const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
-        pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + 1024u + T < limit_dw) ? in_dw[nl + 1024u + T] : 0u;
+        pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + PE_CHUNKS + T < limit_dw) ? in_dw[nl + PE_CHUNKS + T] : 0u;
         pre_ok = true;
       }
-      continue;
+      return 1u;
     }
     // ---- records: every lane keeps two evaluations going side by side.  A lane that is through with a state takes the next
     // path position (kind E) off a shared counter; a lane whose record leads to a state that is not a path state (the run
@@ -965,15 +1006,15 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #define BROTLI_AMD_PE_BULK_NS 2
 #endif
     records_loop(std::integral_constant<uint32_t, BROTLI_AMD_PE_BULK_NS>{}, 0u, c.Rn);
-    __syncthreads();
+    PE_BAR();
     {
       const uint32_t tail_n = pe_ctl_ld(pb, PEC_TAILN) < PE_TAILCAP ? pe_ctl_ld(pb, PEC_TAILN) : PE_TAILCAP;
       if (me < PE_TAIL_WAVES && tail_n != 0u) records_loop(std::integral_constant<uint32_t, 1>{}, 1u, tail_n);
     }
-    __syncthreads();
+    PE_BAR();
     PE_COUNT(24, pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP);
-    const uint32_t wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
-    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pb, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_GROW_BELOW && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pb, PEC_STATE + 8, rbl); }
+    wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
+    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pbs, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_GROW_BELOW && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pbs, PEC_STATE + 8, rbl); }
     PE_PROF(4);
     // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
 #if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 4
@@ -981,11 +1022,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #endif
     // (twelve states a lane side by side -- a region's states in one go, as a rule --: the phase is eight dependent LDS round
     // trips whatever the number of states a lane carries through them)
-    for (uint32_t j0 = T; j0 < c.Rn + wn; j0 += 12u * 64u * SC_WAVES) {
+    for (uint32_t j0 = T; j0 < c.Rn + wn; j0 += 12u * 64u * GW) {
       constexpr uint32_t NW = 12u;
       uint32_t a[NW], ix[NW];
       _Pragma("unroll") for (uint32_t t = 0; t < NW; t++) {
-        const uint32_t j = j0 + t * 64u * SC_WAVES;
+        const uint32_t j = j0 + t * 64u * GW;
         ix[t] = j < c.Rn ? j : j < c.Rn + wn ? PE_RANKS + (j - c.Rn) : PE_STATES;   // the path states, then the closure's
         a[t] = ix[t];
       }
@@ -1000,14 +1041,14 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       _Pragma("unroll") for (uint32_t t = 0; t < NW; t++)
         if (ix[t] < PE_STATES) lds_st16(pb + PE_N8 + (ix[t] << 1), a[t] < PEN_FIRST_SPECIAL ? a[t] : (uint32_t)PEN_NONE);
     }
-    __syncthreads();
+    PE_BAR();
     if (PE_JUMP_LOG == 4) {
       // ... and from it the state sixteen commands on, in place: every thread its own states' (one in 1024), read before the
       // barrier, written behind it
-      constexpr uint32_t PER = (PE_STATES + 64u * SC_WAVES - 1u) / (64u * SC_WAVES);
+      constexpr uint32_t PER = (PE_STATES + 64u * GW - 1u) / (64u * GW);
       uint32_t b2[PER];
       _Pragma("unroll") for (uint32_t t = 0; t < PER; t++) {
-        const uint32_t i = T + t * 64u * SC_WAVES;
+        const uint32_t i = T + t * 64u * GW;
         const bool valid = i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn);
         b2[t] = valid ? lds_ld16(pb + PE_N8 + (i << 1)) : (uint32_t)PEN_NONE;
       }
@@ -1015,14 +1056,18 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         const uint32_t w2 = lds_ld16(pb + PE_N8 + ((b2[t] < PEN_FIRST_SPECIAL ? b2[t] : 0u) << 1));
         b2[t] = b2[t] < PEN_FIRST_SPECIAL ? w2 : (uint32_t)PEN_NONE;
       }
-      __syncthreads();
+      PE_BAR();
       _Pragma("unroll") for (uint32_t t = 0; t < PER; t++) {
-        const uint32_t i = T + t * 64u * SC_WAVES;
+        const uint32_t i = T + t * 64u * GW;
         if (i < c.Rn || (i >= PE_RANKS && i < PE_RANKS + wn)) lds_st16(pb + PE_N8 + (i << 1), b2[t] < PEN_FIRST_SPECIAL ? b2[t] : (uint32_t)PEN_NONE);
       }
-      __syncthreads();
+      PE_BAR();
     }
     PE_PROF(5);
+    return 0u;
+  };
+  // ================= the stream's way through the region: walk, details, resolve, execute =================
+  auto consume = [&]() {
     // ---- the walk (wave 0) and, behind it, the details (the other waves): the stream's states in order, LIST[k] = bit | kind << 15
     // of the state command k starts from.  Wave 0 follows the stream eight commands a hop (NEXT8 knows the way wherever the next
     // eight records are ordinary ones: everywhere but at the region's end) and publishes every anchor as it finds it; then
@@ -1031,14 +1076,38 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // anchors that span it are there (or the walk is over): lane = command, the state it starts from by following the anchor's
     // records, then its fields parsed once more, its distance from the state after.  The fields stay in the lane's registers:
     // the resolve below is by the same wave.
-    const uint32_t bw = (me + SC_WAVES - 1u) & (SC_WAVES - 1u);  // this wave's batch (wave 0, which walks, gets the last one)
+    const uint32_t bw = (me + GW - 1u) & (GW - 1u);  // this wave's batch (wave 0, which walks, gets the last one)
     uint32_t dr0 = 0, dr1 = 0, dr2 = 0, dr3 = 0;
     if (me == 0) {
       __builtin_amdgcn_s_setprio(3);  // (the walk is the one chain everybody waits for: first in line on its SIMD)
       uint32_t id = PE_RANKS, na = 0;
+      uint32_t id_hand = PEN_NONE;   // (two engines) the first of the states the walk added itself: NEXT8 does not know them
+      if (PIPE) {
+        // The tables were built before the stream's entry into the region was known: the state it enters in -- a command starts
+        // at bit `le` -- is evaluated here, and the states it leads to, until one of them is a path state (as a rule the first
+        // or the second).  They join the closure behind the ones the records put there.
+        uint32_t slot = wn, desc = le | 0x8000u;
+        id = PE_RANKS + slot; id_hand = id;
+        if (slot >= PE_WCAP) id = PEN_NONE;   // (no room for the entry's state: nothing listed, the checked loop's)
+        else for (uint32_t tries = 0;; tries++) {
+          if (lane == 0) lds_st16(pb + PE_WST + (slot << 1), desc);
+          if (tries >= PE_PIPE_HAND) { if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), PEN_BYHAND); break; }   // (the region ends in front of this state)
+          const PeParse pr = pe_eval<false, false>(c, desc & 0x7FFFu, desc >> 15, true);
+          const uint32_t cd = rfl(pr.code), nx = rfl(pr.next);
+          const bool more = cd == 1u && slot + 1u < PE_WCAP;
+          if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), cd == 0u ? nx : more ? PE_RANKS + slot + 1u : cd == 1u ? (uint32_t)PEN_BYHAND : (uint32_t)PEN_END);
+          if (!more) break;
+          desc = nx; slot++;
+        }
+        lds_sync();
+      }
       for (;;) {
-        const uint32_t n8 = rfl(lds_ld16(pb + PE_N8 + (id << 1)));
-        if (n8 >= PEN_FIRST_SPECIAL || na >= 960u / PE_JUMP) break;
+        uint32_t n8;
+        if (PIPE && id >= id_hand && id < PEN_FIRST_SPECIAL) {   // eight records on from a state NEXT8 has not seen (the walk's own): by the records
+          n8 = id;
+          for (uint32_t h = 0; h < PE_JUMP; h++) n8 = n8 < PEN_FIRST_SPECIAL ? rfl(lds_ld16(pb + PE_NEXT + (n8 << 1))) : (uint32_t)PEN_NONE;
+        } else n8 = id < PEN_FIRST_SPECIAL ? rfl(lds_ld16(pb + PE_N8 + (id << 1))) : (uint32_t)PEN_NONE;
+        if (n8 >= PEN_FIRST_SPECIAL || na >= (PE_CMDS - 64u) / PE_JUMP) break;
         if (lane == 0) {
           *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + (na << 2)]) = id;
           *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NAPUB]) = na + 1u;
@@ -1047,6 +1116,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
       uint32_t m = PE_JUMP * na, desc;
       for (;;) {
+        if (PIPE && id >= PEN_FIRST_SPECIAL) { desc = le | 0x8000u; break; }   // (no room for the entry's state: nothing listed)
         if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
         const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
         if (nx >= PEN_FIRST_SPECIAL || m >= PE_CMDS) break;
@@ -1057,6 +1127,13 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
       // the last command needs its distance: 64 bits at the closing state
       if (m != 0u && (desc >> 15) == 0u && (desc & 0x7FFFu) + 64u > c.L) m--;
+#ifdef BROTLI_AMD_PE_DEBUG
+      if (PIPE && blockIdx.x == 0 && lane == 0 && kseq >= 33u && kseq <= 36u) {
+        printf("   walk of region %u: le %u, id_hand %u, anchors %u, listed %u, closing state %x (id %u), L %u Lp %u\n", kseq, le, id_hand, na, m, desc, id, c.L, c.Lp);
+        for (uint32_t q = 0; q < 4u; q++) printf("     hand state %u: desc %x next %u\n", q, lds_ld16(pb + PE_WST + ((wn + q) << 1)), lds_ld16(pb + PE_NEXT + ((PE_RANKS + wn + q) << 1)));
+        for (uint32_t q = 0; q < (m < 12u ? m + 1u : 12u); q++) printf("     list %u: %x\n", q, lds_ld16(pb + PE_LIST + (q << 1)));
+      }
+#endif
       pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
       lds_sync();
       pe_ctl_st(pb, PEC_WDONE, 1u);
@@ -1107,7 +1184,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
       }
     }
-    __syncthreads();
+    PE_BAR();
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
     PE_PROF(7);
     // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
@@ -1119,7 +1196,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     const uint32_t nb = (m + 63u) >> 6;
     uint32_t my_exec = 0;  // commands of this wave's batch that are executed
     {
-      const PeStream st = pe_st_load(pb);
+      const PeStream st = pe_st_load(pbs);
       const bool mine = bw < nb;
       const uint32_t k0 = bw << 6;
       const uint32_t K = mine ? (m - k0 < 64u ? m - k0 : 64u) : 0u;
@@ -1177,7 +1254,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
       }
       if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_KP, m);
-      __syncthreads();
+      PE_BAR();
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
       int32_t d0 = st.d0, d1 = st.d1, d2 = st.d2, d3 = st.d3;
@@ -1211,7 +1288,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const bool bigc = (copy > PE_LANE_COPY && dep == 0u) || ins - uu > PE_LANE_LITS;
       const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc);
       if (mine && lane == 0) lds_st32(rs + 48u, (uint32_t)__popcll(dmk) | ((uint32_t)__popcll(bmk) << 16));
-      __syncthreads();
+      PE_BAR();
       const uint32_t kp_total = pe_ctl_ld(pb, PEC_KP);
       my_exec = !mine || kp_total <= k0 ? 0u : (kp_total - k0 < K ? kp_total - k0 : K);
       if (mine && my_exec != 0u) {
@@ -1248,17 +1325,17 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           PeStream sn = st;
           sn.P += out_tot; sn.bl0 -= lit_tot; sn.bl1 -= cmd_tot; sn.bl2 -= dst_tot; sn.quota -= out_tot; sn.mlen -= (int32_t)out_tot; sn.ncmd += cmd_tot;
           sn.d0 = e0; sn.d1 = e1; sn.d2 = e2; sn.d3 = e3;
-          pe_st_store(pb, sn);
+          pe_st_store(pbs, sn);
           pe_ctl_st(pb, PEC_ANYDEP, c_dep + (uint32_t)__popcll(dm2)); pe_ctl_st(pb, PEC_NBIG, c_big + (uint32_t)__popcll(bm2));
           pe_ctl_st(pb, PEC_OUTTOT, out_tot); pe_ctl_st(pb, PEC_STAGED, (PE_STG_CAP != 0u && out_tot <= PE_STG_CAP) ? 1u : 0u);
         }
       }
       if (kp_total == 0u && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); }  // (nothing executed: the state stays)
-      __syncthreads();
+      PE_BAR();
       if (me == 0) {
         // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
         // of the state it starts from)
-        PeStream sn = pe_st_load(pb);
+        PeStream sn = pe_st_load(pbs);
         const uint32_t dsc = rfl(lds_ld16(pb + PE_LIST + (kp_total << 1)));
         uint32_t pbit = dsc & 0x7FFFu;
         if ((dsc >> 15) == 0u) {
@@ -1269,14 +1346,40 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
         sn.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
         // the region went through whole and the next one starts at a command with a long literal run: the next regions are the run's
-        if (kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
+        if (!PIPE && kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
         pe_ctl_st(pb, PEC_NEXT_LBDW, sn.b >> 5);
         // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
-        pe_ctl_st(pb, PEC_CONT, (kp_total == m && m != 0u) ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
-        pe_st_store(pb, sn);
+        bool cont = kp_total == m && m != 0u;
+        if (PIPE && cont && pbit + 64u <= c.L) {
+          // (two engines: a command whose literal run wants regions of its own ends the invocation in front of it -- the one-engine
+          // form has those regions, and the caller is told to take it next)
+          uint32_t lo_, hi_;
+          pe_bits64(pb, pbit, lo_, hi_);
+          const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr);
+          if (rfl(h_.insert) >= PE_PIPE_DECLINE) { cont = false; pe_ctl_st(pbs, PEC_DECLINE, 1u); }
+        }
+#ifdef BROTLI_AMD_PE_DEBUG
+        if (PIPE && blockIdx.x == 0 && lane == 0) printf("   region %u: %u commands listed, %u executed, goes on at %u, cont %u, P now %llu ncmd %u\n", kseq, m, kp_total, sn.b, cont ? 1u : 0u, (unsigned long long)sn.P, sn.ncmd);
+#endif
+        pe_ctl_st(pb, PEC_CONT, cont ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
+        pe_st_store(pbs, sn);
+        if (PIPE) {
+          pe_ctl_st(pb, PEC_MYNEXT, sn.b);
+          // the stream's state is the next region's from here on; the invocation's end is everybody's to know first
+          lds_sync();
+          if (!cont) pe_ctl_st(pbs, PEC_STOP, 1u);
+          lds_sync();
+          pe_ctl_st(pbs, PEC_RESOLVED, kseq + 1u);
+        }
       }
     }
     PE_PROF(11);
+    if (PIPE) {
+      // the region before's output is in memory before this one's copies read it (its engine says so)
+      uint32_t spins = 0;
+      while (pe_ctl_ld(pbs, PEC_EXECUTED) < kseq) { __builtin_amdgcn_s_sleep(2); PE_SPIN_CHECK(spins); }
+      PE_PROF(14);
+    }
     // ---- execute ----
     {
       gu8* const o = out + P0;
@@ -1307,7 +1410,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #ifdef BROTLI_AMD_PE_NO_EXEC_SPLIT
       const bool exec_split = false;
 #else
-      const bool exec_split = nb <= 8u;
+      const bool exec_split = nb <= GW / 2u;
 #endif
       auto path_literals = [&](const uint32_t b, const uint32_t cnt) {
         const uint32_t k = (b << 6) + lane;
@@ -1384,19 +1487,19 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             }
           }
         }
-        if (!exec_split || bw >= 7u) path_literals(bw, my_exec);
-      } else if (exec_split && bw >= 8u && bw < 15u) {
-        const uint32_t b = bw - 8u;
+        if (!exec_split || bw >= GW / 2u - 1u) path_literals(bw, my_exec);
+      } else if (exec_split && bw >= GW / 2u && bw < GW - 1u) {
+        const uint32_t b = bw - GW / 2u;
         const uint32_t cnt = kp_all <= (b << 6) ? 0u : (kp_all - (b << 6) < 64u ? kp_all - (b << 6) : 64u);
         if (cnt != 0u) path_literals(b, cnt);
       }
-      __syncthreads();
+      PE_BAR();
       PE_PROF(8);
       const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
       PE_COUNT(28, kp);
-      if (pe_ctl_ld(pb, PEC_CONT) != 0u) {  // the next region's input is on its way while the rest of this one is executed
+      if (!PIPE && pe_ctl_ld(pb, PEC_CONT) != 0u) {  // the next region's input is on its way while the rest of this one is executed
         const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
-        pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + 1024u + T < limit_dw) ? in_dw[nl + 1024u + T] : 0u;
+        pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + PE_CHUNKS + T < limit_dw) ? in_dw[nl + PE_CHUNKS + T] : 0u;
         pre_ok = true;
       }
       // (b) the commands listed for it get a wave each: long literal runs out of lit[], long copies whose source lies in front
@@ -1436,9 +1539,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         auto big_store = [&](const uint32_t pt, const uint32_t pd, const uint32_t pn) {
           if (lane < pn) { if (staged) lds_st8(sg + pd + lane, pt); else o[pd + lane] = (uint8_t)pt; }
         };
-        for (uint32_t j0 = me; j0 < nbig; j0 += 3u * SC_WAVES) {
+        for (uint32_t j0 = me; j0 < nbig; j0 += 3u * GW) {
           uint32_t t0, d0, n0, t1, d1, n1, t2, d2, n2;
-          big_item(j0, t0, d0, n0); big_item(j0 + SC_WAVES, t1, d1, n1); big_item(j0 + 2u * SC_WAVES, t2, d2, n2);
+          big_item(j0, t0, d0, n0); big_item(j0 + GW, t1, d1, n1); big_item(j0 + 2u * GW, t2, d2, n2);
           big_store(t0, d0, n0); big_store(t1, d1, n1); big_store(t2, d2, n2);
         }
       }
@@ -1451,7 +1554,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         // Which of them only read what (a) and (b) wrote -- literals and copies from in front of the region?  Those whose
         // source does not touch the destination of an earlier dependent copy (destinations lie in command order: a binary
         // search), and that do not overlap themselves.  They go side by side, one wave each (bit 29 of w0); the rest in order.
-        for (uint32_t j = T; j < ndep; j += 64u * SC_WAVES) {
+        for (uint32_t j = T; j < ndep; j += 64u * GW) {
           const uint32_t k = lds_ld16(pb + PE_DLIST + (j << 1));
           const uint32_t ra = pb + PE_REC + (k << 4);
           const uint32_t cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
@@ -1477,8 +1580,8 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           if (ready) lds_st32(ra, lds_ld32(ra) | (1u << 29));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (uint32_t j = me; j < ndep; j += SC_WAVES) {
+        PE_BAR();
+        for (uint32_t j = me; j < ndep; j += GW) {
           const uint32_t k = rfl(lds_ld16(pb + PE_DLIST + (j << 1)));
           const uint32_t ra = pb + PE_REC + (k << 4);
           const uint32_t r0 = rfl(lds_ld32(ra));
@@ -1495,8 +1598,8 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (me == SC_WAVES - 1u) {
+        PE_BAR();
+        if (me == GW - 1u) {
 #ifdef BROTLI_AMD_PROFILE_SCAN
           const uint64_t dep_t0 = __builtin_amdgcn_s_memtime(); uint32_t dep_n = 0;
 #endif
@@ -1540,9 +1643,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       if (ndep != 0u) dependent_copies_in_order();
       if (staged) {
         // the region's output, out of the stage in one piece: sixteen bytes a thread and step
-        __syncthreads();
+        PE_BAR();
         const uint32_t tot = pe_ctl_ld(pb, PEC_OUTTOT);
-        for (uint32_t x = T << 4; x < tot; x += 16u * 64u * SC_WAVES) {
+        for (uint32_t x = T << 4; x < tot; x += 16u * 64u * GW) {
           const u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[sg + x]);
           if (x + 16u <= tot) *reinterpret_cast<gu32x4*>(o + x) = v;
           else {
@@ -1553,16 +1656,115 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
       PE_PROF(10);
     }
+    if (PIPE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PE_BAR();
+      if (T == 0u) { lds_sync(); pe_ctl_st(pbs, PEC_EXECUTED, kseq + 1u); }
+    }
+  };
+#if !PE_CFG_PIPE
+  for (;;) {
+    if (me == 0) {
+      const PeStream st = pe_st_load(pbs);
+      const uint32_t lbdw_ = st.b >> 5;
+      const uint32_t avail = in_limit - (lbdw_ << 5);
+      const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
+      pe_ctl_st(pb, PEC_GO, go ? 1u : 0u);
+      setup_tables(lbdw_, st.b & 31u, avail < st.rbl ? avail : st.rbl, st.run_on, st.b & 31u);
+      setup_walk(st.P);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the region before: its stores are in memory before anyone reads them as copy sources)
+    PE_BAR();
+    if (pe_ctl_ld(pb, PEC_GO) == 0u) break;
+    P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+    const uint32_t how = build();
+    if (how == 1u) continue;
+    if (how == 2u) break;
+    consume();
     if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
   }
+#else
+  // ---- two engines: the stream's regions in turns.  An engine builds the tables of its next region while the other one takes
+  // the stream through its own: the tables do not depend on where the stream enters the region (any chain of literal code
+  // words is a path: they re-synchronise; the records are per state), only the walk does -- it waits for the region before's
+  // resolve (PEC_RESOLVED), and the execute for the region before's output (PEC_EXECUTED).  Where a region's tables start is a
+  // guess: the engine's own last region, carried on by what the stream advanced in it, less a margin.  A guess the stream
+  // does not enter (it ended short of it, or too close to its end) costs the tables once more, built where the stream is.
+  {
+    const uint32_t entry0 = pe_ctl_ld(pbs, SCC_ENTRY);
+    for (kseq = eng;; kseq += 2u) {
+      // -- the window --
+      if (me == 0) {
+        uint32_t wbit = entry0;
+        if (kseq != 0u) {
+          // behind the region before's window, less the margin: a region's walk ends a command or two short of its window's end
+          // wherever it entered it (that window is final once its engine has seen the stream arrive: PEC_NFINAL)
+          uint32_t spins = 0;
+          while (pe_ctl_ld(pbs, PEC_NFINAL) < kseq && pe_ctl_ld(pbs, PEC_STOP) == 0u) { __builtin_amdgcn_s_sleep(2); PE_SPIN_CHECK(spins); }
+          lds_sync();
+          wbit = (pe_ctl_ld(pbs, PEC_WINF + ((kseq - 1u) & 1u)) << 5) + PE_RBL - PE_PIPE_MARGIN;
+        } else { pe_ctl_st(pbs, PEC_WINF, entry0 >> 5); lds_sync(); pe_ctl_st(pbs, PEC_NFINAL, 1u); }   // (the first region's is where the stream is)
+        const uint32_t W = wbit >> 5;
+        const uint32_t avail = (W << 5) < in_limit ? in_limit - (W << 5) : 0u;
+        const bool buildable = td_ok && avail >= PE_MIN_INPUT && pe_ctl_ld(pbs, PEC_STOP) == 0u;
+        setup_tables(W, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
+        pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u);
+      }
+      PE_BAR();
+      PE_PROF(15);   // (waiting for the window)
+      bool built = false;
+      if (pe_ctl_ld(pb, PEC_GO) != 0u) { (void)build(); built = true; }
+      // -- the stream arrives --
+      if (me == 0) {
+        uint32_t spins = 0;
+        while (pe_ctl_ld(pbs, PEC_RESOLVED) < kseq && pe_ctl_ld(pbs, PEC_STOP) == 0u) { __builtin_amdgcn_s_sleep(2); PE_SPIN_CHECK(spins); }
+        lds_sync();
+        uint32_t plan = 2u;   // 0: the tables are the ones, 1: once more where the stream is, 2: the invocation is over
+        if (pe_ctl_ld(pbs, PEC_RESOLVED) >= kseq && pe_ctl_ld(pbs, PEC_STOP) == 0u) {
+          const PeStream st = pe_st_load(pbs);
+          const uint32_t avail = st.b < in_limit ? in_limit - ((st.b >> 5) << 5) : 0u;
+          const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && st.bl1 != 0u;
+          if (go) {
+            const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L);
+            const bool usable = built && st.b >= w0 && st.b + PE_PIPE_USEFUL <= w0 + wl;
+            plan = usable ? 0u : 1u;
+            if (!usable) setup_tables(st.b >> 5, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
+            if (kseq != 0u) { pe_ctl_st(pbs, PEC_WINF + (kseq & 1u), usable ? w0 >> 5 : st.b >> 5); lds_sync(); pe_ctl_st(pbs, PEC_NFINAL, kseq + 1u); }
+          }
+        }
+        if (plan == 2u) pe_ctl_st(pbs, PEC_STOP, 1u);
+        pe_ctl_st(pb, PEC_PLAN, plan);
+      }
+      PE_BAR();
+      PE_PROF(16);   // (waiting for the stream)
+      const uint32_t plan = pe_ctl_ld(pb, PEC_PLAN);
+      if (plan == 2u) break;
+      if (plan == 1u) (void)build();
+      if (me == 0) {
+        const PeStream st = pe_st_load(pbs);
+        pe_ctl_st(pb, PEC_LE, st.b - (pe_ctl_ld(pb, PEC_LBDW) << 5));
+        pe_ctl_st(pb, PEC_MYENTRY, st.b); pe_ctl_st(pb, PEC_MYNEXT, st.b);
+        setup_walk(st.P);
+#ifdef BROTLI_AMD_PE_DEBUG
+        if (blockIdx.x == 0 && lane == 0) printf("region %u (engine %u): window dword %u, %u bits, entry %u (bit %u of it), plan %u, P %llu, bl1 %u, Rn %u wn %u\n", kseq, eng, pe_ctl_ld(pb, PEC_LBDW), pe_ctl_ld(pb, PEC_L), st.b, st.b - (pe_ctl_ld(pb, PEC_LBDW) << 5), plan, (unsigned long long)st.P, st.bl1, pe_ctl_ld(pb, PEC_RN), wn);
+#endif
+      }
+      PE_BAR();
+      le = pe_ctl_ld(pb, PEC_LE);
+      P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+      consume();
+      if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
+    }
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
-  if (me != 0) return 0;
+  if (rfl(me_) != 0u) return 0;
 #ifdef BROTLI_AMD_PROFILE_SCAN
-  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += pe_ctl_ld(pb, PEC_STATE + 6); g_path_prof[33] += 1; }
+  if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += pe_ctl_ld(pbs, PEC_STATE + 6); g_path_prof[33] += 1; }
 #endif
   // ---- hand the stream back in front of the next command (LDS_LEAN, as the scan engine does) ----
-  const PeStream st_ = pe_st_load(pb);
+  const PeStream st_ = pe_st_load(pbs);
   PeStream st = st_;
   if (st.run_on != 0u) {
     // inside a command whose literal run had regions of its own: the checked loop finishes its literals (what the limits kept
@@ -1580,7 +1782,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     return st.ncmd;
   }
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_BEGIN);
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
@@ -1589,3 +1791,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   lds_sync();
   return st.ncmd;
 }
+}  // namespace PE_CFG_NS
+#undef PE_PROF
+#undef PE_COUNT
+#undef PE_LANECOUNT
+#undef PE_TRY_RUN
+#undef PE_BAR
+#undef PE_SPIN_CHECK
