@@ -1331,6 +1331,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
       }
       if (kp_total == 0u && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); }  // (nothing executed: the state stays)
+      // (every wave's stores of the region before are in memory before anyone reads them as copy sources: here, a whole region's
+      // tables later, the wait is over before it starts -- at the region's start it cost the stores' round trip)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PE_BAR();
       if (me == 0) {
         // where the stream goes on: the first bit of command kp_total (its head: behind the distance code, if there is one,
@@ -1673,8 +1676,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       setup_tables(lbdw_, st.b & 31u, avail < st.rbl ? avail : st.rbl, st.run_on, st.b & 31u);
       setup_walk(st.P);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the region before: its stores are in memory before anyone reads them as copy sources)
-    PE_BAR();
+    PE_BAR();   // (the region before's stores: waited for in front of the execute, which is the first to read them -- see the resolve's last barrier)
     if (pe_ctl_ld(pb, PEC_GO) == 0u) break;
     P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
     const uint32_t how = build();
