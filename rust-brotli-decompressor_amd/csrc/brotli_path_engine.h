@@ -1101,6 +1101,30 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
         lds_sync();
       }
+#if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_NO_WALK_ASM)
+      {
+        // The anchors by hand: one dependent LDS read an anchor is all the chain asks for, and the compiled loop wrapped it in
+        // thirty-five instructions (the lane's own execution mask, the counter in a vector register): 330 clocks an anchor.
+        // Here lane 0 alone: the next anchor's read is on its way before this one is stored and published.
+        uint32_t vr, va, vt; uint64_t sv; uint32_t n8s, ts, aa = pb + PE_ANCH;
+        const uint32_t n8base = pb + PE_N8, pubaddr = pb + PE_CTL + 4u * PEC_NAPUB, cap = (PE_CMDS - 64u) / PE_JUMP;
+        asm volatile(
+          "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\t"
+          "s_lshl_b32 %[ts], %[id], 1\n\ts_add_u32 %[ts], %[ts], %[n8base]\n\tv_mov_b32 %[va], %[ts]\n\tds_read_u16 %[vr], %[va]\n"
+          ".Lpe_walk_%=:\n\t"
+          "s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %[n8s], %[vr]\n\t"
+          "s_cmp_ge_u32 %[n8s], 0xfff0\n\ts_cbranch_scc1 .Lpe_walk_done_%=\n\t"
+          "s_cmp_ge_u32 %[na], %[cap]\n\ts_cbranch_scc1 .Lpe_walk_done_%=\n\t"
+          "s_lshl_b32 %[ts], %[n8s], 1\n\ts_add_u32 %[ts], %[ts], %[n8base]\n\tv_mov_b32 %[va], %[ts]\n\tds_read_u16 %[vr], %[va]\n\t"
+          "v_mov_b32 %[vt], %[id]\n\tv_mov_b32 %[va], %[aa]\n\tds_write_b32 %[va], %[vt]\n\t"
+          "s_add_u32 %[na], %[na], 1\n\ts_add_u32 %[aa], %[aa], 4\n\t"
+          "v_mov_b32 %[vt], %[na]\n\tv_mov_b32 %[va], %[pub]\n\tds_write_b32 %[va], %[vt]\n\t"
+          "s_mov_b32 %[id], %[n8s]\n\ts_branch .Lpe_walk_%=\n"
+          ".Lpe_walk_done_%=:\n\ts_mov_b64 exec, %[sv]"
+          : [id] "+s"(id), [na] "+s"(na), [aa] "+s"(aa), [vr] "=&v"(vr), [va] "=&v"(va), [vt] "=&v"(vt), [sv] "=&s"(sv), [n8s] "=&s"(n8s), [ts] "=&s"(ts)
+          : [n8base] "s"(n8base), [pub] "s"(pubaddr), [cap] "s"(cap) : "scc", "memory");
+      }
+#else
       for (;;) {
         uint32_t n8;
         if (PIPE && id >= id_hand && id < PEN_FIRST_SPECIAL) {   // eight records on from a state NEXT8 has not seen (the walk's own): by the records
@@ -1114,17 +1138,30 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         }
         na++; id = n8;
       }
+#endif
+      // ... then the commands behind the last anchor, up to the first record that is no way on: lane j follows the records j
+      // commands on (the lanes side by side: a dozen dependent reads for all of them, where one command after the other by the
+      // wave as a whole cost a third of the walk), the list's entries are theirs
+      if (!PIPE) PE_PROF(15);   // (one engine: the anchors)
       uint32_t m = PE_JUMP * na, desc;
-      for (;;) {
-        if (PIPE && id >= PEN_FIRST_SPECIAL) { desc = le | 0x8000u; break; }   // (no room for the entry's state: nothing listed)
-        if (id < PE_RANKS) desc = rfl(lds_ld16(pb + PE_POR + (id << 1))); else desc = rfl(lds_ld16(pb + PE_WST + ((id - PE_RANKS) << 1)));
-        const uint32_t nx = rfl(lds_ld16(pb + PE_NEXT + (id << 1)));
-        if (nx >= PEN_FIRST_SPECIAL || m >= PE_CMDS) break;
-        if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
-        m++; id = nx;
+      if (PIPE && id >= PEN_FIRST_SPECIAL) desc = le | 0x8000u;   // (no room for the entry's state: nothing listed)
+      else for (;;) {
+        uint32_t sv = id;
+        for (uint32_t h = 0; h < 63u; h++) {
+          const uint32_t nxv = lds_ld16(pb + PE_NEXT + ((sv < PE_STATES ? sv : PE_STATES) << 1));   // (a record that is no way on reads the sentinel: NONE)
+          if (lane > h) sv = nxv;
+          if (rdlane(sv, h + 1u) >= PEN_FIRST_SPECIAL) break;
+        }
+        const uint32_t svc = sv < PE_STATES ? sv : PE_STATES;
+        const uint32_t nxv = lds_ld16(pb + PE_NEXT + (svc << 1));
+        const uint32_t dv = lds_ld16(pb + (svc < PE_RANKS ? PE_POR + (svc << 1) : svc < PE_STATES ? PE_WST + ((svc - PE_RANKS) << 1) : PE_CTL + 4u * PEC_SCRATCH));
+        const uint64_t lm = __ballot(sv < PEN_FIRST_SPECIAL && nxv < PEN_FIRST_SPECIAL && m + lane < PE_CMDS);
+        const uint32_t J = ~lm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~lm);   // commands listed here: lanes 0 .. J - 1; lane J's state closes the list
+        if (lane <= J && lane < 64u && sv < PEN_FIRST_SPECIAL) lds_st16(pb + PE_LIST + ((m + lane) << 1), dv);
+        if (J < 64u) { m += J; desc = rdlane(dv, J); id = rdlane(sv, J); break; }
+        m += 64u; id = rdlane(nxv, 63);
       }
-      // the state the walk stopped at closes the list (the last command's distance is read there)
-      if (lane == 0) lds_st16(pb + PE_LIST + (m << 1), desc);
+      if (!PIPE) PE_PROF(16);   // (one engine: the commands behind the last anchor)
       // the last command needs its distance: 64 bits at the closing state
       if (m != 0u && (desc >> 15) == 0u && (desc & 0x7FFFu) + 64u > c.L) m--;
 #ifdef BROTLI_AMD_PE_DEBUG
