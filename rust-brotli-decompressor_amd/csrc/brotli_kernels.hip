@@ -4235,6 +4235,14 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("scan engine exits: input ends %llu, counts/limits %llu, distance %llu, by-hand precheck %llu, long run %llu; invocations that took < 64 commands %llu\n",
            g_scan_prof[18], g_scan_prof[19], g_scan_prof[20], g_scan_prof[21], g_scan_prof[22], g_scan_prof[23]);
 #endif
+#ifdef BROTLI_AMD_PROFILE_WAVES
+  if (blockIdx.x == 0 && lane_id() == 0)
+    for (int k = 0; k < 96; k++) if (g_wave_prof[k][16] != 0) {
+      printf("barrier %2d (%llu times): ticks of waves 0..15 in front of it:", k, g_wave_prof[k][16]);
+      for (int w = 0; w < 16; w++) printf(" %llu", g_wave_prof[k][w] / g_wave_prof[k][16]);
+      printf("\n");
+    }
+#endif
 #ifdef BROTLI_AMD_PROFILE_SCAN
   if (blockIdx.x == 0 && lane_id() == 0 && g_path_prof[33] != 0) {
     printf("\npath engine: %llu invocations, %llu regions, %llu commands (%llu listed, %llu executed); wave 0 ticks per region: input %llu J1 %llu path %llu records %llu closure %llu next8 %llu walk %llu details %llu resolve %llu execute %llu own copies %llu\n",

@@ -128,7 +128,8 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        // two engines (words of the shared block): what they tell each other
        PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
-       PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */ };
+       PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
+       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ };
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 #ifndef BROTLI_AMD_PATH_PROF_DEFINED
@@ -590,7 +591,20 @@ __device__ __forceinline__ void pe_gbar(const uint32_t pb, uint32_t& target) {
 }
 #define PE_BAR() pe_gbar(pb, gb_target)
 #else
+#ifdef BROTLI_AMD_PROFILE_WAVES
+// (profile: what every wave of block 0 spends between two barriers -- its ticks from the release of one to its arrival at the next,
+// by the barrier's place in the source; the slowest wave of a step is the one the block waits for)
+#ifndef BROTLI_AMD_WAVE_PROF_DEFINED
+#define BROTLI_AMD_WAVE_PROF_DEFINED
+}  // namespace
+__device__ unsigned long long g_wave_prof[96][17];
+namespace PE_CFG_NS {
+#endif
+#define PE_BAR() do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0) { g_wave_prof[__COUNTER__ % 96][me] += t_ - wp_t; if (me == 0) g_wave_prof[(__COUNTER__ - 1) % 96][16] += 1; } \
+                      __syncthreads(); wp_t = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define PE_BAR() __syncthreads()
+#endif
 #define PE_SPIN_CHECK(s_) do { } while (0)
 #endif
 
@@ -603,6 +617,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   const uint32_t T = PIPE ? threadIdx.x % (64u * GW) : threadIdx.x;
   const uint32_t pbs = hc_ld(HC_SCAN_BASE);                       // what the block's engines share
   const uint32_t pb = pbs + PE_SET0 + eng * PE_SET_BYTES;         // this engine's tables
+  if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u);
   if (PIPE) {   // what the two engines tell each other starts from nothing
     if (threadIdx.x < 8u) lds_st32(pbs + PE_CTL + 4u * (PEC_RESOLVED + threadIdx.x), 0u);
     if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_GBAR, 0u);
@@ -668,7 +683,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   const bool td_ok = td_n <= PE_TD_ENTRIES;   // (a table that does not fit: the engine leaves the metablock to the one-wave loop)
   uint32_t pre_a = 0, pre_b = 0; bool pre_ok = false;  // the next region's input dwords of this lane, once they are known
   uint32_t lbdw = 0, le = 0, wn = 0; uint64_t P0 = 0;   // the region: its first dword, the entry's bit in it, its closure states, where its output starts
+#ifdef BROTLI_AMD_PROFILE_WAVES
+  uint64_t wp_t = __builtin_amdgcn_s_memtime(); (void)wp_t;
+#endif
   uint32_t gb_target = 0; (void)gb_target;               // (two engines: this engine's barriers so far, times GW)
+  uint32_t rseq = 0;                                     // regions of this invocation so far (the one at hand included)
   uint32_t kseq = 0; (void)kseq;                         // (two engines: the number of the region this engine is at)
   // What the region's tables start from (the engine's wave 0): the window and the counters of the phases.
   auto setup_tables = [&](const uint32_t lbdw_, const uint32_t le_, const uint32_t bits, const uint32_t mode, const uint32_t ent_) {
@@ -1068,6 +1087,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   };
   // ================= the stream's way through the region: walk, details, resolve, execute =================
   auto consume = [&]() {
+    rseq++;
     // ---- the walk (wave 0) and, behind it, the details (the other waves): the stream's states in order, LIST[k] = bit | kind << 15
     // of the state command k starts from.  Wave 0 follows the stream eight commands a hop (NEXT8 knows the way wherever the next
     // eight records are ordinary ones: everywhere but at the region's end) and publishes every anchor as it finds it; then
@@ -1290,7 +1310,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           if (lane == 0) { lds_st32(rs + 16u + 8u * r, tg); lds_st32(rs + 20u + 8u * r, vl); }
         }
       }
-      if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_KP, m);
+      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); }   // (... and the execute's items are handed out from the first)
       PE_BAR();
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
@@ -1403,6 +1423,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #endif
         pe_ctl_st(pb, PEC_CONT, cont ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
         pe_st_store(pbs, sn);
+        if (!PIPE) { lds_sync(); pe_ctl_st(pb, PEC_NXOK, rseq); }
         if (PIPE) {
           pe_ctl_st(pb, PEC_MYNEXT, sn.b);
           // the stream's state is the next region's from here on; the invocation's end is everybody's to know first
@@ -1533,10 +1554,15 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         const uint32_t cnt = kp_all <= (b << 6) ? 0u : (kp_all - (b << 6) < 64u ? kp_all - (b << 6) : 64u);
         if (cnt != 0u) path_literals(b, cnt);
       }
-      PE_BAR();
+      // (no barrier: what (b) stores lies elsewhere, and a wave that is through with (a) -- most have no batch -- takes items at once;
+      // (c) waits for both)
       PE_PROF(8);
       const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
       PE_COUNT(28, kp);
+      if (!PIPE) {   // (wave 0 says where the stream goes on behind the resolve's last barrier, while the others execute: as a rule long since)
+        while (pe_ctl_ld(pb, PEC_NXOK) != rseq) __builtin_amdgcn_s_sleep(1);
+        lds_sync();
+      }
       if (!PIPE && pe_ctl_ld(pb, PEC_CONT) != 0u) {  // the next region's input is on its way while the rest of this one is executed
         const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
         pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + PE_CHUNKS + T < limit_dw) ? in_dw[nl + PE_CHUNKS + T] : 0u;
@@ -1579,9 +1605,11 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         auto big_store = [&](const uint32_t pt, const uint32_t pd, const uint32_t pn) {
           if (lane < pn) { if (staged) lds_st8(sg + pd + lane, pt); else o[pd + lane] = (uint8_t)pt; }
         };
-        for (uint32_t j0 = me; j0 < nbig; j0 += 3u * GW) {
+        for (;;) {   // (a shared counter hands the items out, three at a time)
+          const uint32_t j0 = pe_atomic_add_uniform(pb + PE_CTL + 4u * PEC_BIGNEXT, 3u);
+          if (j0 >= nbig) break;
           uint32_t t0, d0, n0, t1, d1, n1, t2, d2, n2;
-          big_item(j0, t0, d0, n0); big_item(j0 + GW, t1, d1, n1); big_item(j0 + 2u * GW, t2, d2, n2);
+          big_item(j0, t0, d0, n0); big_item(j0 + 1u, t1, d1, n1); big_item(j0 + 2u, t2, d2, n2);
           big_store(t0, d0, n0); big_store(t1, d1, n1); big_store(t2, d2, n2);
         }
       }
