@@ -323,7 +323,7 @@ __device__ __forceinline__ void pe_eval_n(const PeCtx& c, const uint32_t (&pos)[
     // (the table rounds: the bytes of J1 from Lp on carry the path flag -- sentinels --, so a run that reaches them stops
     // there, and a lane without a state, or whose run starts beyond them, has nothing to hop)
     uint32_t m[NS]; bool part[NS];
-    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = ok[t] && y[t] < c.Lp; m[t] = part[t] ? n[t] : 0u; }
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = (bool)((uint32_t)ok[t] & (uint32_t)(y[t] < c.Lp)); m[t] = part[t] ? n[t] : 0u; }
 #ifndef BROTLI_AMD_PE_NO_HOP_ASM
     if constexpr (NS <= 2u) {
       // The same loop by hand.  A state that has stopped hopping -- no literals left, or on the path -- stays stopped, so the
@@ -438,7 +438,7 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
   uint32_t q[NS], p[NS], kd[NS], lo[NS], hi[NS]; bool ok[NS];
   _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
     const uint32_t pos = d[t] & 0x7FFFu;
-    ok[t] = on[t] && pos + 128u <= c.L; q[t] = ok[t] ? pos : 0u; kd[t] = d[t] >> 15;
+    ok[t] = (bool)((uint32_t)on[t] & (uint32_t)(pos + 128u <= c.L)); q[t] = ok[t] ? pos : 0u; kd[t] = d[t] >> 15;
     lo[t] = pe_bits32(pb, q[t]);
   }
   SC_STAGE();
@@ -492,7 +492,7 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
   // reaches them stops by itself), at most PE_HOPCAP hops
   {
     uint32_t m[NS]; bool part[NS];
-    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = ok[t] && y[t] < c.Lp; m[t] = part[t] ? n[t] : 0u; }
+    _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) { part[t] = (bool)((uint32_t)ok[t] & (uint32_t)(y[t] < c.Lp)); m[t] = part[t] ? n[t] : 0u; }
     const uint32_t jb = pb + PE_J1F;
     uint32_t ya0 = y[0] + jb, ya1 = y[NS - 1u] + jb, m0 = m[0], m1 = m[NS - 1u], f0, f1;
     uint64_t e0, e1, ea, sv;
@@ -545,9 +545,12 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
   SC_STAGE();
   _Pragma("unroll") for (uint32_t t = 0; t < NS; t++) {
     // (flat on purpose: nested branches become execution-mask juggling, these are six selects)
-    const bool live = ok[t] && inside[t], more = n[t] != 0u && !onp[t], over = onp[t] && rk[t] + n[t] >= c.Rn, plain = onp[t] && imp[t] == 0u;
-    code[t] = !live ? 2u : more ? 3u : over ? 2u : plain ? 0u : 1u;
-    next[t] = plain ? rk[t] + n[t] : (onp[t] ? q2[t] : y[t]) | (imp[t] << 15);
+    // (bitwise on purpose too: `&&` between two lanes' conditions comes out as a branch around the second one)
+    const uint32_t live = (uint32_t)ok[t] & (uint32_t)inside[t], onp_ = (uint32_t)onp[t], more = (uint32_t)(n[t] != 0u) & (onp_ ^ 1u), over = onp_ & (uint32_t)(rk[t] + n[t] >= c.Rn), plain = onp_ & (imp[t] ^ 1u);
+    // code: 2 where the state is not live; else 3 (more hops), 2 (beyond the ranks), 0 (a path state next), 1 (another state next)
+    const uint32_t inner = more != 0u ? 3u : over != 0u ? 2u : 1u - plain;
+    code[t] = live != 0u ? inner : 2u;
+    next[t] = plain != 0u ? rk[t] + n[t] : (onp_ != 0u ? q2[t] : y[t]) | (imp[t] << 15);
     ry[t] = y[t]; rn[t] = n[t]; rimp[t] = imp[t];
   }
 }
@@ -958,12 +961,12 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
               const uint32_t rr = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(nm[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm[t], 0u));
               base += (uint32_t)__popcll(nm[t]);
-              bool take = !has[t] && rr < limit;
+              bool take = (bool)((uint32_t)!has[t] & (uint32_t)(rr < limit));
               uint32_t idv = rr;
-              if (source == 1u) { idv = lds_ld16(pb + PE_TAILQ + ((take ? rr : 0u) << 1)); take = take && idv < PEN_FIRST_SPECIAL; }
+              if (source == 1u) { idv = lds_ld16(pb + PE_TAILQ + ((take ? rr : 0u) << 1)); take = (bool)((uint32_t)take & (uint32_t)(idv < PEN_FIRST_SPECIAL)); }
               const uint32_t idc = take ? idv : 0u;
               const uint32_t stv = lds_ld16(pb + (idc < PE_RANKS ? PE_POR + (idc << 1) : PE_WST + ((idc - PE_RANKS) << 1)));
-              has[t] = has[t] || take; res[t] = res[t] && !take;
+              has[t] = (bool)((uint32_t)has[t] | (uint32_t)take); res[t] = (bool)((uint32_t)res[t] & (uint32_t)!take);
               sid[t] = take ? idc : sid[t]; dsc[t] = take ? stv : dsc[t];
             }
           }
@@ -996,7 +999,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         iters++;
         {
           bool app[NSL]; uint64_t am[NSL]; uint32_t slot[NSL]; uint32_t wantw = 0;
-          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { app[t] = has[t] && code[t] == 1u; am[t] = __ballot(app[t]); wantw += (uint32_t)__popcll(am[t]); slot[t] = 0; }
+          _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) { app[t] = (bool)((uint32_t)has[t] & (uint32_t)(code[t] == 1u)); am[t] = __ballot(app[t]); wantw += (uint32_t)__popcll(am[t]); slot[t] = 0; }
           if (wantw != 0u) {  // (appending closure states: one LDS atomic per wave and pass)
             uint32_t base = pe_atomic_add_uniform(pb + PE_CTL + 4u * PEC_WN, wantw);
             _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
@@ -1005,15 +1008,15 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
             }
           }
           _Pragma("unroll") for (uint32_t t = 0; t < NSL; t++) {
-            const bool fin = has[t] && code[t] != 3u;                  // the record is there (code 3: more hops next time, from ry / rn)
-            const bool goes_on = app[t] && slot[t] < PE_WCAP;           // ... and leads to a state that is not a path state: this lane's next
+            const bool fin = (bool)((uint32_t)has[t] & (uint32_t)(code[t] != 3u));                  // the record is there (code 3: more hops next time, from ry / rn)
+            const bool goes_on = (bool)((uint32_t)app[t] & (uint32_t)(slot[t] < PE_WCAP));           // ... and leads to a state that is not a path state: this lane's next
             PE_LANECOUNT(30, app[t] && slot[t] >= PE_WCAP);
             const uint32_t nx = goes_on ? PE_RANKS + slot[t] : code[t] == 0u ? nxt[t] : code[t] == 2u ? (uint32_t)PEN_END : (uint32_t)PEN_BYHAND;
             // (no masks: a lane with nothing to store writes the scratch word)
             lds_st16(goes_on ? pb + PE_WST + (slot[t] << 1) : pb + PE_CTL + 4u * PEC_SCRATCH, nxt[t]);
             lds_st16(fin ? pb + PE_NEXT + (sid[t] << 1) : pb + PE_CTL + 4u * PEC_SCRATCH, nx);
-            res[t] = has[t] && code[t] == 3u;
-            has[t] = res[t] || goes_on;
+            res[t] = (bool)((uint32_t)has[t] & (uint32_t)(code[t] == 3u));
+            has[t] = (bool)((uint32_t)res[t] | (uint32_t)goes_on);
             sid[t] = goes_on ? PE_RANKS + slot[t] : sid[t];
             dsc[t] = goes_on ? nxt[t] : dsc[t];
           }
