@@ -19,8 +19,9 @@ Prints ONE JSON line on rank 0 (contract in the task description), with these ex
                     sample of the same workload: all host threads, one thread, and -- when libbrotlidec.so.1 can
                     be loaded -- Google's C decoder on one thread as a proxy for the reference (a port of it)
   extra_configs  -- (N = 1 only) the other configurations of BASELINE.json, each timed the same way with its own
-                    roofline: C2 1024 x alice29, C4 256 x 4 MiB high-entropy literals, C3 as ONE many-metablock stream,
-                    and the metric's streams twice (512 x 4 MiB: more streams than CUs)
+                    roofline, command rates and CPU legs: C2 1024 x alice29, C4 256 x 4 MiB high-entropy literals, C3 as ONE
+                    many-metablock stream (64 MiB, and 1 GiB as BASELINE writes it), the metric's streams twice (512 x 4 MiB),
+                    the same data at -q9, as 1024 x 1 MiB, and at the make-up of SURVEY 8(a1)'s prototype
 """
 import argparse
 import ctypes
@@ -67,14 +68,15 @@ def build_workload(name, n_unique=None):
     if m or not w.encoder_available():
         n = int(m.group(1)) if m else 1024
         return "%d x alice29.txt.compressed (reference fixture, wbits 22)" % n, w.fixture_streams("alice29.txt.compressed"), n
-    m = re.fullmatch(r"(longbackref|highentropy)(?:q(\d+))?_(\d+)x(\d+)(KiB|MiB)", name)
+    m = re.fullmatch(r"(longbackref|highentropy|surveymix)(?:q(\d+))?_(\d+)x(\d+)(KiB|MiB)", name)
     if not m:
         raise SystemExit("unknown workload " + name)
     kind, quality, n, size = m.group(1), int(m.group(2) or 5), int(m.group(3)), int(m.group(4)) << (10 if m.group(5) == "KiB" else 20)
     nu = min(n, n_unique if n_unique else int(os.environ.get("BROTLI_BENCH_UNIQUE", "256")))
-    seed0 = {"longbackref": 1000, "highentropy": 2000}[kind] if (n % 256, size) == (0, 4 << 20) else 3000  # (512 x 4 MiB: the headline's streams, twice)
-    u = w.make_streams("long_backref" if kind == "longbackref" else "high_entropy", nu, size, seed0, quality=quality)
-    what = "long back-references" if kind == "longbackref" else "high-entropy literals"
+    seed0 = {"longbackref": 1000, "highentropy": 2000, "surveymix": 4000}[kind] if (n % 256, size) == (0, 4 << 20) else 3000  # (512 x 4 MiB: the headline's streams, twice)
+    u = w.make_streams({"longbackref": "long_backref", "highentropy": "high_entropy", "surveymix": "survey_mix"}[kind], nu, size, seed0, quality=quality)
+    what = {"longbackref": "long back-references", "highentropy": "high-entropy literals",
+            "surveymix": "long back-references behind a seed of a quarter of the stream (the make-up of SURVEY 8a1's prototype)"}[kind]
     if (n, size) == (256, 4 << 20):
         label = "1 GiB batch: 256 x 4 MiB streams, wbits 22, brotli -q%d, %s (%d distinct streams)" % (quality, what, nu)
     else:
@@ -114,12 +116,15 @@ class DeviceJob:
         """First decode + bit-exact check against the regenerated raw data (SHA-256 per stream) -> status rows"""
         if not self.indices:
             self.second_pass = 0
+            self.num_commands = self.engine_commands = 0
             return []
         self.batch.decode_device(self.in_ptrs, self.sizes, self.out_ptrs, self.caps, self.pkg.FLAG_LARGE_WINDOW, self.stream)
         res = self.batch.wait()
         # The timed region re-runs the (first-pass) kernel only: it is the whole job as long as no stream needed the
         # second, large-arena launch (reported so that it cannot go unnoticed; then the whole submit + wait is timed).
         self.second_pass = self.batch.last_second_pass_count()
+        self.num_commands = sum(int(r.num_commands) for r in res)
+        self.engine_commands = sum(int(r.engine_commands) for r in res)
         bad = [j for j, r in enumerate(res) if r.result != 1 or r.decoded_size != self.caps[j]]
         if bad:
             raise SystemExit("decode failed: stream %d result %d error %d" % (self.indices[bad[0]], res[bad[0]].result, res[bad[0]].error_code))
@@ -166,7 +171,14 @@ def roofline(comp, raw, kernel_ms, traffic=None):
             "decompressed_frac": round(raw / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
 
-def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None):
+def command_rates(job, seconds_per_step):
+    """what the decode costs is per command: the honest unit beside MB/s"""
+    c = max(1, job.num_commands)
+    return {"commands": job.num_commands, "commands_per_s": round(job.num_commands / seconds_per_step, 1), "bytes_per_command": round(job.raw_total / c, 1),
+            "engine_commands_share": round(job.engine_commands / c, 4), "compression_ratio": round(job.raw_total / max(1, job.comp_total), 2)}
+
+
+def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None, cpu_budget_s=3.0):
     """One configuration on this GPU, bit-exact checked -> extra_configs entry"""
     label, unique, n = build_workload(name, n_unique)
     job = DeviceJob(pkg, torch, dev, unique, range(n))
@@ -181,18 +193,29 @@ def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None):
     out = {"workload": label, "streams": n, "decompressed_bytes": job.raw_total, "compressed_bytes": job.comp_total,
            "value": round(job.raw_total * steps / elapsed / 1e6, 1), "unit": "MB/s", "steps": steps,
            "second_pass_streams": job.second_pass, "roofline": roofline(job.comp_total, job.raw_total, sum(ms) / len(ms))}
+    out.update(command_rates(job, elapsed / steps))
     job.close()
+    if cpu_budget_s:  # the CPU path beside it: the oracle on all host threads and on one, a bounded sample of this leg's streams
+        try:
+            out["cpu_baseline"] = cpu_baseline(unique, cpu_budget_s, proxy=False)
+        except Exception as ex:  # noqa: BLE001 -- a failing CPU leg must not hide the GPU number
+            out["cpu_baseline"] = {"error": str(ex)[:120]}
     return out
 
 
-def cpu_baseline(unique, budget_s=10.0):
+def cpu_baseline(unique, budget_s=10.0, proxy=True):
     """CPU legs on a bounded sample of the same streams: the oracle on all host threads (one stream per thread), on one
     thread, and Google's libbrotlidec on one thread when it can be loaded."""
     import oracle_lib as oracle
     L = oracle.lib()
     cores = os.cpu_count() or 1
-    sample = (unique * ((cores + len(unique) - 1) // len(unique)))[:max(cores, min(len(unique), cores))]
-    n = len(sample)
+    # one thread a stream; small streams several a thread (about 8 MiB of output each: a thread's start-up is not the measurement);
+    # at most 2 GiB of output buffers
+    avg_raw = max(1, sum(sz for _, sz, _ in unique) // len(unique)); max_raw = max(sz for _, sz, _ in unique)
+    n = cores * max(1, (8 << 20) // avg_raw)
+    n = max(1, min(n, 4096, (2 << 30) // (max_raw + 64)))
+    sample = (unique * ((n + len(unique) - 1) // len(unique)))[:n]
+    cores = min(cores, n)
     ins = [ctypes.create_string_buffer(c, len(c)) for c, _, _ in sample]
     outs = [ctypes.create_string_buffer(sz + 64) for _, sz, _ in sample]
     a_in = (ctypes.c_void_p * n)(*[ctypes.addressof(b) for b in ins])
@@ -224,30 +247,33 @@ def cpu_baseline(unique, budget_s=10.0):
     total1 = sum(sz for _, sz, _ in sample[:k1])
     out = {"value": round(total / best / 1e6, 1), "unit": "MB/s decompressed", "cores": cores, "kind": "port",
            "value_1thread": round(total1 / best1 / 1e6, 1),
-           "sample": "%d streams of the workload (%.0f MiB), best of %d passes, one stream per thread; 1 thread: %d streams, best of 5; "
+           "sample": "%d streams of the workload (%.0f MiB) handed out to the threads one at a time, best of %d passes; 1 thread: %d streams, best of 5; "
                      "the Rust reference cannot be built in this image, this is the repo's C restatement (oracle/)" % (n, total / 2**20, reps, k1)}
+    if not proxy:
+        return out
     try:
         import libbrotli_ref as ref
         if ref.available():
-            bestp = None
+            # Google's libbrotlidec (the C decoder the reference is a port of) through the oracle library's pthread harness: its
+            # one-shot entry point called from real threads (the interpreter is not in the timed region)
+            fn = ctypes.cast(ref._dec.BrotliDecoderDecompress, ctypes.c_void_p)
+            L.brotli_oracle_run_batch_fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            ok = (ctypes.c_int * n)()
+            bestn = bestp = None
             for _ in range(3):
                 t = time.time()
-                for c, sz, _ in sample[:k1]:
-                    r = ref.decode(c, sz + 64)
-                    assert r[0] == 1
+                L.brotli_oracle_run_batch_fn(fn, n, a_in, a_is, a_out, a_oc, cores, ok)
+                dt = time.time() - t
+                bestn = dt if bestn is None else min(bestn, dt)
+            assert all(v == 1 for v in ok)
+            for _ in range(3):
+                t = time.time()
+                L.brotli_oracle_run_batch_fn(fn, k1, a_in, a_is, a_out, a_oc, 1, ok)
                 dt = time.time() - t
                 bestp = dt if bestp is None else min(bestp, dt)
-            from concurrent.futures import ThreadPoolExecutor
-            bestn = None
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                for _ in range(3):
-                    t = time.time()
-                    assert all(r[0] == 1 for r in ex.map(lambda cs: ref.decode(cs[0], cs[1] + 64), sample))
-                    dt = time.time() - t
-                    bestn = dt if bestn is None else min(bestn, dt)
-            out["libbrotlidec_proxy"] = {"value_1thread": round(total1 / bestp / 1e6, 1), "value": round(total / bestn / 1e6, 1), "cores": cores, "unit": "MB/s decompressed",
-                                         "note": "Google libbrotlidec 1.0.9 through ctypes, one thread, %d streams, best of 3: a proxy for the "
-                                                 "reference (a port of it); the reference itself was not run" % k1}
+            out["libbrotlidec_proxy"] = {"value": round(total / bestn / 1e6, 1), "value_1thread": round(total1 / bestp / 1e6, 1), "cores": cores, "unit": "MB/s decompressed",
+                                         "note": "Google libbrotlidec 1.0.9, BrotliDecoderDecompress called from %d pthreads (one stream each; 1 thread: %d streams), best of 3: a proxy for "
+                                                 "the reference (a port of it); the reference itself was not run" % (cores, k1)}
     except Exception as e:  # noqa: BLE001 -- the proxy is optional
         out["libbrotlidec_proxy"] = {"error": str(e)[:100]}
     return out
@@ -347,6 +373,8 @@ def main():
             "roofline": roofline(job.comp_total, job.raw_total, mean_kernel_ms, traffic),
         }
         out["roofline"]["traffic_source"] = traffic_source
+        if world == 1:
+            out.update(command_rates(job, elapsed_max / args.steps))
         out["config"]["outputs_poisoned_before_and_hashed_after_the_timed_steps"] = True
     job.close()
     if rank == 0 and world == 1:
@@ -373,10 +401,16 @@ def main():
             legs = [("alice29x1024", 10, None)]
             if w.encoder_available():
                 legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1), ("longbackref_512x4MiB", 3, None),
-                         ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None)]
+                         ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None), ("surveymix_256x4MiB", 5, None)]
+                if os.environ.get("BROTLI_BENCH_NO_1GIB") is None:
+                    legs.append(("longbackref_1x1024MiB", 1, 1))  # BASELINE config 3 as written: ONE stream of 1 GiB
             for name, steps, nu in legs:
                 try:
-                    e = time_single_gpu(pkg, torch, dev, name, steps, 1, nu)
+                    e = time_single_gpu(pkg, torch, dev, name, steps, 0 if name == "longbackref_1x1024MiB" else 1, nu, cpu_budget_s=0.0 if args.no_cpu_baseline else 3.0)
+                    if name == "longbackref_1x1024MiB":
+                        e["workload"] = "BASELINE config 3 as written: ONE stream of 1 GiB, wbits 22, brotli -q5, many metablocks, long back-references (one block of the GPU decodes it; one step)"
+                    if name == "surveymix_256x4MiB":
+                        e["workload"] = "make-up of SURVEY 8(a1)'s prototype (a quarter of every stream is Zipf seed, the rest long copies): " + e["workload"]
                     if name == "longbackref_1x64MiB":
                         e["workload"] = "C3 as ONE stream: 64 MiB, wbits 22, brotli -q5, many metablocks, long back-references (a single stream does not shard: one block of the GPU decodes it)"
                     if name == "longbackref_512x4MiB":

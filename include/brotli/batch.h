@@ -79,6 +79,12 @@ BROTLI_DEC_API float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* batch);
 /* Streams the last BrotliAmdBatchWait had to continue in a second launch with a larger LDS arena (0 in the common case). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch);
 
+/* Streaming (BrotliDecoderDecompressStream, decode.h): the commands the device has decoded for this stream in all the launches
+ * of its calls together.  A call is a launch from the last command boundary reached, so this stays close to the stream's own
+ * number of commands however the input is cut up; a test asserts that instead of timing calls. */
+struct BrotliDecoderStateStruct;
+BROTLI_DEC_API uint64_t BrotliAmdDecoderDeviceCommands(const struct BrotliDecoderStateStruct* state);
+
 /* Text of the last HIP/runtime failure on this thread ("" if none). */
 BROTLI_DEC_API const char* BrotliAmdLastError(void);
 

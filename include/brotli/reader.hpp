@@ -22,11 +22,16 @@ struct InvalidData : std::runtime_error { using std::runtime_error::runtime_erro
 struct UnexpectedEof : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // R needs: size_t read(uint8_t* dst, size_t n)   -- 0 = end of input, may throw
+// every call of the streaming ABI is a kernel launch: a buffer of this size amortises it (the default here; the reference's own default is 4096)
+#ifndef BROTLI_AMD_RECOMMENDED_BUFFER
+#define BROTLI_AMD_RECOMMENDED_BUFFER
+constexpr size_t kRecommendedBufferSize = 1u << 20;
+#endif
 template <class R>
 class Decompressor {
  public:
-  Decompressor(R source, size_t buffer_size = 1u << 20, bool large_window = true)  // (every call of the streaming ABI is a kernel launch: 1 MiB amortises it)
-      : src_(std::move(source)), buf_(buffer_size ? buffer_size : (1u << 20)), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
+  Decompressor(R source, size_t buffer_size = kRecommendedBufferSize, bool large_window = true)  // (0: the reference's 4096, src/reader.rs)
+      : src_(std::move(source)), buf_(buffer_size ? buffer_size : 4096u), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
     if (!state_) throw std::bad_alloc();
     // native constructors of the reference accept large-window streams (src/state.rs:394)
     if (large_window) BrotliDecoderSetParameter(state_, BROTLI_DECODER_PARAM_LARGE_WINDOW, 1);

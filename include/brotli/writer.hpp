@@ -17,11 +17,16 @@
 namespace brotli_amd {
 
 // W needs: void write_all(const uint8_t* p, size_t n)   -- may throw
+// every call of the streaming ABI is a kernel launch: a buffer of this size amortises it (the default here; the reference's own default is 4096)
+#ifndef BROTLI_AMD_RECOMMENDED_BUFFER
+#define BROTLI_AMD_RECOMMENDED_BUFFER
+constexpr size_t kRecommendedBufferSize = 1u << 20;
+#endif
 template <class W>
 class DecompressorWriter {
  public:
-  DecompressorWriter(W sink, size_t buffer_size = 1u << 20, bool large_window = true)  // (every call of the streaming ABI is a kernel launch: 1 MiB amortises it)
-      : sink_(std::move(sink)), buf_(buffer_size ? buffer_size : (1u << 20)), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
+  DecompressorWriter(W sink, size_t buffer_size = kRecommendedBufferSize, bool large_window = true)  // (0: the reference's 4096, src/reader.rs)
+      : sink_(std::move(sink)), buf_(buffer_size ? buffer_size : 4096u), state_(BrotliDecoderCreateInstance(nullptr, nullptr, nullptr)) {
     if (!state_) throw std::bad_alloc();
     if (large_window) BrotliDecoderSetParameter(state_, BROTLI_DECODER_PARAM_LARGE_WINDOW, 1);
   }

@@ -30,7 +30,7 @@ DECODE_H_SYMBOLS = [
 ]
 BATCH_H_SYMBOLS = [
     "BrotliAmdBatchCreate", "BrotliAmdBatchDestroy", "BrotliAmdBatchDecodeDevice", "BrotliAmdBatchRelaunch", "BrotliAmdBatchWait",
-    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdLastError",
+    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdLastError", "BrotliAmdDecoderDeviceCommands",
 ]
 
 
@@ -235,6 +235,12 @@ class DecoderState:
 
     def is_used(self):
         return bool(self._L.BrotliDecoderIsUsed(self._h))
+
+    def device_commands(self):
+        """commands the device has decoded for this stream in all launches together (batch.h: BrotliAmdDecoderDeviceCommands)"""
+        self._L.BrotliAmdDecoderDeviceCommands.restype = ctypes.c_uint64
+        self._L.BrotliAmdDecoderDeviceCommands.argtypes = [ctypes.c_void_p]
+        return int(self._L.BrotliAmdDecoderDeviceCommands(self._h))
 
     def has_more_output(self):
         return bool(self._L.BrotliDecoderHasMoreOutput(self._h))

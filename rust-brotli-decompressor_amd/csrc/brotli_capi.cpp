@@ -43,6 +43,7 @@ constexpr uint64_t kScratchPerBlock = (2u << 20) + BROTLI_AMD_SPEC_SCRATCH;  // 
 constexpr uint32_t kDefaultLdsPerBlock = 36 * 1024;
 
 thread_local std::string g_last_error;
+thread_local std::string g_last_note;   // what a call did differently without failing (engine blocks refused by the device: see launch())
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
 static const bool g_engine_wanted = getenv("BROTLI_AMD_NO_SCAN") == nullptr;  // (whether a device can hold such a block is decided per batch context, at its creation)
@@ -147,11 +148,11 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
   hipError_t le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
                                            b->d_dict, stream, (int)b->waves);
-  if (le != hipSuccess && b->waves == 16u) {
+  if (b->waves == 16u && (le == hipErrorInvalidValue || le == hipErrorLaunchOutOfResources || le == hipErrorSharedObjectInitFailed || le == hipErrorInvalidConfiguration)) {
     // the device refused a block of sixteen waves with the engine's LDS although its properties allow one: this context goes
     // on with blocks of eight waves, and says so (BrotliAmdLastError); streams are no longer sent back for engine blocks
     (void)hipGetLastError();
-    g_last_error = std::string("engine blocks refused (") + hipGetErrorString(le) + "): eight-wave blocks from now on";
+    g_last_note = std::string("engine blocks refused (") + hipGetErrorString(le) + "): eight-wave blocks from now on";   // (a note, not an error: the retry below decides)
     b->engine_ok = false;
     b->waves = 8;
     for (uint32_t i = 0; i < b->n; i++) b->h_descs[i].flags &= ~BROTLI_AMD_FLAG_ENGINE_ONLY;
@@ -787,6 +788,7 @@ struct BrotliDecoderStateStruct {
   uint64_t fetched;        // output bytes already copied off the device
   uint64_t total_out;      // output bytes handed to the caller (partial_pos_out)
   uint8_t* outq; size_t outq_len, outq_off, outq_cap;  // fetched but not yet handed over
+  uint64_t device_commands; // commands the device has decoded for this stream in all its launches together (BrotliAmdDecoderDeviceCommands)
 };
 
 namespace {
@@ -880,6 +882,7 @@ int decode_pass(BrotliDecoderState* s, BrotliAmdStreamStatus* st) {
     if (submit(s->batch, 1, nullptr) != 0) return 1;
     if (BrotliAmdBatchWait(s->batch, nullptr) != 0) return 1;
     *st = s->batch->h_status[0];
+    s->device_commands += st->num_commands;
     if (st->resume.window_bits != 0) { s->resume = st->resume; s->have_resume = true; }
     // bytes the reference would have flushed by now: all of them on success / needs-more-input, the part
     // below the last ring-buffer boundary on a fatal error (decode.rs:2835-2846, 2899-2913)
@@ -1035,6 +1038,7 @@ extern "C" const uint8_t* BrotliDecoderTakeOutput(BrotliDecoderState* s, size_t*
   return p;  // valid until the next call on this instance
 }
 
+extern "C" uint64_t BrotliAmdDecoderDeviceCommands(const BrotliDecoderState* s) { return s ? s->device_commands : 0; }
 extern "C" BROTLI_BOOL BrotliDecoderIsUsed(const BrotliDecoderState* s) { return (s && s->used) ? BROTLI_TRUE : BROTLI_FALSE; }
 extern "C" BROTLI_BOOL BrotliDecoderIsFinished(const BrotliDecoderState* s) {
   return (s && s->finished && !s->pending_error && s->outq_len == s->outq_off) ? BROTLI_TRUE : BROTLI_FALSE;

@@ -2428,7 +2428,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     if (bl1 == 0 || br.next_dw >= safe_dw) break;
     if (br.next_dw >= win_end) { br.rebase(); win_end = br.chunk_base + 50u; }  // (the only place the window moves: between two commands)
     SPLIT_LAP(0);
-    if (rec_ok && !no_run_asm && P < 0xFFF00000ull && front_c <= 0x40000000u) {
+    if (rec_ok && !no_run_asm && P + (uint64_t)quota <= 0xFFFFFFFFull && front_c <= 0x40000000u) {   // (the run keeps the output position in 32 bits and moves it by at most `quota`: ADVICE round 3)
       // ---- a run of commands without literals (see LEAN_REC_RUN_ASM) ----
       uint32_t ok = 1u, rx = rec_v.x, ry = rec_v.y, P32 = rfl((uint32_t)P), pp32 = rfl((uint32_t)pend_pos);
       const uint32_t lim = rfl(safe_dw < win_end ? safe_dw : win_end), ncmd0 = ncmd;  // (rfl: scalar registers for the "s" operands)
@@ -4283,7 +4283,8 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
       // bit 0: the scan engine only; bit 1: no copier wave for context-modelled metablocks (the default: it does not pay, see DESIGN;
       // "split" turns it on); bit 2: no command records ("norec")
       // bit 3: the path engine as two engines of eight waves that take the stream's regions in turns ("path2"; experiment)
-      const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : 2u;
+      // (static storage: the asynchronous copy reads it after this function has returned)
+      static const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : 2u;
       hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
       if (e2 != hipSuccess) return e2;
     }

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def _enc():
     import libbrotli_ref as ref
     if not ref.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     return ref
 
 
@@ -65,7 +65,7 @@ def test_one_large_stream_of_many_metablocks(pkg):
     sys.path.insert(0, ROOT)
     import workloads as w
     if not w.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     raw = w.long_backref_stream(4321, 64 << 20)
     c = w.brotli_compress(raw, 5, 22)
     info, out = oracle.decode(c, len(raw), 1)
@@ -82,7 +82,7 @@ def test_bit_positions_beyond_32_bits(pkg):
     sys.path.insert(0, ROOT)
     import workloads as w
     if not w.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rng = np.random.Generator(np.random.PCG64(77))
     p = np.arange(1, 257, dtype=np.float64) ** -0.6
     p /= p.sum()
@@ -256,7 +256,7 @@ def test_engine_blocks_serving_more_streams_than_cus(pkg):
     sys.path.insert(0, ROOT)
     import workloads as w
     if not w.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     rnd = random.Random(2024)
     m = {e["name"]: e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))}
@@ -307,7 +307,7 @@ def _metric_streams(n, size=1 << 20):
     sys.path.insert(0, ROOT)
     import workloads as w
     if not w.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     return w.make_streams("long_backref", n, size, 1000)
 
 

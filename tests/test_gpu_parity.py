@@ -172,7 +172,7 @@ def test_parameterised_encoder_corpus(pkg):
     import param_corpus
     streams = param_corpus.corpus()
     if not streams:
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     datas = [c for _, c, _ in streams]
     caps = [len(r) + 16 for _, _, r in streams]
     batch = pkg.Batch(len(streams))
@@ -226,7 +226,7 @@ def test_mutated_corpus_streams_match_oracle(pkg, seed):
     import param_corpus
     streams = [(c, len(r)) for _, c, r in param_corpus.corpus() if len(c) < 60000]
     if not streams:
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rnd = random.Random(seed)
     datas, caps = [], []
     for _ in range(1200):
@@ -314,7 +314,7 @@ def test_bench_workload_streams_tight_buffers_and_damage(pkg):
     sys.path.insert(0, ROOT)
     import workloads as w
     if not w.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rnd = random.Random(7)
     streams = w.make_streams("long_backref", 2, 4 << 20, 5000) + w.make_streams("high_entropy", 1, 4 << 20, 6000) + \
         w.make_streams("long_backref", 2, 1 << 20, 7000) + w.make_streams("high_entropy", 1, 256 << 10, 8000)
@@ -370,7 +370,7 @@ def test_helper_rounds_with_a_code_that_never_resynchronises(pkg):
     import numpy as np
     import libbrotli_ref as ref
     if not ref.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rng = np.random.Generator(np.random.PCG64(99))
     syms = rng.permutation(256)[:253].astype(np.uint8)
     block = np.concatenate([np.repeat(syms[:60], 512), np.repeat(syms[60:89], 64), np.repeat(syms[89:93], 8), syms[93:253]])
@@ -426,7 +426,7 @@ def test_literal_runs_of_many_lengths(pkg):
     import numpy as np
     import libbrotli_ref as ref
     if not ref.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rng = np.random.Generator(np.random.PCG64(2024))
     datas, raws = [], []
     for skew, nsym in ((0.2, 256), (1.0, 256), (2.0, 64), (3.0, 8), (0.0, 200)):
@@ -471,7 +471,7 @@ def test_long_literal_runs_across_ring_flush_points(pkg):
     import numpy as np
     import libbrotli_ref as ref
     if not ref.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rng = np.random.Generator(np.random.PCG64(4242))
     p = np.arange(1, 257, dtype=np.float64) ** -0.5
     p /= p.sum()
@@ -495,7 +495,7 @@ def test_literal_heavy_streams_of_random_makeup(pkg, seed):
     import numpy as np
     import libbrotli_ref as ref
     if not ref.encoder_available():
-        pytest.skip("libbrotlienc not available")
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams (a skip here would let a third of the suite go green unrun)")
     rng = np.random.Generator(np.random.PCG64(seed))
     datas, caps = [], []
     for _ in range(20):

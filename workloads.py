@@ -39,7 +39,7 @@ def brotli_compress(data: bytes, quality=5, lgwin=22) -> bytes:
     return out.raw[:n.value]
 
 
-def long_backref_stream(seed: int, size: int = 4 << 20) -> bytes:
+def long_backref_stream(seed: int, size: int = 4 << 20, seed_shift: int = 3) -> bytes:
     """C3 of SURVEY.md section 8d, per 4 MiB-window stream: a Zipf(s=1) text-like seed region over 64 symbols,
     then 90 % copies of U[32,4096) bytes from far back (U[64 KiB, pos) bytes, at most the 4 MiB window) and
     10 % short runs of fresh symbols -- many long back-references, few literals."""
@@ -47,7 +47,7 @@ def long_backref_stream(seed: int, size: int = 4 << 20) -> bytes:
     ranks = np.arange(1, 65, dtype=np.float64)
     p = (1.0 / ranks) / np.sum(1.0 / ranks)
     out = np.empty(size, dtype=np.uint8)
-    seed_len = min(size, max(1024, size >> 3))  # 512 KiB of a 4 MiB stream
+    seed_len = min(size, max(1024, size >> seed_shift))  # 512 KiB of a 4 MiB stream (seed_shift 2: a quarter, as 4 MiB of SURVEY 8(a1)'s 16 MiB prototype)
     out[:seed_len] = (rng.choice(64, size=seed_len, p=p) + 32).astype(np.uint8)
     pos = seed_len
     max_back = (4 << 20) - 16
@@ -80,8 +80,8 @@ _made = {}
 
 
 def make_streams(kind: str, n_unique: int, size: int, seed0: int, quality=5, lgwin=22, threads=None):
-    """-> list of (compressed bytes, raw size, sha256 of raw).  kind in {'long_backref', 'high_entropy'}."""
-    gen = long_backref_stream if kind == "long_backref" else high_entropy_stream
+    """-> list of (compressed bytes, raw size, sha256 of raw).  kind in {'long_backref', 'high_entropy', 'survey_mix'}."""
+    gen = long_backref_stream if kind == "long_backref" else (lambda sd, sz: long_backref_stream(sd, sz, 2)) if kind == "survey_mix" else high_entropy_stream
     key = (kind, n_unique, size, seed0, quality, lgwin)
     if key in _made:  # (bench legs that reuse the headline's streams)
         return _made[key]
