@@ -209,10 +209,10 @@ def cpu_baseline(unique, budget_s=10.0, proxy=True):
     import oracle_lib as oracle
     L = oracle.lib()
     cores = os.cpu_count() or 1
-    # one thread a stream; small streams several a thread (about 8 MiB of output each: a thread's start-up is not the measurement);
+    # one thread a stream; small streams several a thread (about 4 MiB of output each: a thread's start-up is not the measurement);
     # at most 2 GiB of output buffers
     avg_raw = max(1, sum(sz for _, sz, _ in unique) // len(unique)); max_raw = max(sz for _, sz, _ in unique)
-    n = cores * max(1, (8 << 20) // avg_raw)
+    n = cores * max(1, (4 << 20) // avg_raw)   # (4 MiB streams: one a thread, the workload's own shape)
     n = max(1, min(n, 4096, (2 << 30) // (max_raw + 64)))
     sample = (unique * ((n + len(unique) - 1) // len(unique)))[:n]
     cores = min(cores, n)

@@ -3088,6 +3088,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
   const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
   uint32_t scan_fails = 0;
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter;
+#endif
   bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
   // ahead of this wave (rec_wave; the lean loop takes commands out of them); on request (BROTLI_AMD_ENGINE=split) wave 1 executes
@@ -3150,7 +3153,13 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         hc_st(HC_KIND, use_pipe ? (uint32_t)HK_PATH2 : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
+#ifdef BROTLI_AMD_PROFILE_SCAN
+        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0 && pp_exit != 0) { g_path_prof[36] += t_ - pp_exit; g_path_prof[37] += 1; } pp_enter = t_; }
+#endif
         const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+#ifdef BROTLI_AMD_PROFILE_SCAN
+        pp_exit = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0) g_path_prof[38] += pp_exit - pp_enter;
+#endif
         prefer_one_engine = false;
         engine_commands += took;
         {  // the literal rounds' mailbox words lie in the engine's rings: back to their idle state
@@ -4258,6 +4267,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);
     printf("\npath engine, two engines (engine 0's wave 0, ticks per region): waiting for the window %llu, for the stream %llu, for the region before's output %llu\n", g_path_prof[15] / g_path_prof[20], g_path_prof[16] / g_path_prof[20], g_path_prof[14] / g_path_prof[20]);
+    printf("\nbetween two invocations of the engine in one metablock: %llu ticks in all, %llu times; inside the engine's calls %llu\n", g_path_prof[36], g_path_prof[37], g_path_prof[38]);
     { unsigned long long eng = 0; for (int k = 0; k <= 11; k++) eng += g_path_prof[k]; eng += g_path_prof[14] + g_path_prof[15] + g_path_prof[16]; eng += g_path_prof[17] + g_path_prof[18];
       printf("\nkernel ticks of block 0 in this launch: %llu; the path engine's regions so far (all launches): %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0), eng); }
   }

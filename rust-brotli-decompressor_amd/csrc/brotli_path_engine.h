@@ -58,6 +58,8 @@ constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this lon
 constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this long from in front of the region are done by their command's lane (16-byte loads, 16 .. 64)
 static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
 constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own: the path's literals are the run's
+constexpr uint32_t PE_RUN_SB = 128;               // a long literal run's regions: stream bits a lane decodes one code word after the other
+constexpr uint32_t PE_RUN_RBL = 64u * GW * PE_RUN_SB;   // ... and the bits of such a region (no tables per bit: its input lies in the input's and J1's room)
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
 constexpr uint32_t PE_PIPE_MARGIN = 1024;          // two engines: a region's tables start this many bits in front of where the stream is expected to enter it
 constexpr uint32_t PE_PIPE_USEFUL = 4096;          // ... and are used if the stream enters them with at least this many bits to go
@@ -107,6 +109,10 @@ constexpr uint32_t PE_TAILCAP = PE_CMDS;
 #endif
 constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see the thin end of the records through
 constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
+constexpr uint32_t PE_RUN_LIT = PE_POR;                            // a long literal run's region: its literals (the room of the ranks, literals, records and closure states)
+constexpr uint32_t PE_RUN_LITCAP = PE_LIST - PE_POR - 64u;         // ... at most
+constexpr uint32_t PE_RUN_EX = PE_PM;                              // ... u8 per lane: where its last code word ends (bits into the next lane's part)
+static_assert((PE_RUN_RBL / 32u + 8u) * 4u <= PE_PM - PE_IN && 64u * GW <= PE_CHUNKS * 4u, "a run region's input and exits");
 constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine's tables
 // What the engines of a block share: the invocation's parameters, the stream's state, the records' two tables.  One engine: at the
 // end of its tables (the control words are its own); two engines: in front of theirs, with a block of control words of its own.
@@ -498,6 +504,20 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
     uint64_t e0, e1, ea, sv;
     // (a state that has stopped hopping -- no literals left, or on the path -- stays stopped: the lanes still hopping are an
     // execution mask that only ever narrows; v_cmpx drops the lanes, the step itself is an add and a decrement)
+#ifndef BROTLI_AMD_PE_REC_HOPS
+#define BROTLI_AMD_PE_REC_HOPS 8
+#endif
+#if BROTLI_AMD_PE_REC_HOPS == 8
+#define PE_HOPS_REC(H) H H H H H H H H
+#elif BROTLI_AMD_PE_REC_HOPS == 6
+#define PE_HOPS_REC(H) H H H H H H
+#elif BROTLI_AMD_PE_REC_HOPS == 5
+#define PE_HOPS_REC(H) H H H H H
+#elif BROTLI_AMD_PE_REC_HOPS == 4
+#define PE_HOPS_REC(H) H H H H
+#elif BROTLI_AMD_PE_REC_HOPS == 12
+#define PE_HOPS_REC(H) H H H H H H H H H H H H
+#endif
 #define PE_HOP1 \
       "s_mov_b64 exec, %[e0]\n\tds_read_u8 %[f0], %[y0]\n\ts_waitcnt lgkmcnt(0)\n\tv_cmpx_gt_u32 vcc, %[c80], %[f0]\n\tv_add_u32 %[y0], %[y0], %[f0]\n\t" \
       "v_subrev_u32 %[m0], 1, %[m0]\n\tv_cmpx_ne_u32 vcc, 0, %[m0]\n\ts_mov_b64 %[e0], exec\n\ts_cmp_eq_u64 %[e0], 0\n\ts_cbranch_scc1 .Lpe_hopr_done_%=\n\t"
@@ -509,7 +529,7 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
       "s_or_b64 %[ea], %[e0], %[e1]\n\ts_cbranch_scc0 .Lpe_hopr_done_%=\n\t"
     if constexpr (NS == 1u) {
       asm volatile("s_mov_b64 %[sv], exec\n\tv_cmp_ne_u32 %[e0], 0, %[m0]\n\ts_cmp_eq_u64 %[e0], 0\n\ts_cbranch_scc1 .Lpe_hopr_done_%=\n\t"
-                   PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1 PE_HOP1
+                   PE_HOPS_REC(PE_HOP1)
                    ".Lpe_hopr_done_%=:\n\ts_mov_b64 exec, %[sv]"
                    : [y0] "+v"(ya0), [m0] "+v"(m0), [f0] "=&v"(f0), [e0] "=&s"(e0), [sv] "=&s"(sv)
                    : [c80] "v"(0x80u) : "vcc", "scc", "memory");
@@ -518,7 +538,7 @@ __device__ __forceinline__ void pe_eval_rec(const PeCtx& c, const uint32_t (&d)[
       if (part[0]) n[0] = m0;
     } else {
       asm volatile("s_mov_b64 %[sv], exec\n\tv_cmp_ne_u32 %[e0], 0, %[m0]\n\tv_cmp_ne_u32 %[e1], 0, %[m1]\n\ts_or_b64 %[ea], %[e0], %[e1]\n\ts_cbranch_scc0 .Lpe_hopr_done_%=\n\t"
-                   PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2 PE_HOP2
+                   PE_HOPS_REC(PE_HOP2)
                    ".Lpe_hopr_done_%=:\n\ts_mov_b64 exec, %[sv]"
                    : [y0] "+v"(ya0), [m0] "+v"(m0), [f0] "=&v"(f0), [y1] "+v"(ya1), [m1] "+v"(m1), [f1] "=&v"(f1), [e0] "=&s"(e0), [e1] "=&s"(e1), [ea] "=&s"(ea), [sv] "=&s"(sv)
                    : [c80] "v"(0x80u) : "vcc", "scc", "memory");
@@ -704,6 +724,119 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
     pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P_); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P_ >> 32));
   };
+  // ================= a region of a long literal run (one engine) =================
+  // Nothing but literals from an exactly known bit on: no tables per bit.  Lane t decodes the code words of bits 128 t .. 128 t + 127
+  // one after the other (decode.rs:2393-2462) from where the word that straddles into its part ends -- a guess (0) at first, then
+  // the lane before's exit, decoded again wherever that changed, until nothing does (prefix codes re-synchronise: two or three
+  // rounds; a cap cuts the region in front of the first lane that has not settled).  Ranks by prefix sum; one more pass puts the
+  // literals where they belong.  As many as the run, the literal block, the output limits and the region hold (one short of
+  // every limit: what happens AT a limit is the checked loop's) go out; the next region starts behind them.
+  auto run_region = [&]() -> uint32_t {
+    const uint32_t ent = pe_ctl_ld(pb, PEC_ENT), et = ent / PE_RUN_SB;
+    const uint32_t lim = c.L > 16u ? c.L - 16u : 0u;       // (a code word at or beyond may reach beyond the input)
+    // the rest of the region's input (the first PE_CHUNKS + 6 dwords are there)
+    { const uint32_t ndw = (c.L + 31u) / 32u + 6u;
+      for (uint32_t i = PE_CHUNKS + 6u + T; i < ndw; i += 64u * GW) lds_st32(pb + PE_IN + (i << 2), lbdw + i < limit_dw ? in_dw[lbdw + i] : 0u); }
+    PE_BAR();
+    const uint32_t base = T * PE_RUN_SB;
+    const bool act = T >= et && base < lim;
+    uint32_t e = T == et ? ent % PE_RUN_SB : 0u, ex = 0, cnt = 0, np = 0;
+    // the lane's code words from bit `e` of its part: how many, and where the last one ends; `emit`: the literals to their ranks
+    auto decode = [&](const bool on, const bool emit, const uint32_t rank0, const uint32_t want) {
+      uint32_t y = e, k = 0;
+      for (;;) {
+        const bool go = (bool)((uint32_t)on & (uint32_t)(y < PE_RUN_SB) & (uint32_t)(base + y < lim));
+        if (__ballot(go) == 0ull) break;
+        const uint32_t pos = go ? base + y : 0u;
+        uint32_t sy, ln;
+        sc_lookup(c.lit_tree, pe_bits32(pb, pos), sy, ln);
+        if (emit) { lds_st8(go ? pb + PE_RUN_LIT + rank0 + k : pb + PE_CTL + 4u * PEC_SCRATCH, sy); if (go && rank0 + k == want) np = pos; }
+        y += go ? ln : 0u; k += go ? 1u : 0u;
+      }
+      if (on) { cnt = k; ex = y >= PE_RUN_SB ? y - PE_RUN_SB : 0u; }
+    };
+    PE_PROF(1);
+    decode(act, false, 0u, 0u);
+    PE_PROF(17);
+    uint32_t tmin = 64u * GW;
+    for (uint32_t round = 0;; round++) {
+      // (whether any lane's entry moved: a word of three in turns, as the path's rounds have it -- the library's block-wide `or`
+      // brings LDS of its own, and this kernel's addresses are absolute)
+      const uint32_t fw = pb + PE_CTL + 4u * (PEC_CHG + round % 3u);
+      if (T == 0u) lds_st32(pb + PE_CTL + 4u * (PEC_CHG + (round + 1u) % 3u), 0u);
+      lds_st8(pb + PE_RUN_EX + T, ex);
+      PE_BAR();
+      const uint32_t ne = T > et ? lds_ld8(pb + PE_RUN_EX + T - 1u) : e;
+      const bool changed = (bool)((uint32_t)act & (uint32_t)(T > et) & (uint32_t)(ne != e));
+      if (round >= 24u) { if (changed) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T); PE_BAR(); tmin = pe_ctl_ld(pb, PEC_TMIN); break; }   // (a code that does not re-synchronise: the region ends where it has not)
+      if (changed) lds_st32(fw, 1u);
+      PE_BAR();
+      if (rfl(lds_ld32(fw)) == 0u) break;
+      if (changed) e = ne;
+      decode(changed, false, 0u, 0u);
+    }
+    PE_PROF(18);
+    if (T >= tmin) cnt = 0;
+    // ranks: exclusive prefix sum of the lanes' counts over the block; the region ends in front of the lane the literals' room runs out in
+    uint32_t incl = sc_scan(cnt);
+    if (lane == 63u) lds_st32(pb + PE_CTL + 4u * (PEC_WSUM + me), incl);
+    PE_BAR();
+    uint32_t wbase;
+    { const uint32_t ws = lane < GW ? lds_ld32(pb + PE_CTL + 4u * (PEC_WSUM + lane)) : 0u; const uint32_t wi = sc_scan(ws); wbase = rdlane(wi - ws, me); }
+    uint32_t cb = wbase + incl - cnt;
+    if (cb + cnt > PE_RUN_LITCAP) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T);
+    PE_BAR();
+    tmin = pe_ctl_ld(pb, PEC_TMIN);
+    if (T >= tmin) cnt = 0;
+    if (T == tmin || (tmin >= 64u * GW && T == 64u * GW - 1u)) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_RN]) = T == tmin ? cb : cb + cnt;
+    PE_BAR();
+    const uint32_t Rn = pe_ctl_ld(pb, PEC_RN);
+    PE_COUNT(22, Rn);
+    if (me == 0) {
+      const PeStream st = pe_st_load(pbs);
+      uint32_t take = st.run_rem;
+      const uint32_t cap1 = Rn != 0u ? Rn - 1u : 0u, cap2 = st.quota > 1u ? st.quota - 1u : 0u;
+      take = take < cap1 ? take : cap1; take = take < st.bl0 ? take : st.bl0; take = take < cap2 ? take : cap2;
+      pe_ctl_st(pb, PEC_TAKE, take);
+#ifdef BROTLI_AMD_PE_DEBUG
+      if (blockIdx.x == 0 && lane == 0) printf("run region: L %u entry %u Rn %u run_rem %u bl0 %u quota %u mlen %d -> take %u\n", c.L, ent, Rn, st.run_rem, st.bl0, st.quota, st.mlen, take);
+#endif
+    }
+    PE_BAR();
+    const uint32_t take = pe_ctl_ld(pb, PEC_TAKE);
+    PE_PROF(2);
+    // the literals to their ranks (and the bit of the first one that does not go out: where the stream goes on)
+    decode(cnt != 0u && cb <= take, true, cb, take);
+    if (cnt != 0u && cb <= take && take < cb + cnt) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NEXTRANK]) = np;
+    PE_BAR();
+    PE_PROF(4);
+    {
+      gu8* const o = out + P0;
+      for (uint32_t i = T << 2; i < take; i += 4u * 64u * GW) {
+        const uint32_t v = lds_ld32(pb + PE_RUN_LIT + i);
+        if (i + 4u <= take) *reinterpret_cast<gu32*>(o + i) = v;
+        else { o[i] = (uint8_t)v; if (i + 1u < take) o[i + 1u] = (uint8_t)(v >> 8); if (i + 2u < take) o[i + 2u] = (uint8_t)(v >> 16); }
+      }
+    }
+    if (me == 0) {
+      PeStream st = pe_st_load(pbs);
+      st.P += take; st.quota -= take; st.bl0 -= take; st.mlen -= (int32_t)take; st.run_rem -= take;
+      const uint32_t npb = take != 0u ? pe_ctl_ld(pb, PEC_NEXTRANK) : ent;
+      st.b = (lbdw << 5) + npb;
+      pe_ctl_st(pb, PEC_CONT, (take != 0u && st.run_rem != 0u) ? 1u : 0u); pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
+      PE_COUNT(19, take);
+      pe_st_store(pbs, st);
+    }
+    PE_BAR();
+    PE_PROF(5);
+    if (pe_ctl_ld(pb, PEC_CONT) == 0u) return 2u;
+    {
+      const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
+      pre_a = nl + T < limit_dw ? in_dw[nl + T] : 0u; pre_b = (T < 6u && nl + PE_CHUNKS + T < limit_dw) ? in_dw[nl + PE_CHUNKS + T] : 0u;
+      pre_ok = true;
+    }
+    return 1u;
+  };
   // ================= the region's tables: input, J1, the path, the records, NEXT8 =================
   // (0: there they are; 1: the region was one of a long literal run and is done, on to the next; 2: the invocation ends)
   auto build = [&]() -> uint32_t {
@@ -728,6 +861,10 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       }
       pe_st_store(pbs, st);
     }
+#if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_OLD_RUN_REGIONS)
+    PE_BAR();   // (the first region's mode is wave 0's word)
+    if (pe_ctl_ld(pb, PEC_MODE) != 0u) return run_region();
+#endif
     // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
 #if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 1
     for (int rep_ = 0; rep_ < 2; rep_++)
@@ -1741,7 +1878,12 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t avail = in_limit - (lbdw_ << 5);
       const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
       pe_ctl_st(pb, PEC_GO, go ? 1u : 0u);
-      setup_tables(lbdw_, st.b & 31u, avail < st.rbl ? avail : st.rbl, st.run_on, st.b & 31u);
+#ifndef BROTLI_AMD_PE_OLD_RUN_REGIONS
+      const uint32_t want_bits = st.run_on != 0u ? PE_RUN_RBL : st.rbl;   // (a long literal run's regions take no tables per bit: four times the bits)
+#else
+      const uint32_t want_bits = st.rbl;
+#endif
+      setup_tables(lbdw_, st.b & 31u, avail < want_bits ? avail : want_bits, st.run_on, st.b & 31u);
       setup_walk(st.P);
     }
     PE_BAR();   // (the region before's stores: waited for in front of the execute, which is the first to read them -- see the resolve's last barrier)
@@ -1867,4 +2009,5 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #undef PE_LANECOUNT
 #undef PE_TRY_RUN
 #undef PE_BAR
+#undef PE_HOPS_REC
 #undef PE_SPIN_CHECK
