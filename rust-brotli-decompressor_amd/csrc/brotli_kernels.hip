@@ -3089,7 +3089,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
   uint32_t scan_fails = 0;
 #ifdef BROTLI_AMD_PROFILE_SCAN
-  uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter;
+  uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter; const uint64_t pp_start = __builtin_amdgcn_s_memtime(); bool pp_first = true; (void)pp_first;
 #endif
   bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
@@ -3154,9 +3154,15 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
 #ifdef BROTLI_AMD_PROFILE_SCAN
-        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0 && pp_exit != 0) { g_path_prof[36] += t_ - pp_exit; g_path_prof[37] += 1; } pp_enter = t_; }
+        { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0 && pp_exit != 0) { g_path_prof[36] += t_ - pp_exit; g_path_prof[37] += 1; } if (blockIdx.x == 0 && lane == 0 && pp_exit == 0) g_path_prof[29] += t_ - pp_start; pp_enter = t_; }
+#endif
+#ifdef BROTLI_AMD_PE_DEBUG
+        if (blockIdx.x == 0 && lane == 0) printf("engine in: P %llu bl1 %u quota %u mlen %d commands so far %llu\n", (unsigned long long)P, bl1, quota, mlen, (unsigned long long)num_commands);
 #endif
         const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+#ifdef BROTLI_AMD_PE_DEBUG
+        if (blockIdx.x == 0 && lane == 0) printf("engine out: tick %llu took %u, P %llu form %u\n", (unsigned long long)__builtin_amdgcn_s_memtime(), took, (unsigned long long)(LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32)), LEAN_LD(L_SC_POS_HI));
+#endif
 #ifdef BROTLI_AMD_PROFILE_SCAN
         pp_exit = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane == 0) g_path_prof[38] += pp_exit - pp_enter;
 #endif
@@ -3171,6 +3177,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
         br.seek(pos);
+#ifdef BROTLI_AMD_PE_DEBUG
+        if (blockIdx.x == 0 && lane == 0) printf("  after seek: tick %llu\n", (unsigned long long)__builtin_amdgcn_s_memtime());
+#endif
         const uint64_t P_before = P;
         P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
         quota = LEAN_LD(L_QUOTA); mlen = (int32_t)LEAN_LD(L_MLEN);
@@ -3704,6 +3713,12 @@ command_done:
 #undef STOP
 #undef RING_CROSS
 done:
+#ifdef BROTLI_AMD_PE_DEBUG
+  if (blockIdx.x == 0 && lane == 0) printf("done: tick %llu P %llu mlen %d result %d\n", (unsigned long long)__builtin_amdgcn_s_memtime(), (unsigned long long)P, mlen, result);
+#endif
+#ifdef BROTLI_AMD_PROFILE_SCAN
+  if (blockIdx.x == 0 && lane == 0) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (pp_exit != 0) g_path_prof[39] += t_ - pp_exit; else g_path_prof[39] += 0; g_path_prof[31] += t_ - pp_start; }
+#endif
   FLUSH_LITERALS();
   FLUSH_PENDING();
   if (helpers_on) {  // the helpers go back to sleep (HC_KIND stays: a helper that looks late must find nothing to do)
@@ -4267,7 +4282,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     printf("\npath engine literal-run regions: %llu literals in all\n", g_path_prof[19]);
     printf("\npath engine path phase: chains and entries %llu, ranks %llu (the rest: positions and literals)\n", g_path_prof[17] / g_path_prof[20], g_path_prof[18] / g_path_prof[20]);
     printf("\npath engine, two engines (engine 0's wave 0, ticks per region): waiting for the window %llu, for the stream %llu, for the region before's output %llu\n", g_path_prof[15] / g_path_prof[20], g_path_prof[16] / g_path_prof[20], g_path_prof[14] / g_path_prof[20]);
-    printf("\nbetween two invocations of the engine in one metablock: %llu ticks in all, %llu times; inside the engine's calls %llu\n", g_path_prof[36], g_path_prof[37], g_path_prof[38]);
+    printf("\nbetween two invocations of the engine in one metablock: %llu ticks in all, %llu times; inside the engine's calls %llu; from the command loop's start to the first invocation %llu; from the last one's end to the loop's end %llu; the command loops in all %llu\n", g_path_prof[36], g_path_prof[37], g_path_prof[38], g_path_prof[29], g_path_prof[39], g_path_prof[31]);
     { unsigned long long eng = 0; for (int k = 0; k <= 11; k++) eng += g_path_prof[k]; eng += g_path_prof[14] + g_path_prof[15] + g_path_prof[16]; eng += g_path_prof[17] + g_path_prof[18];
       printf("\nkernel ticks of block 0 in this launch: %llu; the path engine's regions so far (all launches): %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0), eng); }
   }

@@ -57,7 +57,8 @@ constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this lon
 #endif
 constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this long from in front of the region are done by their command's lane (16-byte loads, 16 .. 64)
 static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
-constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own: the path's literals are the run's
+constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own (2048 was tried: slower, C3 6.56 -> 6.75 ms:
+                                                  // every run ends the invocation)
 constexpr uint32_t PE_RUN_SB = 128;               // a long literal run's regions: stream bits a lane decodes one code word after the other
 constexpr uint32_t PE_RUN_RBL = 64u * GW * PE_RUN_SB;   // ... and the bits of such a region (no tables per bit: its input lies in the input's and J1's room)
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
@@ -589,13 +590,15 @@ __device__ __forceinline__ PeParse pe_eval(const PeCtx& c, uint32_t pos, uint32_
 // command's head; on success the stream stands at the run's first literal.
 #ifdef BROTLI_AMD_NO_TRYRUN
 #define PE_TRY_RUN(st_, hp_) do { } while (0)
+#define PE_TRY_RUN_FROM(st_, hp_, min_) do { } while (0)
 #else
-#define PE_TRY_RUN(st_, hp_) do { \
+#define PE_TRY_RUN(st_, hp_) PE_TRY_RUN_FROM(st_, hp_, PE_RUN_MIN)
+#define PE_TRY_RUN_FROM(st_, hp_, min_) do { \
     uint32_t lo_, hi_; \
     pe_bits64(pb, (hp_), lo_, hi_); \
     const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr); \
     const uint32_t hins_ = rfl(h_.insert), hbits_ = rfl(h_.bits); \
-    if (hins_ >= PE_RUN_MIN && hbits_ != 0u && (st_).bl1 != 0u && (rfl(h_.implicit) != 0u || (st_).bl2 != 0u)) { \
+    if (hins_ >= (min_) && hbits_ != 0u && (st_).bl1 != 0u && (rfl(h_.implicit) != 0u || (st_).bl2 != 0u)) { \
       (st_).run_on = 1u; (st_).run_rem = hins_; (st_).run_copy = rfl(h_.copy); (st_).run_implicit = rfl(h_.implicit); (st_).run_dctx = rfl(h_.dctx); \
       (st_).bl1 -= 1u; (st_).ncmd += 1u; (st_).b += hbits_; \
     } } while (0)
@@ -1547,9 +1550,13 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         sn.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
         // the region went through whole and the next one starts at a command with a long literal run: the next regions are the run's
         if (!PIPE && kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
+        // ... or the region listed nothing because its first command's literal run is more than its path holds (4300 literals of
+        // 7.5 bits) though less than PE_RUN_MIN: regions of its own all the same -- giving the command back would keep the engine
+        // away from the commands behind it too (seen on the high-entropy streams: the rest of a metablock on one wave)
+        if (!PIPE && m == 0u && pbit + 64u <= c.L) PE_TRY_RUN_FROM(sn, pbit, 1024u);
         pe_ctl_st(pb, PEC_NEXT_LBDW, sn.b >> 5);
         // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
-        bool cont = kp_total == m && m != 0u;
+        bool cont = (kp_total == m && m != 0u) || (!PIPE && m == 0u && sn.run_on != 0u);
         if (PIPE && cont && pbit + 64u <= c.L) {
           // (two engines: a command whose literal run wants regions of its own ends the invocation in front of it -- the one-engine
           // form has those regions, and the caller is told to take it next)
@@ -1878,6 +1885,9 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       const uint32_t avail = in_limit - (lbdw_ << 5);
       const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && (st.bl1 != 0u || st.run_on != 0u);
       pe_ctl_st(pb, PEC_GO, go ? 1u : 0u);
+#ifdef BROTLI_AMD_PE_DEBUG
+      if (blockIdx.x == 0 && lane == 0 && !go) printf("  engine: no go: td_ok %d b %u in_limit %u avail %u quota %u bl1 %u run_on %u\n", (int)td_ok, st.b, in_limit, avail, st.quota, st.bl1, st.run_on);
+#endif
 #ifndef BROTLI_AMD_PE_OLD_RUN_REGIONS
       const uint32_t want_bits = st.run_on != 0u ? PE_RUN_RBL : st.rbl;   // (a long literal run's regions take no tables per bit: four times the bits)
 #else
@@ -2008,6 +2018,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 #undef PE_COUNT
 #undef PE_LANECOUNT
 #undef PE_TRY_RUN
+#undef PE_TRY_RUN_FROM
 #undef PE_BAR
 #undef PE_HOPS_REC
 #undef PE_SPIN_CHECK
