@@ -745,16 +745,30 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     const bool act = T >= et && base < lim;
     uint32_t e = T == et ? ent % PE_RUN_SB : 0u, ex = 0, cnt = 0, np = 0;
     // the lane's code words from bit `e` of its part: how many, and where the last one ends; `emit`: the literals to their ranks
+    // A table of the literal code by its first eleven bits -- symbol << 4 | length, 0 where eleven bits do not hold the code
+    // word -- in J1's room behind the input: one look-up a literal where the tree's two levels take two
+    const uint32_t wt = pb + PE_J1F + 16384u;
+    for (uint32_t i = T; i < 2048u; i += 64u * GW) { uint32_t sy, ln; sc_lookup(c.lit_tree, i, sy, ln); lds_st16(wt + (i << 1), ln <= 11u ? (sy << 4) | ln : 0u); }
+    PE_BAR();
+    // The lane's stream bits live in five registers (its 128 and the 32 behind them), moved down by every code word's length
     auto decode = [&](const bool on, const bool emit, const uint32_t rank0, const uint32_t want) {
       uint32_t y = e, k = 0;
+      const u32x4 wv = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_IN + (T << 4)]);
+      uint32_t w0 = wv.x, w1 = wv.y, w2 = wv.z, w3 = wv.w, w4 = lds_ld32(pb + PE_IN + (T << 4) + 16u);
+      for (uint32_t q = e >> 5; __ballot(q != 0u) != 0ull; q = q != 0u ? q - 1u : 0u) if (q != 0u) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = 0u; }   // (the run's first lane enters anywhere in its part)
+      { const uint32_t r5 = e & 31u; w0 = __builtin_amdgcn_alignbit(w1, w0, r5); w1 = __builtin_amdgcn_alignbit(w2, w1, r5); w2 = __builtin_amdgcn_alignbit(w3, w2, r5); w3 = __builtin_amdgcn_alignbit(w4, w3, r5); w4 >>= r5; }
       for (;;) {
         const bool go = (bool)((uint32_t)on & (uint32_t)(y < PE_RUN_SB) & (uint32_t)(base + y < lim));
         if (__ballot(go) == 0ull) break;
-        const uint32_t pos = go ? base + y : 0u;
-        uint32_t sy, ln;
-        sc_lookup(c.lit_tree, pe_bits32(pb, pos), sy, ln);
-        if (emit) { lds_st8(go ? pb + PE_RUN_LIT + rank0 + k : pb + PE_CTL + 4u * PEC_SCRATCH, sy); if (go && rank0 + k == want) np = pos; }
-        y += go ? ln : 0u; k += go ? 1u : 0u;
+        uint32_t ent = lds_ld16(wt + ((w0 & 0x7FFu) << 1));
+        if (__ballot((bool)((uint32_t)go & (uint32_t)(ent == 0u))) != 0ull) {   // (a code word of twelve bits and more: the tree's own two levels)
+          uint32_t sy, ln; sc_lookup(c.lit_tree, w0, sy, ln);
+          ent = ent == 0u ? (sy << 4) | ln : ent;
+        }
+        const uint32_t ln = go ? ent & 15u : 0u;
+        if (emit) { lds_st8(go ? pb + PE_RUN_LIT + rank0 + k : pb + PE_CTL + 4u * PEC_SCRATCH, ent >> 4); if (go && rank0 + k == want) np = base + y; }
+        w0 = __builtin_amdgcn_alignbit(w1, w0, ln); w1 = __builtin_amdgcn_alignbit(w2, w1, ln); w2 = __builtin_amdgcn_alignbit(w3, w2, ln); w3 = __builtin_amdgcn_alignbit(w4, w3, ln); w4 >>= ln;
+        y += ln; k += go ? 1u : 0u;
       }
       if (on) { cnt = k; ex = y >= PE_RUN_SB ? y - PE_RUN_SB : 0u; }
     };
