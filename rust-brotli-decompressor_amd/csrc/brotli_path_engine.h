@@ -114,6 +114,7 @@ constexpr uint32_t PE_RUN_LIT = PE_POR;                            // a long lit
 constexpr uint32_t PE_RUN_LITCAP = PE_LIST - PE_POR - 64u;         // ... at most
 constexpr uint32_t PE_RUN_EX = PE_PM;                              // ... u8 per lane: where its last code word ends (bits into the next lane's part)
 static_assert((PE_RUN_RBL / 32u + 8u) * 4u <= PE_PM - PE_IN && 64u * GW <= PE_CHUNKS * 4u, "a run region's input and exits");
+static_assert(PE_RUN_LIT % 16 == 0 && PE_STG % 16 == 0, "what write_out reads line by line");
 constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine's tables
 // What the engines of a block share: the invocation's parameters, the stream's state, the records' two tables.  One engine: at the
 // end of its tables (the control words are its own); two engines: in front of theirs, with a block of control words of its own.
@@ -727,6 +728,17 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
     pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P_); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P_ >> 32));
   };
+  // n bytes out of LDS to memory in whole sixteen-byte lines: the bytes in front of the first line of `dst` and behind the last one
+  // singly, every store between them aligned.  `src` is congruent to `dst` modulo sixteen -- whoever puts the bytes together in LDS
+  // starts that many bytes in --, so a line of memory is a line of LDS.  (The stores of the round-3 write-out started wherever the
+  // region's output did: WRITE_SIZE 1.4 to 2.5 times the bytes.)
+  auto write_out = [&](const uint32_t src, gu8* const dst, const uint32_t n) {
+    const uint32_t head0 = (16u - ((uint32_t)(uintptr_t)dst & 15u)) & 15u, head = head0 < n ? head0 : n, nb = (n - head) >> 4, tail0 = head + (nb << 4);
+    if (T < head) dst[T] = (uint8_t)lds_ld8(src + T);
+    if (T < n - tail0) dst[tail0 + T] = (uint8_t)lds_ld8(src + tail0 + T);
+    for (uint32_t q = T; q < nb; q += 64u * GW)
+      *reinterpret_cast<gu32x4*>(dst + head + ((uint64_t)q << 4)) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[src + head + (q << 4)]);
+  };
   // ================= a region of a long literal run (one engine) =================
   // Nothing but literals from an exactly known bit on: no tables per bit.  Lane t decodes the code words of bits 128 t .. 128 t + 127
   // one after the other (decode.rs:2393-2462) from where the word that straddles into its part ends -- a guess (0) at first, then
@@ -747,6 +759,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     // the lane's code words from bit `e` of its part: how many, and where the last one ends; `emit`: the literals to their ranks
     // A table of the literal code by its first eleven bits -- symbol << 4 | length, 0 where eleven bits do not hold the code
     // word -- in J1's room behind the input: one look-up a literal where the tree's two levels take two
+    const uint32_t rl = pb + PE_RUN_LIT + ((uint32_t)P0 & 15u);   // (the literals in LDS as they lie in memory, modulo sixteen: see write_out)
     const uint32_t wt = pb + PE_J1F + 16384u;
     for (uint32_t i = T; i < 2048u; i += 64u * GW) { uint32_t sy, ln; sc_lookup(c.lit_tree, i, sy, ln); lds_st16(wt + (i << 1), ln <= 11u ? (sy << 4) | ln : 0u); }
     PE_BAR();
@@ -766,7 +779,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
           ent = ent == 0u ? (sy << 4) | ln : ent;
         }
         const uint32_t ln = go ? ent & 15u : 0u;
-        if (emit) { lds_st8(go ? pb + PE_RUN_LIT + rank0 + k : pb + PE_CTL + 4u * PEC_SCRATCH, ent >> 4); if (go && rank0 + k == want) np = base + y; }
+        if (emit) { lds_st8(go ? rl + rank0 + k : pb + PE_CTL + 4u * PEC_SCRATCH, ent >> 4); if (go && rank0 + k == want) np = base + y; }
         w0 = __builtin_amdgcn_alignbit(w1, w0, ln); w1 = __builtin_amdgcn_alignbit(w2, w1, ln); w2 = __builtin_amdgcn_alignbit(w3, w2, ln); w3 = __builtin_amdgcn_alignbit(w4, w3, ln); w4 >>= ln;
         y += ln; k += go ? 1u : 0u;
       }
@@ -827,14 +840,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     if (cnt != 0u && cb <= take && take < cb + cnt) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NEXTRANK]) = np;
     PE_BAR();
     PE_PROF(4);
-    {
-      gu8* const o = out + P0;
-      for (uint32_t i = T << 2; i < take; i += 4u * 64u * GW) {
-        const uint32_t v = lds_ld32(pb + PE_RUN_LIT + i);
-        if (i + 4u <= take) *reinterpret_cast<gu32*>(o + i) = v;
-        else { o[i] = (uint8_t)v; if (i + 1u < take) o[i + 1u] = (uint8_t)(v >> 8); if (i + 2u < take) o[i + 2u] = (uint8_t)(v >> 16); }
-      }
-    }
+    write_out(rl, out + P0, take);
     if (me == 0) {
       PeStream st = pe_st_load(pbs);
       st.P += take; st.quota -= take; st.bl0 -= take; st.mlen -= (int32_t)take; st.run_rem -= take;
@@ -1614,7 +1620,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // out in one piece at the end: the stores of (a) are a few bytes each at addresses all over the place, and the copies
       // of (c) wait for each other -- through LDS both cost a fraction of what they cost through memory.
       const bool staged = pe_ctl_ld(pb, PEC_STAGED) != 0u;
-      const uint32_t sg = pb + PE_STG;
+      const uint32_t sg = pb + PE_STG + ((uint32_t)P0 & 15u);   // (the stage as the output lies in memory, modulo sixteen: see write_out; J1's room has 64 bytes to spare)
       // (a wave's LZ77 copy into the stage, decode.rs:2641-2720: byte q comes from byte q mod distance of the `distance` bytes
       // in front of the destination, which lie in the stage or, in front of the region, in memory)
       auto stage_copy = [&](const uint32_t dpos, const uint32_t n, const uint32_t dist) {
@@ -1874,14 +1880,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
         // the region's output, out of the stage in one piece: sixteen bytes a thread and step
         PE_BAR();
         const uint32_t tot = pe_ctl_ld(pb, PEC_OUTTOT);
-        for (uint32_t x = T << 4; x < tot; x += 16u * 64u * GW) {
-          const u32x4 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[sg + x]);
-          if (x + 16u <= tot) *reinterpret_cast<gu32x4*>(o + x) = v;
-          else {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            _Pragma("unroll") for (uint32_t q = 0; q < 16u; q++) if (x + q < tot) o[x + q] = (uint8_t)(w[q >> 2] >> ((q & 3u) * 8u));
-          }
-        }
+        write_out(sg, o, tot);
       }
       PE_PROF(10);
     }
