@@ -59,7 +59,11 @@ constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this
 static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
 constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own (2048 was tried: slower, C3 6.56 -> 6.75 ms:
                                                   // every run ends the invocation)
-constexpr uint32_t PE_RUN_SB = 128;               // a long literal run's regions: stream bits a lane decodes one code word after the other
+#ifndef BROTLI_AMD_PE_RUN_SB
+#define BROTLI_AMD_PE_RUN_SB 256
+#endif
+constexpr uint32_t PE_RUN_SB = BROTLI_AMD_PE_RUN_SB;   // a long literal run's regions: stream bits a lane decodes one code word after the other (128 or 256: the longer the part,
+                                                  // the likelier the lane's last word ends where it does whatever bit the lane entered at, and the fewer rounds the entries take)
 constexpr uint32_t PE_RUN_RBL = 64u * GW * PE_RUN_SB;   // ... and the bits of such a region (no tables per bit: its input lies in the input's and J1's room)
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
 constexpr uint32_t PE_PIPE_MARGIN = 1024;          // two engines: a region's tables start this many bits in front of where the stream is expected to enter it
@@ -115,6 +119,7 @@ constexpr uint32_t PE_RUN_LITCAP = PE_LIST - PE_POR - 64u;         // ... at mos
 constexpr uint32_t PE_RUN_EX = PE_PM;                              // ... u8 per lane: where its last code word ends (bits into the next lane's part)
 static_assert((PE_RUN_RBL / 32u + 8u) * 4u <= PE_PM - PE_IN && 64u * GW <= PE_CHUNKS * 4u, "a run region's input and exits");
 static_assert(PE_RUN_LIT % 16 == 0 && PE_STG % 16 == 0, "what write_out reads line by line");
+static_assert(PIPE || 64u * GW + 4096u <= PE_EX - PE_PM, "a run region's exits and its table of the literal code (one engine: two never take a run)");
 constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine's tables
 // What the engines of a block share: the invocation's parameters, the stream's state, the records' two tables.  One engine: at the
 // end of its tables (the control words are its own); two engines: in front of theirs, with a block of control words of its own.
@@ -758,29 +763,36 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
     uint32_t e = T == et ? ent % PE_RUN_SB : 0u, ex = 0, cnt = 0, np = 0;
     // the lane's code words from bit `e` of its part: how many, and where the last one ends; `emit`: the literals to their ranks
     // A table of the literal code by its first eleven bits -- symbol << 4 | length, 0 where eleven bits do not hold the code
-    // word -- in J1's room behind the input: one look-up a literal where the tree's two levels take two
+    // word: one look-up a literal where the tree's two levels take two
     const uint32_t rl = pb + PE_RUN_LIT + ((uint32_t)P0 & 15u);   // (the literals in LDS as they lie in memory, modulo sixteen: see write_out)
-    const uint32_t wt = pb + PE_J1F + 16384u;
+    const uint32_t wt = pb + PE_RUN_EX + 64u * GW;   // (behind the lanes' exits, in the room of the path's chunk words)
     for (uint32_t i = T; i < 2048u; i += 64u * GW) { uint32_t sy, ln; sc_lookup(c.lit_tree, i, sy, ln); lds_st16(wt + (i << 1), ln <= 11u ? (sy << 4) | ln : 0u); }
     PE_BAR();
     // The lane's stream bits live in five registers (its 128 and the 32 behind them), moved down by every code word's length
     auto decode = [&](const bool on, const bool emit, const uint32_t rank0, const uint32_t want) {
       uint32_t y = e, k = 0;
-      const u32x4 wv = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_IN + (T << 4)]);
-      uint32_t w0 = wv.x, w1 = wv.y, w2 = wv.z, w3 = wv.w, w4 = lds_ld32(pb + PE_IN + (T << 4) + 16u);
-      for (uint32_t q = e >> 5; __ballot(q != 0u) != 0ull; q = q != 0u ? q - 1u : 0u) if (q != 0u) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = 0u; }   // (the run's first lane enters anywhere in its part)
-      { const uint32_t r5 = e & 31u; w0 = __builtin_amdgcn_alignbit(w1, w0, r5); w1 = __builtin_amdgcn_alignbit(w2, w1, r5); w2 = __builtin_amdgcn_alignbit(w3, w2, r5); w3 = __builtin_amdgcn_alignbit(w4, w3, r5); w4 >>= r5; }
+      constexpr uint32_t NW = PE_RUN_SB / 32u + 1u;
+      uint32_t w[NW];
+      _Pragma("unroll") for (uint32_t j = 0; j < NW - 1u; j += 4u) {
+        const u32x4 wv = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_IN + T * (PE_RUN_SB / 8u) + 4u * j]);
+        w[j] = wv.x; w[j + 1u] = wv.y; w[j + 2u] = wv.z; w[j + 3u] = wv.w;
+      }
+      w[NW - 1u] = lds_ld32(pb + PE_IN + T * (PE_RUN_SB / 8u) + 4u * (NW - 1u));
+      for (uint32_t q = e >> 5; __ballot(q != 0u) != 0ull; q = q != 0u ? q - 1u : 0u)   // (the run's first lane enters anywhere in its part)
+        if (q != 0u) { _Pragma("unroll") for (uint32_t j = 0; j + 1u < NW; j++) w[j] = w[j + 1u]; w[NW - 1u] = 0u; }
+      { const uint32_t r5 = e & 31u; _Pragma("unroll") for (uint32_t j = 0; j + 1u < NW; j++) w[j] = __builtin_amdgcn_alignbit(w[j + 1u], w[j], r5); w[NW - 1u] >>= r5; }
       for (;;) {
         const bool go = (bool)((uint32_t)on & (uint32_t)(y < PE_RUN_SB) & (uint32_t)(base + y < lim));
         if (__ballot(go) == 0ull) break;
-        uint32_t ent = lds_ld16(wt + ((w0 & 0x7FFu) << 1));
+        uint32_t ent = lds_ld16(wt + ((w[0] & 0x7FFu) << 1));
         if (__ballot((bool)((uint32_t)go & (uint32_t)(ent == 0u))) != 0ull) {   // (a code word of twelve bits and more: the tree's own two levels)
-          uint32_t sy, ln; sc_lookup(c.lit_tree, w0, sy, ln);
+          uint32_t sy, ln; sc_lookup(c.lit_tree, w[0], sy, ln);
           ent = ent == 0u ? (sy << 4) | ln : ent;
         }
         const uint32_t ln = go ? ent & 15u : 0u;
         if (emit) { lds_st8(go ? rl + rank0 + k : pb + PE_CTL + 4u * PEC_SCRATCH, ent >> 4); if (go && rank0 + k == want) np = base + y; }
-        w0 = __builtin_amdgcn_alignbit(w1, w0, ln); w1 = __builtin_amdgcn_alignbit(w2, w1, ln); w2 = __builtin_amdgcn_alignbit(w3, w2, ln); w3 = __builtin_amdgcn_alignbit(w4, w3, ln); w4 >>= ln;
+        _Pragma("unroll") for (uint32_t j = 0; j + 1u < NW; j++) w[j] = __builtin_amdgcn_alignbit(w[j + 1u], w[j], ln);
+        w[NW - 1u] >>= ln;
         y += ln; k += go ? 1u : 0u;
       }
       if (on) { cnt = k; ex = y >= PE_RUN_SB ? y - PE_RUN_SB : 0u; }
