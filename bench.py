@@ -352,7 +352,7 @@ def main():
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         # HBM bytes per launch from the PMC passes of the committed profile (same command, separate rocprofv3 runs)
         traffic, traffic_source = None, None
-        for prof in ("pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
+        for prof in ("pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 if pmc["workload"] == desc[0]:

@@ -1316,8 +1316,8 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     lds_acquire();
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
-    if (kind == HK_PATH) { pe16::path_engine(me); continue; }
-    if (kind == HK_PATH2) { pe8::path_engine(me); continue; }
+    if (kind == HK_PATH) { seq = rfl(pe16::path_engine(me)); continue; }   // (back with the last request it answered: see there)
+    if (kind == HK_PATH2) { seq = rfl(pe8::path_engine(me)); continue; }
     if (kind == HK_SPLIT) {  // a context-modelled metablock: wave 1 copies (if asked to), wave 2 parses command records; the others go back to sleep
       if (rfl(me) == 1u && (g_engine_mode & 2u) == 0u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave();
       continue;

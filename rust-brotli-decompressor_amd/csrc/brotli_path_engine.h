@@ -642,7 +642,15 @@ namespace PE_CFG_NS {
 
 // One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
 // Returns (wave 0) the number of commands it took; exit form and state in LDS_LEAN as the scan engine leaves them.
+// A wave other than the decoding wave stays in here until the block is asked for something else than this engine: a call
+// saves and restores the registers the caller may count on (38 vector registers a lane: 155 KB of scratch a block and
+// invocation, more than a metablock's output is long; the lines are long out of L2 when the epilogue asks for them).  That, not
+// the shape of the stores, was the WRITE_SIZE of 1.41 (long back-references) and 2.71 (high-entropy literals) times the
+// output: 1.15 and 1.29 with the waves staying (tools/ubench/write_calib.hip: the counter is exact for every store pattern of
+// this kernel).  The loop around the function's body costs the metric 1 % (the compiler's register allocation of the whole
+// kernel shifts; -DBROTLI_AMD_PE_NO_STAY for the A/B).  Such a wave returns the number of the last request it has answered.
 __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
+pe_again:
   const uint32_t lane = lane_id();
   const uint32_t eng = PIPE ? rfl(me_) / GW : 0u;                 // the engine this wave belongs to
   const uint32_t me = PIPE ? rfl(me_) % GW : rfl(me_);            // ... and its number in it
@@ -1339,7 +1347,7 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
       // wave as a whole cost a third of the walk), the list's entries are theirs
       if (!PIPE) PE_PROF(15);   // (one engine: the anchors)
       uint32_t m = PE_JUMP * na, desc;
-      if (PIPE && id >= PEN_FIRST_SPECIAL) desc = le | 0x8000u;   // (no room for the entry's state: nothing listed)
+      if (PIPE && id >= PEN_FIRST_SPECIAL) { desc = le | 0x8000u; if (lane == 0) lds_st16(pb + PE_LIST, desc); }   // (no room for the entry's state: nothing listed -- the list's closing entry says where the stream stands)
       else for (;;) {
         uint32_t sv = id;
         for (uint32_t h = 0; h < 63u; h++) {
@@ -2005,8 +2013,20 @@ __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
   }
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t seq_ = hc_ld(HC_SEQ);   // (the request this invocation answers: the decoding wave posts the next one behind the barrier)
   __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
-  if (rfl(me_) != 0u) return 0;
+  if (rfl(me_) != 0u) {
+#ifdef BROTLI_AMD_PE_NO_STAY   // (for A/B: every wave returns after every invocation, as in round 3)
+    return seq_;
+#endif
+    for (uint32_t idle = 0;; idle++) {   // (as helper_wave idles)
+      if (hc_ld(HC_SEQ) != seq_) break;
+      if (idle < 256u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(127);
+    }
+    lds_acquire();
+    if (hc_ld(HC_SEQ) == seq_ + 1u && hc_ld(HC_KIND) == (PIPE ? (uint32_t)HK_PATH2 : (uint32_t)HK_PATH)) goto pe_again;
+    return seq_;
+  }
 #ifdef BROTLI_AMD_PROFILE_SCAN
   if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += pe_ctl_ld(pbs, PEC_STATE + 6); g_path_prof[33] += 1; }
 #endif

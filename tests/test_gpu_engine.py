@@ -201,6 +201,81 @@ def test_regions_put_together_in_lds(pkg):
     _check_against_oracle(pkg, datas, caps, 1, "lds stage")
 
 
+@pytest.mark.parametrize("alphabet", [2, 5, 64, 256])
+def test_regions_of_long_literal_runs(pkg, alphabet):
+    """Round 4: a command whose literal run is longer than a region's path gets regions of its own, decoded a stretch of the
+    stream a lane out of registers (csrc/brotli_path_engine.h, run_region).  Runs of every length around the hand-over points
+    (what a region's path holds, PE_RUN_MIN, several regions) with short copies between them, under literal codes from one bit
+    a symbol (a lane's stretch is hundreds of literals: the region's literal room is what ends it) to fifteen (code words
+    beyond the wide table's eleven bits); whole, short of output inside a run, truncated inside a run, damaged."""
+    import numpy as np
+    ref = _enc()
+    rng = np.random.Generator(np.random.PCG64(8800 + alphabet))
+    rnd = random.Random(8800 + alphabet)
+    if alphabet == 256:
+        # lengths 6, 9, 12 and 15: four groups of symbols whose frequencies are 512 : 64 : 8 : 1
+        syms = rng.permutation(256)[:253].astype(np.uint8)
+        block = np.concatenate([np.repeat(syms[:60], 512), np.repeat(syms[60:89], 64), np.repeat(syms[89:93], 8), syms[93:253]])
+
+        def lits(n):
+            return np.tile(rng.permutation(block), n // len(block) + 1)[:n].tobytes()
+    else:
+        pr = np.arange(1, alphabet + 1, dtype=np.float64) ** (-1.2 if alphabet > 5 else -0.3)
+        pr /= pr.sum()
+        base = rng.permutation(200)[:alphabet].astype(np.uint8) + 20
+
+        def lits(n):
+            return base[rng.choice(alphabet, size=n, p=pr)].tobytes()
+
+    length_sets = ((1000, 1023, 1024, 1025, 2000, 3000, 4000, 4300, 4400, 5000, 5999, 6000, 6001, 6500, 6656, 6657, 7000),
+                   (13000, 13312, 13313, 20000, 26000, 40000, 66000, 131072, 300000),
+                   None)
+    datas, caps = [], []
+    if alphabet <= 5:
+        # (an encoder finds copies everywhere in data of so few symbols: the commands are written by the repository's own
+        # emitter, tools/brotli_emit.py, insert lengths as they are wanted)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import brotli_emit as be
+        for lengths in length_sets:
+            hist, cmds = bytearray(), []
+            for k in range(14 if lengths and lengths[0] > 7000 else 30):
+                n = rnd.choice(lengths) + rnd.randrange(-2, 3) if lengths else rnd.randrange(900, 30000)
+                ins = lits(n)
+                hist += ins
+                m = rnd.choice([2, 4, 7, 20, 300, 5000])
+                dist = rnd.randrange(1, min(len(hist), 60000) + 1)
+                cmds.append((ins, m, dist))
+                for _ in range(m):
+                    hist.append(hist[-dist])
+            tail = lits(rnd.choice([1, 700, 6100]))
+            cmds.append((tail, 0, 0)); hist += tail
+            w = be.BitWriter()
+            be.write_stream_header(w, 22)
+            made = be.emit_compressed(w, cmds, be.Plan(), True)
+            c = w.finish()
+            assert bytes(made) == bytes(hist)
+            info, exp = oracle.decode(c, len(hist), 1)
+            assert info.result == 1 and exp == bytes(hist)
+            d, cp = _variants(rnd, c, len(hist), damaged=4)
+            datas += d; caps += cp
+    else:
+        for lengths in length_sets:
+            out = bytearray(lits(40000))
+            for k in range(40):
+                n = rnd.choice(lengths) + rnd.randrange(-2, 3) if lengths else rnd.randrange(900, 30000)
+                out += lits(n)
+                for _ in range(rnd.randrange(1, 4)):   # copies the encoder will find: far back and close by
+                    m = rnd.choice([4, 7, 20, 300, 5000])
+                    o = rnd.randrange(0, len(out) - m)
+                    out += out[o:o + m]
+            raw = bytes(out)
+            for q, lgwin in ((5, 22), (rnd.choice([2, 4, 6, 9]), rnd.choice([18, 20, 24]))):
+                c = ref.encode(raw, q, lgwin)
+                d, cp = _variants(rnd, c, len(raw), damaged=4)
+                datas += d; caps += cp
+    _check_against_oracle(pkg, datas, caps, 1, "literal runs, alphabet %d" % alphabet)
+
+
 def test_many_block_types(pkg):
     """literal, command and distance statistics that change every few KiB: the encoder answers with many block types and
     short blocks (block switches every few dozen commands: the engine's part ends at each of them)"""
@@ -348,22 +423,24 @@ print(json.dumps([[r.result, r.error_code, r.decoded_size, r.consumed, r.num_com
 
 
 def test_the_engines_and_the_one_wave_path_agree(pkg):
-    """The same batch (whole, truncated, damaged, one byte short) three times in fresh processes: default (path engine), the
-    scan engine only (BROTLI_AMD_ENGINE=scan), no engine blocks at all (BROTLI_AMD_NO_SCAN=1) -- same status words and bytes;
+    """The same batch (whole, truncated, damaged, one byte short) four times in fresh processes: default (path engine), two
+    engines of eight waves a block taking regions in turn (BROTLI_AMD_ENGINE=path2, round 4: kept as an opt-in), the scan
+    engine only (BROTLI_AMD_ENGINE=scan), no engine blocks at all (BROTLI_AMD_NO_SCAN=1) -- same status words and bytes;
     extra to, not instead of, the comparison with the oracle above."""
     import json
     import subprocess
     _metric_streams(1)  # (skips without an encoder)
     rows = {}
-    for name, env in (("path", {}), ("scan", {"BROTLI_AMD_ENGINE": "scan"}), ("none", {"BROTLI_AMD_NO_SCAN": "1"})):
+    for name, env in (("path", {}), ("path2", {"BROTLI_AMD_ENGINE": "path2"}), ("scan", {"BROTLI_AMD_ENGINE": "scan"}), ("none", {"BROTLI_AMD_NO_SCAN": "1"})):
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, "-c", _AB_SCRIPT, ROOT], env=e, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         rows[name] = json.loads(out.stdout.strip().splitlines()[-1])
     strip = lambda rs: [r[:5] + r[6:] for r in rs]  # everything but engine_commands
-    assert strip(rows["path"]) == strip(rows["scan"]) == strip(rows["none"])
+    assert strip(rows["path"]) == strip(rows["path2"]) == strip(rows["scan"]) == strip(rows["none"])
     assert all(r[5] == 0 for r in rows["none"]), rows["none"]
-    assert all(r[5] >= 0.9 * r[4] for r in rows["path"][:2]) and all(r[5] >= 0.9 * r[4] for r in rows["scan"][:2]), (rows["path"], rows["scan"])
+    for name in ("path", "path2", "scan"):
+        assert all(r[5] >= 0.9 * r[4] for r in rows[name][:2]), (name, rows[name])
 
 
 def test_large_window_streams_fall_back_to_the_one_wave_path(pkg):
