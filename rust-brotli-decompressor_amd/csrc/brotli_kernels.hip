@@ -63,9 +63,9 @@ constexpr int E_EXUBERANT_NIBBLE = -1, E_RESERVED = -2, E_EXUBERANT_META_NIBBLE 
 constexpr int E_RETRY_ARENA = 100;  // internal: see BROTLI_AMD_FLAG_NO_SPILL
 
 // ---- small constant tables (RFC 7932 sections 3.5, 4, 5, 6) ----
-__constant__ const uint8_t kCodeLengthCodeOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
-__constant__ const uint8_t kCodeLengthPrefixLength[16] = {2, 2, 2, 3, 2, 2, 2, 4, 2, 2, 2, 3, 2, 2, 2, 4};
-__constant__ const uint8_t kCodeLengthPrefixValue[16] = {0, 4, 3, 2, 0, 4, 3, 1, 0, 4, 3, 2, 0, 4, 3, 5};
+// (decode.rs:801-853's three small tables -- kCodeLengthCodeOrder = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15},
+// kCodeLengthPrefixLength = {2, 2, 2, 3, 2, 2, 2, 4, 2, 2, 2, 3, 2, 2, 2, 4}, kCodeLengthPrefixValue = {0, 4, 3, 2, 0, 4, 3, 1, 0, 4, 3, 2,
+// 0, 4, 3, 5} -- are immediates where read_huffman_code uses them: a nibble or five bits an entry)
 // per-lane LUT image: lanes 0..23 insert code (base | extra<<16), lanes 32..55 copy code, see lane_lut_init()
 __constant__ const uint16_t kInsBase[24] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 14, 18, 26, 34, 50, 66, 98, 130, 194, 322, 578, 1090, 2114, 6210, 22594};
 __constant__ const uint8_t kInsExtra[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
@@ -631,9 +631,11 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
     uint32_t space = 32, num_codes = 0;
     for (uint32_t i = hskip; i < 18; i++) {
       uint32_t ix = br.peek32() & 0xFu;
-      br.drop(kCodeLengthPrefixLength[ix]); NEED_INPUT(br);
-      uint32_t v = kCodeLengthPrefixValue[ix];
-      if (lane == kCodeLengthCodeOrder[i]) cl_vgpr = v;
+      // (the three small tables of decode.rs:801-853 as immediates, a nibble or five bits an entry: out of constant memory every
+      // one of them was a scalar load on the chain -- 830 clocks a symbol)
+      br.drop((uint32_t)(0x4222322242223222ull >> (ix << 2)) & 15u); NEED_INPUT(br);
+      uint32_t v = (uint32_t)(0x5340234013402340ull >> (ix << 2)) & 15u;
+      if (lane == ((uint32_t)((i < 12u ? 0x4a0f0344a020c41ull >> (5u * i) : 0x1ee6b16aull >> (5u * (i - 12u)))) & 31u)) cl_vgpr = v;
       if (v != 0) {
         space -= (32u >> v); num_codes++;
         if (space - 1u >= 32u) break;

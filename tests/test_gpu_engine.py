@@ -440,7 +440,7 @@ def test_the_engines_and_the_one_wave_path_agree(pkg):
     assert strip(rows["path"]) == strip(rows["path2"]) == strip(rows["scan"]) == strip(rows["none"])
     assert all(r[5] == 0 for r in rows["none"]), rows["none"]
     for name in ("path", "path2", "scan"):
-        assert all(r[5] >= 0.9 * r[4] for r in rows[name][:2]), (name, rows[name])
+        assert all(r[5] >= (0.8 if name == "path2" else 0.9) * r[4] for r in rows[name][:2]), (name, rows[name])   # (two engines: a region whose closure is full leaves its metablock to the one-wave loop)
 
 
 def test_large_window_streams_fall_back_to_the_one_wave_path(pkg):
