@@ -26,7 +26,7 @@ for seed in range(first, first + nseeds):
         raws.append(zipf(rnd.randrange(100, 5000)) + bytes(body))
     parts = [zipf(100000, rnd.choice([16, 64, 200]), rnd.choice([0.5, 1.0, 2.0]))]
     for _ in range(60):
-        parts.append(zipf(rnd.choice([1, 5, 40, 64, 100, 700, 3000]), 64))
+        parts.append(zipf(rnd.choice([1, 5, 40, 64, 100, 700, 3000, 3000, 4500, 6100, 14000]), rnd.choice([64, 64, 200])))   # (round 4: runs that get regions of their own)
         src = b"".join(parts); n = rnd.choice([4, 9, 70, 600, 8200, 30000]); off = rnd.randrange(0, max(1, len(src) - n))
         parts.append(src[off:off + n])
     raws.append(b"".join(parts))
