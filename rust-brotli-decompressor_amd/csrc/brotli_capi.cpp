@@ -47,7 +47,8 @@ thread_local std::string g_last_note;   // what a call did differently without f
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
 static const bool g_engine_wanted = getenv("BROTLI_AMD_NO_SCAN") == nullptr;  // (whether a device can hold such a block is decided per batch context, at its creation)
-constexpr uint64_t kEngineQueueMinBytes = 32768;  // mean compressed size from which a batch of cus < n <= 3 cus streams gets engine blocks
+constexpr uint64_t kEngineQueueMinBytes = 32768;  // mean compressed size from which a batch of cus < n <= kEngineQueueMaxPerCu cus streams gets engine blocks
+constexpr uint32_t kEngineQueueMaxPerCu = 3;      // (BROTLI_AMD_ENGINE_QUEUE_MAX overrides: experiments)
 constexpr uint32_t kScanArena = 40960;  // table arena of such a block (with the engine's rings: about 108 KiB of LDS)
 
 bool hip_ok(hipError_t e, const char* what) {
@@ -210,7 +211,8 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     can16 = arena16 <= room && (!b->auto_arena || arena16 >= 16384u);
   }
   bool engine_queue = false;
-  if (can16 && !no_wide && b->auto_arena && b->grid > b->cus && n <= 3u * b->cus) {
+  static const uint32_t queue_max = getenv("BROTLI_AMD_ENGINE_QUEUE_MAX") ? (uint32_t)atoi(getenv("BROTLI_AMD_ENGINE_QUEUE_MAX")) : kEngineQueueMaxPerCu;  // (streams per CU)
+  if (can16 && !no_wide && b->auto_arena && b->grid > b->cus && n <= queue_max * b->cus) {
     uint64_t in_total = 0;
     for (uint32_t i = 0; i < n; i++) in_total += b->h_descs[i].in_size;
     if (in_total / n >= kEngineQueueMinBytes) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }

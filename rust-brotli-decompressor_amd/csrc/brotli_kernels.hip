@@ -3086,9 +3086,10 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   }
 
   // ---- the command engine (brotli_scan_engine.h): blocks of sixteen waves, metablocks whose literals never depend on
-  // context, no large window.  It takes commands until one needs the checked code below (or the input runs short) and
+  // context (large-window streams: the path engine only).  It takes commands until one needs the checked code below (or the input runs short) and
   // hands the stream back in front of that command; an invocation that got nowhere makes the next ones rarer.
-  const bool scan_block = LDS_ONLY && CTX_NEVER && rfl(args->large_window) == 0u && hc_ld(HC_SCAN_BASE) != 0u;
+  const bool scan_block = LDS_ONLY && CTX_NEVER && hc_ld(HC_SCAN_BASE) != 0u;
+  const bool large_window = rfl(args->large_window) != 0u;   // (the path engine takes such streams since round 4, the scan engine does not)
   uint32_t scan_fails = 0;
 #ifdef BROTLI_AMD_PROFILE_SCAN
   uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter; const uint64_t pp_start = __builtin_amdgcn_s_memtime(); bool pp_first = true; (void)pp_first;
@@ -3134,7 +3135,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       const uint64_t avail = BitReader::total_bits() + BitReader::skip_bits() - origin;
       // the path engine where the four distance contexts share one prefix code (its states do not carry the context)
       const bool use_path = dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && (g_engine_mode & 1u) == 0u;
-      if (avail >= (use_path ? 2u * PE_MIN_INPUT : 8u * SC_N) && (origin >> 5) < 0xFFFFFFFFull) {
+      if ((use_path || !large_window) && avail >= (use_path ? 2u * PE_MIN_INPUT : 8u * SC_N) && (origin >> 5) < 0xFFFFFFFFull) {
         FLUSH_LITERALS();
         FLUSH_PENDING();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the other waves read the output as copy sources

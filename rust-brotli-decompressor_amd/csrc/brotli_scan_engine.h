@@ -187,6 +187,9 @@ __device__ __forceinline__ ScDist sc_dist_finish(uint32_t code, uint32_t L, uint
     dc = ((offset - 4u + extra) << postfix_bits) + postfix + num_direct;
   }
   d.kind = SCK_EXPLICIT; d.val = dc - 16u + 1u; d.bits = L + nbits;
+  // (a large-window stream's distance codes go up to 62 extra bits -- decode.rs:152-187 --: one with more than 24 is a
+  // distance no window of 2^30 holds, or an invalid one; its length is right, its value says "the checked loop's")
+  if (nbits > 24u) d.val = 1u << 30;
   return d;
 }
 __device__ __forceinline__ ScDist sc_dist(uint32_t lo, uint32_t hi, uint32_t dtree_addr, uint32_t postfix_bits, uint32_t num_direct) {

@@ -28,6 +28,8 @@ for q in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
         b.relaunch(); b.wait(); best = min(best, b.last_kernel_ms())
     ok = all(r.result == 1 and r.decoded_size == size for r in res) and hashlib.sha256(out[:size].cpu().numpy().tobytes()).hexdigest() == sha \
         and hashlib.sha256(out[(n - 1) * so:(n - 1) * so + size].cpu().numpy().tobytes()).hexdigest() == sha
-    print("%s q%-2d csize %7d  first-pass kernel %7.2f ms  %7.1f MB/s  second pass %4d streams  spilled metablocks %d  %s" %
-          (name, q, len(c), best, n * size / best / 1e3, second, sum(r.spilled_metablocks for r in res), "bit-exact" if ok else "MISMATCH"), flush=True)
+    cmds = sum(r.num_commands for r in res)
+    print("%s q%-2d csize %7d  first-pass kernel %7.2f ms  %7.1f MB/s  %5.2f G commands/s (%4.1f B a command, %3.0f %% by a command engine)  second pass %4d streams  spilled metablocks %d  %s" %
+          (name, q, len(c), best, n * size / best / 1e3, cmds / best / 1e6, n * size / max(cmds, 1), 100.0 * sum(r.engine_commands for r in res) / max(cmds, 1), second,
+           sum(r.spilled_metablocks for r in res), "bit-exact" if ok else "MISMATCH"), flush=True)
     b.close()
