@@ -64,6 +64,16 @@ def build_workload(name, n_unique=None):
     m = re.fullmatch(r"fixture:([\w.]+)x(\d+)", name)  # any of the reference's fixtures, n copies (cliff hunting)
     if m:
         return "%s x %s (reference fixture)" % (m.group(2), m.group(1)), w.fixture_streams(m.group(1)), int(m.group(2))
+    m = re.fullmatch(r"recompressed:([\w.]+)q(\d+)x(\d+)", name)  # a fixture's text through the image's encoder at another quality, n copies
+    if m and w.encoder_available():
+        import hashlib
+        (comp, size, sha), = w.fixture_streams(m.group(1))
+        info, raw = load_pkg().brotli_decode(comp, size)   # (the product decodes the fixture: checked against the manifest's hash)
+        if info.result != 1 or hashlib.sha256(raw).hexdigest() != sha:
+            raise SystemExit("fixture %s did not decode" % m.group(1))
+        q = int(m.group(2))
+        return ("%s x %s recompressed with brotli -q%d, wbits 22 (real text: literals without context at this quality, a word of the static dictionary every few dozen commands; copies of ONE stream)"
+                % (m.group(3), m.group(1), q)), [(w.brotli_compress(raw, q, 22), size, sha)], int(m.group(3))
     m = re.fullmatch(r"alice29x(\d+)", name)
     if m or not w.encoder_available():
         n = int(m.group(1)) if m else 1024
@@ -401,7 +411,8 @@ def main():
             legs = [("alice29x1024", 10, None)]
             if w.encoder_available():
                 legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1), ("longbackref_512x4MiB", 3, None),
-                         ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None), ("surveymix_256x4MiB", 5, None)]
+                         ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None), ("surveymix_256x4MiB", 5, None),
+                         ("recompressed:lcet10.txt.compressedq5x256", 3, None), ("recompressed:lcet10.txt.compressedq5x1024", 3, None)]
                 if os.environ.get("BROTLI_BENCH_NO_1GIB") is None:
                     legs.append(("longbackref_1x1024MiB", 1, 1))  # BASELINE config 3 as written: ONE stream of 1 GiB
             for name, steps, nu in legs:

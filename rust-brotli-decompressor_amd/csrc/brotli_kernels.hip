@@ -3152,6 +3152,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         sc_ctl_st(sb, SCC_DT0, LDS_FIXED + dt0); sc_ctl_st(sb, SCC_DT0 + 1, LDS_FIXED + dt1); sc_ctl_st(sb, SCC_DT0 + 2, LDS_FIXED + dt2); sc_ctl_st(sb, SCC_DT0 + 3, LDS_FIXED + dt3);
         sc_ctl_st(sb, SCC_POSTFIX, postfix_bits); sc_ctl_st(sb, SCC_NUM_DIRECT, num_direct);
         sc_ctl_st(sb, SCC_OUT_LO, (uint32_t)(uintptr_t)out); sc_ctl_st(sb, SCC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
+        sc_ctl_st(sb, SCC_DICT_LO, (uint32_t)(uintptr_t)dict); sc_ctl_st(sb, SCC_DICT_HI, (uint32_t)((uint64_t)(uintptr_t)dict >> 32));
         const bool use_pipe = use_path && (g_engine_mode & 8u) != 0u && !prefer_one_engine;   // (two engines of eight waves, regions in turns: BROTLI_AMD_ENGINE=path2 -- measured slower than one of sixteen, see DESIGN)
         hc_st(HC_KIND, use_pipe ? (uint32_t)HK_PATH2 : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();

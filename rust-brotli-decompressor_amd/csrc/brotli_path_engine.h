@@ -142,7 +142,20 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
-       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ };
+       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */ };
+// Words of the static dictionary (decode.rs:2593-2640; one command in 33 to 87 of text at -q 4 .. 9, tools/eligibility_survey.py).
+// Round 4's engine stopped in front of each: an invocation and a region's tables for some fifty commands, 3200 clocks a command.
+// Now (one engine): the resolve lets the first such command of what is listed through with its literals alone, wave 0 puts the
+// word behind them when the pass's output is complete, and the resolve and the execute run again for the commands behind it --
+// the region's tables, the walk's list and the details in the waves' registers hold for every pass.  A word that is not a plain
+// one (unknown transform, an empty word, one that does not fit the limits) ends the invocation behind the command's distance:
+// the checked loop says what it is.
+#if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_NO_DICT)
+#define PE_DICT 1
+#else
+#define PE_DICT 0
+#endif
+
 
 #ifdef BROTLI_AMD_PROFILE_SCAN
 #ifndef BROTLI_AMD_PATH_PROF_DEFINED
@@ -642,6 +655,42 @@ namespace PE_CFG_NS {
 
 // One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
 // Returns (wave 0) the number of commands it took; exit form and state in LDS_LEAN as the scan engine leaves them.
+#if PE_DICT
+// (PE_DICT) Wave 0, behind a pass that ended with the literals of a command whose copy is a word of the static dictionary: the
+// word goes out behind them (decode.rs:2593-2640, as lean_rec_commands takes them) and the stream's state moves on; PEC_AGAIN
+// says whether the commands behind it get a pass.  A function of its own: it is rare, and the engine's loops stay as they were.
+__device__ __noinline__ void pe_dict_word(const uint32_t pbs, const uint32_t pb, gu8* const out, gcu8* const dict, const uint32_t m) {
+  const uint32_t lane = lane_id();
+  PeStream sw = pe_st_load(pbs);
+  const uint32_t dd = pe_ctl_ld(pb, PEC_DICTD), wn_ = pe_ctl_ld(pb, PEC_DICTN), kd = pe_ctl_ld(pb, PEC_DICTK);
+  const uint32_t maxd = sw.P < (uint64_t)(uint32_t)sw.max_backward ? (uint32_t)sw.P : (uint32_t)sw.max_backward;
+  bool word = false; WordShape w = {}; uint32_t word_offset = 0;
+  if (dd > maxd && wn_ >= 4u && wn_ <= 24u) {
+    const uint32_t shift = kDictSizeBitsByLength[wn_];
+    const uint32_t word_id = dd - maxd - 1u;
+    const uint32_t transform_idx = word_id >> shift;
+    if (transform_idx < (uint32_t)BROTLI_NUM_TRANSFORMS) {
+      word_offset = kDictOffsetsByLength[wn_] + (word_id & mask_bits(shift)) * wn_;
+      w = word_shape(wn_, transform_idx);
+      word = w.total != 0u && w.total < sw.quota && (int32_t)w.total <= sw.mlen;
+    }
+  }
+  uint32_t again = 0;
+  if (word) {   // (the ring is not touched: decode.rs:2643-2644)
+    const uint32_t ob = dictionary_word_bytes(dict, word_offset, w);
+    if (lane < w.total) out[sw.P + lane] = (uint8_t)ob;
+    sw.P += w.total; sw.quota -= w.total; sw.mlen -= (int32_t)w.total;
+    pe_st_store(pbs, sw);
+    again = (kd + 1u < m && sw.quota >= SC_MIN_QUOTA && sw.bl1 != 0u) ? 1u : 0u;
+    if (again != 0u) { pe_ctl_st(pb, PEC_KS, kd + 1u); pe_ctl_st(pb, PEC_P0_LO, (uint32_t)sw.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(sw.P >> 32)); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {   // not a plain word: the checked loop says what it is, from behind the command's distance on
+    pe_ctl_st(pb, PEC_PDX, 1u); pe_ctl_st(pb, PEC_CONT, 0u);
+  }
+  pe_ctl_st(pb, PEC_AGAIN, again);
+}
+
+#endif
 // A wave other than the decoding wave stays in here until the block is asked for something else than this engine: a call
 // saves and restores the registers the caller may count on (38 vector registers a lane: 155 KB of scratch a block and
 // invocation, more than a metablock's output is long; the lines are long out of L2 when the epilogue asks for them).  That, not
@@ -657,7 +706,7 @@ pe_again:
   const uint32_t T = PIPE ? threadIdx.x % (64u * GW) : threadIdx.x;
   const uint32_t pbs = hc_ld(HC_SCAN_BASE);                       // what the block's engines share
   const uint32_t pb = pbs + PE_SET0 + eng * PE_SET_BYTES;         // this engine's tables
-  if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u);
+  if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u); lds_st32(pb + PE_CTL + 4u * PEC_PDX, 0u); }
   if (PIPE) {   // what the two engines tell each other starts from nothing
     if (threadIdx.x < 8u) lds_st32(pbs + PE_CTL + 4u * (PEC_RESOLVED + threadIdx.x), 0u);
     if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_GBAR, 0u);
@@ -672,6 +721,7 @@ pe_again:
   c.postfix_bits = pe_ctl_ld(pbs, SCC_POSTFIX); c.num_direct = pe_ctl_ld(pbs, SCC_NUM_DIRECT);
   const uint32_t base_dw = pe_ctl_ld(pbs, SCC_BASE_DW), in_limit = pe_ctl_ld(pbs, SCC_IN_LIMIT);
   gu8* const out = (gu8*)(uintptr_t)((uint64_t)pe_ctl_ld(pbs, SCC_OUT_LO) | ((uint64_t)pe_ctl_ld(pbs, SCC_OUT_HI) << 32));
+  gcu8* const dict = (gcu8*)(uintptr_t)((uint64_t)pe_ctl_ld(pbs, SCC_DICT_LO) | ((uint64_t)pe_ctl_ld(pbs, SCC_DICT_HI) << 32)); (void)dict;
   gcu32* const in_dw = BitReader::base() + base_dw;
   const uint32_t limit_dw = (in_limit + 31u) >> 5;
   c.lut_vgpr = 0;
@@ -1434,13 +1484,15 @@ pe_again:
     // after a barrier every wave puts the batches in front of it together.  Then every limit the reference checks, as in
     // the scan engine; the first command that needs the checked loop ends the engine's part in front of it.
     const uint32_t nb = (m + 63u) >> 6;
-    uint32_t my_exec = 0;  // commands of this wave's batch that are executed
+    uint32_t ks = 0;       // the pass's first command (PE_DICT: the commands in front of it went out in the passes before)
+pe_pass:
+    uint32_t my_exec = 0;  // commands of this wave's batch that are executed (counted from the batch's first: those below ks are not)
     {
       const PeStream st = pe_st_load(pbs);
       const bool mine = bw < nb;
       const uint32_t k0 = bw << 6;
       const uint32_t K = mine ? (m - k0 < 64u ? m - k0 : 64u) : 0u;
-      const bool active = lane < K;
+      const bool active = lane < K && k0 + lane >= ks;
       const uint32_t ra = pb + PE_REC + ((mine ? k0 + (active ? lane : 0u) : 0u) << 4);
       const uint32_t r0 = dr0, r1 = dr1, r2 = dr2, r3 = dr3;  // (the details above: this wave's batch, in its registers)
       const uint32_t ins = active ? r1 & 0xFFFFu : 0u, copy = active ? r2 : 0u;
@@ -1493,7 +1545,7 @@ pe_again:
           if (lane == 0) { lds_st32(rs + 16u + 8u * r, tg); lds_st32(rs + 20u + 8u * r, vl); }
         }
       }
-      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); }   // (... and the execute's items are handed out from the first)
+      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DICTK, 0xFFFFFFFFu); }   // (... and the execute's items are handed out from the first)
       PE_BAR();
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
@@ -1513,19 +1565,24 @@ pe_again:
       const uint64_t out_a = (uint64_t)c_out + s2;
       bool ok = !odd && !big && lit_a <= st.bl0 && cmd_a <= st.bl1 && dst_a <= st.bl2 && out_a < (uint64_t)st.quota;
       const uint64_t rel = (uint64_t)c_out + out_excl;   // where the command's output starts, from the region's
+      bool dictc = false;   // (PE_DICT) the copy is a word of the static dictionary and the command's literals clear every limit
       {
         // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
         const uint64_t pk = st.P + rel + ins;
         const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
+        if (PE_DICT) dictc = active && ok && kind == SCK_EXPLICIT && dist > maxd && rel + ins < (uint64_t)st.quota;
         ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
       }
       const uint64_t stopmask = __ballot(active && !ok);
-      const uint32_t kpb = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
-      if (mine && kpb < K && lane == 0) pe_atomic_min(pb + PE_CTL + 4u * PEC_KP, k0 + kpb);
+      uint32_t kpb = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
+      const uint64_t dictmask = PE_DICT ? __ballot(dictc) : 0ull;
+      if (PE_DICT && stopmask != 0ull && ((dictmask >> kpb) & 1ull) != 0ull) kpb++;   // (the pass ends BEHIND such a command's literals)
+      if (mine && stopmask != 0ull && lane == 0) pe_atomic_min(pb + PE_CTL + 4u * PEC_KP, k0 + kpb);
       // a copy whose source reaches into the region's own output is done afterwards (bit 31 of w0); long items get a wave
-      const uint32_t dep = (copy != 0u && rel + ins + copy > (uint64_t)(uint32_t)dist) ? 1u : 0u;
+      const uint32_t copy_x = dictc ? 0u : copy;   // (a dictionary word is not the execute's)
+      const uint32_t dep = (copy_x != 0u && rel + ins + copy_x > (uint64_t)(uint32_t)dist) ? 1u : 0u;
       uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
-      const bool bigc = (copy > PE_LANE_COPY && dep == 0u) || ins - uu > PE_LANE_LITS;
+      const bool bigc = (copy_x > PE_LANE_COPY && dep == 0u) || ins - uu > PE_LANE_LITS;
       const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc);
       if (mine && lane == 0) lds_st32(rs + 48u, (uint32_t)__popcll(dmk) | ((uint32_t)__popcll(bmk) << 16));
       PE_BAR();
@@ -1541,19 +1598,23 @@ pe_again:
           c_dep = tot & 0xFFFFu; c_big = tot >> 16;
         }
         const uint64_t dm2 = dmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull)), bm2 = bmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull));
-        if (lane < my_exec) {
+        if (lane < my_exec && active) {
           if (dep != 0u) lds_st16(pb + PE_DLIST + ((c_dep + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm2, 0u))) << 1), k0 + lane);
           if (bigc) lds_st16(pb + PE_BLIST + ((c_big + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm2, 0u))) << 1), k0 + lane);
-          lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 4u, r1); lds_st32(ra + 8u, r2); lds_st32(ra + 12u, (uint32_t)dist);
+          lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 4u, r1); lds_st32(ra + 8u, copy_x); lds_st32(ra + 12u, (uint32_t)dist);
           lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
         }
         // the batch the engine's part ends in leaves the stream's state: sums up to there, the ring behind its executed pushes
         const bool last = kp_total <= k0 + K;
         if (last) {
           const uint32_t kp = my_exec;
-          const uint32_t lit_tot = c_lit + rdlane(lit_incl, kp - 1u), t1 = rdlane(s1, kp - 1u), out_tot = c_out + rdlane(s2, kp - 1u);
+          // (PE_DICT: the pass's last command is one whose copy is a dictionary word -- wave 0's, behind the execute: its copy length
+          // is not output of this pass, its distance not one for the ring, decode.rs:2643-2644)
+          const bool dlast = PE_DICT && ((dictmask >> (kp - 1u)) & 1ull) != 0ull;
+          const uint32_t lit_tot = c_lit + rdlane(lit_incl, kp - 1u), t1 = rdlane(s1, kp - 1u), out_tot = c_out + rdlane(s2, kp - 1u) - (dlast ? rdlane(copy, kp - 1u) : 0u);
           const uint32_t cmd_tot = c_cmd + (t1 & 0xFFFFu), dst_tot = c_dst + (t1 >> 16);
-          const uint32_t got = (uint32_t)__popcll(pmk & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)));
+          const uint32_t got = (uint32_t)__popcll(pmk & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)) & ~(dlast ? 1ull << (kp - 1u) : 0ull));
+          if (dlast) { pe_ctl_st(pb, PEC_DICTK, k0 + kp - 1u); pe_ctl_st(pb, PEC_DICTD, rdlane((uint32_t)dist, kp - 1u)); pe_ctl_st(pb, PEC_DICTN, rdlane(copy, kp - 1u)); }
           int32_t e0 = d0, e1 = d1, e2 = d2, e3 = d3;
           if (got != 0u) {
             const uint32_t dperm = bperm(perm << 2, (uint32_t)dist);  // lane r: the distance of the r-th push
@@ -1570,7 +1631,7 @@ pe_again:
           pe_ctl_st(pb, PEC_OUTTOT, out_tot); pe_ctl_st(pb, PEC_STAGED, (PE_STG_CAP != 0u && out_tot <= PE_STG_CAP) ? 1u : 0u);
         }
       }
-      if (kp_total == 0u && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); }  // (nothing executed: the state stays)
+      if (kp_total <= ks && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); }  // (nothing executed: the state stays)
       // (every wave's stores of the region before are in memory before anyone reads them as copy sources: here, a whole region's
       // tables later, the wait is over before it starts -- at the region's start it cost the stores' round trip)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1589,7 +1650,8 @@ pe_again:
         }
         sn.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
         // the region went through whole and the next one starts at a command with a long literal run: the next regions are the run's
-        if (!PIPE && kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
+        const bool dict_ends = PE_DICT && pe_ctl_ld(pb, PEC_DICTK) != 0xFFFFFFFFu;   // (the pass ends with a dictionary word still to come: no run region from here -- the next region finds the run itself)
+        if (!PIPE && !dict_ends && kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
         // ... or the region listed nothing because its first command's literal run is more than its path holds (4300 literals of
         // 7.5 bits) though less than PE_RUN_MIN: regions of its own all the same -- giving the command back would keep the engine
         // away from the commands behind it too (seen on the high-entropy streams: the rest of a metablock on one wave)
@@ -1662,7 +1724,7 @@ pe_again:
 #endif
       auto path_literals = [&](const uint32_t b, const uint32_t cnt) {
         const uint32_t k = (b << 6) + lane;
-        const bool on = lane < cnt;
+        const bool on = lane < cnt && k >= ks;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
         const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u);
         const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
@@ -1690,7 +1752,7 @@ pe_again:
       };
       if (my_exec != 0u) {
         const uint32_t k = (bw << 6) + lane;
-        const bool on = lane < my_exec;
+        const bool on = lane < my_exec && k >= ks;
         const uint32_t ra = pb + PE_REC + ((on ? k : 0u) << 4);
         const uint32_t r0 = lds_ld32(ra), r1 = lds_ld32(ra + 4u), cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
         const uint32_t off = lds_ld32(pb + PE_OFF + ((on ? k : 0u) << 2));
@@ -1858,11 +1920,11 @@ pe_again:
 #ifdef BROTLI_AMD_PROFILE_SCAN
           const uint64_t dep_t0 = __builtin_amdgcn_s_memtime(); uint32_t dep_n = 0;
 #endif
-          for (uint32_t k0 = 0; k0 < kp; k0 += 64u) {
+          for (uint32_t k0 = ks & ~63u; k0 < kp; k0 += 64u) {
             const uint32_t k = k0 + lane;
             const uint32_t ra = pb + PE_REC + ((k < kp ? k : 0u) << 4);
             const uint32_t x0 = lds_ld32(ra), x1 = lds_ld32(ra + 4u), xn = lds_ld32(ra + 8u), xd = lds_ld32(ra + 12u), xo = lds_ld32(pb + PE_OFF + ((k < kp ? k : 0u) << 2));
-            uint64_t dm = __ballot(k < kp && (x0 >> 31) != 0u && ((x0 >> 29) & 1u) == 0u);
+            uint64_t dm = __ballot(k >= ks && k < kp && (x0 >> 31) != 0u && ((x0 >> 29) & 1u) == 0u);
             while (dm) {
               const uint32_t kk = (uint32_t)__builtin_ctzll(dm);
               dm &= dm - 1ull;
@@ -1904,6 +1966,22 @@ pe_again:
       }
       PE_PROF(10);
     }
+#if PE_DICT
+    if (pe_ctl_ld(pb, PEC_DICTK) != 0xFFFFFFFFu) {
+      // the pass ended behind the literals of a command whose copy is a word of the static dictionary (decode.rs:2593-2640, as
+      // lean_rec_commands takes them): wave 0 puts it behind them, and the commands behind it get a pass of their own
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PE_BAR();   // (the pass's output is complete, nobody reads its records any more)
+      if (me == 0) pe_dict_word(pbs, pb, out, dict, m);
+      PE_BAR();
+      if (pe_ctl_ld(pb, PEC_AGAIN) != 0u) {
+        ks = pe_ctl_ld(pb, PEC_KS);
+        P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+        rseq++;
+        goto pe_pass;
+      }
+    }
+#endif
     if (PIPE) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PE_BAR();
@@ -2048,12 +2126,13 @@ pe_again:
     lds_sync();
     return st.ncmd;
   }
+  const bool pdx = PE_DICT && pe_ctl_ld(pb, PEC_PDX) != 0u;   // (behind the distance of a command whose literals are out: postReadDistance, decode.rs:2583)
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u));
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
-    LEAN_ST(L_INSERT, 0u); LEAN_ST(L_COPY, 0u); LEAN_ST(L_DCODE, 0); LEAN_ST(L_DCTX, 0u); LEAN_ST(L_LITS_LEFT, 0u);
+    LEAN_ST(L_INSERT, 0u); LEAN_ST(L_COPY, pdx ? pe_ctl_ld(pb, PEC_DICTN) : 0u); LEAN_ST(L_DCODE, pdx ? (int32_t)pe_ctl_ld(pb, PEC_DICTD) : 0); LEAN_ST(L_DCTX, 0u); LEAN_ST(L_LITS_LEFT, 0u);
   }
   lds_sync();
   return st.ncmd;
@@ -2066,4 +2145,5 @@ pe_again:
 #undef PE_TRY_RUN_FROM
 #undef PE_BAR
 #undef PE_HOPS_REC
+#undef PE_DICT
 #undef PE_SPIN_CHECK

@@ -78,7 +78,7 @@ static_assert(SC_WAVES * HL_SLOT <= 8 * SC_N2, "the literal rounds' slots of a s
 // posts per tick: a group of up to SC_GROUP batches (entries in SC_XL, per batch its entry count and output position) and
 // two flags -- the walk stopped short of its limit because the group was full; the engine's part ends with this group
 enum { SCC_BASE_DW = 4, SCC_IN_LIMIT = 5, SCC_LIT_TREE = 6, SCC_CMD_TREE = 7, SCC_DT0 = 8, SCC_POSTFIX = 12, SCC_NUM_DIRECT = 13,
-       SCC_OUT_LO = 14, SCC_OUT_HI = 15, SCC_ENTRY = 16, SCC_FLAGS = 18,
+       SCC_OUT_LO = 14, SCC_OUT_HI = 15, SCC_ENTRY = 16, SCC_FLAGS = 18, SCC_DICT_LO = 20, SCC_DICT_HI = 21 /* the static dictionary (path engine) */,
        // the two group buffers (posted in even / odd ticks): words from SCC_GRP + 16 * parity
        SCC_GRP = 32, SCG_NG = 0, SCG_ANYDEP = 1, SCG_K = 2 /* + batch */, SCG_P = 6 /* + 2 * batch */ };
 enum { SCF_BEHIND = 1, SCF_LEAVE = 2 };
