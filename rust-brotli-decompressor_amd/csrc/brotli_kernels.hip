@@ -79,6 +79,10 @@ __constant__ const uint16_t kMaxTableSize[37] = {256, 402, 436, 468, 500, 534, 5
                                                   1464, 1496, 1528};
 
 constexpr int ROOT_BITS = 8;
+// the LDS part of the table arena as a cache of the trees in use (run_commands): a literal tree (630 entries at most), a command
+// tree (1080), four distance trees (920 each: 520 symbols), sixteen-byte steps
+constexpr uint32_t TREE_CACHE_LIT = 0, TREE_CACHE_LIT_BYTES = 1264, TREE_CACHE_CMD = 1280, TREE_CACHE_CMD_BYTES = 2160, TREE_CACHE_DIST = 3456, TREE_CACHE_DIST_BYTES = 1856,
+                   TREE_CACHE_BYTES = TREE_CACHE_DIST + 4u * TREE_CACHE_DIST_BYTES;
 constexpr uint32_t MAX_ALPHABET = 1152;  // 16 + 120 + (62 << 4) = 1128 for large-window distance codes
 
 // ---- fixed LDS carve (bytes); the arena follows ----
@@ -3004,7 +3008,16 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t prof_fast_batches = 0, prof_fast_syms = 0; (void)prof_fast_batches; (void)prof_fast_syms;
   uint32_t prof_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)prof_stage;
 
-  uint32_t cmd_tree = a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4);
+  // (the LDS part as a cache of the trees in use: see run_commands)
+  const bool tree_cache = LDS_ONLY && CTX_NEVER && rfl(args->reserved_) != 0u;
+  auto cached_tree = [&](const uint32_t tree, const uint32_t slot, const uint32_t bytes) -> uint32_t {
+    if (!tree_cache) return tree;
+    for (uint32_t off = lane * 16u; off < bytes; off += 1024u)
+      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(&g_smem[LDS_FIXED + slot + off]) = *reinterpret_cast<gu32x4*>(a.glb + tree + off);
+    lds_sync();
+    return slot;
+  };
+  uint32_t cmd_tree = cached_tree(a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4), TREE_CACHE_CMD, TREE_CACHE_CMD_BYTES);
   uint32_t ctx_slice = 0, lit_tree = 0, trivial = 0, ctx_lut = LDS_CTX_LUT, lit_zero = 0, ctx_tree_v = 0;
   // PrepareLiteralDecoding, decode.rs:1554-1570
   auto prepare_literal = [&]() {
@@ -3014,7 +3027,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     uint32_t mine = a.ld8_lane<false>(HOTC(H_CTX_MAP) + ctx_slice + lane);
     uint32_t first = rdlane(mine, 0);
     trivial = (__ballot(mine != first) == 0ull) ? 1u : 0u;
-    lit_tree = a.ld32<false>(HOTC(H_LIT_TREES) + first * 4);
+    lit_tree = cached_tree(a.ld32<false>(HOTC(H_LIT_TREES) + first * 4), TREE_CACHE_LIT, TREE_CACHE_LIT_BYTES);
     // lane c: the tree of literal context c in this block type (context map and tree group folded into one readlane)
     if (!CTX_NEVER) {
       uint32_t toff = HOTC(H_LIT_TREES) + mine * 4;
@@ -3030,6 +3043,13 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     uint32_t m = HOTC(H_DIST_CTX_MAP) + (HOTC(H_RING + 5) << 2), g = HOTC(H_DIST_TREES);
     dt0 = a.ld32<false>(g + a.ld8<false>(m + 0) * 4); dt1 = a.ld32<false>(g + a.ld8<false>(m + 1) * 4);
     dt2 = a.ld32<false>(g + a.ld8<false>(m + 2) * 4); dt3 = a.ld32<false>(g + a.ld8<false>(m + 3) * 4);
+    if (tree_cache) {   // (contexts that share a tree share its copy: the path engine asks whether the four are one)
+      const uint32_t g0 = dt0, g1 = dt1, g2 = dt2, g3 = dt3;
+      dt0 = cached_tree(g0, TREE_CACHE_DIST, TREE_CACHE_DIST_BYTES);
+      dt1 = g1 == g0 ? dt0 : cached_tree(g1, TREE_CACHE_DIST + TREE_CACHE_DIST_BYTES, TREE_CACHE_DIST_BYTES);
+      dt2 = g2 == g0 ? dt0 : g2 == g1 ? dt1 : cached_tree(g2, TREE_CACHE_DIST + 2u * TREE_CACHE_DIST_BYTES, TREE_CACHE_DIST_BYTES);
+      dt3 = g3 == g0 ? dt0 : g3 == g1 ? dt1 : g3 == g2 ? dt2 : cached_tree(g3, TREE_CACHE_DIST + 3u * TREE_CACHE_DIST_BYTES, TREE_CACHE_DIST_BYTES);
+    }
   };
   prepare_distance();
   // Literal context never matters in this metablock when every literal block type has a trivial context map
@@ -3304,7 +3324,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       int r;
       BLOCK_SWITCH(1, bl1, r);
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
-      if (r == BS_SWITCHED) { cmd_tree = a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4); continue; }
+      if (r == BS_SWITCHED) { cmd_tree = cached_tree(a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4), TREE_CACHE_CMD, TREE_CACHE_CMD_BYTES); continue; }
     }
     {
       uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
@@ -3798,23 +3818,37 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
   h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
   h.spec_scratch = (uint64_t)(uintptr_t)(s.ar.glb + s.ar_end);
   h.num_commands = s.num_commands;
-  h.engine_commands = s.engine_commands;
+  h.engine_commands = s.engine_commands; h.reserved_ = 0u;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
   int e;
-  if (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) {
-    // every literal block type with a constant context map (DetectTrivialLiteralBlockTypes, decode.rs:1525-1553)?
-    bool ctx_never = true;
+  // every literal block type with a constant context map (DetectTrivialLiteralBlockTypes, decode.rs:1525-1553)?
+  bool ctx_never = true;
+  Arena ar_ = s.ar; ar_.uniformize();
+  {
     const uint32_t nbt0 = rfl(s.nbt0), ctx_map = rfl(s.ctx_map);
-    Arena ar_ = s.ar; ar_.uniformize();
     for (uint32_t bt = 0; bt < nbt0; bt++) {
       uint32_t mine = ar_.ld8_lane<false>(ctx_map + (bt << 6) + lane_id());
       if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
     }
+  }
+  if (rfl(s.ar.top) <= rfl(s.ar.lds_limit)) {
     if (!ctx_never && (rfl(s.flags) & BROTLI_AMD_FLAG_ENGINE_ONLY) && rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN) {
       s.num_metablocks--; return E_RETRY_ARENA;  // (see the flag; nothing of this metablock has been output yet)
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
+  } else if (ctx_never && ar_.lds_limit >= TREE_CACHE_BYTES && (g_engine_mode & 16u) == 0u) {
+    // More tables than the LDS part holds (binaries at -q 5 and up: dozens of block types, a tree each), but literals that do not
+    // depend on context: at any time the loop reads ONE literal tree, one command tree and the distance trees of one block type.
+    // What lies in the LDS part goes to its place in the block's global scratch (the arena addresses both with the same offsets),
+    // the LDS part becomes a cache of the trees in use -- refilled at the block switches, every few hundred commands --, and the
+    // loop is the one for tables in LDS, command engine and all.  (Round 4; before: every table lookup of such a metablock a round
+    // trip to memory, 1.1 GB/s for 256 copies of libc.so.6 at -q 5.)
+    for (uint32_t off = lane_id() * 16u; off < ar_.lds_limit; off += 1024u)
+      *reinterpret_cast<gu32x4*>(ar_.glb + off) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[LDS_FIXED + off]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    h.reserved_ = 1u; h.ar.lds_limit = 0u;
+    e = process_commands<true, true>(&h);
   } else {
     if (rfl(s.flags) & BROTLI_AMD_FLAG_NO_SPILL) { s.num_metablocks--; return E_RETRY_ARENA; }  // nothing of this metablock has been output yet (the next pass counts it)
     s.num_spilled++;
@@ -4312,8 +4346,9 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
       // bit 0: the scan engine only; bit 1: no copier wave for context-modelled metablocks (the default: it does not pay, see DESIGN;
       // "split" turns it on); bit 2: no command records ("norec")
       // bit 3: the path engine as two engines of eight waves that take the stream's regions in turns ("path2"; experiment)
+      // bit 4: tables beyond the LDS part are read where they lie instead of the trees in use being cached ("nocache": A/B)
       // (static storage: the asynchronous copy reads it after this function has returned)
-      static const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : 2u;
+      static const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : strcmp(eng, "nocache") == 0 ? 18u : 2u;
       hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
       if (e2 != hipSuccess) return e2;
     }

@@ -304,6 +304,55 @@ def test_words_of_the_static_dictionary_in_the_engine(pkg):
     _check_against_oracle(pkg, datas, caps, 1, "dictionary words")
 
 
+_CACHE_SCRIPT = r"""
+import importlib.util, json, os, sys, hashlib
+ROOT = sys.argv[1]
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import libbrotli_ref as ref
+spec = importlib.util.spec_from_file_location("rust_brotli_decompressor_amd", os.path.join(ROOT, "rust-brotli-decompressor_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec); sys.modules["rust_brotli_decompressor_amd"] = pkg; spec.loader.exec_module(pkg)
+raw = open(sys.executable, "rb").read()[: 3 << 20]
+datas = [ref.encode(raw, 5, 22), ref.encode(raw, 9, 22)]
+datas.append(datas[0][: len(datas[0]) * 2 // 3])
+bad = bytearray(datas[1]); bad[len(bad) // 2] ^= 16; datas.append(bytes(bad))
+caps = [len(raw), len(raw), len(raw), len(raw)]
+n = int(sys.argv[2])
+datas = datas * n; caps = caps * n
+b = pkg.Batch(len(datas))
+res, outs = b.decode_host(datas, caps, 1)
+b.close()
+print(json.dumps([[r.result, r.error_code, r.decoded_size, r.consumed, r.num_commands, r.engine_commands, r.spilled_metablocks, hashlib.sha256(o).hexdigest()] for r, o in zip(res, outs)]))
+"""
+
+
+@pytest.mark.parametrize("copies", [1, 300])
+def test_more_tables_than_lds_holds(pkg, copies):
+    """Round 4: a metablock whose prefix-code tables do not fit the LDS part of the table arena (an executable at -q 5 / 9: dozens
+    of block types, a tree each) but whose literals do not depend on context runs with the LDS part as a cache of the trees in
+    use (run_commands / cached_tree in csrc/brotli_kernels.hip), in blocks of sixteen waves (4 streams) and in small blocks (1200).
+    Against the oracle, and against the same batch with the tables read where they lie (BROTLI_AMD_ENGINE=nocache, a fresh
+    process each); without the cache every such metablock counts as spilled, with it none of the whole streams' do."""
+    import json
+    import subprocess
+    _enc()
+    rows = {}
+    for name, env in (("cache", {}), ("nocache", {"BROTLI_AMD_ENGINE": "nocache"})):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", _CACHE_SCRIPT, ROOT, str(copies)], env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows[name] = json.loads(out.stdout.strip().splitlines()[-1])
+    strip = lambda rs: [r[:5] + r[7:] for r in rs]   # everything but engine_commands and spilled_metablocks
+    assert strip(rows["cache"]) == strip(rows["nocache"])
+    ref = _enc()
+    raw = open(sys.executable, "rb").read()[: 3 << 20]
+    for i, q in ((0, 5), (1, 9)):
+        info, exp = oracle.decode(ref.encode(raw, q, 22), len(raw), 1)
+        assert exp == raw
+        for r in rows["cache"][i::4]:
+            assert r[:5] == [info.result, info.error_code, info.decoded_size, info.consumed, info.num_commands] and r[7] == hashlib.sha256(raw).hexdigest(), r
+    assert any(r[6] != 0 for r in rows["nocache"][:2]), rows["nocache"][:2]   # (else the test streams do not test what they are for)
+
+
 def test_many_block_types(pkg):
     """literal, command and distance statistics that change every few KiB: the encoder answers with many block types and
     short blocks (block switches every few dozen commands: the engine's part ends at each of them)"""

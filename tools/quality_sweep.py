@@ -10,10 +10,13 @@ from conftest import load_pkg
 pkg = load_pkg()
 name = sys.argv[1] if len(sys.argv) > 1 else "lcet10.txt.compressed"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-(comp, size, sha), = w.fixture_streams(name)
-info, raw = pkg.brotli_decode(comp, size)
-assert info.result == 1 and hashlib.sha256(raw).hexdigest() == sha
-for q in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+if os.path.exists(name):   # (any file of the box instead of a fixture: its first 8 MiB)
+    raw = open(name, "rb").read()[: 8 << 20]; size = len(raw); sha = hashlib.sha256(raw).hexdigest(); name = os.path.basename(name)
+else:
+    (comp, size, sha), = w.fixture_streams(name)
+    info, raw = pkg.brotli_decode(comp, size)
+    assert info.result == 1 and hashlib.sha256(raw).hexdigest() == sha
+for q in [int(x) for x in os.environ.get("SWEEP_Q", "0 1 2 3 4 5 6 7 8 9 10 11").split()]:
     c = w.brotli_compress(raw, q, 22)
     si, so = (len(c) + 255) // 256 * 256, (size + 255) // 256 * 256
     src = torch.frombuffer(bytearray(c), dtype=torch.uint8).cuda()
