@@ -3115,6 +3115,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter; const uint64_t pp_start = __builtin_amdgcn_s_memtime(); bool pp_first = true; (void)pp_first;
 #endif
   bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
+  bool prefer_scan = false;         // ... or the scan engine: the path engine found its regions bound by their closure (see there)
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
   // ahead of this wave (rec_wave; the lean loop takes commands out of them); on request (BROTLI_AMD_ENGINE=split) wave 1 executes
   // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
@@ -3154,7 +3155,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       const uint64_t origin = abs_bit & ~63ull;
       const uint64_t avail = BitReader::total_bits() + BitReader::skip_bits() - origin;
       // the path engine where the four distance contexts share one prefix code (its states do not carry the context)
-      const bool use_path = dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && (g_engine_mode & 1u) == 0u;
+      const bool use_path = dt0 == dt1 && dt0 == dt2 && dt0 == dt3 && (g_engine_mode & 1u) == 0u && (!prefer_scan || large_window);
       if ((use_path || !large_window) && avail >= (use_path ? 2u * PE_MIN_INPUT : 8u * SC_N) && (origin >> 5) < 0xFFFFFFFFull) {
         FLUSH_LITERALS();
         FLUSH_PENDING();
@@ -3197,7 +3198,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
           for (uint32_t t = lane; t < SC_WAVES * 16u; t += 64u) lds_st32(hb_ + (t >> 4) * HL_SLOT + HL_CTL + 4u * (t & 15u), 0u);
         }
         const uint32_t form_raw = LEAN_LD(L_SC_POS_HI), form = form_raw & 0xFFu;
-        const bool declined = (form_raw >> 8) != 0u;   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
+        const bool declined = ((form_raw >> 8) & 1u) != 0u;
+        if (((form_raw >> 9) & 1u) != 0u) prefer_scan = true;   // (the path engine's regions were bound by their closure: a stream of few literals -- the scan engine's from here on)   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
         br.seek(pos);

@@ -142,7 +142,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
-       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */ };
+       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */ };
 // Words of the static dictionary (decode.rs:2593-2640; one command in 33 to 87 of text at -q 4 .. 9, tools/eligibility_survey.py).
 // Round 4's engine stopped in front of each: an invocation and a region's tables for some fifty commands, 3200 clocks a command.
 // Now (one engine): the resolve lets the first such command of what is listed through with its literals alone, wave 0 puts the
@@ -706,7 +706,7 @@ pe_again:
   const uint32_t T = PIPE ? threadIdx.x % (64u * GW) : threadIdx.x;
   const uint32_t pbs = hc_ld(HC_SCAN_BASE);                       // what the block's engines share
   const uint32_t pb = pbs + PE_SET0 + eng * PE_SET_BYTES;         // this engine's tables
-  if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u); lds_st32(pb + PE_CTL + 4u * PEC_PDX, 0u); }
+  if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u); lds_st32(pb + PE_CTL + 4u * PEC_PDX, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OVF, 0u); }
   if (PIPE) {   // what the two engines tell each other starts from nothing
     if (threadIdx.x < 8u) lds_st32(pbs + PE_CTL + 4u * (PEC_RESOLVED + threadIdx.x), 0u);
     if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_GBAR, 0u);
@@ -1266,7 +1266,17 @@ pe_again:
     PE_BAR();
     PE_COUNT(24, pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP);
     wn = pe_ctl_ld(pb, PEC_WN) < PE_WCAP ? pe_ctl_ld(pb, PEC_WN) : PE_WCAP;
-    if (me == 0) { const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pbs, PEC_STATE + 8); if (raw > PE_WCAP - PE_WCAP / 8u) rbl = rbl > 8192u ? rbl >> 1 : rbl; else if (raw < PE_GROW_BELOW && rbl < PE_RBL) rbl <<= 1; pe_ctl_st(pbs, PEC_STATE + 8, rbl); }
+    if (me == 0) {
+      const uint32_t raw = pe_ctl_ld(pb, PEC_WN); uint32_t rbl = pe_ctl_ld(pbs, PEC_STATE + 8);
+      if (raw > PE_WCAP - PE_WCAP / 8u) {
+        rbl = rbl > 8192u ? rbl >> 1 : rbl;
+        // (a stream of few literals -- an executable: short copies one after the other -- has few path positions and long chains of
+        // states beside the path; three such regions and the invocation ends with word to the caller: the scan engine's kind of
+        // stream, a parse at every bit and no chains.  256 x libc.so.6 at -q 5: 0.39 against 0.77 G commands/s)
+        pe_ctl_st(pb, PEC_OVF, pe_ctl_ld(pb, PEC_OVF) + 1u);
+      } else if (raw < PE_GROW_BELOW && rbl < PE_RBL) rbl <<= 1;
+      pe_ctl_st(pbs, PEC_STATE + 8, rbl);
+    }
     PE_PROF(4);
     // ---- NEXT8: the state eight commands on (PEN_NONE where the way there is not all records) ----
 #if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 4
@@ -1659,6 +1669,7 @@ pe_pass:
         pe_ctl_st(pb, PEC_NEXT_LBDW, sn.b >> 5);
         // an invocation goes on with the next region while whole regions go through; anything else is the checked loop's
         bool cont = (kp_total == m && m != 0u) || (!PIPE && m == 0u && sn.run_on != 0u);
+        if (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u && sn.run_on == 0u) cont = false;   // (closure-bound: see the records)
         if (PIPE && cont && pbit + 64u <= c.L) {
           // (two engines: a command whose literal run wants regions of its own ends the invocation in front of it -- the one-engine
           // form has those regions, and the caller is told to take it next)
@@ -2128,7 +2139,7 @@ pe_pass:
   }
   const bool pdx = PE_DICT && pe_ctl_ld(pb, PEC_PDX) != 0u;   // (behind the distance of a command whose literals are out: postReadDistance, decode.rs:2583)
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u));
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
