@@ -2970,7 +2970,9 @@ struct HotArgs {
 //  * long copies move 16 bytes per lane per step when source and destination are at least a step apart;
 //  * the last two output bytes (literal context) are taken from registers where they still are, from memory
 //    only after a long copy.
-template <bool LDS_ONLY, bool CTX_NEVER>
+// (CACHED: the LDS part of the arena as a cache of the trees in use, see run_commands -- an instantiation of its own, so that the
+// loop for tables that fit LDS stays the code it was: with the cache as a run-time switch the metric lost 1.3 %)
+template <bool LDS_ONLY, bool CTX_NEVER, bool CACHED = false>
 __device__ __noinline__ int process_commands(HotArgs* args) {
   BitReader br = args->br; br.uniformize();
   Arena a_ = args->ar; a_.uniformize();
@@ -3009,7 +3011,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint32_t prof_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)prof_stage;
 
   // (the LDS part as a cache of the trees in use: see run_commands)
-  const bool tree_cache = LDS_ONLY && CTX_NEVER && rfl(args->reserved_) != 0u;
+  constexpr bool tree_cache = CACHED;
+  static_assert(!CACHED || (LDS_ONLY && CTX_NEVER), "the cache is for the loop that reads its tables out of LDS, literals without context");
   auto cached_tree = [&](const uint32_t tree, const uint32_t slot, const uint32_t bytes) -> uint32_t {
     if (!tree_cache) return tree;
     for (uint32_t off = lane * 16u; off < bytes; off += 1024u)
@@ -3849,8 +3852,8 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
     for (uint32_t off = lane_id() * 16u; off < ar_.lds_limit; off += 1024u)
       *reinterpret_cast<gu32x4*>(ar_.glb + off) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[LDS_FIXED + off]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    h.reserved_ = 1u; h.ar.lds_limit = 0u;
-    e = process_commands<true, true>(&h);
+    h.ar.lds_limit = 0u;
+    e = process_commands<true, true, true>(&h);
   } else {
     if (rfl(s.flags) & BROTLI_AMD_FLAG_NO_SPILL) { s.num_metablocks--; return E_RETRY_ARENA; }  // nothing of this metablock has been output yet (the next pass counts it)
     s.num_spilled++;

@@ -1580,7 +1580,7 @@ pe_pass:
         // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
         const uint64_t pk = st.P + rel + ins;
         const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
-        if (PE_DICT) dictc = active && ok && kind == SCK_EXPLICIT && dist > maxd && rel + ins < (uint64_t)st.quota;
+        if (PE_DICT) dictc = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd));   // (`ok` so far: an active lane, its counts and its output -- the copy's length for the word's -- inside every limit)
         ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
       }
       const uint64_t stopmask = __ballot(active && !ok);
