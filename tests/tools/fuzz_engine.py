@@ -19,6 +19,11 @@ for seed in range(first, first + nseeds):
         return (rng.choice(nsym, size=n, p=pr) + base).astype(np.uint8).tobytes()
     raws = [w.long_backref_stream(seed * 7 + k, rnd.choice([64 << 10, 256 << 10, 1 << 20])) for k in range(3)]
     raws += [r for _, _, r in rnd.sample(param_corpus.corpus(), 6) if len(r) > 2000]
+    # (round 4: a stretch of an executable -- dozens of block types at -q 5 and up, more tables than LDS holds: the LDS part as a cache
+    # of the trees in use; few literals: regions bound by their closure, the scan engine's)
+    exe = open(sys.executable, "rb").read()
+    off = rnd.randrange(0, max(1, len(exe) - (3 << 20)))
+    raws.append(exe[off:off + rnd.choice([200 << 10, 1 << 20, 3 << 20])])
     for _ in range(3):
         period = rnd.choice([1, 2, 3, 4, 7, 9, 31, 64, 77, 130, 500])
         body = bytearray(zipf(period) * (120000 // period + 1))[:120000]
