@@ -82,7 +82,9 @@ constexpr int ROOT_BITS = 8;
 // the LDS part of the table arena as a cache of the trees in use (run_commands): a literal tree (630 entries at most), a command
 // tree (1080), four distance trees (920 each: 520 symbols), sixteen-byte steps
 constexpr uint32_t TREE_CACHE_LIT = 0, TREE_CACHE_LIT_BYTES = 1264, TREE_CACHE_CMD = 1280, TREE_CACHE_CMD_BYTES = 2160, TREE_CACHE_DIST = 3456, TREE_CACHE_DIST_BYTES = 1856,
-                   TREE_CACHE_BYTES = TREE_CACHE_DIST + 4u * TREE_CACHE_DIST_BYTES;
+                   TREE_CACHE_BYTES = TREE_CACHE_DIST + 4u * TREE_CACHE_DIST_BYTES,
+                   // ... and, where literals depend on context, the trees of ONE literal block type (its 64 contexts name sixteen different ones at most)
+                   TREE_CACHE_CTX_LITS = 16, TREE_CACHE_LIT_STRIDE = 1280, TREE_CACHE_CTX_BYTES = TREE_CACHE_BYTES + TREE_CACHE_CTX_LITS * TREE_CACHE_LIT_STRIDE;
 constexpr uint32_t MAX_ALPHABET = 1152;  // 16 + 120 + (62 << 4) = 1128 for large-window distance codes
 
 // ---- fixed LDS carve (bytes); the arena follows ----
@@ -2941,6 +2943,17 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
   return rfl(stage);
 }
 
+// (tree cache, context-modelled literals: does every literal block type's context map name at most TREE_CACHE_CTX_LITS trees?)
+__device__ __forceinline__ bool lit_types_fit_cache(const Arena& ar, const uint32_t nbt0, const uint32_t ctx_map) {
+  for (uint32_t bt = 0; bt < nbt0; bt++) {
+    const uint32_t mine = ar.ld8_lane<false>(ctx_map + (bt << 6) + lane_id());
+    uint64_t todo = ~0ull; uint32_t n = 0;
+    while (todo != 0ull) { const uint32_t idx = rdlane(mine, (uint32_t)__builtin_ctzll(todo)); todo &= ~__ballot(mine == idx); n++; }
+    if (n > TREE_CACHE_CTX_LITS) return false;
+  }
+  return true;
+}
+
 // ===================================== the command loop (hot path) =====================================
 // Argument block of the command loop.  The loop is a real function (one per table placement) so that it gets a
 // register allocation of its own: everything uniform lives in SGPRs for the whole metablock and nothing of the
@@ -3011,8 +3024,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint32_t prof_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)prof_stage;
 
   // (the LDS part as a cache of the trees in use: see run_commands)
+  uint32_t rec_base = 0;   // (the command records' ring, where wave 2 parses ahead: see below)
   constexpr bool tree_cache = CACHED;
-  static_assert(!CACHED || (LDS_ONLY && CTX_NEVER), "the cache is for the loop that reads its tables out of LDS, literals without context");
+  // (cached tables: a tree that changes keeps its address -- the records' parser is told by a word of the ring's header that the
+  // codes it parses with are no longer the ones, and lean_rec_commands starts a new epoch: it compares addresses)
+  auto records_stale = [&]() { if (tree_cache && !CTX_NEVER && rec_base != 0u) { if (lane == 0) lds_st32(rec_base + 4u * (uint32_t)XW_CMD_TREE, 0u); lds_sync(); } };
+  static_assert(!CACHED || LDS_ONLY, "the cache is for the loops that read their tables out of LDS");
   auto cached_tree = [&](const uint32_t tree, const uint32_t slot, const uint32_t bytes) -> uint32_t {
     if (!tree_cache) return tree;
     for (uint32_t off = lane * 16u; off < bytes; off += 1024u)
@@ -3035,6 +3052,18 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     if (!CTX_NEVER) {
       uint32_t toff = HOTC(H_LIT_TREES) + mine * 4;
       ctx_tree_v = toff < a.lds_limit ? lds_ld32(LDS_FIXED + toff) : (uint32_t)*reinterpret_cast<gu32*>(a.glb + toff);
+      if (tree_cache) {   // (the block type's trees, each once, into the cache's literal slots: the caller has counted them)
+        uint64_t todo = ~0ull; uint32_t slot = TREE_CACHE_BYTES;
+        while (todo != 0ull) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(todo);
+          const uint32_t idx = rdlane(mine, l), t = rdlane(ctx_tree_v, l);
+          const uint64_t same = __ballot(mine == idx) & todo;
+          (void)cached_tree(t, slot, TREE_CACHE_LIT_BYTES);
+          if (mine == idx) ctx_tree_v = slot;
+          todo &= ~same; slot += TREE_CACHE_LIT_STRIDE;
+        }
+        lit_tree = rdlane(ctx_tree_v, 0);
+      }
     }
     ctx_lut = LDS_CTX_LUT + 512u * (a.ld8<false>(HOTC(H_CTX_MODES) + bt) & 3u);
     if (LDS_ONLY) lit_zero = (rfl(lds_ld16(LDS_FIXED + lit_tree)) & 15u) == 0u ? 1u : 0u;  // one-symbol code: zero bits per literal
@@ -3052,6 +3081,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       dt1 = g1 == g0 ? dt0 : cached_tree(g1, TREE_CACHE_DIST + TREE_CACHE_DIST_BYTES, TREE_CACHE_DIST_BYTES);
       dt2 = g2 == g0 ? dt0 : g2 == g1 ? dt1 : cached_tree(g2, TREE_CACHE_DIST + 2u * TREE_CACHE_DIST_BYTES, TREE_CACHE_DIST_BYTES);
       dt3 = g3 == g0 ? dt0 : g3 == g1 ? dt1 : g3 == g2 ? dt2 : cached_tree(g3, TREE_CACHE_DIST + 3u * TREE_CACHE_DIST_BYTES, TREE_CACHE_DIST_BYTES);
+      records_stale();
     }
   };
   prepare_distance();
@@ -3124,14 +3154,14 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
   // metablock is done.
   bool split_on = false, helpers_on = false;
-  uint32_t rec_base = 0;
   if (LDS_ONLY && !CTX_NEVER && hc_ld(HC_NW_ALL) >= 4u && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS && mlen >= (int32_t)SP_MIN_MLEN && (g_engine_mode & 6u) != 6u) {
     split_on = (g_engine_mode & 2u) == 0u;
     // the records' ring: what is left of the LDS arena now that the tables of this metablock are built (no large window: a
     // record's distance has at most 24 extra bits); positions count from the dword the reader is in now
-    const uint32_t free_at = (a.top + 15u) & ~15u;
+    const uint32_t free_at = tree_cache ? TREE_CACHE_CTX_BYTES : (a.top + 15u) & ~15u;   // (cached tables: behind the cache; `reserved_` is the LDS part's real size)
+    const uint32_t lds_room = tree_cache ? rfl(args->reserved_) : a.lds_limit;
     const uint32_t origin_dw = (br.next_dw - ((br.cnt + 31u) >> 5)) & ~1u;
-    if ((g_engine_mode & 4u) == 0u && a.lds_limit >= free_at + SPX_BYTES && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u) rec_base = LDS_FIXED + free_at;
+    if ((g_engine_mode & 4u) == 0u && lds_room >= free_at + SPX_BYTES && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u) rec_base = LDS_FIXED + free_at;
     if (split_on || rec_base != 0u) {
       helpers_on = true;
       lds_sync();
@@ -3329,7 +3359,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       int r;
       BLOCK_SWITCH(1, bl1, r);
       if (r == BS_NEEDS_INPUT) STOP(E_NEEDS_MORE_INPUT);
-      if (r == BS_SWITCHED) { cmd_tree = cached_tree(a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4), TREE_CACHE_CMD, TREE_CACHE_CMD_BYTES); continue; }
+      if (r == BS_SWITCHED) { cmd_tree = cached_tree(a.ld32<false>(HOTC(H_CMD_TREES) + HOTC(H_RING + 3) * 4), TREE_CACHE_CMD, TREE_CACHE_CMD_BYTES); records_stale(); continue; }
     }
     {
       uint32_t cmd = read_symbol<LDS_ONLY>(br, a, cmd_tree);
@@ -3854,6 +3884,15 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     h.ar.lds_limit = 0u;
     e = process_commands<true, true, true>(&h);
+  } else if (!ctx_never && ar_.lds_limit >= TREE_CACHE_CTX_BYTES && (g_engine_mode & 16u) == 0u && lit_types_fit_cache(ar_, rfl(s.nbt0), rfl(s.ctx_map)) &&
+             !((rfl(s.flags) & BROTLI_AMD_FLAG_ENGINE_ONLY) && rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN)) {   // (engine blocks hand such a metablock back, as above)
+    // ... and the same where literals do depend on context, as long as no literal block type names more trees than the cache has
+    // slots for: the loop for context-modelled metablocks out of LDS, command records included (their ring lies behind the cache)
+    for (uint32_t off = lane_id() * 16u; off < ar_.lds_limit; off += 1024u)
+      *reinterpret_cast<gu32x4*>(ar_.glb + off) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[LDS_FIXED + off]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    h.reserved_ = ar_.lds_limit; h.ar.lds_limit = 0u;
+    e = process_commands<true, false, true>(&h);
   } else {
     if (rfl(s.flags) & BROTLI_AMD_FLAG_NO_SPILL) { s.num_metablocks--; return E_RETRY_ARENA; }  // nothing of this metablock has been output yet (the next pass counts it)
     s.num_spilled++;
