@@ -83,8 +83,10 @@ constexpr int ROOT_BITS = 8;
 // tree (1080), four distance trees (920 each: 520 symbols), sixteen-byte steps
 constexpr uint32_t TREE_CACHE_LIT = 0, TREE_CACHE_LIT_BYTES = 1264, TREE_CACHE_CMD = 1280, TREE_CACHE_CMD_BYTES = 2160, TREE_CACHE_DIST = 3456, TREE_CACHE_DIST_BYTES = 1856,
                    TREE_CACHE_BYTES = TREE_CACHE_DIST + 4u * TREE_CACHE_DIST_BYTES,
-                   // ... and, where literals depend on context, the trees of ONE literal block type (its 64 contexts name sixteen different ones at most)
-                   TREE_CACHE_CTX_LITS = 16, TREE_CACHE_LIT_STRIDE = 1280, TREE_CACHE_CTX_BYTES = TREE_CACHE_BYTES + TREE_CACHE_CTX_LITS * TREE_CACHE_LIT_STRIDE;
+                   // ... and, where literals depend on context, the trees of ONE literal block type: as many slots as the LDS part has room for (its 64
+                   // contexts name 64 different trees at most), eight at least
+                   TREE_CACHE_LIT_STRIDE = 1280, TREE_CACHE_CTX_BYTES = TREE_CACHE_BYTES + 8u * TREE_CACHE_LIT_STRIDE;
+__device__ __forceinline__ uint32_t tree_cache_lit_slots(uint32_t lds_bytes) { const uint32_t n = (lds_bytes - TREE_CACHE_BYTES) / TREE_CACHE_LIT_STRIDE; return n < 64u ? n : 64u; }
 constexpr uint32_t MAX_ALPHABET = 1152;  // 16 + 120 + (62 << 4) = 1128 for large-window distance codes
 
 // ---- fixed LDS carve (bytes); the arena follows ----
@@ -2943,13 +2945,13 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
   return rfl(stage);
 }
 
-// (tree cache, context-modelled literals: does every literal block type's context map name at most TREE_CACHE_CTX_LITS trees?)
-__device__ __forceinline__ bool lit_types_fit_cache(const Arena& ar, const uint32_t nbt0, const uint32_t ctx_map) {
+// (tree cache, context-modelled literals: does every literal block type's context map name at most `slots` trees?)
+__device__ __forceinline__ bool lit_types_fit_cache(const Arena& ar, const uint32_t nbt0, const uint32_t ctx_map, const uint32_t slots) {
   for (uint32_t bt = 0; bt < nbt0; bt++) {
     const uint32_t mine = ar.ld8_lane<false>(ctx_map + (bt << 6) + lane_id());
     uint64_t todo = ~0ull; uint32_t n = 0;
     while (todo != 0ull) { const uint32_t idx = rdlane(mine, (uint32_t)__builtin_ctzll(todo)); todo &= ~__ballot(mine == idx); n++; }
-    if (n > TREE_CACHE_CTX_LITS) return false;
+    if (n > slots) return false;
   }
   return true;
 }
@@ -3158,7 +3160,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     split_on = (g_engine_mode & 2u) == 0u;
     // the records' ring: what is left of the LDS arena now that the tables of this metablock are built (no large window: a
     // record's distance has at most 24 extra bits); positions count from the dword the reader is in now
-    const uint32_t free_at = tree_cache ? TREE_CACHE_CTX_BYTES : (a.top + 15u) & ~15u;   // (cached tables: behind the cache; `reserved_` is the LDS part's real size)
+    const uint32_t free_at = tree_cache ? TREE_CACHE_BYTES + tree_cache_lit_slots(rfl(args->reserved_)) * TREE_CACHE_LIT_STRIDE : (a.top + 15u) & ~15u;   // (cached tables: behind the cache; `reserved_` is the LDS part's real size)
     const uint32_t lds_room = tree_cache ? rfl(args->reserved_) : a.lds_limit;
     const uint32_t origin_dw = (br.next_dw - ((br.cnt + 31u) >> 5)) & ~1u;
     if ((g_engine_mode & 4u) == 0u && lds_room >= free_at + SPX_BYTES && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u) rec_base = LDS_FIXED + free_at;
@@ -3884,9 +3886,9 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     h.ar.lds_limit = 0u;
     e = process_commands<true, true, true>(&h);
-  } else if (!ctx_never && ar_.lds_limit >= TREE_CACHE_CTX_BYTES && (g_engine_mode & 16u) == 0u && lit_types_fit_cache(ar_, rfl(s.nbt0), rfl(s.ctx_map)) &&
+  } else if (!ctx_never && ar_.lds_limit >= TREE_CACHE_CTX_BYTES && (g_engine_mode & 16u) == 0u && lit_types_fit_cache(ar_, rfl(s.nbt0), rfl(s.ctx_map), tree_cache_lit_slots(ar_.lds_limit)) &&
              !((rfl(s.flags) & BROTLI_AMD_FLAG_ENGINE_ONLY) && rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN)) {   // (engine blocks hand such a metablock back, as above)
-    // ... and the same where literals do depend on context, as long as no literal block type names more trees than the cache has
+    // ... and the same where literals do depend on context, as long as no literal block type names more trees than the LDS part has
     // slots for: the loop for context-modelled metablocks out of LDS, command records included (their ring lies behind the cache)
     for (uint32_t off = lane_id() * 16u; off < ar_.lds_limit; off += 1024u)
       *reinterpret_cast<gu32x4*>(ar_.glb + off) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[LDS_FIXED + off]);
