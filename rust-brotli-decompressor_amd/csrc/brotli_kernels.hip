@@ -905,9 +905,10 @@ __device__ __forceinline__ uint32_t max_distance_symbol(uint32_t ndirect, uint32
 struct WordShape { uint32_t pre, plen, suf, slen, skip, wlen, t, total; };
 __device__ __forceinline__ WordShape word_shape(uint32_t len, uint32_t transform_idx) {
   WordShape w;
-  w.pre = kTransforms[transform_idx * 3]; w.t = kTransforms[transform_idx * 3 + 1]; w.suf = kTransforms[transform_idx * 3 + 2];
-  w.plen = 0; while (kAffixPool[w.pre + w.plen]) w.plen++;
-  w.slen = 0; while (kAffixPool[w.suf + w.slen]) w.slen++;
+  // (one load: the affix lengths are in the table -- counting them out of kAffixPool was a dependent load a byte, and a word of the
+  // dictionary is one command in nine of the reference's text fixtures)
+  const uint32_t ti = kTransformInfo[transform_idx];
+  w.pre = ti & 0xFFu; w.t = (ti >> 8) & 31u; w.suf = (ti >> 13) & 0xFFu; w.plen = (ti >> 21) & 15u; w.slen = ti >> 25;
   w.skip = w.t < 12 ? 0 : w.t - 11;
   if (w.skip > len) w.skip = len;
   int32_t wl = (int32_t)(len - w.skip);
