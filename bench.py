@@ -173,6 +173,20 @@ class DeviceJob:
         self.batch.close()
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch from the PMC passes of the newest committed profile of this workload (separate rocprofv3 runs of the same
+    command: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, tools/collect_profiles.sh) -> (bytes or None, file)"""
+    import glob
+    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_r*.json")), reverse=True):
+        try:
+            pmc = json.load(open(prof))
+            if pmc["workload"] == workload and pmc.get("traffic_bytes_per_launch"):
+                return pmc["traffic_bytes_per_launch"], "profiles/" + os.path.basename(prof)
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
+
+
 def roofline(comp, raw, kernel_ms, traffic=None):
     achieved = (comp + raw) / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -200,16 +214,21 @@ def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None, cpu_bud
     ms = [job.step() for _ in range(steps)]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    out = {"workload": label, "streams": n, "decompressed_bytes": job.raw_total, "compressed_bytes": job.comp_total,
-           "value": round(job.raw_total * steps / elapsed / 1e6, 1), "unit": "MB/s", "steps": steps,
-           "second_pass_streams": job.second_pass, "roofline": roofline(job.comp_total, job.raw_total, sum(ms) / len(ms))}
-    out.update(command_rates(job, elapsed / steps))
+    kms = sum(ms) / len(ms)
+    traffic, _ = pmc_traffic(name)
+    rl = roofline(job.comp_total, job.raw_total, kms, traffic)
+    cr = command_rates(job, elapsed / steps)
+    # one short record a leg (the driver keeps the last 8 KB of this line): ids and units in `extra_legend`
+    out = {"id": name, "n": n, "D": job.raw_total, "C": job.comp_total, "MBps": round(job.raw_total * steps / elapsed / 1e6, 1), "kernel_ms": rl["kernel_ms"],
+           "frac": rl["frac"], "dfrac": rl["decompressed_frac"], "traffic": traffic, "Mcmd_s": round(cr["commands_per_s"] / 1e6, 1), "B_cmd": cr["bytes_per_command"],
+           "eng": cr["engine_commands_share"], "pass2": job.second_pass}
     job.close()
     if cpu_budget_s:  # the CPU path beside it: the oracle on all host threads and on one, a bounded sample of this leg's streams
         try:
-            out["cpu_baseline"] = cpu_baseline(unique, cpu_budget_s, proxy=False)
+            cb = cpu_baseline(unique, cpu_budget_s, proxy=False)
+            out["cpu"] = [cb["value"], cb["value_1thread"], cb["cores"]]
         except Exception as ex:  # noqa: BLE001 -- a failing CPU leg must not hide the GPU number
-            out["cpu_baseline"] = {"error": str(ex)[:120]}
+            out["cpu"] = str(ex)[:60]
     return out
 
 
@@ -257,8 +276,7 @@ def cpu_baseline(unique, budget_s=10.0, proxy=True):
     total1 = sum(sz for _, sz, _ in sample[:k1])
     out = {"value": round(total / best / 1e6, 1), "unit": "MB/s decompressed", "cores": cores, "kind": "port",
            "value_1thread": round(total1 / best1 / 1e6, 1),
-           "sample": "%d streams of the workload (%.0f MiB) handed out to the threads one at a time, best of %d passes; 1 thread: %d streams, best of 5; "
-                     "the Rust reference cannot be built in this image, this is the repo's C restatement (oracle/)" % (n, total / 2**20, reps, k1)}
+           "sample": "%d streams of the workload (%.0f MiB), one a thread at a time, best of %d passes; 1 thread: %d streams; oracle/ (the Rust reference cannot be built here)" % (n, total / 2**20, reps, k1)}
     if not proxy:
         return out
     try:
@@ -282,8 +300,7 @@ def cpu_baseline(unique, budget_s=10.0, proxy=True):
                 dt = time.time() - t
                 bestp = dt if bestp is None else min(bestp, dt)
             out["libbrotlidec_proxy"] = {"value": round(total / bestn / 1e6, 1), "value_1thread": round(total1 / bestp / 1e6, 1), "cores": cores, "unit": "MB/s decompressed",
-                                         "note": "Google libbrotlidec 1.0.9, BrotliDecoderDecompress called from %d pthreads (one stream each; 1 thread: %d streams), best of 3: a proxy for "
-                                                 "the reference (a port of it); the reference itself was not run" % (cores, k1)}
+                                         "note": "Google libbrotlidec 1.0.9 from %d pthreads (1 thread: %d streams), best of 3: a proxy for the reference, which was not run" % (cores, k1)}
     except Exception as e:  # noqa: BLE001 -- the proxy is optional
         out["libbrotlidec_proxy"] = {"error": str(e)[:100]}
     return out
@@ -361,16 +378,9 @@ def main():
         value = total_raw * args.steps / elapsed_max / 1e6
         mean_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         # HBM bytes per launch from the PMC passes of the committed profile (same command, separate rocprofv3 runs)
-        traffic, traffic_source = None, None
-        for prof in ("pmc_r04.json", "pmc_r03.json", "pmc_r02.json", "pmc_r01.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", prof)))
-                if pmc["workload"] == desc[0]:
-                    traffic = pmc["traffic_bytes_per_launch"]
-                    traffic_source = "profiles/%s: separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), not measured in this run" % prof
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        traffic, traffic_source = pmc_traffic(desc[0])
+        if traffic_source:
+            traffic_source += ": separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), not measured in this run"
         out = {
             "metric": "decompressed MB/s (bit-exact vs reference fixtures; HIP decode kernel, inputs resident in HBM)",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -391,48 +401,51 @@ def main():
         if not args.no_cpu_baseline:  # (a host-side baseline: rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(unique)
             try:  # the same batch from pageable host memory and back (BrotliAmdBatchDecodeHost): PCIe-inclusive, never the `value`
-                datas = [unique[i % len(unique)][0] for i in range(per_gpu)]
+                datas = [np.frombuffer(unique[i % len(unique)][0], dtype=np.uint8).copy() for i in range(per_gpu)]
                 caps_h = [unique[i % len(unique)][1] for i in range(per_gpu)]
+                outs_h = [np.empty(c, dtype=np.uint8) for c in caps_h]
                 hb = pkg.Batch(per_gpu)
-                hb.decode_host(datas[:8], caps_h[:8], pkg.FLAG_LARGE_WINDOW)  # (staging buffers allocated)
-                th = time.perf_counter()
-                res_h, outs_h = hb.decode_host(datas, caps_h, pkg.FLAG_LARGE_WINDOW)
-                dt_h = time.perf_counter() - th
+                args_h = ([a.ctypes.data for a in datas], [a.size for a in datas], [a.ctypes.data for a in outs_h], caps_h, pkg.FLAG_LARGE_WINDOW)
+                hb.decode_host_raw(*args_h)  # (staging buffers allocated and pinned)
+                best_h = None
+                for _ in range(3):
+                    for a in outs_h:
+                        a[:64] = 0xA5
+                    th = time.perf_counter()
+                    res_h = hb.decode_host_raw(*args_h)
+                    dt_h = time.perf_counter() - th
+                    best_h = dt_h if best_h is None else min(best_h, dt_h)
                 hb.close()
                 assert all(r.result == 1 for r in res_h)
-                out["host_buffers"] = {"value": round(sum(caps_h) / dt_h / 1e6, 1), "unit": "MB/s decompressed", "seconds": round(dt_h, 4),
-                                       "note": "BrotliAmdBatchDecodeHost: upload from and download to pageable host memory included (through the ctypes binding, which also copies the outputs into Python bytes)"}
-                del outs_h
+                for i in (0, per_gpu // 2, per_gpu - 1):
+                    assert hashlib.sha256(outs_h[i].tobytes()).hexdigest() == unique[i % len(unique)][2]
+                out["host_buffers"] = {"value": round(sum(caps_h) / best_h / 1e6, 1), "unit": "MB/s decompressed", "seconds": round(best_h, 4),
+                                       "note": "BrotliAmdBatchDecodeHost, caller's pageable buffers both ways (pinned staging inside, transfers in pieces side by side with the host's copies); best of 3"}
+                del outs_h, datas
             except Exception as ex:  # noqa: BLE001 -- an optional leg
                 out["host_buffers"] = {"error": str(ex)[:120]}
         if not args.no_extra and desc[0] == "longbackref_256x4MiB":
             import workloads as w
             extra = []
-            legs = [("alice29x1024", 10, None)]
+            legs = []
             if w.encoder_available():
-                legs += [("highentropy_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1), ("longbackref_512x4MiB", 3, None),
-                         ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None), ("surveymix_256x4MiB", 5, None),
-                         ("recompressed:lcet10.txt.compressedq5x256", 3, None), ("recompressed:lcet10.txt.compressedq5x1024", 3, None)]
+                legs += [("longbackref_512x4MiB", 3, None), ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None),
+                         ("recompressed:lcet10.txt.compressedq5x1024", 3, None), ("recompressed:lcet10.txt.compressedq5x256", 3, None),
+                         ("surveymix_256x4MiB", 5, None), ("longbackref_1x64MiB", 2, 1)]
                 if os.environ.get("BROTLI_BENCH_NO_1GIB") is None:
                     legs.append(("longbackref_1x1024MiB", 1, 1))  # BASELINE config 3 as written: ONE stream of 1 GiB
+                legs.append(("highentropy_256x4MiB", 5, None))
+            legs.append(("alice29x1024", 10, None))   # (the BASELINE configurations last: the end of the line is what a truncated copy keeps)
             for name, steps, nu in legs:
                 try:
-                    e = time_single_gpu(pkg, torch, dev, name, steps, 0 if name == "longbackref_1x1024MiB" else 1, nu, cpu_budget_s=0.0 if args.no_cpu_baseline else 3.0)
-                    if name == "longbackref_1x1024MiB":
-                        e["workload"] = "BASELINE config 3 as written: ONE stream of 1 GiB, wbits 22, brotli -q5, many metablocks, long back-references (one block of the GPU decodes it; one step)"
-                    if name == "surveymix_256x4MiB":
-                        e["workload"] = "make-up of SURVEY 8(a1)'s prototype (a quarter of every stream is Zipf seed, the rest long copies): " + e["workload"]
-                    if name == "longbackref_1x64MiB":
-                        e["workload"] = "C3 as ONE stream: 64 MiB, wbits 22, brotli -q5, many metablocks, long back-references (a single stream does not shard: one block of the GPU decodes it)"
-                    if name == "longbackref_512x4MiB":
-                        e["workload"] = "the metric's 256 streams twice: 512 x 4 MiB, two streams per CU (engine blocks take them one after the other)"
-                    if name == "longbackrefq9_256x4MiB":
-                        e["workload"] = "the metric's data compressed with brotli -q9 (SURVEY 8d asks for both): " + e["workload"]
-                    if name == "longbackref_1024x1MiB":
-                        e["workload"] = "the metric's make-up cut into 1024 x 1 MiB streams (four streams per CU: the one-wave path): " + e["workload"]
-                    extra.append(e)
+                    extra.append(time_single_gpu(pkg, torch, dev, name, steps, 0 if name == "longbackref_1x1024MiB" else 1, nu, cpu_budget_s=0.0 if args.no_cpu_baseline else 3.0))
                 except SystemExit as ex:  # a failing leg must not hide the headline
-                    extra.append({"workload": name, "error": str(ex)})
+                    extra.append({"id": name, "error": str(ex)[:100]})
+            out["extra_legend"] = ("id = bench.py --workload name (alice29x1024 = BASELINE config 2; highentropy_256x4MiB = config 4; longbackref_1x1024MiB = config 3 as written, ONE 1 GiB stream, "
+                                   "1x64MiB the same at 64 MiB; surveymix = SURVEY 8(a1)'s make-up, a quarter of each stream Zipf seed; 512x4MiB = the metric's streams twice; q9 = the metric's data at -q9; "
+                                   "1024x1MiB = its make-up in 1 MiB streams; recompressed:lcet10 = real text at -q5, 256 / 1024 copies); n streams, D / C bytes out / in, MBps decompressed whole job, "
+                                   "frac = (C+D)/t/8 TB/s, dfrac = D/t/8 TB/s, traffic = HBM bytes a launch from profiles/pmc_r*_<id>.json (null: no PMC pass committed), Mcmd_s = million commands/s, "
+                                   "B_cmd bytes a command, eng = share of commands a command engine took, pass2 = streams that needed a second launch, cpu = [oracle MB/s on all host threads, on 1 thread, threads]")
             out["extra_configs"] = extra
     if rank == 0:
         print(json.dumps(out))

@@ -88,6 +88,16 @@ BROTLI_DEC_API uint64_t BrotliAmdDecoderDeviceCommands(const struct BrotliDecode
 /* Text of the last HIP/runtime failure on this thread ("" if none). */
 BROTLI_DEC_API const char* BrotliAmdLastError(void);
 
+/* What the last call on this thread did differently without failing ("" if nothing): a device that refused blocks of sixteen
+ * waves makes its batch context go on with blocks of eight (slower on batches of one stream a CU), and this says so. */
+BROTLI_DEC_API const char* BrotliAmdLastNote(void);
+
+/* Test hook, not part of the decode path: builds the device's prefix-code table for alphabet_size code lengths (0 = unused symbol;
+ * a complete code, as src/huffman/mod.rs:273-386 is given them) and decodes every fifteen-bit value v through it the way the
+ * kernel's symbol reader does: decoded[v] = symbol << 4 | code length (32768 entries).  table_entries = the table's size.
+ * Returns 0 on success. */
+BROTLI_DEC_API int BrotliAmdDebugBuildTree(const uint8_t* code_lengths, uint32_t alphabet_size, uint16_t* decoded, uint32_t* table_entries);
+
 #if defined(__cplusplus)
 } /* extern "C" */
 #endif

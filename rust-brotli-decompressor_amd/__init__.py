@@ -30,7 +30,7 @@ DECODE_H_SYMBOLS = [
 ]
 BATCH_H_SYMBOLS = [
     "BrotliAmdBatchCreate", "BrotliAmdBatchDestroy", "BrotliAmdBatchDecodeDevice", "BrotliAmdBatchRelaunch", "BrotliAmdBatchWait",
-    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdLastError", "BrotliAmdDecoderDeviceCommands",
+    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
 ]
 
 
@@ -104,6 +104,7 @@ def load_library():
     L.BrotliAmdBatchLastSecondPassCount.restype = ctypes.c_uint32
     L.BrotliAmdBatchLastSecondPassCount.argtypes = [vp]
     L.BrotliAmdLastError.restype = ctypes.c_char_p
+    L.BrotliAmdLastNote.restype = ctypes.c_char_p
     _lib = L
     return L
 
@@ -187,6 +188,19 @@ class Batch:
         self.n = n
         results = list(res)[:n]
         return results, [outs[i].raw[:min(results[i].decoded_size, out_caps[i])] for i in range(n)]
+
+    def decode_host_raw(self, in_ptrs, in_sizes, out_ptrs, out_caps, flags=FLAG_LARGE_WINDOW):
+        """BrotliAmdBatchDecodeHost on buffers the caller owns (host addresses as integers): nothing is copied on the Python side"""
+        n = len(in_ptrs)
+        a_in = (ctypes.c_void_p * n)(*in_ptrs)
+        a_is = (ctypes.c_size_t * n)(*in_sizes)
+        a_out = (ctypes.c_void_p * n)(*out_ptrs)
+        a_oc = (ctypes.c_size_t * n)(*out_caps)
+        res = (BatchResult * max(1, n))()
+        if self._L.BrotliAmdBatchDecodeHost(self._h, n, a_in, a_is, a_out, a_oc, flags, res) != 0:
+            raise RuntimeError("BrotliAmdBatchDecodeHost failed: " + last_error())
+        self.n = n
+        return list(res)[:n]
 
 
 # ------------------------------------------------------------------ streaming state (src/ffi/mod.rs:390-463)

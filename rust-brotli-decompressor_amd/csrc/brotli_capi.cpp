@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "brotli/batch.h"
@@ -124,6 +125,11 @@ struct BrotliAmdBatch {
   // staging for BrotliAmdBatchDecodeHost
   uint8_t* d_stage_in = nullptr; size_t stage_in_cap = 0;
   uint8_t* d_stage_out = nullptr; size_t stage_out_cap = 0;
+  // ... and its pinned host side: the caller's buffers are pageable as a rule, a copy engine wants pinned memory (one transfer per
+  // direction in pieces, the host's own copies on several threads side by side with the transfers)
+  uint8_t* h_pin_in = nullptr; size_t pin_in_cap = 0;
+  uint8_t* h_pin_out = nullptr; size_t pin_out_cap = 0;
+  hipStream_t copy_stream = nullptr;
   // streams that ran out of output get the reference's verdict (settle_output_limits): set by the batch entry points
   bool exact_limit = false;
   // blocks of sixteen waves with a command engine: the device's LDS holds one (decided at creation), nothing has refused one since
@@ -151,7 +157,7 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
                                            b->d_dict, stream, (int)b->waves);
   if (b->waves == 16u && (le == hipErrorInvalidValue || le == hipErrorLaunchOutOfResources || le == hipErrorSharedObjectInitFailed || le == hipErrorInvalidConfiguration)) {
     // the device refused a block of sixteen waves with the engine's LDS although its properties allow one: this context goes
-    // on with blocks of eight waves, and says so (BrotliAmdLastError); streams are no longer sent back for engine blocks
+    // on with blocks of eight waves, and says so (BrotliAmdLastNote); streams are no longer sent back for engine blocks
     (void)hipGetLastError();
     g_last_note = std::string("engine blocks refused (") + hipGetErrorString(le) + "): eight-wave blocks from now on";   // (a note, not an error: the retry below decides)
     b->engine_ok = false;
@@ -440,6 +446,9 @@ extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (b->h_retry_status) (void)hipHostFree(b->h_retry_status);
   if (b->d_stage_in) (void)hipFree(b->d_stage_in);
   if (b->d_stage_out) (void)hipFree(b->d_stage_out);
+  if (b->h_pin_in) (void)hipHostFree(b->h_pin_in);
+  if (b->h_pin_out) (void)hipHostFree(b->h_pin_out);
+  if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
   if (b->d_settle) (void)hipFree(b->d_settle);
   if (b->h_descs) (void)hipHostFree(b->h_descs);
   if (b->h_status) (void)hipHostFree(b->h_status);
@@ -529,8 +538,48 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
     if (!hip_ok(hipMalloc(&b->d_stage_out, out_total), "hipMalloc(output arena)")) return -1;
     b->stage_out_cap = out_total;
   }
+  // pinned staging on the host (kept with the batch object) and a stream for the transfers
+  if (in_total > b->pin_in_cap) {
+    if (b->h_pin_in) (void)hipHostFree(b->h_pin_in);
+    b->h_pin_in = nullptr; b->pin_in_cap = 0;
+    if (!hip_ok(hipHostMalloc(&b->h_pin_in, in_total, hipHostMallocDefault), "hipHostMalloc(input staging)")) return -1;
+    b->pin_in_cap = in_total;
+  }
+  if (out_total > b->pin_out_cap) {
+    if (b->h_pin_out) (void)hipHostFree(b->h_pin_out);
+    b->h_pin_out = nullptr; b->pin_out_cap = 0;
+    if (!hip_ok(hipHostMalloc(&b->h_pin_out, out_total, hipHostMallocDefault), "hipHostMalloc(output staging)")) return -1;
+    b->pin_out_cap = out_total;
+  }
+  if (!b->copy_stream && !hip_ok(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return -1;
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  // streams [lo, hi) copied by up to `hw` threads, split by bytes
+  auto parallel_copy = [&](uint32_t lo, uint32_t hi, auto&& one) {
+    size_t bytes = 0; for (uint32_t i = lo; i < hi; i++) bytes += one(i, false);
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(hw, bytes >> 20));
+    if (nt <= 1) { for (uint32_t i = lo; i < hi; i++) (void)one(i, true); return; }
+    std::vector<std::thread> ts; const size_t per = (bytes + nt - 1) / nt; uint32_t i0 = lo;
+    for (unsigned t = 0; t < nt && i0 < hi; t++) {
+      uint32_t i1 = i0; size_t acc = 0;
+      while (i1 < hi && (acc < per || t + 1 == nt)) acc += one(i1++, false);
+      ts.emplace_back([=, &one]() { for (uint32_t i = i0; i < i1; i++) (void)one(i, true); });
+      i0 = i1;
+    }
+    for (auto& t : ts) t.join();
+  };
+  // upload: the inputs packed into pinned memory by several threads, piece by piece, each piece's transfer behind it
+  {
+    uint32_t lo = 0;
+    while (lo < n) {
+      uint32_t hi = lo; size_t acc = 0;
+      while (hi < n && acc < ((size_t)32 << 20)) acc += in_sizes[hi++];
+      parallel_copy(lo, hi, [&](uint32_t i, bool go) -> size_t { if (go && in_sizes[i]) std::memcpy(b->h_pin_in + in_off[i], in[i], in_sizes[i]); return in_sizes[i]; });
+      const size_t o0 = in_off[lo], o1 = hi < n ? in_off[hi] : in_total;
+      if (!hip_ok(hipMemcpyAsync(b->d_stage_in + o0, b->h_pin_in + o0, o1 - o0, hipMemcpyHostToDevice, b->copy_stream), "hipMemcpyAsync(input)")) return -1;
+      lo = hi;
+    }
+  }
   for (uint32_t i = 0; i < n; i++) {
-    if (in_sizes[i] && !hip_ok(hipMemcpyAsync(b->d_stage_in + in_off[i], in[i], in_sizes[i], hipMemcpyHostToDevice, nullptr), "hipMemcpyAsync(input)")) return -1;
     BrotliAmdStreamDesc& d = b->h_descs[i];
     std::memset(&d, 0, sizeof d);
     d.in = b->d_stage_in + in_off[i]; d.in_size = in_sizes[i];
@@ -538,19 +587,61 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
     d.flags = flags & (BROTLI_AMD_FLAG_LARGE_WINDOW | BROTLI_AMD_FLAG_NO_CANNY | BROTLI_AMD_BATCH_SPILL_IN_PLACE);
   }
   b->exact_limit = !(flags & BROTLI_AMD_BATCH_EAGER_OUTPUT_LIMIT);
+  if (!hip_ok(hipStreamSynchronize(b->copy_stream), "hipStreamSynchronize(upload)")) return -1;
   if (submit(b, n, nullptr) != 0) return -1;
   std::vector<BrotliAmdResult> local;
   if (!results) { local.resize(n); results = local.data(); }
   if (BrotliAmdBatchWait(b, results) != 0) return -1;
-  for (uint32_t i = 0; i < n; i++) {
-    size_t got = (size_t)std::min<uint64_t>(results[i].decoded_size, out_caps[i]);
-    if (got && !hip_ok(hipMemcpyAsync(out[i], b->d_stage_out + out_off[i], got, hipMemcpyDeviceToHost, nullptr), "hipMemcpyAsync(output)")) return -1;
+  // download: pieces of about 32 MiB into pinned memory, the copies into the caller's buffers (several threads) side by side with the
+  // next piece's transfer
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> pieces; std::vector<hipEvent_t> evs;
+    uint32_t lo = 0;
+    bool ok = true;
+    while (lo < n && ok) {
+      uint32_t hi = lo; size_t acc = 0;
+      while (hi < n && acc < ((size_t)32 << 20)) { acc += (size_t)std::min<uint64_t>(results[hi].decoded_size, out_caps[hi]); hi++; }
+      const size_t o0 = out_off[lo];
+      const size_t last = (size_t)std::min<uint64_t>(results[hi - 1].decoded_size, out_caps[hi - 1]);
+      const size_t o1 = out_off[hi - 1] + last;
+      if (o1 > o0) ok = hip_ok(hipMemcpyAsync(b->h_pin_out + o0, b->d_stage_out + o0, o1 - o0, hipMemcpyDeviceToHost, b->copy_stream), "hipMemcpyAsync(output)");
+      hipEvent_t ev = nullptr;
+      ok = ok && hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate") && hip_ok(hipEventRecord(ev, b->copy_stream), "hipEventRecord");
+      evs.push_back(ev); pieces.emplace_back(lo, hi);
+      lo = hi;
+    }
+    for (size_t k = 0; k < pieces.size() && ok; k++) {
+      ok = hip_ok(hipEventSynchronize(evs[k]), "hipEventSynchronize");
+      if (ok) parallel_copy(pieces[k].first, pieces[k].second, [&](uint32_t i, bool go) -> size_t {
+        const size_t got = (size_t)std::min<uint64_t>(results[i].decoded_size, out_caps[i]);
+        if (go && got) std::memcpy(out[i], b->h_pin_out + out_off[i], got);
+        return got; });
+    }
+    (void)hipStreamSynchronize(b->copy_stream);
+    for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    if (!ok) return -1;
   }
-  if (!hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) return -1;
   return 0;
 }
 
 extern "C" const char* BrotliAmdLastError(void) { return g_last_error.c_str(); }
+extern "C" const char* BrotliAmdLastNote(void) { return g_last_note.c_str(); }
+
+// Test hook: the device's table builder alone (see brotli_amd_debug_build_tree_kernel).
+extern "C" hipError_t brotli_amd_launch_debug_build_tree(const uint8_t* d_lengths, uint32_t n_sym, uint16_t* d_decoded, uint32_t* d_entries, hipStream_t stream);
+extern "C" int BrotliAmdDebugBuildTree(const uint8_t* code_lengths, uint32_t alphabet_size, uint16_t* decoded, uint32_t* table_entries) {
+  if (code_lengths == nullptr || decoded == nullptr || table_entries == nullptr || alphabet_size == 0u || alphabet_size > 1128u) return -1;
+  uint8_t* d_len = nullptr; uint16_t* d_dec = nullptr; uint32_t* d_n = nullptr;
+  bool ok = hip_ok(hipMalloc(&d_len, alphabet_size), "hipMalloc") && hip_ok(hipMalloc(&d_dec, 32768 * sizeof(uint16_t)), "hipMalloc") && hip_ok(hipMalloc(&d_n, sizeof(uint32_t)), "hipMalloc");
+  ok = ok && hip_ok(hipMemcpy(d_len, code_lengths, alphabet_size, hipMemcpyHostToDevice), "hipMemcpy");
+  ok = ok && hip_ok(brotli_amd_launch_debug_build_tree(d_len, alphabet_size, d_dec, d_n, nullptr), "brotli_amd_debug_build_tree_kernel launch");
+  ok = ok && hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  ok = ok && hip_ok(hipMemcpy(decoded, d_dec, 32768 * sizeof(uint16_t), hipMemcpyDeviceToHost), "hipMemcpy") && hip_ok(hipMemcpy(table_entries, d_n, sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy");
+  if (d_len) (void)hipFree(d_len);
+  if (d_dec) (void)hipFree(d_dec);
+  if (d_n) (void)hipFree(d_n);
+  return ok && *table_entries != 0u ? 0 : -1;
+}
 
 // ============================================ error strings ============================================
 // reference src/state.rs:533-578 (including the historical "FL_SPACE" spelling of CL_SPACE)

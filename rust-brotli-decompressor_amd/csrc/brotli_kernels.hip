@@ -3035,8 +3035,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   static_assert(!CACHED || LDS_ONLY, "the cache is for the loops that read their tables out of LDS");
   auto cached_tree = [&](const uint32_t tree, const uint32_t slot, const uint32_t bytes) -> uint32_t {
     if (!tree_cache) return tree;
-    for (uint32_t off = lane * 16u; off < bytes; off += 1024u)
-      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(&g_smem[LDS_FIXED + slot + off]) = *reinterpret_cast<gu32x4*>(a.glb + tree + off);
+    // (a dword a lane: the arena aligns a tree to four bytes, no more -- ADVICE round 4)
+    for (uint32_t off = lane * 4u; off < bytes; off += 256u)
+      lds_st32(LDS_FIXED + slot + off, *reinterpret_cast<gu32*>(a.glb + tree + off));
     lds_sync();
     return slot;
   };
@@ -3875,7 +3876,9 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
       s.num_metablocks--; return E_RETRY_ARENA;  // (see the flag; nothing of this metablock has been output yet)
     }
     e = ctx_never ? process_commands<true, true>(&h) : process_commands<true, false>(&h);
-  } else if (ctx_never && ar_.lds_limit >= TREE_CACHE_BYTES && (g_engine_mode & 16u) == 0u) {
+  } else if (ctx_never && ar_.lds_limit >= TREE_CACHE_BYTES && (g_engine_mode & 16u) == 0u && rfl(s.large_window) == 0u) {
+    // (not for large-window streams: a cache slot for a distance tree holds the 928 entries the 520-symbol alphabet takes at
+    // most, a large-window alphabet of up to 1128 symbols builds tables of up to 1528 -- ADVICE round 4; such a metablock spills)
     // More tables than the LDS part holds (binaries at -q 5 and up: dozens of block types, a tree each), but literals that do not
     // depend on context: at any time the loop reads ONE literal tree, one command tree and the distance trees of one block type.
     // What lies in the LDS part goes to its place in the block's global scratch (the arena addresses both with the same offsets),
@@ -3887,7 +3890,7 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     h.ar.lds_limit = 0u;
     e = process_commands<true, true, true>(&h);
-  } else if (!ctx_never && ar_.lds_limit >= TREE_CACHE_CTX_BYTES && (g_engine_mode & 16u) == 0u && lit_types_fit_cache(ar_, rfl(s.nbt0), rfl(s.ctx_map), tree_cache_lit_slots(ar_.lds_limit)) &&
+  } else if (!ctx_never && ar_.lds_limit >= TREE_CACHE_CTX_BYTES && (g_engine_mode & 16u) == 0u && rfl(s.large_window) == 0u && lit_types_fit_cache(ar_, rfl(s.nbt0), rfl(s.ctx_map), tree_cache_lit_slots(ar_.lds_limit)) &&
              !((rfl(s.flags) & BROTLI_AMD_FLAG_ENGINE_ONLY) && rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN)) {   // (engine blocks hand such a metablock back, as above)
     // ... and the same where literals do depend on context, as long as no literal block type names more trees than the LDS part has
     // slots for: the loop for context-modelled metablocks out of LDS, command records included (their ring lies behind the cache)
@@ -4410,6 +4413,36 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   // four-wave blocks): such batches gain more from streams in flight than from helper waves in long literal runs.
   hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(64u * waves), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
+  return hipGetLastError();
+}
+
+// Test hook (BrotliAmdDebugBuildTree, include/brotli/batch.h): the table builder alone.  One wave builds the two-level table of
+// `n_sym` code lengths (src/huffman/mod.rs:273-386) where a metablock's first table would lie and then decodes every fifteen-bit
+// value through it as read_symbol does: decoded[v] = symbol << 4 | code length.  The test compares that -- not the table's layout,
+// which is this kernel's own -- with the known-answer tables of src/huffman/tests.rs.
+extern "C" __global__ __launch_bounds__(64) void brotli_amd_debug_build_tree_kernel(const uint8_t* __restrict__ lengths, uint32_t n_sym, uint16_t* __restrict__ decoded,
+                                                                                 uint32_t* __restrict__ entries, uint32_t lds_arena_bytes) {
+  const uint32_t lane = lane_id();
+  if (rfl((uint32_t)(uintptr_t)g_dynamic_lds) != 0u) { if (lane == 0) *entries = 0u; return; }
+  for (uint32_t i = lane; i < MAX_ALPHABET; i += 64) lds_st8(LDS_LENGTHS + i, i < n_sym ? lengths[i] : 0u);
+  lds_sync();
+  Arena a; a.glb = nullptr; a.lds_limit = lds_arena_bytes; a.top = 0; a.cold = 0;
+  const uint32_t tree = a.alloc(max_table_entries(n_sym) * 2u);
+  const uint32_t size = build_tree(a, tree, n_sym);
+  lds_sync();
+  for (uint32_t v = lane; v < 32768u; v += 64u) {
+    uint32_t e = lds_ld16(LDS_FIXED + tree + ((v & 0xFFu) << 1)), len = e & 15u;
+    if (len > ROOT_BITS) {
+      e = lds_ld16(LDS_FIXED + tree + (((e >> 4) + ((v >> ROOT_BITS) & mask_bits(len - ROOT_BITS))) << 1));
+      len = ROOT_BITS + (e & 15u);
+    }
+    decoded[v] = (uint16_t)(((e >> 4) << 4) | len);
+  }
+  if (lane == 0) *entries = size;
+}
+extern "C" hipError_t brotli_amd_launch_debug_build_tree(const uint8_t* d_lengths, uint32_t n_sym, uint16_t* d_decoded, uint32_t* d_entries, hipStream_t stream) {
+  const uint32_t arena = 8192u;
+  hipLaunchKernelGGL(brotli_amd_debug_build_tree_kernel, dim3(1), dim3(64), (size_t)LDS_FIXED + arena, stream, d_lengths, n_sym, d_decoded, d_entries, arena);
   return hipGetLastError();
 }
 

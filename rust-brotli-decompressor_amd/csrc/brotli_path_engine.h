@@ -123,7 +123,11 @@ static_assert(PIPE || 64u * GW + 4096u <= PE_EX - PE_PM, "a run region's exits a
 constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine's tables
 // What the engines of a block share: the invocation's parameters, the stream's state, the records' two tables.  One engine: at the
 // end of its tables (the control words are its own); two engines: in front of theirs, with a block of control words of its own.
-constexpr uint32_t PE_TD_ENTRIES = 1024;                          // (920 is the most a distance alphabet without large window takes)
+// A record is parsed where 128 bits of the region are left in front of it (pos + 128 <= L); its reads reach further: a distance
+// code of up to 15 + 62 bits (large window) in front of a head whose 64-bit read takes three dwords, i.e. bit pos + 77 + 96 at
+// most -- 45 bits beyond L, inside the six dwords (192 bits) of input that every region stages behind its last one.
+static_assert(15u + 62u + 96u <= 128u + 6u * 32u, "a record's reads stay inside the region's input slack");
+constexpr uint32_t PE_TD_ENTRIES = 1024;                          // (920 is the most a distance alphabet without large window takes; a large-window table that needs more keeps its metablock off the engine: td_ok)
 constexpr uint32_t PE_SHARED_CTL = PIPE ? 1024u : 0u;             // the shared control words (two engines)
 constexpr uint32_t PE_TD = PIPE ? PE_SHARED_CTL : PE_SET_BYTES;   // u16 per entry of the distance code's table: the same two levels, a leaf's value = bits of the whole distance code (symbol + extra)
 constexpr uint32_t PE_TC = PE_TD + PE_TD_ENTRIES * 2;             // u32 per command symbol: insert base | insert extra bits << 15 | copy extra bits << 20 | implicit distance << 25
