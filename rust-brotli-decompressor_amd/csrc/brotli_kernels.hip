@@ -438,6 +438,7 @@ struct Stream {
   uint32_t num_metablocks, num_spilled;
   uint64_t num_commands;
   uint32_t engine_commands;
+  uint32_t general_engine;  // (see HotArgs)
   uint32_t peak_trees, peak_maps, any_compressed;  // what the reference's allocators would have been asked for (see BrotliAmdStreamStatus)
 #ifdef BROTLI_AMD_PROFILE
   uint64_t prof[6];
@@ -919,17 +920,19 @@ __device__ __forceinline__ WordShape word_shape(uint32_t len, uint32_t transform
 }
 
 // decode.rs:2593-2640 + transform.rs:737-795.  Returns the bytes of the (transformed) word, one per lane.
-__device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t offset, const WordShape& w) {
+// (`stage`: 128 bytes of LDS for the two transforms that walk the word: the decoding wave's LDS_WORD, or a wave's own where several
+// waves put words together side by side -- the path engine's execute)
+__device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t offset, const WordShape& w, const uint32_t stage = LDS_WORD) {
   const uint32_t lane = lane_id();
   uint32_t b = 0;
   if (lane < w.plen) b = kAffixPool[w.pre + lane];
   else if (lane < w.plen + w.wlen) b = dict[offset + w.skip + (lane - w.plen)];
   if (w.t == 10 || w.t == 11) {  // transform.rs:720-735 -- serial over UTF-8 sequences, staged through LDS
-    lds_st8(LDS_WORD + lane, b);
-    lds_st8(LDS_WORD + 64 + lane, 0);  // bytes after the word are zero so that a stray write past it is harmless
+    lds_st8(stage + lane, b);
+    lds_st8(stage + 64u + lane, 0);  // bytes after the word are zero so that a stray write past it is harmless
     lds_sync();
     if (lane == 0) {
-      uint32_t p = LDS_WORD + w.plen;
+      uint32_t p = stage + w.plen;
       int32_t remaining = (w.t == 10) ? 1 : (int32_t)w.wlen;
       while (remaining > 0) {
         int step;
@@ -942,7 +945,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
       }
     }
     lds_sync();
-    b = lds_ld8(LDS_WORD + lane);
+    b = lds_ld8(stage + lane);
     lds_sync();
   }
   if (lane >= w.plen + w.wlen && lane < w.total) b = kAffixPool[w.suf + (lane - w.plen - w.wlen)];
@@ -986,7 +989,7 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
        HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */,
        HC_EXT_BASE = 13 /* LDS base of the command-record ring of the parse / copy split (SPX_BYTES, in the free tail of the table arena); 0 = this metablock has none */ };
-enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6, HK_PATH2 = 7 };  // HC_KIND
+enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6, HK_PATH2 = 7, HK_PATHG = 8 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
        // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
@@ -1155,7 +1158,8 @@ __device__ __noinline__ void spec_chunk(uint32_t w, uint32_t dw0, uint32_t sh, u
 }
 
 __device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
-namespace pe16 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }   // one engine of sixteen waves
+namespace pe16 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }   // one engine of sixteen waves, the lean form: no words of the static dictionary
+namespace pe16g { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }  // ... the general form
 namespace pe8 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }    // two engines of eight, regions in turns
 // which command engine blocks of sixteen waves use: 0 = the path engine where it applies (brotli_path_engine.h), 1 = the scan
 // engine only (experiments, A/B tests: BROTLI_AMD_ENGINE=scan)
@@ -1328,6 +1332,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     const uint32_t kind = hc_ld(HC_KIND);
     if (kind == HK_SCAN) { scan_engine(me); continue; }  // every wave of the block runs the command engine
     if (kind == HK_PATH) { seq = rfl(pe16::path_engine(me)); continue; }   // (back with the last request it answered: see there)
+    if (kind == HK_PATHG) { seq = rfl(pe16g::path_engine(me)); continue; }
     if (kind == HK_PATH2) { seq = rfl(pe8::path_engine(me)); continue; }
     if (kind == HK_SPLIT) {  // a context-modelled metablock: wave 1 copies (if asked to), wave 2 parses command records; the others go back to sleep
       if (rfl(me) == 1u && (g_engine_mode & 2u) == 0u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave();
@@ -1801,20 +1806,29 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 #define PE_CFG_WAVES 16
 #define PE_CFG_RBL 32768
 #define PE_CFG_PIPE 0
+#define PE_CFG_DICT 0
+#include "brotli_path_engine.h"
+#undef PE_CFG_NS
+#undef PE_CFG_DICT
+#define PE_CFG_NS pe16g
+#define PE_CFG_DICT 1
 #include "brotli_path_engine.h"
 #undef PE_CFG_NS
 #undef PE_CFG_WAVES
 #undef PE_CFG_RBL
 #undef PE_CFG_PIPE
+#undef PE_CFG_DICT
 #define PE_CFG_NS pe8
 #define PE_CFG_WAVES 8
 #define PE_CFG_RBL 16384
 #define PE_CFG_PIPE 1
+#define PE_CFG_DICT 0
 #include "brotli_path_engine.h"
 #undef PE_CFG_NS
 #undef PE_CFG_WAVES
 #undef PE_CFG_RBL
 #undef PE_CFG_PIPE
+#undef PE_CFG_DICT
 using pe16::PE_MIN_INPUT;
 
 // The pending copy of the lean loop lives in registers the compiler does not know about: v[120:123] (16 bytes per lane)
@@ -2975,6 +2989,7 @@ struct HotArgs {
   uint64_t spec_scratch;   // global address of the helper waves' literal scratch
   uint64_t num_commands;
   uint32_t engine_commands, reserved_;  // commands a command engine (scan or path) took
+  uint32_t general_engine;  // the stream has words of the static dictionary: the path engine's general form from here on (see PE_CFG_DICT)
   uint64_t resume_out;     // global address of the status' BrotliAmdResume: command boundaries close to the end of the input are noted there
   uint64_t prof[6];
 };
@@ -3153,6 +3168,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #endif
   bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
   bool prefer_scan = false;         // ... or the scan engine: the path engine found its regions bound by their closure (see there)
+  bool prefer_general = rfl(args->general_engine) != 0u;   // ... or the path engine's general form: the lean one has stopped in front of a dictionary reference in this stream
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
   // ahead of this wave (rec_wave; the lean loop takes commands out of them); on request (BROTLI_AMD_ENGINE=split) wave 1 executes
   // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
@@ -3212,7 +3228,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         sc_ctl_st(sb, SCC_OUT_LO, (uint32_t)(uintptr_t)out); sc_ctl_st(sb, SCC_OUT_HI, (uint32_t)((uint64_t)(uintptr_t)out >> 32));
         sc_ctl_st(sb, SCC_DICT_LO, (uint32_t)(uintptr_t)dict); sc_ctl_st(sb, SCC_DICT_HI, (uint32_t)((uint64_t)(uintptr_t)dict >> 32));
         const bool use_pipe = use_path && (g_engine_mode & 8u) != 0u && !prefer_one_engine;   // (two engines of eight waves, regions in turns: BROTLI_AMD_ENGINE=path2 -- measured slower than one of sixteen, see DESIGN)
-        hc_st(HC_KIND, use_pipe ? (uint32_t)HK_PATH2 : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
+        const bool use_general = use_path && !use_pipe && prefer_general;
+        hc_st(HC_KIND, use_pipe ? (uint32_t)HK_PATH2 : use_general ? (uint32_t)HK_PATHG : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
 #ifdef BROTLI_AMD_PROFILE_SCAN
@@ -3221,7 +3238,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #ifdef BROTLI_AMD_PE_DEBUG
         if (blockIdx.x == 0 && lane == 0) printf("engine in: P %llu bl1 %u quota %u mlen %d commands so far %llu\n", (unsigned long long)P, bl1, quota, mlen, (unsigned long long)num_commands);
 #endif
-        const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+        const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_general ? rfl(pe16g::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
 #ifdef BROTLI_AMD_PE_DEBUG
         if (blockIdx.x == 0 && lane == 0) printf("engine out: tick %llu took %u, P %llu form %u\n", (unsigned long long)__builtin_amdgcn_s_memtime(), took, (unsigned long long)(LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32)), LEAN_LD(L_SC_POS_HI));
 #endif
@@ -3236,6 +3253,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         }
         const uint32_t form_raw = LEAN_LD(L_SC_POS_HI), form = form_raw & 0xFFu;
         const bool declined = ((form_raw >> 8) & 1u) != 0u;
+        if (((form_raw >> 10) & 1u) != 0u) prefer_general = true;   // (the lean form stopped in front of a dictionary reference)
         if (((form_raw >> 9) & 1u) != 0u) prefer_scan = true;   // (the path engine's regions were bound by their closure: a stream of few literals -- the scan engine's from here on)   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
@@ -3799,7 +3817,7 @@ done:
   args->P = P; args->next_boundary = next_boundary; args->mlen = mlen;
   args->d0 = d0; args->d1 = d1; args->d2 = d2; args->d3 = d3;
   args->num_commands = num_commands;
-  args->engine_commands = engine_commands;
+  args->engine_commands = engine_commands; args->general_engine = prefer_general ? 1u : 0u;
 #ifdef BROTLI_AMD_PROFILE
   if (lane == 0 && blockIdx.x == 0) printf("lean exits by stage: %u %u %u %u %u %u %u %u\n", prof_stage[0], prof_stage[1], prof_stage[2], prof_stage[3], prof_stage[4], prof_stage[5], prof_stage[6], prof_stage[7]);
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
@@ -3857,7 +3875,7 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
   h.lut_vgpr = s.lut_vgpr; h.bl_vgpr = s.bl_vgpr;
   h.spec_scratch = (uint64_t)(uintptr_t)(s.ar.glb + s.ar_end);
   h.num_commands = s.num_commands;
-  h.engine_commands = s.engine_commands; h.reserved_ = 0u;
+  h.engine_commands = s.engine_commands; h.reserved_ = 0u; h.general_engine = s.general_engine;
   h.prof[0] = h.prof[1] = h.prof[2] = h.prof[3] = h.prof[4] = h.prof[5] = 0;
   // tables entirely in the LDS part of the arena (the common case) take the ds_read-only instantiation
   int e;
@@ -3910,6 +3928,7 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
   s.dist_rb0 = rfl(h.d0); s.dist_rb1 = rfl(h.d1); s.dist_rb2 = rfl(h.d2); s.dist_rb3 = rfl(h.d3);
   s.num_commands = rfl(h.num_commands);
   s.engine_commands = rfl(h.engine_commands);
+  s.general_engine = rfl(h.general_engine);
 #ifdef BROTLI_AMD_PROFILE
   s.prof[0] += h.prof[0]; s.prof[1] += h.prof[1]; s.prof[2] += h.prof[2]; s.prof[3] += h.prof[3]; s.prof[4] += h.prof[4]; s.prof[5] += h.prof[5];
 #endif
@@ -4217,7 +4236,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     s.in_bytes = as_global<gcu8>(d.in);
     s.flags = d.flags;
     s.lut_vgpr = lut; s.bl_vgpr = bl;
-    s.num_metablocks = 0; s.num_spilled = 0; s.num_commands = 0; s.engine_commands = 0;
+    s.num_metablocks = 0; s.num_spilled = 0; s.num_commands = 0; s.engine_commands = 0; s.general_engine = 0;
     s.peak_trees = 0; s.peak_maps = 0; s.any_compressed = 0;
     s.mlen = 0;
 #ifdef BROTLI_AMD_PROFILE

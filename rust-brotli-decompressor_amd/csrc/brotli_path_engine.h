@@ -34,7 +34,7 @@
 // BYHAND: a cap was hit), and the walk starts at the stream's real position.
 // (no include guard: brotli_kernels.hip includes this file once per configuration -- PE_CFG_NS the namespace, PE_CFG_WAVES the
 // waves of one engine, PE_CFG_RBL its region in stream bits, PE_CFG_PIPE whether two engines of a block take turns)
-#if !defined(PE_CFG_NS) || !defined(PE_CFG_WAVES) || !defined(PE_CFG_RBL) || !defined(PE_CFG_PIPE)
+#if !defined(PE_CFG_NS) || !defined(PE_CFG_WAVES) || !defined(PE_CFG_RBL) || !defined(PE_CFG_PIPE) || !defined(PE_CFG_DICT)
 #error "brotli_path_engine.h: configuration macros missing"
 #endif
 namespace PE_CFG_NS {
@@ -98,6 +98,8 @@ constexpr uint32_t PE_REC = PE_WST;                               // 16 bytes pe
 constexpr uint32_t PE_BLIST = PE_NEXT + 2 * PE_CMDS;                // u16 per command with a long copy from in front of the region or a long literal run: its index
 constexpr uint32_t PE_RS = PE_NEXT + 4 * PE_CMDS;                   // 64 bytes per batch of the resolve: its sums, the ring it ends with, its list counts
 constexpr uint32_t PE_DLIST = PE_NEXT;                            // u16 per copy that reads the region's own output: its command (the records are dead by then)
+constexpr uint32_t PE_WLIST = PE_NEXT + 4 * PE_CMDS + 1024;        // u16 per command whose copy is a word of the static dictionary that goes out inside the pass (PE_DICT)
+static_assert(PE_WLIST + 2 * PE_CMDS <= PE_NEXT + PE_STATES * 2, "the words' list lies in the records' room");
 constexpr uint32_t PE_WSTB = PE_WCAP * 2 > PE_CMDS * 16 ? PE_WCAP * 2 : PE_CMDS * 16;  // (bytes of that room: its larger tenant)
 constexpr uint32_t PE_LIST = PE_WST + PE_WSTB;                    // u16 per listed command (+ 1): its state as bit | kind << 15
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
@@ -146,7 +148,9 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
-       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */ };
+       PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
+       PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
+       PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
 // Words of the static dictionary (decode.rs:2593-2640; one command in 33 to 87 of text at -q 4 .. 9, tools/eligibility_survey.py).
 // Round 4's engine stopped in front of each: an invocation and a region's tables for some fifty commands, 3200 clocks a command.
 // Now (one engine): the resolve lets the first such command of what is listed through with its literals alone, wave 0 puts the
@@ -154,7 +158,11 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
 // the region's tables, the walk's list and the details in the waves' registers hold for every pass.  A word that is not a plain
 // one (unknown transform, an empty word, one that does not fit the limits) ends the invocation behind the command's distance:
 // the checked loop says what it is.
-#if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_NO_DICT)
+// The engine compiles twice for that (round 5): PE_CFG_DICT 0 is the LEAN form -- it stops in front of a dictionary reference, as round 3's
+// did, and tells the caller, who takes the general form (PE_CFG_DICT 1) for the rest of the stream.  A stream without such words -- the
+// metric's -- never runs the general form: what that form carries had cost it 4 % through the allocation of one very large function's
+// registers (128 a wave, and the function spills).
+#if PE_CFG_DICT && !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_NO_DICT)
 #define PE_DICT 1
 #else
 #define PE_DICT 0
@@ -710,7 +718,7 @@ pe_again:
   const uint32_t T = PIPE ? threadIdx.x % (64u * GW) : threadIdx.x;
   const uint32_t pbs = hc_ld(HC_SCAN_BASE);                       // what the block's engines share
   const uint32_t pb = pbs + PE_SET0 + eng * PE_SET_BYTES;         // this engine's tables
-  if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u); lds_st32(pb + PE_CTL + 4u * PEC_PDX, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OVF, 0u); }
+  if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u); lds_st32(pb + PE_CTL + 4u * PEC_PDX, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OVF, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DSEEN, 0u); }
   if (PIPE) {   // what the two engines tell each other starts from nothing
     if (threadIdx.x < 8u) lds_st32(pbs + PE_CTL + 4u * (PEC_RESOLVED + threadIdx.x), 0u);
     if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_GBAR, 0u);
@@ -783,6 +791,12 @@ pe_again:
   uint32_t gb_target = 0; (void)gb_target;               // (two engines: this engine's barriers so far, times GW)
   uint32_t rseq = 0;                                     // regions of this invocation so far (the one at hand included)
   uint32_t kseq = 0; (void)kseq;                         // (two engines: the number of the region this engine is at)
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+  uint64_t rg_ts[10] = {}; uint64_t rg_prev_end = 0;
+#define RG_STAMP(k) do { rg_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RG_STAMP(k) do { } while (0)
+#endif
   // What the region's tables start from (the engine's wave 0): the window and the counters of the phases.
   auto setup_tables = [&](const uint32_t lbdw_, const uint32_t le_, const uint32_t bits, const uint32_t mode, const uint32_t ent_) {
     pe_ctl_st(pb, PEC_LBDW, lbdw_); pe_ctl_st(pb, PEC_LE, le_); pe_ctl_st(pb, PEC_L, bits);
@@ -792,7 +806,7 @@ pe_again:
   };
   // ... and what the walk and what follows it start from: where the region's output begins, nothing published yet
   auto setup_walk = [&](const uint64_t P_) {
-    pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u);
+    pe_ctl_st(pb, PEC_NAPUB, 0u); pe_ctl_st(pb, PEC_WDONE, 0u); pe_ctl_st(pb, PEC_DCAND, 0u);
     pe_ctl_st(pb, PEC_P0_LO, (uint32_t)P_); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(P_ >> 32));
   };
   // n bytes out of LDS to memory in whole sixteen-byte lines: the bytes in front of the first line of `dst` and behind the last one
@@ -1489,6 +1503,7 @@ pe_again:
       }
     }
     PE_BAR();
+    RG_STAMP(0);   // walk + details done
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
     PE_PROF(7);
     // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
@@ -1522,110 +1537,184 @@ pe_pass:
       // the ring, against an unknown ring at the batch's start: (dtag, dval) = entry dtag of that ring plus dval, or (4, the distance)
       const bool need = kind == SCK_SHORT || kind == SCK_IMPLICIT;
       const uint32_t code = kind == SCK_SHORT ? val : 0u;
-      const bool pushes = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
-      const uint64_t pmk = __ballot(pushes);
-      uint32_t dtag = kind == SCK_EXPLICIT ? 4u : 0u; int32_t dval = kind == SCK_EXPLICIT ? (int32_t)val : 0;
-      const uint32_t npush = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmk, 0u));  // pushes in front of this lane
-      const uint32_t n_all = (uint32_t)__popcll(pmk);
-      const uint32_t perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((pushes ? npush : n_all + lane - npush) << 2), (int)lane);
-      if (__ballot(need) != 0ull) {
-        const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
-        const bool from_carry = npush <= back;
-        const uint32_t ci = back - npush;  // (meaningful when from_carry)
-        const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
-        uint32_t resolved = need ? 0u : 1u;
-        const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
-        while (__ballot(resolved == 0u) != 0ull) {
-          const uint32_t stg = bperm(src << 2, dtag);
-          const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dval);
-          const uint32_t sr = bperm(src << 2, resolved);
-          const bool can = resolved == 0u && (from_carry || sr != 0u);
-          const uint32_t bt = from_carry ? ci : stg;
-          const int32_t bv = from_carry ? 0 : sv;
-          const int32_t nv = code == 0u ? bv : (code & 1u) ? bv + mag : bv - mag;  // (a result <= 0 is invalid: seen once the ring is known)
-          dtag = can ? bt : dtag; dval = can ? nv : dval; resolved = can ? 1u : resolved;
-        }
-      }
-      // the batch's sums and the ring it ends with (all its pushes: a batch that stops short is the last one that counts)
       const uint32_t rs = pb + PE_RS + (bw << 6);
-      if (mine) {
-        const uint32_t tperm = bperm(perm << 2, dtag), vperm = bperm(perm << 2, (uint32_t)dval);  // lane r: the r-th push
-        if (lane == 0) {
-          lds_st32(rs, rdlane(lit_incl, 63)); lds_st32(rs + 4u, rdlane(s1, 63)); lds_st32(rs + 8u, rdlane(s2, 63));
+      uint64_t pmk; uint32_t dtag; int32_t dval; uint32_t n_all, perm;
+      // (`pushes`: an explicit distance, or a ring code other than "the last one" -- but not the distance of a dictionary word,
+      // decode.rs:2643-2644: PE_DICT resolves a second time once it knows which commands those are)
+      auto ring_resolve = [&](const bool pushes) {
+        pmk = __ballot(pushes);
+        dtag = kind == SCK_EXPLICIT ? 4u : 0u; dval = kind == SCK_EXPLICIT ? (int32_t)val : 0;
+        const uint32_t npush = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmk, 0u));  // pushes in front of this lane
+        n_all = (uint32_t)__popcll(pmk);
+        perm = (uint32_t)__builtin_amdgcn_ds_permute((int)((pushes ? npush : n_all + lane - npush) << 2), (int)lane);
+        if (__ballot(need) != 0ull) {
+          const uint32_t back = code == 0u ? 0u : 3u - ((0xaaafff1bu >> (code << 1)) & 3u);
+          const bool from_carry = npush <= back;
+          const uint32_t ci = back - npush;  // (meaningful when from_carry)
+          const uint32_t src = bperm(((npush - 1u - back) & 63u) << 2, perm);
+          uint32_t resolved = need ? 0u : 1u;
+          const int32_t mag = (int32_t)((0xfa5fa500u >> (code << 1)) & 3u);
+          while (__ballot(resolved == 0u) != 0ull) {
+            const uint32_t stg = bperm(src << 2, dtag);
+            const int32_t sv = (int32_t)bperm(src << 2, (uint32_t)dval);
+            const uint32_t sr = bperm(src << 2, resolved);
+            const bool can = resolved == 0u && (from_carry || sr != 0u);
+            const uint32_t bt = from_carry ? ci : stg;
+            const int32_t bv = from_carry ? 0 : sv;
+            const int32_t nv = code == 0u ? bv : (code & 1u) ? bv + mag : bv - mag;  // (a result <= 0 is invalid: seen once the ring is known)
+            dtag = can ? bt : dtag; dval = can ? nv : dval; resolved = can ? 1u : resolved;
+          }
         }
-        _Pragma("unroll") for (uint32_t r = 0; r < 4u; r++) {
-          const uint32_t tg = n_all > r ? rdlane(tperm, (n_all - 1u - r) & 63u) : r - n_all;
-          const uint32_t vl = n_all > r ? rdlane(vperm, (n_all - 1u - r) & 63u) : 0u;
-          if (lane == 0) { lds_st32(rs + 16u + 8u * r, tg); lds_st32(rs + 20u + 8u * r, vl); }
+        // the ring the batch ends with (all its pushes: a batch that stops short is the last one that counts)
+        if (mine) {
+          const uint32_t tperm = bperm(perm << 2, dtag), vperm = bperm(perm << 2, (uint32_t)dval);  // lane r: the r-th push
+          _Pragma("unroll") for (uint32_t r = 0; r < 4u; r++) {
+            const uint32_t tg = n_all > r ? rdlane(tperm, (n_all - 1u - r) & 63u) : r - n_all;
+            const uint32_t vl = n_all > r ? rdlane(vperm, (n_all - 1u - r) & 63u) : 0u;
+            if (lane == 0) { lds_st32(rs + 16u + 8u * r, tg); lds_st32(rs + 20u + 8u * r, vl); }
+          }
         }
+      };
+      const bool pushes0 = kind == SCK_EXPLICIT || (kind == SCK_SHORT && val != 0u);
+      ring_resolve(pushes0);
+      // the batch's sums
+      if (mine && lane == 0) { lds_st32(rs, rdlane(lit_incl, 63)); lds_st32(rs + 4u, rdlane(s1, 63)); lds_st32(rs + 8u, rdlane(s2, 63)); }
+      if (PE_DICT) {
+        // may any command of the pass be a word of the static dictionary?  An explicit distance beyond what the stream had put out
+        // when the pass began (or beyond the window) is the only kind that can be (decode.rs:2583-2593): where there is none -- the
+        // rule -- the pass is as it was
+        const uint32_t reach = st.P < (uint64_t)(uint32_t)st.max_backward ? (uint32_t)st.P : (uint32_t)st.max_backward;
+        if (__ballot(active && kind == SCK_EXPLICIT && val > reach) != 0ull && lane == 0) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_DCAND]) = 1u;
       }
-      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DICTK, 0xFFFFFFFFu); }   // (... and the execute's items are handed out from the first)
+      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DICTK, 0xFFFFFFFFu); lds_st32(pb + PE_CTL + 4u * PEC_WNEXT, 0u); }   // (... and the execute's items are handed out from the first)
       PE_BAR();
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
       int32_t d0 = st.d0, d1 = st.d1, d2 = st.d2, d3 = st.d3;
+#define PE_RING_AT(tg_, vl_) ((tg_) == 4u ? (int32_t)(vl_) : ((tg_) == 0u ? o0 : (tg_) == 1u ? o1 : (tg_) == 2u ? o2 : o3) + (int32_t)(vl_))
       for (uint32_t j = 0; j < bw && mine; j++) {
         const uint32_t rj = pb + PE_RS + (j << 6);
         const uint32_t w = lds_ld32(rj + (lane < 12u ? lane << 2 : 0u));   // (one read: lane k word k)
         c_lit += rdlane(w, 0); const uint32_t t1 = rdlane(w, 1); c_cmd += t1 & 0xFFFFu; c_dst += t1 >> 16; c_out += rdlane(w, 2);
         const int32_t o0 = d0, o1 = d1, o2 = d2, o3 = d3;
-#define PE_RING_AT(tg_, vl_) ((tg_) == 4u ? (int32_t)(vl_) : ((tg_) == 0u ? o0 : (tg_) == 1u ? o1 : (tg_) == 2u ? o2 : o3) + (int32_t)(vl_))
         d0 = PE_RING_AT(rdlane(w, 4), rdlane(w, 5)); d1 = PE_RING_AT(rdlane(w, 6), rdlane(w, 7));
         d2 = PE_RING_AT(rdlane(w, 8), rdlane(w, 9)); d3 = PE_RING_AT(rdlane(w, 10), rdlane(w, 11));
-#undef PE_RING_AT
       }
+      // (PE_DICT) Words of the static dictionary INSIDE the pass.  A word's output is not its copy length long (transform.rs:737-795),
+      // and while the window is not full yet its number depends on where it stands (decode.rs:2583-2603: distance - max_distance - 1),
+      // i.e. on the lengths of the words before it.  Round 4 ended a pass at every word (a resolve and an execute per word: three
+      // quarters of a text stream's time at -q 5).  Now a fixed point over the whole region: every lane classifies its command with the
+      // words in front of it as the round before left them (`dex`: what they add to, or take from, the copy lengths' sum), the
+      // lengths' differences are summed up over the block, and when a round changes no lane's difference the classification is the
+      // stream's.  A word's length follows from its copy length and transform alone, and a shift of a few bytes rarely moves a word to
+      // another transform: two rounds as a rule, a barrier each.  What does not settle in eight falls back to a pass per word.
+      bool isw = false, plainw = false;   // the copy is a dictionary reference; ... one that goes out inside this pass
+      uint32_t wdesc = 0, wdelta = 0, dex = 0;   // the word (offset | transform << 17 | length << 24); its length less the copy's; that, summed over the commands in front of this one
+      if (PE_DICT && pe_ctl_ld(pb, PEC_DCAND) != 0u) {
+        auto classify = [&](const bool plain_ok) {
+          const uint64_t pk = st.P + (uint64_t)(c_out + out_excl + ins + dex);
+          const uint32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (uint32_t)pk : (uint32_t)st.max_backward;
+          isw = (bool)((uint32_t)active & (uint32_t)!odd & (uint32_t)!big & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(val > maxd));
+          plainw = false; wdesc = 0; wdelta = 0;
+          if (plain_ok && isw && copy >= 4u && copy <= 24u) {
+            const uint32_t shift = kDictSizeBitsByLength[copy], id = val - maxd - 1u, tix = id >> shift;
+            if (tix < (uint32_t)BROTLI_NUM_TRANSFORMS) {
+              const WordShape w = word_shape(copy, tix);
+              if (w.total != 0u) { plainw = true; wdelta = w.total - copy; wdesc = (kDictOffsetsByLength[copy] + (id & mask_bits(shift)) * copy) | (tix << 17) | (copy << 24); }
+            }
+          }
+        };
+        uint32_t prev = 0; bool settled = false;
+        for (uint32_t it = 0; it < 8u; it++) {
+          classify(true);
+          const uint32_t dincl = sc_scan(wdelta);
+          const bool chg = __ballot(wdelta != prev) != 0ull;
+          prev = wdelta;
+          const uint32_t slot = 52u + 4u * (it & 1u);
+          if (lane == 0) lds_st32(rs + slot, (rdlane(dincl, 63) << 1) | (chg ? 1u : 0u));   // (every wave: one without a batch says 0)
+          PE_BAR();
+          const uint32_t wv = lane < GW ? lds_ld32(pb + PE_RS + (lane << 6) + slot) : 0u;
+          const bool anychg = __ballot((wv & 1u) != 0u) != 0ull;
+          const uint32_t sincl = sc_scan((uint32_t)((int32_t)wv >> 1));
+          dex = (bw == 0u ? 0u : rdlane(sincl, (bw - 1u) & 63u)) + dincl - wdelta;
+          if (!anychg) { settled = true; break; }   // (this round's differences were the round before's: so is what they sum up to)
+        }
+        if (!settled) { dex = 0; classify(false); }   // (up to the first word nothing has moved: the pass ends there, as round 4's did)
+        // ... and the ring once more: a dictionary word's distance is not pushed
+        if (__ballot(isw) != 0ull || true) {   // (uniform over the block: every wave resolves again and meets the others at the barrier)
+          ring_resolve(pushes0 && !isw);
+          PE_BAR();
+          d0 = st.d0; d1 = st.d1; d2 = st.d2; d3 = st.d3;
+          for (uint32_t j = 0; j < bw && mine; j++) {
+            const uint32_t rj = pb + PE_RS + (j << 6);
+            const uint32_t w = lds_ld32(rj + (lane < 12u ? lane << 2 : 0u));
+            const int32_t o0 = d0, o1 = d1, o2 = d2, o3 = d3;
+            d0 = PE_RING_AT(rdlane(w, 4), rdlane(w, 5)); d1 = PE_RING_AT(rdlane(w, 6), rdlane(w, 7));
+            d2 = PE_RING_AT(rdlane(w, 8), rdlane(w, 9)); d3 = PE_RING_AT(rdlane(w, 10), rdlane(w, 11));
+          }
+        }
+      }
+#undef PE_RING_AT
       const int32_t dist = dtag == 4u ? dval : (dtag == 0u ? d0 : dtag == 1u ? d1 : dtag == 2u ? d2 : d3) + dval;
       const uint32_t lit_a = c_lit + lit_incl, cmd_a = c_cmd + (s1 & 0xFFFFu), dst_a = c_dst + (s1 >> 16);
-      const uint64_t out_a = (uint64_t)c_out + s2;
+      const uint32_t dcum = dex + wdelta;   // (the words' differences up to and with this command's)
+      const uint64_t out_a = (uint64_t)(c_out + s2 + dcum);
       bool ok = !odd && !big && lit_a <= st.bl0 && cmd_a <= st.bl1 && dst_a <= st.bl2 && out_a < (uint64_t)st.quota;
-      const uint64_t rel = (uint64_t)c_out + out_excl;   // where the command's output starts, from the region's
-      bool dictc = false;   // (PE_DICT) the copy is a word of the static dictionary and the command's literals clear every limit
+      const uint64_t rel = (uint64_t)(c_out + out_excl + dex);   // where the command's output starts, from the region's
+      bool dictc = false;   // (PE_DICT) the copy is a dictionary reference that does NOT go out inside the pass, and the command's literals clear every limit
+      bool dref = false;    // (lean form) ... a dictionary reference at all
       {
         // max distance at the copy (decode.rs:2583-2589); beyond it the distance names a dictionary word
         const uint64_t pk = st.P + rel + ins;
         const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
-        if (PE_DICT) dictc = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd));   // (`ok` so far: an active lane, its counts and its output -- the copy's length for the word's -- inside every limit)
-        ok = ok && (kind == SCK_NONE || (dist > 0 && dist <= maxd));
+        if (PE_DICT) dictc = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd) & (uint32_t)!plainw);   // (`ok` so far: an active lane, its counts and its output -- the copy's length for the word's -- inside every limit)
+        if (!PE_DICT && !PIPE) dref = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd));
+        ok = ok && (kind == SCK_NONE || plainw || (dist > 0 && dist <= maxd));
       }
       const uint64_t stopmask = __ballot(active && !ok);
       uint32_t kpb = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
       const uint64_t dictmask = PE_DICT ? __ballot(dictc) : 0ull;
+      const uint64_t drefmask = (!PE_DICT && !PIPE) ? __ballot(dref) : 0ull;
       if (PE_DICT && stopmask != 0ull && ((dictmask >> kpb) & 1ull) != 0ull) kpb++;   // (the pass ends BEHIND such a command's literals)
       if (mine && stopmask != 0ull && lane == 0) pe_atomic_min(pb + PE_CTL + 4u * PEC_KP, k0 + kpb);
       // a copy whose source reaches into the region's own output is done afterwards (bit 31 of w0); long items get a wave
-      const uint32_t copy_x = dictc ? 0u : copy;   // (a dictionary word is not the execute's)
+      const uint32_t copy_x = (dictc || plainw) ? 0u : copy;   // (a dictionary word is no LZ77 copy: wave 0's behind the pass, or -- inside it -- an item of its own list)
       const uint32_t dep = (copy_x != 0u && rel + ins + copy_x > (uint64_t)(uint32_t)dist) ? 1u : 0u;
       uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
       const bool bigc = (copy_x > PE_LANE_COPY && dep == 0u) || ins - uu > PE_LANE_LITS;
-      const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc);
-      if (mine && lane == 0) lds_st32(rs + 48u, (uint32_t)__popcll(dmk) | ((uint32_t)__popcll(bmk) << 16));
+      const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc), wmk = PE_DICT ? __ballot(lane < kpb && plainw) : 0ull;
+      if (mine && lane == 0) { lds_st32(rs + 48u, (uint32_t)__popcll(dmk) | ((uint32_t)__popcll(bmk) << 16)); if (PE_DICT) lds_st32(rs + 12u, (uint32_t)__popcll(wmk)); }
       PE_BAR();
       const uint32_t kp_total = pe_ctl_ld(pb, PEC_KP);
       my_exec = !mine || kp_total <= k0 ? 0u : (kp_total - k0 < K ? kp_total - k0 : K);
       if (mine && my_exec != 0u) {
         // (every batch in front of one that executes anything went through whole: its counts are its lists' lengths)
-        uint32_t c_dep = 0, c_big = 0;
+        uint32_t c_dep = 0, c_big = 0, c_word = 0;
         {
           const uint32_t w = lane < bw ? lds_ld32(pb + PE_RS + (lane << 6) + 48u) : 0u;
           const uint32_t sum = sc_scan(w);  // (two 16-bit sums side by side: at most 1024 each)
           const uint32_t tot = rdlane(sum, 63);
           c_dep = tot & 0xFFFFu; c_big = tot >> 16;
+          if (PE_DICT && pe_ctl_ld(pb, PEC_DCAND) != 0u) c_word = rdlane(sc_scan(lane < bw ? lds_ld32(pb + PE_RS + (lane << 6) + 12u) : 0u), 63);
         }
+        const uint64_t wm2 = wmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull));
         const uint64_t dm2 = dmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull)), bm2 = bmk & ((my_exec >= 64u) ? ~0ull : ((1ull << my_exec) - 1ull));
         if (lane < my_exec && active) {
           if (dep != 0u) lds_st16(pb + PE_DLIST + ((c_dep + __builtin_amdgcn_mbcnt_hi((uint32_t)(dm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm2, 0u))) << 1), k0 + lane);
           if (bigc) lds_st16(pb + PE_BLIST + ((c_big + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm2, 0u))) << 1), k0 + lane);
-          lds_st32(ra, r0 | (dep << 31)); lds_st32(ra + 4u, r1); lds_st32(ra + 8u, copy_x); lds_st32(ra + 12u, (uint32_t)dist);
+          if (PE_DICT && plainw) lds_st16(pb + PE_WLIST + ((c_word + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm2, 0u))) << 1), k0 + lane);
+          lds_st32(ra, r0 | (dep << 31) | (plainw ? 1u << 28 : 0u)); lds_st32(ra + 4u, r1); lds_st32(ra + 8u, copy_x); lds_st32(ra + 12u, plainw ? wdesc : (uint32_t)dist);
           lds_st32(pb + PE_OFF + ((k0 + lane) << 2), (uint32_t)rel);
         }
         // the batch the engine's part ends in leaves the stream's state: sums up to there, the ring behind its executed pushes
         const bool last = kp_total <= k0 + K;
         if (last) {
           const uint32_t kp = my_exec;
+          if (!PE_DICT && !PIPE && kp < 64u && ((drefmask >> kp) & 1ull) != 0ull) pe_ctl_st(pb, PEC_DSEEN, 1u);   // (the command the engine's part ends in front of)
           // (PE_DICT: the pass's last command is one whose copy is a dictionary word -- wave 0's, behind the execute: its copy length
           // is not output of this pass, its distance not one for the ring, decode.rs:2643-2644)
           const bool dlast = PE_DICT && ((dictmask >> (kp - 1u)) & 1ull) != 0ull;
-          const uint32_t lit_tot = c_lit + rdlane(lit_incl, kp - 1u), t1 = rdlane(s1, kp - 1u), out_tot = c_out + rdlane(s2, kp - 1u) - (dlast ? rdlane(copy, kp - 1u) : 0u);
+          const uint32_t lit_tot = c_lit + rdlane(lit_incl, kp - 1u), t1 = rdlane(s1, kp - 1u), out_tot = c_out + rdlane(s2, kp - 1u) + rdlane(dcum, kp - 1u) - (dlast ? rdlane(copy, kp - 1u) : 0u);
           const uint32_t cmd_tot = c_cmd + (t1 & 0xFFFFu), dst_tot = c_dst + (t1 >> 16);
           const uint32_t got = (uint32_t)__popcll(pmk & ((kp >= 64u) ? ~0ull : ((1ull << kp) - 1ull)) & ~(dlast ? 1ull << (kp - 1u) : 0ull));
           if (dlast) { pe_ctl_st(pb, PEC_DICTK, k0 + kp - 1u); pe_ctl_st(pb, PEC_DICTD, rdlane((uint32_t)dist, kp - 1u)); pe_ctl_st(pb, PEC_DICTN, rdlane(copy, kp - 1u)); }
@@ -1641,11 +1730,11 @@ pe_pass:
           sn.P += out_tot; sn.bl0 -= lit_tot; sn.bl1 -= cmd_tot; sn.bl2 -= dst_tot; sn.quota -= out_tot; sn.mlen -= (int32_t)out_tot; sn.ncmd += cmd_tot;
           sn.d0 = e0; sn.d1 = e1; sn.d2 = e2; sn.d3 = e3;
           pe_st_store(pbs, sn);
-          pe_ctl_st(pb, PEC_ANYDEP, c_dep + (uint32_t)__popcll(dm2)); pe_ctl_st(pb, PEC_NBIG, c_big + (uint32_t)__popcll(bm2));
+          pe_ctl_st(pb, PEC_ANYDEP, c_dep + (uint32_t)__popcll(dm2)); pe_ctl_st(pb, PEC_NBIG, c_big + (uint32_t)__popcll(bm2)); pe_ctl_st(pb, PEC_NWORD, c_word + (uint32_t)__popcll(wm2));
           pe_ctl_st(pb, PEC_OUTTOT, out_tot); pe_ctl_st(pb, PEC_STAGED, (PE_STG_CAP != 0u && out_tot <= PE_STG_CAP) ? 1u : 0u);
         }
       }
-      if (kp_total <= ks && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); }  // (nothing executed: the state stays)
+      if (kp_total <= ks && T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_ANYDEP, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NBIG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_STAGED, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OUTTOT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_NWORD, 0u); }  // (nothing executed: the state stays)
       // (every wave's stores of the region before are in memory before anyone reads them as copy sources: here, a whole region's
       // tables later, the wait is over before it starts -- at the region's start it cost the stores' round trip)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1706,6 +1795,7 @@ pe_pass:
       PE_PROF(14);
     }
     // ---- execute ----
+    RG_STAMP(1);   // resolve done
     {
       gu8* const o = out + P0;
       // (a) lane = command: the literals in front of the path, decoded again one after the other; the literals on the path out
@@ -1821,6 +1911,7 @@ pe_pass:
       // (no barrier: what (b) stores lies elsewhere, and a wave that is through with (a) -- most have no batch -- takes items at once;
       // (c) waits for both)
       PE_PROF(8);
+      RG_STAMP(2);   // (a) done
       const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
       PE_COUNT(28, kp);
       if (!PIPE) {   // (wave 0 says where the stream goes on behind the resolve's last barrier, while the others execute: as a rule long since)
@@ -1877,7 +1968,24 @@ pe_pass:
           big_store(t0, d0, n0); big_store(t1, d1, n1); big_store(t2, d2, n2);
         }
       }
+#if PE_DICT
+      {
+        // (b') the pass's words of the static dictionary (decode.rs:2593-2640, transform.rs:737-795), a wave each: lane = byte of the word
+        const uint32_t nword = pe_ctl_ld(pb, PEC_NWORD);
+        if (nword != 0u) for (;;) {
+          const uint32_t j = pe_atomic_add_uniform(pb + PE_CTL + 4u * PEC_WNEXT, 1u);
+          if (j >= nword) break;
+          const uint32_t k = rfl(lds_ld16(pb + PE_WLIST + (j << 1)));
+          const uint32_t ra = pb + PE_REC + (k << 4);
+          const uint32_t r1 = rfl(lds_ld32(ra + 4u)), wd = rfl(lds_ld32(ra + 12u)), at = rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (r1 & 0xFFFFu);
+          const WordShape w = word_shape(wd >> 24, (wd >> 17) & 127u);
+          const uint32_t ob = dictionary_word_bytes(dict, wd & 0x1FFFFu, w, pb + PE_CB + me * 128u);   // (the chunks' rank bases are nobody's any more: 128 bytes a wave for the transforms that walk the word)
+          if (lane < w.total) { if (staged) lds_st8(sg + at + lane, ob); else o[at + lane] = (uint8_t)ob; }
+        }
+      }
+#endif
       PE_PROF(9);
+      RG_STAMP(3);   // (b) done (this wave's share)
       // (c) copies that read the region's own output.
       const uint32_t ndep = pe_ctl_ld(pb, PEC_ANYDEP);
       PE_COUNT(13, ndep);
@@ -1913,6 +2021,7 @@ pe_pass:
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PE_BAR();
+        RG_STAMP(4);   // dependent copies classified, everybody's (a) and (b) in memory
         for (uint32_t j = me; j < ndep; j += GW) {
           const uint32_t k = rfl(lds_ld16(pb + PE_DLIST + (j << 1)));
           const uint32_t ra = pb + PE_REC + (k << 4);
@@ -1923,17 +2032,21 @@ pe_pass:
           gu8* const dst = o + rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (rfl(lds_ld32(ra + 4u)) & 0xFFFFu); gu8* const src = dst - dist;
           if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
           else {
-            const uint32_t n16 = cn >> 4;
-            for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
-            const uint32_t tail = n16 << 4;
-            if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
-          }
+              const uint32_t n16 = cn >> 4;
+              for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+              const uint32_t tail = n16 << 4;
+              if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PE_BAR();
+        RG_STAMP(5);   // the ready ones done
         if (me == GW - 1u) {
 #ifdef BROTLI_AMD_PROFILE_SCAN
           const uint64_t dep_t0 = __builtin_amdgcn_s_memtime(); uint32_t dep_n = 0;
+#endif
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+          const uint64_t rg_io0 = __builtin_amdgcn_s_memtime(); uint32_t rg_ion = 0;
 #endif
           for (uint32_t k0 = ks & ~63u; k0 < kp; k0 += 64u) {
             const uint32_t k = k0 + lane;
@@ -1945,6 +2058,9 @@ pe_pass:
               dm &= dm - 1ull;
 #ifdef BROTLI_AMD_PROFILE_SCAN
               dep_n++;
+#endif
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+              rg_ion++;
 #endif
               const uint32_t n = rdlane(xn, kk), dist = rdlane(xd, kk), dpos = rdlane(xo, kk) + (rdlane(x1, kk) & 0xFFFFu);
               if (staged) { stage_copy(dpos, n, dist); continue; }
@@ -1958,13 +2074,17 @@ pe_pass:
                 }
               } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
               else {
-                const uint32_t n16 = n >> 4;
-                for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
-                const uint32_t tail = n16 << 4;
-                if (tail + lane < n) dst[tail + lane] = src[tail + lane];
-              }
+              const uint32_t n16 = n >> 4;
+              for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+              const uint32_t tail = n16 << 4;
+              if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+            }
             }
           }
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (blockIdx.x == 0 && lane == 0) printf("   in order: %u copies, %llu ticks\n", rg_ion, (unsigned long long)(__builtin_amdgcn_s_memtime() - rg_io0));
+#endif
 #ifdef BROTLI_AMD_PROFILE_SCAN
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (blockIdx.x == 0 && lane == 0) { atomicAdd(&g_path_prof[34], (unsigned long long)(__builtin_amdgcn_s_memtime() - dep_t0)); atomicAdd(&g_path_prof[35], (unsigned long long)dep_n); }
@@ -1987,7 +2107,7 @@ pe_pass:
       // lean_rec_commands takes them): wave 0 puts it behind them, and the commands behind it get a pass of their own
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PE_BAR();   // (the pass's output is complete, nobody reads its records any more)
-      if (me == 0) pe_dict_word(pbs, pb, out, dict, m);
+      if (me == 0) { pe_dict_word(pbs, pb, out, dict, m); pe_ctl_st(pb, PEC_DCAND, 0u); }
       PE_BAR();
       if (pe_ctl_ld(pb, PEC_AGAIN) != 0u) {
         ks = pe_ctl_ld(pb, PEC_KS);
@@ -2025,10 +2145,27 @@ pe_pass:
     PE_BAR();   // (the region before's stores: waited for in front of the execute, which is the first to read them -- see the resolve's last barrier)
     if (pe_ctl_ld(pb, PEC_GO) == 0u) break;
     P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+#ifdef BROTLI_AMD_PROFILE_REGIONS   // (block 0: one line a region -- what it held and what it cost)
+    const uint64_t rg_t0 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && rg_prev_end != 0) printf("   (wave 0 waited %llu ticks for the region before's last wave + set-up)\n", (unsigned long long)(rg_t0 - rg_prev_end));
+#endif
     const uint32_t how = build();
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+    const uint64_t rg_t1 = __builtin_amdgcn_s_memtime();
+    if (how != 0u && blockIdx.x == 0 && threadIdx.x == 0) printf("region (literal run, how %u): %llu ticks\n", how, (unsigned long long)(rg_t1 - rg_t0));
+#endif
     if (how == 1u) continue;
     if (how == 2u) break;
     consume();
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      printf("region: bits %u path %u closure %u listed %u executed %u out %u big %u dep %u staged %u | build %llu consume %llu\n", c.L, c.Rn, wn, pe_ctl_ld(pb, PEC_M), pe_ctl_ld(pb, PEC_KP),
+             pe_ctl_ld(pb, PEC_OUTTOT), pe_ctl_ld(pb, PEC_NBIG), pe_ctl_ld(pb, PEC_ANYDEP), pe_ctl_ld(pb, PEC_STAGED), (unsigned long long)(rg_t1 - rg_t0), (unsigned long long)(__builtin_amdgcn_s_memtime() - rg_t1));
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      printf("   consume: walk+details %llu resolve %llu exec(a) %llu (b) %llu classify+wait %llu ready %llu rest(wave 0) %llu\n", (unsigned long long)(rg_ts[0] - rg_t1), (unsigned long long)(rg_ts[1] - rg_ts[0]), (unsigned long long)(rg_ts[2] - rg_ts[1]),
+             (unsigned long long)(rg_ts[3] - rg_ts[2]), (unsigned long long)(rg_ts[4] > rg_ts[3] ? rg_ts[4] - rg_ts[3] : 0), (unsigned long long)(rg_ts[5] > rg_ts[4] ? rg_ts[5] - rg_ts[4] : 0), (unsigned long long)(__builtin_amdgcn_s_memtime() - (rg_ts[5] > rg_ts[3] ? rg_ts[5] : rg_ts[3])));
+    rg_prev_end = __builtin_amdgcn_s_memtime(); rg_ts[4] = rg_ts[5] = 0;
+#endif
     if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
   }
 #else
@@ -2143,7 +2280,7 @@ pe_pass:
   }
   const bool pdx = PE_DICT && pe_ctl_ld(pb, PEC_PDX) != 0u;   // (behind the distance of a command whose literals are out: postReadDistance, decode.rs:2583)
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u));
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
@@ -2162,3 +2299,4 @@ pe_pass:
 #undef PE_HOPS_REC
 #undef PE_DICT
 #undef PE_SPIN_CHECK
+#undef RG_STAMP

@@ -46,6 +46,7 @@ static void simulate(const void* state, uint64_t from) {
   uint64_t* tp = malloc((size_t)cap * 8); uint32_t* ti = malloc((size_t)cap * 4); uint8_t* td = malloc((size_t)cap); uint64_t tnext;
   int tn = brotli_oracle_probe_chain2(state, from, g_total_bits, tp, ti, td, cap, &tnext);
   { uint64_t lits = 0, dists = 0; int k = 0;
+    if (getenv("WM_NOSWITCH")) { bl[0] = bl[2] = 1u << 30; bl[1] = (uint32_t)atoi(getenv("WM_NOSWITCH")); }   /* (as if block switches did not end a round: the parse behind one is not the stream's, its statistics are) */
     for (; k < tn; k++) { if ((uint32_t)k >= bl[1]) break; lits += ti[k]; dists += td[k]; if (lits > bl[0] || dists > bl[2]) break; }
     if (k < tn) tnext = tp[k];
     tn = k; }
@@ -124,7 +125,7 @@ static void simulate(const void* state, uint64_t from) {
   free(tp); free(ti); free(td);
 }
 void oracle_stats_metablock(uint64_t first_bit, const void* state) { simulate(state, first_bit); }
-void oracle_stats_switch(int category, uint64_t bit, uint64_t resume_bit, const void* state) { (void)category; (void)bit; simulate(state, resume_bit); }
+void oracle_stats_switch(int category, uint64_t bit, uint64_t resume_bit, const void* state) { (void)category; (void)bit; if (!getenv("WM_NOSWITCH")) simulate(state, resume_bit); }
 void oracle_stats_cmd(uint64_t a, uint64_t b, uint64_t c, int32_t d, int32_t e, uint32_t f, int32_t g, uint64_t h) { (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; }
 
 int main(int argc, char** argv) {
