@@ -117,11 +117,15 @@ constexpr uint32_t PE_TAILCAP = PE_CMDS;
 constexpr uint32_t PE_TAIL_WAVES = BROTLI_AMD_PE_TAIL_WAVES;  // waves that see the thin end of the records through
 constexpr uint32_t PE_TAIL_AT = BROTLI_AMD_PE_TAIL_AT;        // busy slots (of 128) below which a wave hands over what it holds
 constexpr uint32_t PE_RUN_LIT = PE_POR;                            // a long literal run's region: its literals (the room of the ranks, literals, records and closure states)
-constexpr uint32_t PE_RUN_LITCAP = PE_LIST - PE_POR - 64u;         // ... at most
+constexpr uint32_t PE_RUN_WORK = 64u * GW * 2u * 3u;                 // (behind the literals: u16 per part -- its code words -- and two lists of parts whose entry has moved)
+constexpr uint32_t PE_RUN_LITCAP = PE_LIST - PE_POR - 64u - PE_RUN_WORK;   // ... at most
+constexpr uint32_t PE_RUN_CNT = PE_RUN_LIT + PE_RUN_LITCAP + 64u;  // u16 per part: code words that start in it
+constexpr uint32_t PE_RUN_QA = PE_RUN_CNT + 64u * GW * 2u;         // u16 per entry, two lists in turns: part | (its new entry, bits into it) << 11
+static_assert(PE_RUN_QA + 64u * GW * 4u <= PE_LIST && PE_RUN_CNT % 4 == 0 && 64u * GW <= 2048u, "a run region's work lists");
 constexpr uint32_t PE_RUN_EX = PE_PM;                              // ... u8 per lane: where its last code word ends (bits into the next lane's part)
 static_assert((PE_RUN_RBL / 32u + 8u) * 4u <= PE_PM - PE_IN && 64u * GW <= PE_CHUNKS * 4u, "a run region's input and exits");
 static_assert(PE_RUN_LIT % 16 == 0 && PE_STG % 16 == 0, "what write_out reads line by line");
-static_assert(PIPE || 64u * GW + 4096u <= PE_EX - PE_PM, "a run region's exits and its table of the literal code (one engine: two never take a run)");
+static_assert(PIPE || 64u * GW * 2u + 4096u <= PE_EX - PE_PM, "a run region's exits and its table of the literal code (one engine: two never take a run)");
 constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine's tables
 // What the engines of a block share: the invocation's parameters, the stream's state, the records' two tables.  One engine: at the
 // end of its tables (the control words are its own); two engines: in front of theirs, with a block of control words of its own.
@@ -221,6 +225,7 @@ struct PeStream {
   uint64_t P; uint32_t quota, bl0, bl1, bl2, ncmd, b, rbl, run_on, run_rem, run_copy, run_implicit, run_dctx;
   int32_t mlen, d0, d1, d2, d3, max_backward;
   uint32_t first;  // the invocation's first region is still to come
+  uint32_t s_bits, s_cmds, s_lits, s_dsts;  // what the region (or pass) before took: stream bits, commands, literals, distance codes -- the next region is as long as its block counts last at that rate
 };
 __device__ __forceinline__ PeStream pe_st_load(uint32_t pb) {
   PeStream st;
@@ -232,6 +237,7 @@ __device__ __forceinline__ PeStream pe_st_load(uint32_t pb) {
   st.run_rem = rdlane(v, 10); st.run_copy = rdlane(v, 11); st.run_implicit = rdlane(v, 12); st.run_dctx = rdlane(v, 13);
   st.mlen = (int32_t)rdlane(v, 14); st.d0 = (int32_t)rdlane(v, 15); st.d1 = (int32_t)rdlane(v, 16);
   st.d2 = (int32_t)rdlane(v, 17); st.d3 = (int32_t)rdlane(v, 18); st.max_backward = (int32_t)rdlane(v, 19); st.first = rdlane(v, 20);
+  st.s_bits = rdlane(v, 21); st.s_cmds = rdlane(v, 22); st.s_lits = rdlane(v, 23); st.s_dsts = rdlane(v, 24);
   return st;
 }
 __device__ __forceinline__ void pe_st_store(uint32_t pb, const PeStream& st) {
@@ -242,6 +248,7 @@ __device__ __forceinline__ void pe_st_store(uint32_t pb, const PeStream& st) {
   pe_ctl_st(pb, a + 10, st.run_rem); pe_ctl_st(pb, a + 11, st.run_copy); pe_ctl_st(pb, a + 12, st.run_implicit); pe_ctl_st(pb, a + 13, st.run_dctx);
   pe_ctl_st(pb, a + 14, (uint32_t)st.mlen); pe_ctl_st(pb, a + 15, (uint32_t)st.d0); pe_ctl_st(pb, a + 16, (uint32_t)st.d1);
   pe_ctl_st(pb, a + 17, (uint32_t)st.d2); pe_ctl_st(pb, a + 18, (uint32_t)st.d3); pe_ctl_st(pb, a + 19, (uint32_t)st.max_backward); pe_ctl_st(pb, a + 20, st.first);
+  pe_ctl_st(pb, a + 21, st.s_bits); pe_ctl_st(pb, a + 22, st.s_cmds); pe_ctl_st(pb, a + 23, st.s_lits); pe_ctl_st(pb, a + 24, st.s_dsts);
 }
 
 // What every phase needs to know about the region (uniform)
@@ -754,6 +761,7 @@ pe_again:
     st.run_on = 0; st.run_rem = 0; st.run_copy = 0; st.run_implicit = 0; st.run_dctx = 0;
     st.rbl = PE_RBL;  // bits the next region takes: halved where the closure ran out of room, doubled back where it is small
     st.first = 1u;
+    st.s_bits = 0u; st.s_cmds = 0u; st.s_lits = 0u; st.s_dsts = 0u;
     pe_st_store(pbs, st);
   }
   // ---- the records' tables (see pe_eval_rec) ----
@@ -792,7 +800,7 @@ pe_again:
   uint32_t rseq = 0;                                     // regions of this invocation so far (the one at hand included)
   uint32_t kseq = 0; (void)kseq;                         // (two engines: the number of the region this engine is at)
 #ifdef BROTLI_AMD_PROFILE_REGIONS
-  uint64_t rg_ts[10] = {}; uint64_t rg_prev_end = 0;
+  uint64_t rg_ts[10] = {}; uint64_t rg_prev_end = 0; uint64_t rg_rt[4] = {}; uint32_t rg_rn[4] = {};
 #define RG_STAMP(k) do { rg_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RG_STAMP(k) do { } while (0)
@@ -830,9 +838,12 @@ pe_again:
   auto run_region = [&]() -> uint32_t {
     const uint32_t ent = pe_ctl_ld(pb, PEC_ENT), et = ent / PE_RUN_SB;
     const uint32_t lim = c.L > 16u ? c.L - 16u : 0u;       // (a code word at or beyond may reach beyond the input)
-    // the rest of the region's input (the first PE_CHUNKS + 6 dwords are there)
+    // the rest of the region's input (the first PE_CHUNKS + 6 dwords are there): asked for side by side, then stored
     { const uint32_t ndw = (c.L + 31u) / 32u + 6u;
-      for (uint32_t i = PE_CHUNKS + 6u + T; i < ndw; i += 64u * GW) lds_st32(pb + PE_IN + (i << 2), lbdw + i < limit_dw ? in_dw[lbdw + i] : 0u); }
+      constexpr uint32_t NI = (PE_RUN_RBL / 32u + 6u - PE_CHUNKS - 6u + 64u * GW - 1u) / (64u * GW);
+      uint32_t iv[NI];
+      _Pragma("unroll") for (uint32_t q = 0; q < NI; q++) { const uint32_t i = PE_CHUNKS + 6u + T + q * 64u * GW; iv[q] = (i < ndw && lbdw + i < limit_dw) ? in_dw[lbdw + i] : 0u; }
+      _Pragma("unroll") for (uint32_t q = 0; q < NI; q++) { const uint32_t i = PE_CHUNKS + 6u + T + q * 64u * GW; if (i < ndw) lds_st32(pb + PE_IN + (i << 2), iv[q]); } }
     PE_BAR();
     const uint32_t base = T * PE_RUN_SB;
     const bool act = T >= et && base < lim;
@@ -845,15 +856,19 @@ pe_again:
     for (uint32_t i = T; i < 2048u; i += 64u * GW) { uint32_t sy, ln; sc_lookup(c.lit_tree, i, sy, ln); lds_st16(wt + (i << 1), ln <= 11u ? (sy << 4) | ln : 0u); }
     PE_BAR();
     // The lane's stream bits live in five registers (its 128 and the 32 behind them), moved down by every code word's length
-    auto decode = [&](const bool on, const bool emit, const uint32_t rank0, const uint32_t want) {
+    // The lane's stream bits live in five registers (its 128 and the 32 behind them), moved down by every code word's length
+    // (`part`: the 256 bits the lane decodes -- its own, T, in the passes over the whole region; any, where only the parts whose entry
+    // has moved are decoded again, by the block's first lanes)
+    auto decode = [&](const bool on, const bool emit, const uint32_t rank0, const uint32_t want, const uint32_t part, const uint32_t e) {
+      const uint32_t base = part * PE_RUN_SB;
       uint32_t y = e, k = 0;
       constexpr uint32_t NW = PE_RUN_SB / 32u + 1u;
       uint32_t w[NW];
       _Pragma("unroll") for (uint32_t j = 0; j < NW - 1u; j += 4u) {
-        const u32x4 wv = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_IN + T * (PE_RUN_SB / 8u) + 4u * j]);
+        const u32x4 wv = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[pb + PE_IN + part * (PE_RUN_SB / 8u) + 4u * j]);
         w[j] = wv.x; w[j + 1u] = wv.y; w[j + 2u] = wv.z; w[j + 3u] = wv.w;
       }
-      w[NW - 1u] = lds_ld32(pb + PE_IN + T * (PE_RUN_SB / 8u) + 4u * (NW - 1u));
+      w[NW - 1u] = lds_ld32(pb + PE_IN + part * (PE_RUN_SB / 8u) + 4u * (NW - 1u));
       for (uint32_t q = e >> 5; __ballot(q != 0u) != 0ull; q = q != 0u ? q - 1u : 0u)   // (the run's first lane enters anywhere in its part)
         if (q != 0u) { _Pragma("unroll") for (uint32_t j = 0; j + 1u < NW; j++) w[j] = w[j + 1u]; w[NW - 1u] = 0u; }
       { const uint32_t r5 = e & 31u; _Pragma("unroll") for (uint32_t j = 0; j + 1u < NW; j++) w[j] = __builtin_amdgcn_alignbit(w[j + 1u], w[j], r5); w[NW - 1u] >>= r5; }
@@ -871,29 +886,73 @@ pe_again:
         w[NW - 1u] >>= ln;
         y += ln; k += go ? 1u : 0u;
       }
-      if (on) { cnt = k; ex = y >= PE_RUN_SB ? y - PE_RUN_SB : 0u; }
+      if (on && !emit) { cnt = k; ex = y >= PE_RUN_SB ? y - PE_RUN_SB : 0u; }
     };
     PE_PROF(1);
-    decode(act, false, 0u, 0u);
+    RG_STAMP(6);
+    decode(act, false, 0u, 0u, T, e);
+    RG_STAMP(7);
     PE_PROF(17);
+    // The entries settle: a part whose entry is not where the part before it ends is decoded again from there.  The first such round
+    // is nearly everybody's (the guesses were guesses) and goes lane by part as the first pass did; in the rounds behind it few parts
+    // are left -- a high-entropy code re-synchronises slowly, one part in seven or so passes a wrong exit on -- and those go on a list
+    // that the block's first lanes take, a part each: a round costs what its parts cost, not a pass of all sixteen waves (round 4:
+    // three and a half passes' worth of rounds; the list leaves one and a bit).
     uint32_t tmin = 64u * GW;
+    const uint32_t exa = pb + PE_RUN_EX, cna = pb + PE_RUN_CNT, ena = pb + PE_RUN_EX + 64u * GW + 4096u;   // u8 exit, u16 count, u8 entry per part
+    lds_st8(exa + T, act ? ex : 0u); lds_st16(cna + (T << 1), act ? cnt : 0u); lds_st8(ena + T, e);
     for (uint32_t round = 0;; round++) {
-      // (whether any lane's entry moved: a word of three in turns, as the path's rounds have it -- the library's block-wide `or`
-      // brings LDS of its own, and this kernel's addresses are absolute)
-      const uint32_t fw = pb + PE_CTL + 4u * (PEC_CHG + round % 3u);
+      const uint32_t qn = pb + PE_CTL + 4u * (PEC_CHG + round % 3u);      // (a counter of three in turns: this round's list length)
+      const uint32_t qa = pb + PE_RUN_QA + (round & 1u) * 64u * GW * 2u;
       if (T == 0u) lds_st32(pb + PE_CTL + 4u * (PEC_CHG + (round + 1u) % 3u), 0u);
-      lds_st8(pb + PE_RUN_EX + T, ex);
       PE_BAR();
-      const uint32_t ne = T > et ? lds_ld8(pb + PE_RUN_EX + T - 1u) : e;
-      const bool changed = (bool)((uint32_t)act & (uint32_t)(T > et) & (uint32_t)(ne != e));
+      // part T: does it start where part T - 1 ends?
+      const uint32_t ne = T > et ? lds_ld8(exa + T - 1u) : lds_ld8(ena + T);
+      const bool changed = (bool)((uint32_t)act & (uint32_t)(T > et) & (uint32_t)(ne != lds_ld8(ena + T)));
+      // (bit 15 of a part's count: on this round's list -- a lane that goes on into the next part, below, stops in front of such a one)
+      { const uint32_t cv = lds_ld16(cna + (T << 1)); lds_st16(cna + (T << 1), (cv & 0x7FFFu) | (changed ? 0x8000u : 0u)); }
       if (round >= 24u) { if (changed) pe_atomic_min(pb + PE_CTL + 4u * PEC_TMIN, T); PE_BAR(); tmin = pe_ctl_ld(pb, PEC_TMIN); break; }   // (a code that does not re-synchronise: the region ends where it has not)
-      if (changed) lds_st32(fw, 1u);
+      {
+        const uint64_t cm = __ballot(changed);
+        if (cm != 0ull) {
+          uint32_t b0 = 0;
+          if (lane == 0) b0 = pe_atomic_add(qn, (uint32_t)__popcll(cm));
+          b0 = rfl(b0);
+          if (changed) lds_st16(qa + ((b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))) << 1), T | (ne << 11));
+        }
+      }
       PE_BAR();
-      if (rfl(lds_ld32(fw)) == 0u) break;
-      if (changed) e = ne;
-      decode(changed, false, 0u, 0u);
+      const uint32_t nq = rfl(lds_ld32(qn));
+#ifdef BROTLI_AMD_PROFILE_REGIONS
+      if (round < 4u) { rg_rt[round] = __builtin_amdgcn_s_memtime() - rg_ts[7]; rg_rn[round] = nq; }
+#endif
+      if (nq == 0u) break;
+      if (nq >= 32u * GW) {   // most of the region: lane by part
+        if (changed) lds_st8(ena + T, ne);
+        decode(changed, false, 0u, 0u, T, ne);
+        if (changed) { lds_st8(exa + T, ex); lds_st16(cna + (T << 1), cnt | 0x8000u); }
+      } else if (T < nq) {   // the list, a part a lane (the waves behind its end have nothing to do)
+        // ... and on into the parts behind it while the exit it finds is not the entry they were decoded from (nobody else's this
+        // round: a part on the list is its lane's): what a moved exit sets off ends in this round instead of one round a part
+        const uint32_t it = lds_ld16(qa + (T << 1));
+        uint32_t pt = it & 2047u, pe_ = it >> 11; bool mine_ = true, listed = true;
+        while (__ballot(mine_) != 0ull) {
+          if (mine_) lds_st8(ena + pt, pe_);
+          decode(mine_, false, 0u, 0u, mine_ ? pt : 0u, pe_);
+          if (mine_) {
+            lds_st8(exa + pt, ex); lds_st16(cna + (pt << 1), cnt | (listed ? 0x8000u : 0u));
+            const uint32_t nx = pt + 1u;
+            mine_ = nx < 64u * GW && nx * PE_RUN_SB < lim && lds_ld8(ena + nx) != ex && (lds_ld16(cna + (nx << 1)) & 0x8000u) == 0u;
+            pt = nx; pe_ = ex; listed = false;
+          }
+        }
+      }
     }
+    // part T's entry and count, as they settled
+    PE_BAR();
+    e = lds_ld8(ena + T); cnt = act ? lds_ld16(cna + (T << 1)) & 0x7FFFu : 0u;
     PE_PROF(18);
+    RG_STAMP(8);
     if (T >= tmin) cnt = 0;
     // ranks: exclusive prefix sum of the lanes' counts over the block; the region ends in front of the lane the literals' room runs out in
     uint32_t incl = sc_scan(cnt);
@@ -923,8 +982,9 @@ pe_again:
     PE_BAR();
     const uint32_t take = pe_ctl_ld(pb, PEC_TAKE);
     PE_PROF(2);
+    RG_STAMP(9);
     // the literals to their ranks (and the bit of the first one that does not go out: where the stream goes on)
-    decode(cnt != 0u && cb <= take, true, cb, take);
+    decode(cnt != 0u && cb <= take, true, cb, take, T, e);
     if (cnt != 0u && cb <= take && take < cb + cnt) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NEXTRANK]) = np;
     PE_BAR();
     PE_PROF(4);
@@ -968,13 +1028,18 @@ pe_again:
       st.first = 0u;
       if (c.L >= 256u) {
         PE_TRY_RUN(st, le);
-        if (st.run_on != 0u) { pe_ctl_st(pb, PEC_MODE, 1u); pe_ctl_st(pb, PEC_ENT, st.b - (lbdw << 5)); }
+        if (st.run_on != 0u) {
+          // (the run's region takes four times an ordinary one's bits -- the window was laid out before anybody knew: round 4 ran every
+          // run's first region with an ordinary region's 32 Kbit, 4 300 literals for what 34 700 cost)
+          const uint32_t avail_ = in_limit - (lbdw << 5);
+          pe_ctl_st(pb, PEC_MODE, 1u); pe_ctl_st(pb, PEC_ENT, st.b - (lbdw << 5)); pe_ctl_st(pb, PEC_L, avail_ < PE_RUN_RBL ? avail_ : PE_RUN_RBL);
+        }
       }
       pe_st_store(pbs, st);
     }
 #if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_OLD_RUN_REGIONS)
     PE_BAR();   // (the first region's mode is wave 0's word)
-    if (pe_ctl_ld(pb, PEC_MODE) != 0u) return run_region();
+    if (pe_ctl_ld(pb, PEC_MODE) != 0u) { c.L = pe_ctl_ld(pb, PEC_L); return run_region(); }
 #endif
     // ---- J1: the length of the literal code word at every bit, eight bits per lane and pass ----
 #if defined(BROTLI_AMD_PE_REPEAT) && BROTLI_AMD_PE_REPEAT == 1
@@ -1729,6 +1794,7 @@ pe_pass:
           PeStream sn = st;
           sn.P += out_tot; sn.bl0 -= lit_tot; sn.bl1 -= cmd_tot; sn.bl2 -= dst_tot; sn.quota -= out_tot; sn.mlen -= (int32_t)out_tot; sn.ncmd += cmd_tot;
           sn.d0 = e0; sn.d1 = e1; sn.d2 = e2; sn.d3 = e3;
+          sn.s_cmds = cmd_tot; sn.s_lits = lit_tot; sn.s_dsts = dst_tot;   // (s_bits: wave 0, below, once it knows where the stream goes on)
           pe_st_store(pbs, sn);
           pe_ctl_st(pb, PEC_ANYDEP, c_dep + (uint32_t)__popcll(dm2)); pe_ctl_st(pb, PEC_NBIG, c_big + (uint32_t)__popcll(bm2)); pe_ctl_st(pb, PEC_NWORD, c_word + (uint32_t)__popcll(wm2));
           pe_ctl_st(pb, PEC_OUTTOT, out_tot); pe_ctl_st(pb, PEC_STAGED, (PE_STG_CAP != 0u && out_tot <= PE_STG_CAP) ? 1u : 0u);
@@ -1751,7 +1817,7 @@ pe_pass:
           const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
           pbit += rfl(d.bits);
         }
-        sn.b = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit;
+        { const uint32_t nb_ = (pe_ctl_ld(pb, PEC_LBDW) << 5) + pbit; sn.s_bits = kp_total > ks ? nb_ - sn.b : 0u; if (kp_total <= ks) sn.s_cmds = 0u; sn.b = nb_; }
         // the region went through whole and the next one starts at a command with a long literal run: the next regions are the run's
         const bool dict_ends = PE_DICT && pe_ctl_ld(pb, PEC_DICTK) != 0xFFFFFFFFu;   // (the pass ends with a dictionary word still to come: no run region from here -- the next region finds the run itself)
         if (!PIPE && !dict_ends && kp_total == m && m != 0u && pbit + 64u <= c.L) PE_TRY_RUN(sn, pbit);
@@ -2135,7 +2201,20 @@ pe_pass:
       if (blockIdx.x == 0 && lane == 0 && !go) printf("  engine: no go: td_ok %d b %u in_limit %u avail %u quota %u bl1 %u run_on %u\n", (int)td_ok, st.b, in_limit, avail, st.quota, st.bl1, st.run_on);
 #endif
 #ifndef BROTLI_AMD_PE_OLD_RUN_REGIONS
-      const uint32_t want_bits = st.run_on != 0u ? PE_RUN_RBL : st.rbl;   // (a long literal run's regions take no tables per bit: four times the bits)
+      uint32_t want_bits = st.run_on != 0u ? PE_RUN_RBL : st.rbl;   // (a long literal run's regions take no tables per bit: four times the bits)
+#ifndef BROTLI_AMD_PE_NO_CUT
+      if (st.run_on == 0u && st.s_cmds != 0u && st.s_bits != 0u) {
+        // A block count that runs out ends the engine's part (decode.rs:1469-1524: the switch is the checked loop's), and what the region
+        // holds behind that command was built for nothing -- 3.6 regions' worth a stream of the metric's, 2.6 % of its time.  The region is
+        // as long as the counts last at the rate of the region before, and an eighth.
+        const float rate = (float)st.s_bits;
+        float need = (float)st.bl1 * rate / (float)st.s_cmds;
+        if (st.s_dsts != 0u) { const float nd = (float)st.bl2 * rate / (float)st.s_dsts; need = nd < need ? nd : need; }
+        if (st.s_lits != 0u) { const float nl = (float)st.bl0 * rate / (float)st.s_lits; need = nl < need ? nl : need; }
+        need = need * 1.125f + 1024.0f;
+        if (need < (float)want_bits) { const uint32_t nb_ = ((uint32_t)need + 31u) & ~31u; want_bits = nb_ < PE_MIN_INPUT ? PE_MIN_INPUT : nb_; }
+      }
+#endif
 #else
       const uint32_t want_bits = st.rbl;
 #endif
@@ -2152,7 +2231,9 @@ pe_pass:
     const uint32_t how = build();
 #ifdef BROTLI_AMD_PROFILE_REGIONS
     const uint64_t rg_t1 = __builtin_amdgcn_s_memtime();
-    if (how != 0u && blockIdx.x == 0 && threadIdx.x == 0) printf("region (literal run, how %u): %llu ticks\n", how, (unsigned long long)(rg_t1 - rg_t0));
+    if (how != 0u && blockIdx.x == 0 && threadIdx.x == 0) printf("region (literal run, how %u): %llu ticks: input+table %llu first decode %llu settle %llu ranks %llu emit+write %llu; literals %u bits %u\n", how, (unsigned long long)(rg_t1 - rg_t0),
+        (unsigned long long)(rg_ts[6] - rg_t0), (unsigned long long)(rg_ts[7] - rg_ts[6]), (unsigned long long)(rg_ts[8] - rg_ts[7]), (unsigned long long)(rg_ts[9] - rg_ts[8]), (unsigned long long)(rg_t1 - rg_ts[9]), pe_ctl_ld(pb, PEC_TAKE), c.L);
+    if (how != 0u && blockIdx.x == 0 && threadIdx.x == 0) printf("      rounds (parts @ tick behind the first pass): %u @ %llu, %u @ %llu, %u @ %llu, %u @ %llu\n", rg_rn[0], (unsigned long long)rg_rt[0], rg_rn[1], (unsigned long long)rg_rt[1], rg_rn[2], (unsigned long long)rg_rt[2], rg_rn[3], (unsigned long long)rg_rt[3]);
 #endif
     if (how == 1u) continue;
     if (how == 2u) break;
