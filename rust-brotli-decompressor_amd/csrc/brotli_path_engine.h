@@ -153,6 +153,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
        PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
+       PEC_FIN = 156 /* a long literal run has ended in this region: its command's distance and copy are wave 0's, in place */,
        PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
        PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
 // Words of the static dictionary (decode.rs:2593-2640; one command in 33 to 87 of text at -q 4 .. 9, tools/eligibility_survey.py).
@@ -995,11 +996,72 @@ pe_again:
       const uint32_t npb = take != 0u ? pe_ctl_ld(pb, PEC_NEXTRANK) : ent;
       st.b = (lbdw << 5) + npb;
       pe_ctl_st(pb, PEC_CONT, (take != 0u && st.run_rem != 0u) ? 1u : 0u); pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
+      pe_ctl_st(pb, PEC_FIN, (st.run_rem == 0u && npb + 96u <= c.L + 128u) ? 1u : 0u);
       PE_COUNT(19, take);
       pe_st_store(pbs, st);
     }
     PE_BAR();
     PE_PROF(5);
+#ifndef BROTLI_AMD_PE_NO_RUN_FINISH
+    if (pe_ctl_ld(pb, PEC_FIN) != 0u) {
+      // The run is over: what is left of its command is a distance and a copy (decode.rs:2066-2131, 2583-2720).  Round 4 handed every
+      // such command to the checked loop -- the invocation ended, the loop finished the command, and the engine came back for the next one
+      // (a stream of high-entropy literals is nothing but such commands).  Now wave 0 takes the plain case in place -- a distance inside
+      // the window, a copy inside every limit -- and the next region starts at the next command; anything else is the checked loop's as before.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the run's literals are in memory before the copy reads them)
+      PE_BAR();
+      if (me == 0) {
+        PeStream st = pe_st_load(pbs);
+        const uint32_t yb = st.b - (lbdw << 5);
+        uint32_t dbits = 0, push = 0; int32_t dist = st.d0; bool ok_ = true;
+        if (st.run_implicit == 0u) {
+          uint32_t lo, hi;
+          pe_bits64(pb, yb, lo, hi);
+          const ScDist d = sc_dist(lo, hi, c.dtree, c.postfix_bits, c.num_direct);
+          const uint32_t kd = rfl(d.kind), dv = rfl(d.val); dbits = rfl(d.bits);
+          ok_ = st.bl2 != 0u && (st.b + dbits) <= in_limit;
+          if (kd == SCK_EXPLICIT) { dist = (int32_t)dv; push = 1u; ok_ = ok_ && dv < (1u << 30); }
+          else if (kd == SCK_SHORT) {
+            if (dv != 0u) {   // TakeDistanceFromRingBuffer, decode.rs:2017-2049
+              const uint32_t sh = dv << 1, back = 3u - ((0xaaafff1bu >> sh) & 3u);
+              int32_t v = back == 0u ? st.d0 : back == 1u ? st.d1 : back == 2u ? st.d2 : st.d3;
+              const int32_t mag = (int32_t)((0xfa5fa500u >> sh) & 3u);
+              if (dv & 1u) v += mag; else v -= mag;
+              dist = v; push = 1u;
+            }
+          } else ok_ = false;
+        }
+        const uint32_t n = st.run_copy;
+        const uint32_t maxd = st.P < (uint64_t)(uint32_t)st.max_backward ? (uint32_t)st.P : (uint32_t)st.max_backward;
+        ok_ = ok_ && dist > 0 && (uint32_t)dist <= maxd && n < st.quota && n < (1u << 24);
+        if (ok_) {
+          gu8* const dst = out + st.P; gu8* const src = dst - (uint32_t)dist;
+          const uint32_t ud = (uint32_t)dist;
+          if (ud < n) {   // the copy repeats itself (decode.rs:2657-2663, 2690-2720)
+            if (ud >= 64u) { for (uint32_t q = lane; q < n + lane; q += 64u) if (q < n) dst[q] = src[q]; }
+            else { uint32_t mm = lane % ud; const uint32_t step = 64u % ud; for (uint32_t q = 0; q < n; q += 64u) { if (q + lane < n) dst[q + lane] = src[mm]; mm += step; if (mm >= ud) mm -= ud; } }
+          } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
+          else {
+            const uint32_t n16 = n >> 4;
+            for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+            const uint32_t tail = n16 << 4;
+            if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          st.P += n; st.quota -= n; st.mlen -= (int32_t)n;
+          if (st.run_implicit == 0u) st.bl2 -= 1u;
+          if (push != 0u) { st.d3 = st.d2; st.d2 = st.d1; st.d1 = st.d0; st.d0 = dist; }
+          st.b += dbits;
+          st.run_on = 0u; st.run_rem = 0u; st.run_copy = 0u; st.run_implicit = 0u; st.run_dctx = 0u;
+          st.first = 1u;   // (the next region looks at its first command as an invocation's first region does: another long run, as a rule)
+          st.s_cmds = 0u;
+          pe_st_store(pbs, st);
+          pe_ctl_st(pb, PEC_CONT, 1u); pe_ctl_st(pb, PEC_NEXT_LBDW, st.b >> 5);
+        }
+      }
+      PE_BAR();
+    }
+#endif
     if (pe_ctl_ld(pb, PEC_CONT) == 0u) return 2u;
     {
       const uint32_t nl = pe_ctl_ld(pb, PEC_NEXT_LBDW);
