@@ -104,7 +104,8 @@ def load_library():
     L.BrotliAmdBatchLastSecondPassCount.restype = ctypes.c_uint32
     L.BrotliAmdBatchLastSecondPassCount.argtypes = [vp]
     L.BrotliAmdLastError.restype = ctypes.c_char_p
-    L.BrotliAmdLastNote.restype = ctypes.c_char_p
+    if hasattr(L, "BrotliAmdLastNote"):   # (an older build of the library, loaded through BROTLI_AMD_LIB for an A/B, has no such symbol)
+        L.BrotliAmdLastNote.restype = ctypes.c_char_p
     _lib = L
     return L
 

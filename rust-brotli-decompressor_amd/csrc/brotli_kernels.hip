@@ -679,6 +679,102 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
     // symbol code lengths (decode.rs:661-797, 558-658)
     uint32_t symbol = 0, prev_code_len = 8, repeat = 0, repeat_code_len = 0;
     space = 32768;
+#ifndef BROTLI_AMD_SERIAL_LENGTHS
+    // Sixty-four stream bits a step instead of one code word (round 5; one word at a time took 275 clocks a symbol, 40 % of a metablock
+    // header): lane j decodes the code word that WOULD start at bit j; the chain of the words that do -- from bit 0 on, a word
+    // ends where the next one starts -- comes out of pointer doubling (R_k[j]: the bit 2^k words on from bit j), lane t taking the
+    // t-th word's place by the binary digits of t; then the loop's arithmetic for all words side by side: the repeat codes' run
+    // lengths (decode.rs:607-650: a run of sixteens, or of seventeens, is a number in base four, or eight) link by link along
+    // the runs -- few and short --, symbol indices and code space by prefix sums, the first word that ends the loop (alphabet full,
+    // space used up, input short, a repeat that overshoots) by ballots.  Same words, same order, same verdicts as the loop below,
+    // which stays for a code-length code of ONE symbol (its words are no bits long: no chain).
+    if (num_codes != 1) while (symbol < max_symbol && space > 0) {
+      const auto bp = [](uint32_t lane_idx, uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane_idx << 2), (int)v); };
+      br.need32();
+      uint64_t wlo, whi;
+      br.window128(wlo, whi);   // (at least 96 bits from the reader's position)
+      const uint64_t tb = BitReader::total_bits(), ps = br.pos();
+      const uint32_t rem = tb > ps ? (tb - ps > 4096ull ? 4096u : (uint32_t)(tb - ps)) : 0u;   // bits of input left
+      const uint32_t bj = (uint32_t)(lane == 0 ? wlo : (wlo >> lane) | (whi << (64u - lane))) & 0xFFu;
+      const uint32_t ce = bp(bj & 31u, cl_table);
+      const uint32_t sym_j = ce >> 4, nb_j = ce & 15u, eb_j = sym_j == 16u ? 2u : sym_j == 17u ? 3u : 0u;
+      const uint32_t ev = sym_j | ((nb_j + eb_j) << 5) | (((bj >> nb_j) & ((1u << eb_j) - 1u)) << 9);   // symbol, bits of the word with its extra bits, their value
+      // the chain
+      uint32_t R0 = lane + nb_j + eb_j, R1, R2, R3, R4, R5;
+      { const uint32_t g = bp(R0 & 63u, R0); R1 = R0 < 64u ? g : R0; }   // (every lane asks, whatever it keeps: a lane that does not take part in a permute is read as zero)
+      { const uint32_t g = bp(R1 & 63u, R1); R2 = R1 < 64u ? g : R1; }
+      { const uint32_t g = bp(R2 & 63u, R2); R3 = R2 < 64u ? g : R2; }
+      { const uint32_t g = bp(R3 & 63u, R3); R4 = R3 < 64u ? g : R3; }
+      { const uint32_t g = bp(R4 & 63u, R4); R5 = R4 < 64u ? g : R4; }
+      uint32_t pt = 0;   // where word t starts (64 and more: behind the window)
+      { uint32_t g;
+        g = bp(pt & 63u, R0); pt = ((lane & 1u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R1); pt = ((lane & 2u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R2); pt = ((lane & 4u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R3); pt = ((lane & 8u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R4); pt = ((lane & 16u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R5); pt = ((lane & 32u) && pt < 64u) ? g : pt; }
+      const bool valid = pt < 64u;
+      const uint32_t et = bp(pt & 63u, ev);
+      const uint32_t cl = et & 31u, endp = pt + ((et >> 5) & 15u), xv = et >> 9;
+      const bool islen = valid && cl < 16u, isrep = valid && cl >= 16u;
+      const uint64_t below = (1ull << lane) - 1ull;
+      // the code length a sixteen repeats: the last one that was not zero
+      const uint64_t nzm = __ballot(islen && cl != 0u);
+      const uint32_t pvg = bp((nzm & below) != 0ull ? 63u - (uint32_t)__clzll((long long)(nzm & below)) : 0u, cl);
+      const uint32_t pv = (nzm & below) != 0ull ? pvg : prev_code_len;
+      const uint32_t new_len = cl == 16u ? pv : 0u;
+      const uint32_t clp = bp((lane + 63u) & 63u, cl);   // the word before
+      const bool cont0 = repeat > 0u && repeat_code_len == new_len;   // (lane 0: the run goes on from the window before)
+      const bool conts = isrep && (lane == 0u ? cont0 : clp == cl);
+      const uint64_t heads = __ballot(isrep && (lane == 0u || !conts));
+      const uint32_t depth = isrep ? lane - (63u - (uint32_t)__clzll((long long)(heads & (below | (1ull << lane))))) : 0u;
+      const uint32_t ebt = cl == 16u ? 2u : 3u;
+      uint32_t rp = 0, delta = 0;
+      for (uint32_t dd = 0; __ballot(isrep && depth >= dd) != 0ull; dd++) {
+        const uint32_t before = bp((lane + 63u) & 63u, rp);
+        if (isrep && depth == dd) {
+          const uint32_t pr = dd == 0u ? (lane == 0u && cont0 ? repeat : 0u) : before;
+          rp = (pr > 0u ? (pr - 2u) << ebt : 0u) + xv + 3u;
+          delta = rp - pr;
+        }
+      }
+      const uint32_t adv = islen ? 1u : isrep ? delta : 0u;
+      const uint32_t used = (islen && cl != 0u) ? 32768u >> cl : (isrep && new_len != 0u) ? delta << (15u - new_len) : 0u;
+      const auto scan = [](uint32_t v) -> uint32_t {   // inclusive prefix sum over the lanes (row shifts and row broadcasts, as the engines' sc_scan)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+        return v;
+      };
+      const uint32_t a_in = scan(adv), u_in = scan(used);
+      const uint32_t symidx = symbol + a_in - adv, space_before = space - (u_in - used);
+      const bool goes = valid && symidx < max_symbol && space_before != 0u;   // the loop's condition in front of this word
+      const uint64_t stopm = ~__ballot(goes);
+      const uint32_t s_n = stopm != 0ull ? (uint32_t)__builtin_ctzll(stopm) : 64u;   // words the loop takes here
+      const uint64_t taken = s_n >= 64u ? ~0ull : (1ull << s_n) - 1ull;
+      const uint64_t shortm = __ballot(valid && endp > rem) & taken, overm = __ballot(isrep && symidx + delta > max_symbol) & taken;
+      if ((shortm | overm) != 0ull) {
+        const uint32_t fs = shortm != 0ull ? (uint32_t)__builtin_ctzll(shortm) : 64u, fo = overm != 0ull ? (uint32_t)__builtin_ctzll(overm) : 64u;
+        if (fs <= fo) { br.advance(rdlane(endp, fs)); NEED_INPUT(br); return E_NEEDS_MORE_INPUT; }
+        FAIL(br, E_HUFFMAN_SPACE);   // (decode.rs:640-643: the repeat overshoots the alphabet)
+      }
+      if (s_n == 0u) break;   // (cannot happen: the loop's condition held)
+      if (lane < s_n) {
+        if (islen && cl != 0u) lds_st8(LDS_LENGTHS + symidx, cl);
+        if (isrep && new_len != 0u) for (uint32_t k = 0; k < delta; k++) lds_st8(LDS_LENGTHS + symidx + k, new_len);
+      }
+      const uint32_t last = s_n - 1u;
+      symbol = rdlane(symidx + adv, last);
+      space = rdlane(space_before - used, last);
+      { const uint64_t nzt = nzm & taken; if (nzt != 0ull) prev_code_len = rdlane(cl, 63u - (uint32_t)__clzll((long long)nzt)); }
+      { const uint32_t lc = rdlane(cl, last); repeat = lc >= 16u ? rdlane(rp, last) : 0u; if (lc >= 16u) repeat_code_len = rdlane(new_len, last); }
+      br.advance(rdlane(endp, last));
+    }
+#endif
     while (symbol < max_symbol && space > 0) {
       uint32_t p = rdlane(cl_table, br.peek32() & 31u);
       uint32_t code_len = p >> 4;
