@@ -466,11 +466,12 @@ struct Stream {
 // Same codes as src/huffman/mod.rs:273-386, different (documented) entry layout.
 struct CodeOfLane { uint32_t len, code; };
 template <int LMIN>
-__device__ __forceinline__ CodeOfLane lane_code(uint32_t L, const uint32_t (&first_code)[16], uint32_t (&run)[16]) {
+__device__ __forceinline__ CodeOfLane lane_code(uint32_t L, const uint32_t (&first_code)[16], uint32_t (&run)[16], const uint32_t (&cnt)[16]) {
   const uint64_t lt = (1ull << lane_id()) - 1ull;
   CodeOfLane r; r.len = L; r.code = 0;
 #pragma unroll
   for (int l = LMIN; l < 16; l++) {
+    if (cnt[l] == 0u) continue;   // (no symbol of the alphabet has this length: uniform)
     uint64_t m = __ballot(L == (uint32_t)l);
     if (L == (uint32_t)l) r.code = first_code[l] + run[l] + (uint32_t)__popcll(m & lt);
     run[l] += (uint32_t)__popcll(m);
@@ -478,8 +479,19 @@ __device__ __forceinline__ CodeOfLane lane_code(uint32_t L, const uint32_t (&fir
   return r;
 }
 
-__device__ __forceinline__ uint32_t build_tree(const Arena& a, uint32_t tree, uint32_t n_sym) {
+#ifdef BROTLI_AMD_PROFILE_HDR
+__device__ unsigned long long g_hdr_prof[8];  // ticks: code-length code, symbol lengths, build_tree (3, 6, 7: its histogram, its first pass, the rest); counts: codes, symbols
+#define BT_PROF(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane_id() == 0) g_hdr_prof[k] += t_ - bt_t; bt_t = t_; } while (0)
+#else
+#define BT_PROF(k) do { } while (0)
+#endif
+// (a function of its own -- and the reader of the code lengths below another: inlined into the kernel's body, at the limit of its 128
+// registers a wave, their vectors spilt to scratch in the middle of the headers' loops -- 4096 tiny streams took half as long again)
+__device__ __noinline__ uint32_t build_tree(const Arena& a, uint32_t tree, uint32_t n_sym) {
   const uint32_t lane = lane_id();
+#ifdef BROTLI_AMD_PROFILE_HDR
+  uint64_t bt_t = __builtin_amdgcn_s_memtime();
+#endif
   // 1. histogram of code lengths (uniform, via ballots) and first code per length
   uint32_t cnt[16], first_code[16], run[16];
 #pragma unroll
@@ -500,39 +512,46 @@ __device__ __forceinline__ uint32_t build_tree(const Arena& a, uint32_t tree, ui
       if (cnt[l]) max_len = l;
     }
   }
+  BT_PROF(3);
   const bool two_level = max_len > ROOT_BITS;
-  if (two_level) {
-    for (uint32_t i = lane; i < 256; i += 64) lds_st8(LDS_SUBDEPTH + i, 0);
-    lds_sync();
-  }
+  // The root's 256 entries by who OWNS them (round 5): in the order of the codes -- most significant bit first -- a code of L <= 8 bits
+  // covers the 2^(8 - L) entries from code << (8 - L) on, and a complete code's ranges tile the root.  Every symbol notes its entry at
+  // its range's first place (one store), the places in between take the last note in front of them (a scan), and the entry goes to
+  // the table where the stream's bit order has it.  (Round 4: the symbol's lane wrote all its copies itself, 2^(8 - L) stores one after
+  // the other -- a literal code whose best symbol has two bits kept its lane, and the wave, at it for sixty-four rounds.)
+  constexpr uint32_t LDS_OWN = LDS_LENINFO;   // u16 x 256 (the spare room, the word staging and the move-to-front list: nobody's while a table is built)
+  static_assert(LDS_MTF + 256u - LDS_LENINFO >= 512u, "the root's owners");
+  for (uint32_t i = lane; i < 128; i += 64) lds_st32(LDS_OWN + 4u * i, 0u);
+  if (two_level) for (uint32_t i = lane; i < 256; i += 64) lds_st8(LDS_SUBDEPTH + i, 0);
+  lds_sync();
   // 2. pass A: codes of <= 8 bits fill the root (replicated); longer codes record the depth their
   //    8-bit prefix needs (byte-wise max through compare-and-swap on the containing LDS dword)
   for (uint32_t b = 0; b < n_sym; b += 64) {
     uint32_t sym = b + lane;
-    CodeOfLane c = lane_code<1>(sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0, first_code, run);
+    CodeOfLane c = lane_code<1>(sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0, first_code, run, cnt);
     if (c.len != 0) {
       if (c.len <= ROOT_BITS) {
-        uint32_t e = (sym << 4) | c.len;
-        for (uint32_t j = rev_bits(c.code, c.len); j < 256; j += (1u << c.len)) a.st16_lane(tree + (j << 1), e);
+        lds_st16(LDS_OWN + ((c.code << (ROOT_BITS - c.len)) << 1), (sym << 4) | c.len);
       } else {
+        // (the depth a prefix needs is the largest its codes ask for: every code sets the bit of its own depth in the prefix' byte -- one
+        // atomic `or`, no answer waited for; round 4 raised the byte through compare-and-swap, a round trip and a retry for every lane
+        // that shared a dword with another: half a table's time)
         uint32_t d = c.len - ROOT_BITS;
         uint32_t p = c.code >> d;
         __attribute__((address_space(3))) uint32_t* w = reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(&g_smem[LDS_SUBDEPTH + (p & ~3u)]);
-        uint32_t sh = (p & 3u) * 8;
-        uint32_t old = *w;
-        while (((old >> sh) & 0xFFu) < d) {  // on failure `old` is refreshed with what is there
-          if (__hip_atomic_compare_exchange_strong(w, &old, (old & ~(0xFFu << sh)) | (d << sh), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        }
+        (void)__hip_atomic_fetch_or(w, (1u << (d - 1u)) << ((p & 3u) * 8u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
+  BT_PROF(6);
   uint32_t total = 256;
   if (two_level) {
     lds_sync();
     // 3. 2nd-level bases: exclusive prefix sum of 2^depth over the 256 prefixes (4 per lane, in code order)
     uint32_t dd = lds_ld32(LDS_SUBDEPTH + lane * 4);
-    uint32_t d0 = dd & 0xFF, d1 = (dd >> 8) & 0xFF, d2 = (dd >> 16) & 0xFF, d3 = dd >> 24;
+    // (a byte of depth bits -> the largest depth; written back as a number for the second pass)
+    uint32_t d0 = 32u - (uint32_t)__clz(dd & 0xFFu), d1 = 32u - (uint32_t)__clz((dd >> 8) & 0xFFu), d2 = 32u - (uint32_t)__clz((dd >> 16) & 0xFFu), d3 = 32u - (uint32_t)__clz(dd >> 24);
+    lds_st32(LDS_SUBDEPTH + lane * 4, d0 | (d1 << 8) | (d2 << 16) | (d3 << 24));
     uint32_t s0 = d0 ? (1u << d0) : 0, s1 = d1 ? (1u << d1) : 0, s2 = d2 ? (1u << d2) : 0, s3 = d3 ? (1u << d3) : 0;
     uint32_t mine = s0 + s1 + s2 + s3;
     uint32_t incl = mine;
@@ -545,18 +564,18 @@ __device__ __forceinline__ uint32_t build_tree(const Arena& a, uint32_t tree, ui
     uint32_t b0 = 256 + incl - mine, b1 = b0 + s0, b2 = b1 + s1, b3 = b2 + s2;
     lds_st16(LDS_SUBBASE + lane * 8 + 0, b0); lds_st16(LDS_SUBBASE + lane * 8 + 2, b1);
     lds_st16(LDS_SUBBASE + lane * 8 + 4, b2); lds_st16(LDS_SUBBASE + lane * 8 + 6, b3);
-    // root entries that point down
-    if (d0) a.st16_lane(tree + (rev_bits(lane * 4 + 0, 8) << 1), (b0 << 4) | (ROOT_BITS + d0));
-    if (d1) a.st16_lane(tree + (rev_bits(lane * 4 + 1, 8) << 1), (b1 << 4) | (ROOT_BITS + d1));
-    if (d2) a.st16_lane(tree + (rev_bits(lane * 4 + 2, 8) << 1), (b2 << 4) | (ROOT_BITS + d2));
-    if (d3) a.st16_lane(tree + (rev_bits(lane * 4 + 3, 8) << 1), (b3 << 4) | (ROOT_BITS + d3));
+    // root entries that point down (a prefix with longer codes below it owns its one place)
+    if (d0) lds_st16(LDS_OWN + ((lane * 4 + 0) << 1), (b0 << 4) | (ROOT_BITS + d0));
+    if (d1) lds_st16(LDS_OWN + ((lane * 4 + 1) << 1), (b1 << 4) | (ROOT_BITS + d1));
+    if (d2) lds_st16(LDS_OWN + ((lane * 4 + 2) << 1), (b2 << 4) | (ROOT_BITS + d2));
+    if (d3) lds_st16(LDS_OWN + ((lane * 4 + 3) << 1), (b3 << 4) | (ROOT_BITS + d3));
     lds_sync();
     // 4. pass B: fill the 2nd-level tables
 #pragma unroll
     for (int l = 0; l < 16; l++) run[l] = 0;
     for (uint32_t b = 0; b < n_sym; b += 64) {
       uint32_t sym = b + lane;
-      CodeOfLane c = lane_code<ROOT_BITS + 1>(sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0, first_code, run);
+      CodeOfLane c = lane_code<ROOT_BITS + 1>(sym < n_sym ? lds_ld8(LDS_LENGTHS + sym) : 0, first_code, run, cnt);
       if (c.len > ROOT_BITS) {
         uint32_t sl = c.len - ROOT_BITS;
         uint32_t p = c.code >> sl;
@@ -568,6 +587,25 @@ __device__ __forceinline__ uint32_t build_tree(const Arena& a, uint32_t tree, ui
     }
   }
   lds_sync();
+  {
+    // the root: four places a lane, the last note in front of each (over the lanes: a scan that keeps the right-hand note where there is one)
+    const uint32_t w0 = lds_ld32(LDS_OWN + lane * 8u), w1 = lds_ld32(LDS_OWN + lane * 8u + 4u);
+    const uint32_t v0 = w0 & 0xFFFFu, v1 = w0 >> 16, v2 = w1 & 0xFFFFu, v3 = w1 >> 16;
+    uint32_t x = v3 ? v3 : v2 ? v2 : v1 ? v1 : v0;
+    { uint32_t t;
+      t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = x ? x : t;
+      t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); x = x ? x : t;
+      t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x = x ? x : t;
+      t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); x = x ? x : t;
+      t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x = x ? x : t;
+      t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = x ? x : t; }
+    const uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);   // (the lane before's: wave_shr 1)
+    const uint32_t e0 = v0 ? v0 : carry, e1 = v1 ? v1 : e0, e2 = v2 ? v2 : e1, e3 = v3 ? v3 : e2;
+    a.st16_lane(tree + (rev_bits(lane * 4 + 0, 8) << 1), e0); a.st16_lane(tree + (rev_bits(lane * 4 + 1, 8) << 1), e1);
+    a.st16_lane(tree + (rev_bits(lane * 4 + 2, 8) << 1), e2); a.st16_lane(tree + (rev_bits(lane * 4 + 3, 8) << 1), e3);
+  }
+  lds_sync();
+  BT_PROF(7);
   return total;
 }
 
@@ -578,10 +616,116 @@ __device__ __forceinline__ uint32_t max_table_entries(uint32_t alphabet) {
 
 __device__ __forceinline__ uint32_t log2floor_plus1(uint32_t x) { return x ? 32u - (uint32_t)__clz(x) : 0u; }
 
+// The symbol code lengths of one prefix code (decode.rs:661-797, 558-658) -- see read_huffman_code, which calls this where the
+// code-length code has more than one symbol.  In: the reader (its copy in memory), the code-length code's table (lane k: symbol << 4 |
+// bits for the five stream bits k).  Out: the lengths in LDS_LENGTHS, the reader behind them, what is left of the code space.
+struct LengthsOut { uint32_t symbol, space; };
+__device__ __noinline__ int read_symbol_lengths_wide(BitReader* const brp, const uint32_t cl_table, const uint32_t max_symbol_, LengthsOut* const res) {
+  BitReader br = *brp; br.uniformize();
+  const uint32_t lane = lane_id(), max_symbol = rfl(max_symbol_);
+  uint32_t symbol = 0, prev_code_len = 8, repeat = 0, repeat_code_len = 0, space = 32768;
+    // Sixty-four stream bits a step instead of one code word (round 5; one word at a time took 275 clocks a symbol, 40 % of a metablock
+  // header): lane j decodes the code word that WOULD start at bit j; the chain of the words that do -- from bit 0 on, a word
+  // ends where the next one starts -- comes out of pointer doubling (R_k[j]: the bit 2^k words on from bit j), lane t taking the
+  // t-th word's place by the binary digits of t; then the loop's arithmetic for all words side by side: the repeat codes' run
+  // lengths (decode.rs:607-650: a run of sixteens, or of seventeens, is a number in base four, or eight) link by link along
+  // the runs -- few and short --, symbol indices and code space by prefix sums, the first word that ends the loop (alphabet full,
+  // space used up, input short, a repeat that overshoots) by ballots.  Same words, same order, same verdicts as the loop below,
+  // which stays for a code-length code of ONE symbol (its words are no bits long: no chain).
+  while (symbol < max_symbol && space > 0) {
+      const auto bp = [](uint32_t lane_idx, uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane_idx << 2), (int)v); };
+      br.need32();
+      uint64_t wlo, whi;
+      br.window128(wlo, whi);   // (at least 96 bits from the reader's position)
+      const uint64_t tb = BitReader::total_bits(), ps = br.pos();
+      const uint32_t rem = tb > ps ? (tb - ps > 4096ull ? 4096u : (uint32_t)(tb - ps)) : 0u;   // bits of input left
+      const uint32_t bj = (uint32_t)(lane == 0 ? wlo : (wlo >> lane) | (whi << (64u - lane))) & 0xFFu;
+      const uint32_t ce = bp(bj & 31u, cl_table);
+      const uint32_t sym_j = ce >> 4, nb_j = ce & 15u, eb_j = sym_j == 16u ? 2u : sym_j == 17u ? 3u : 0u;
+      const uint32_t ev = sym_j | ((nb_j + eb_j) << 5) | (((bj >> nb_j) & ((1u << eb_j) - 1u)) << 9);   // symbol, bits of the word with its extra bits, their value
+      // the chain
+      uint32_t R0 = lane + nb_j + eb_j, R1, R2, R3, R4, R5;
+      { const uint32_t g = bp(R0 & 63u, R0); R1 = R0 < 64u ? g : R0; }   // (every lane asks, whatever it keeps: a lane that does not take part in a permute is read as zero)
+      { const uint32_t g = bp(R1 & 63u, R1); R2 = R1 < 64u ? g : R1; }
+      { const uint32_t g = bp(R2 & 63u, R2); R3 = R2 < 64u ? g : R2; }
+      { const uint32_t g = bp(R3 & 63u, R3); R4 = R3 < 64u ? g : R3; }
+      { const uint32_t g = bp(R4 & 63u, R4); R5 = R4 < 64u ? g : R4; }
+      uint32_t pt = 0;   // where word t starts (64 and more: behind the window)
+      { uint32_t g;
+        g = bp(pt & 63u, R0); pt = ((lane & 1u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R1); pt = ((lane & 2u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R2); pt = ((lane & 4u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R3); pt = ((lane & 8u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R4); pt = ((lane & 16u) && pt < 64u) ? g : pt;
+        g = bp(pt & 63u, R5); pt = ((lane & 32u) && pt < 64u) ? g : pt; }
+      const bool valid = pt < 64u;
+      const uint32_t et = bp(pt & 63u, ev);
+      const uint32_t cl = et & 31u, endp = pt + ((et >> 5) & 15u), xv = et >> 9;
+      const bool islen = valid && cl < 16u, isrep = valid && cl >= 16u;
+      const uint64_t below = (1ull << lane) - 1ull;
+      // the code length a sixteen repeats: the last one that was not zero
+      const uint64_t nzm = __ballot(islen && cl != 0u);
+      const uint32_t pvg = bp((nzm & below) != 0ull ? 63u - (uint32_t)__clzll((long long)(nzm & below)) : 0u, cl);
+      const uint32_t pv = (nzm & below) != 0ull ? pvg : prev_code_len;
+      const uint32_t new_len = cl == 16u ? pv : 0u;
+      const uint32_t clp = bp((lane + 63u) & 63u, cl);   // the word before
+      const bool cont0 = repeat > 0u && repeat_code_len == new_len;   // (lane 0: the run goes on from the window before)
+      const bool conts = isrep && (lane == 0u ? cont0 : clp == cl);
+      const uint64_t heads = __ballot(isrep && (lane == 0u || !conts));
+      const uint32_t depth = isrep ? lane - (63u - (uint32_t)__clzll((long long)(heads & (below | (1ull << lane))))) : 0u;
+      const uint32_t ebt = cl == 16u ? 2u : 3u;
+      uint32_t rp = 0, delta = 0;
+      for (uint32_t dd = 0; __ballot(isrep && depth >= dd) != 0ull; dd++) {
+        const uint32_t before = bp((lane + 63u) & 63u, rp);
+        if (isrep && depth == dd) {
+          const uint32_t pr = dd == 0u ? (lane == 0u && cont0 ? repeat : 0u) : before;
+          rp = (pr > 0u ? (pr - 2u) << ebt : 0u) + xv + 3u;
+          delta = rp - pr;
+        }
+      }
+      const uint32_t adv = islen ? 1u : isrep ? delta : 0u;
+      const uint32_t used = (islen && cl != 0u) ? 32768u >> cl : (isrep && new_len != 0u) ? delta << (15u - new_len) : 0u;
+      const auto scan = [](uint32_t v) -> uint32_t {   // inclusive prefix sum over the lanes (row shifts and row broadcasts, as the engines' sc_scan)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+        return v;
+      };
+      const uint32_t a_in = scan(adv), u_in = scan(used);
+      const uint32_t symidx = symbol + a_in - adv, space_before = space - (u_in - used);
+      const bool goes = valid && symidx < max_symbol && space_before != 0u;   // the loop's condition in front of this word
+      const uint64_t stopm = ~__ballot(goes);
+      const uint32_t s_n = stopm != 0ull ? (uint32_t)__builtin_ctzll(stopm) : 64u;   // words the loop takes here
+      const uint64_t taken = s_n >= 64u ? ~0ull : (1ull << s_n) - 1ull;
+      const uint64_t shortm = __ballot(valid && endp > rem) & taken, overm = __ballot(isrep && symidx + delta > max_symbol) & taken;
+      if ((shortm | overm) != 0ull) {
+        const uint32_t fs = shortm != 0ull ? (uint32_t)__builtin_ctzll(shortm) : 64u, fo = overm != 0ull ? (uint32_t)__builtin_ctzll(overm) : 64u;
+        if (fs <= fo) { br.advance(rdlane(endp, fs)); *brp = br; return E_NEEDS_MORE_INPUT; }
+        { *brp = br; return E_HUFFMAN_SPACE; }   // (decode.rs:640-643: the repeat overshoots the alphabet)
+      }
+      if (s_n == 0u) break;   // (cannot happen: the loop's condition held)
+      if (lane < s_n) {
+        if (islen && cl != 0u) lds_st8(LDS_LENGTHS + symidx, cl);
+        if (isrep && new_len != 0u) for (uint32_t k = 0; k < delta; k++) lds_st8(LDS_LENGTHS + symidx + k, new_len);
+      }
+      const uint32_t last = s_n - 1u;
+      symbol = rdlane(symidx + adv, last);
+      space = rdlane(space_before - used, last);
+      { const uint64_t nzt = nzm & taken; if (nzt != 0ull) prev_code_len = rdlane(cl, 63u - (uint32_t)__clzll((long long)nzt)); }
+      { const uint32_t lc = rdlane(cl, last); repeat = lc >= 16u ? rdlane(rp, last) : 0u; if (lc >= 16u) repeat_code_len = rdlane(new_len, last); }
+      br.advance(rdlane(endp, last));
+    }
+  *brp = br;
+  res->symbol = symbol; res->space = space;
+  return E_SUCCESS;
+}
+
 // src/decode.rs:868-1013.  Reads one prefix code, builds its table at a fresh arena allocation, returns the
 // arena offset in *tree_off.  The one helper that is a real function call (7 call sites, cold).
 #ifdef BROTLI_AMD_PROFILE_HDR
-__device__ unsigned long long g_hdr_prof[8];  // ticks: code-length code, symbol lengths, build_tree; counts: codes, symbols
 #define HDR_PROF(k) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && lane_id() == 0) g_hdr_prof[k] += t_ - hp_t; hp_t = t_; } while (0)
 #else
 #define HDR_PROF(k) do { } while (0)
@@ -680,99 +824,13 @@ __device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_si
     uint32_t symbol = 0, prev_code_len = 8, repeat = 0, repeat_code_len = 0;
     space = 32768;
 #ifndef BROTLI_AMD_SERIAL_LENGTHS
-    // Sixty-four stream bits a step instead of one code word (round 5; one word at a time took 275 clocks a symbol, 40 % of a metablock
-    // header): lane j decodes the code word that WOULD start at bit j; the chain of the words that do -- from bit 0 on, a word
-    // ends where the next one starts -- comes out of pointer doubling (R_k[j]: the bit 2^k words on from bit j), lane t taking the
-    // t-th word's place by the binary digits of t; then the loop's arithmetic for all words side by side: the repeat codes' run
-    // lengths (decode.rs:607-650: a run of sixteens, or of seventeens, is a number in base four, or eight) link by link along
-    // the runs -- few and short --, symbol indices and code space by prefix sums, the first word that ends the loop (alphabet full,
-    // space used up, input short, a repeat that overshoots) by ballots.  Same words, same order, same verdicts as the loop below,
-    // which stays for a code-length code of ONE symbol (its words are no bits long: no chain).
-    if (num_codes != 1) while (symbol < max_symbol && space > 0) {
-      const auto bp = [](uint32_t lane_idx, uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane_idx << 2), (int)v); };
-      br.need32();
-      uint64_t wlo, whi;
-      br.window128(wlo, whi);   // (at least 96 bits from the reader's position)
-      const uint64_t tb = BitReader::total_bits(), ps = br.pos();
-      const uint32_t rem = tb > ps ? (tb - ps > 4096ull ? 4096u : (uint32_t)(tb - ps)) : 0u;   // bits of input left
-      const uint32_t bj = (uint32_t)(lane == 0 ? wlo : (wlo >> lane) | (whi << (64u - lane))) & 0xFFu;
-      const uint32_t ce = bp(bj & 31u, cl_table);
-      const uint32_t sym_j = ce >> 4, nb_j = ce & 15u, eb_j = sym_j == 16u ? 2u : sym_j == 17u ? 3u : 0u;
-      const uint32_t ev = sym_j | ((nb_j + eb_j) << 5) | (((bj >> nb_j) & ((1u << eb_j) - 1u)) << 9);   // symbol, bits of the word with its extra bits, their value
-      // the chain
-      uint32_t R0 = lane + nb_j + eb_j, R1, R2, R3, R4, R5;
-      { const uint32_t g = bp(R0 & 63u, R0); R1 = R0 < 64u ? g : R0; }   // (every lane asks, whatever it keeps: a lane that does not take part in a permute is read as zero)
-      { const uint32_t g = bp(R1 & 63u, R1); R2 = R1 < 64u ? g : R1; }
-      { const uint32_t g = bp(R2 & 63u, R2); R3 = R2 < 64u ? g : R2; }
-      { const uint32_t g = bp(R3 & 63u, R3); R4 = R3 < 64u ? g : R3; }
-      { const uint32_t g = bp(R4 & 63u, R4); R5 = R4 < 64u ? g : R4; }
-      uint32_t pt = 0;   // where word t starts (64 and more: behind the window)
-      { uint32_t g;
-        g = bp(pt & 63u, R0); pt = ((lane & 1u) && pt < 64u) ? g : pt;
-        g = bp(pt & 63u, R1); pt = ((lane & 2u) && pt < 64u) ? g : pt;
-        g = bp(pt & 63u, R2); pt = ((lane & 4u) && pt < 64u) ? g : pt;
-        g = bp(pt & 63u, R3); pt = ((lane & 8u) && pt < 64u) ? g : pt;
-        g = bp(pt & 63u, R4); pt = ((lane & 16u) && pt < 64u) ? g : pt;
-        g = bp(pt & 63u, R5); pt = ((lane & 32u) && pt < 64u) ? g : pt; }
-      const bool valid = pt < 64u;
-      const uint32_t et = bp(pt & 63u, ev);
-      const uint32_t cl = et & 31u, endp = pt + ((et >> 5) & 15u), xv = et >> 9;
-      const bool islen = valid && cl < 16u, isrep = valid && cl >= 16u;
-      const uint64_t below = (1ull << lane) - 1ull;
-      // the code length a sixteen repeats: the last one that was not zero
-      const uint64_t nzm = __ballot(islen && cl != 0u);
-      const uint32_t pvg = bp((nzm & below) != 0ull ? 63u - (uint32_t)__clzll((long long)(nzm & below)) : 0u, cl);
-      const uint32_t pv = (nzm & below) != 0ull ? pvg : prev_code_len;
-      const uint32_t new_len = cl == 16u ? pv : 0u;
-      const uint32_t clp = bp((lane + 63u) & 63u, cl);   // the word before
-      const bool cont0 = repeat > 0u && repeat_code_len == new_len;   // (lane 0: the run goes on from the window before)
-      const bool conts = isrep && (lane == 0u ? cont0 : clp == cl);
-      const uint64_t heads = __ballot(isrep && (lane == 0u || !conts));
-      const uint32_t depth = isrep ? lane - (63u - (uint32_t)__clzll((long long)(heads & (below | (1ull << lane))))) : 0u;
-      const uint32_t ebt = cl == 16u ? 2u : 3u;
-      uint32_t rp = 0, delta = 0;
-      for (uint32_t dd = 0; __ballot(isrep && depth >= dd) != 0ull; dd++) {
-        const uint32_t before = bp((lane + 63u) & 63u, rp);
-        if (isrep && depth == dd) {
-          const uint32_t pr = dd == 0u ? (lane == 0u && cont0 ? repeat : 0u) : before;
-          rp = (pr > 0u ? (pr - 2u) << ebt : 0u) + xv + 3u;
-          delta = rp - pr;
-        }
-      }
-      const uint32_t adv = islen ? 1u : isrep ? delta : 0u;
-      const uint32_t used = (islen && cl != 0u) ? 32768u >> cl : (isrep && new_len != 0u) ? delta << (15u - new_len) : 0u;
-      const auto scan = [](uint32_t v) -> uint32_t {   // inclusive prefix sum over the lanes (row shifts and row broadcasts, as the engines' sc_scan)
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-        return v;
-      };
-      const uint32_t a_in = scan(adv), u_in = scan(used);
-      const uint32_t symidx = symbol + a_in - adv, space_before = space - (u_in - used);
-      const bool goes = valid && symidx < max_symbol && space_before != 0u;   // the loop's condition in front of this word
-      const uint64_t stopm = ~__ballot(goes);
-      const uint32_t s_n = stopm != 0ull ? (uint32_t)__builtin_ctzll(stopm) : 64u;   // words the loop takes here
-      const uint64_t taken = s_n >= 64u ? ~0ull : (1ull << s_n) - 1ull;
-      const uint64_t shortm = __ballot(valid && endp > rem) & taken, overm = __ballot(isrep && symidx + delta > max_symbol) & taken;
-      if ((shortm | overm) != 0ull) {
-        const uint32_t fs = shortm != 0ull ? (uint32_t)__builtin_ctzll(shortm) : 64u, fo = overm != 0ull ? (uint32_t)__builtin_ctzll(overm) : 64u;
-        if (fs <= fo) { br.advance(rdlane(endp, fs)); NEED_INPUT(br); return E_NEEDS_MORE_INPUT; }
-        FAIL(br, E_HUFFMAN_SPACE);   // (decode.rs:640-643: the repeat overshoots the alphabet)
-      }
-      if (s_n == 0u) break;   // (cannot happen: the loop's condition held)
-      if (lane < s_n) {
-        if (islen && cl != 0u) lds_st8(LDS_LENGTHS + symidx, cl);
-        if (isrep && new_len != 0u) for (uint32_t k = 0; k < delta; k++) lds_st8(LDS_LENGTHS + symidx + k, new_len);
-      }
-      const uint32_t last = s_n - 1u;
-      symbol = rdlane(symidx + adv, last);
-      space = rdlane(space_before - used, last);
-      { const uint64_t nzt = nzm & taken; if (nzt != 0ull) prev_code_len = rdlane(cl, 63u - (uint32_t)__clzll((long long)nzt)); }
-      { const uint32_t lc = rdlane(cl, last); repeat = lc >= 16u ? rdlane(rp, last) : 0u; if (lc >= 16u) repeat_code_len = rdlane(new_len, last); }
-      br.advance(rdlane(endp, last));
+    if (num_codes != 1) {
+      LengthsOut lo_;
+      const int e_ = rfl(read_symbol_lengths_wide(&br, cl_table, max_symbol, &lo_));
+      COLD_UNIFORMIZE(br.uniformize();)
+      if (e_ == E_NEEDS_MORE_INPUT) { NEED_INPUT(br); return E_NEEDS_MORE_INPUT; }
+      if (e_ != E_SUCCESS) FAIL(br, e_);
+      symbol = max_symbol; space = rfl(lo_.space);   // (the loop below has nothing left to do)
     }
 #endif
     while (symbol < max_symbol && space > 0) {
@@ -4380,8 +4438,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     int e = decode_stream(s, resume, d.in_size, st, mid ? &descs[idx].resume : nullptr);
 #ifdef BROTLI_AMD_PROFILE_HDR
     if (blockIdx.x == 0 && lane == 0)
-      printf("prefix codes (complex form): %llu, %llu symbols; ticks: code-length code %llu, symbol lengths %llu, build_tree %llu\n",
-             g_hdr_prof[4], g_hdr_prof[5], g_hdr_prof[0], g_hdr_prof[1], g_hdr_prof[2]);
+      printf("prefix codes (complex form): %llu, %llu symbols; ticks: code-length code %llu, symbol lengths %llu, build_tree %llu (all tables: histogram %llu, first pass %llu, second level + root %llu)\n",
+             g_hdr_prof[4], g_hdr_prof[5], g_hdr_prof[0], g_hdr_prof[1], g_hdr_prof[2], g_hdr_prof[3], g_hdr_prof[6], g_hdr_prof[7]);
     if (blockIdx.x == 0 && lane == 0)
       printf("block 0: %llu ticks before the stream, %llu in it: headers %llu, command loops %llu (x 256)\n", (unsigned long long)(hdr_prof_t1 - hdr_prof_t0),
              (unsigned long long)(__builtin_amdgcn_s_memtime() - hdr_prof_t1), (unsigned long long)s.prof[4], (unsigned long long)s.prof[5]);
