@@ -730,7 +730,7 @@ __device__ __noinline__ int read_symbol_lengths_wide(BitReader* const brp, const
 #else
 #define HDR_PROF(k) do { } while (0)
 #endif
-__device__ __forceinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off, bool cold = false) {
+__device__ __noinline__ int read_huffman_code(Stream& s, uint32_t alphabet_size, uint32_t max_symbol, uint32_t* tree_off, bool cold = false) {
 #ifdef BROTLI_AMD_PROFILE_HDR
   uint64_t hp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -969,7 +969,7 @@ __device__ __forceinline__ int block_switch(BitReader& br, const Arena& ar, uint
 }
 
 // decode.rs:1272-1428.  The map is written to the arena; *num_trees gets NTREES.
-__device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint32_t* num_trees, uint32_t* map_off) {
+__device__ __noinline__ int decode_context_map(Stream& s, uint32_t size, uint32_t* num_trees, uint32_t* map_off) {
   ColdScope c(s);
   BitReader& br = c.br;
   const uint32_t lane = lane_id();
@@ -1033,7 +1033,7 @@ __device__ __forceinline__ int decode_context_map(Stream& s, uint32_t size, uint
 }
 
 // decode.rs:1130-1219: `ntrees` prefix codes; their arena offsets go to a u32 array
-__device__ __forceinline__ int decode_tree_group(Stream& s, uint32_t alphabet, uint32_t max_symbol, uint32_t ntrees, uint32_t* group_off) {
+__device__ __noinline__ int decode_tree_group(Stream& s, uint32_t alphabet, uint32_t max_symbol, uint32_t ntrees, uint32_t* group_off) {
   uint32_t g = s.ar.alloc_cold(ntrees * 4);
   *group_off = g;
   for (uint32_t t = 0; t < ntrees; t++) {
@@ -4090,7 +4090,7 @@ __device__ __forceinline__ int run_commands(Stream& s, const BrotliAmdResume* mi
 }
 
 // decode.rs:1754-1806: stored metablock = byte-aligned memcpy of MLEN bytes, all lanes
-__device__ __forceinline__ int copy_uncompressed(Stream& s) {
+__device__ __noinline__ int copy_uncompressed(Stream& s) {
   BitReader br = s.br; br.uniformize();
   const uint32_t lane = lane_id();
   uint64_t byte = br.pos() >> 3;
