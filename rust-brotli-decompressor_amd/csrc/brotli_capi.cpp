@@ -48,8 +48,9 @@ thread_local std::string g_last_note;   // what a call did differently without f
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
 static const bool g_engine_wanted = getenv("BROTLI_AMD_NO_SCAN") == nullptr;  // (whether a device can hold such a block is decided per batch context, at its creation)
-constexpr uint64_t kEngineQueueMinBytes = 32768;  // mean compressed size from which a batch of cus < n <= kEngineQueueMaxPerCu cus streams gets engine blocks
-constexpr uint32_t kEngineQueueMaxPerCu = 3;      // (BROTLI_AMD_ENGINE_QUEUE_MAX overrides: experiments)
+constexpr uint32_t kEngineQueueMaxPerCu = 4;      // streams per CU up to which blocks of sixteen waves, one a CU, take a batch's streams one after the other -- where the
+                                                  // DEVICE says they are a command engine's kind (probe_streams); beyond, streams in flight beat the engine (2048 x 1 MiB of the
+                                                  // metric's make-up: 220 GB/s eight to a CU in one-wave blocks, 151 through engine blocks)
 constexpr uint32_t kScanArena = 40960;  // table arena of such a block (with the engine's rings: about 108 KiB of LDS)
 
 bool hip_ok(hipError_t e, const char* what) {
@@ -162,7 +163,7 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
     g_last_note = std::string("engine blocks refused (") + hipGetErrorString(le) + "): eight-wave blocks from now on";   // (a note, not an error: the retry below decides)
     b->engine_ok = false;
     b->waves = 8;
-    for (uint32_t i = 0; i < b->n; i++) b->h_descs[i].flags &= ~BROTLI_AMD_FLAG_ENGINE_ONLY;
+    for (uint32_t i = 0; i < b->n; i++) b->h_descs[i].flags &= ~(BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER);
     if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * b->n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
     le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena, b->d_dict, stream, 8);
   }
@@ -177,6 +178,29 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
 uint32_t small_arena(const BrotliAmdBatch* b, uint32_t per_cu) {
   const uint32_t per_block = (uint32_t)(b->lds_per_cu / per_cu) & ~255u;
   return per_block > b->lds_fixed + kMinSmallArena ? (per_block - b->lds_fixed) & ~15u : 0u;
+}
+
+// What kind of stream is each of the batch's?  A launch of the shape at hand in which nothing is decoded: every stream's header is read up
+// to the literal context map of its first compressed metablock (BROTLI_AMD_FLAG_PROBE).  kind[i]: bit 0 there is such a metablock,
+// bit 1 its literals do not depend on context, bit 2 it is large enough for a command engine.  (Round 4 guessed from the batch's size and its
+// mean compressed size: 1024 x 1 MiB of engine-shaped streams went through one-wave blocks -- 129 GB/s where engine blocks do 148 --, and
+// could not be told from 1024 context-modelled texts, which engine blocks take at half speed.  The probe costs a launch of some tens of
+// microseconds and reads the facts.)
+int probe_streams(BrotliAmdBatch* b, uint32_t n, hipStream_t stream, std::vector<uint8_t>& kind) {
+  kind.assign(n, 0);
+  if (!ensure_scratch(b, b->grid)) return -1;
+  for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags |= BROTLI_AMD_FLAG_PROBE;
+  bool ok = hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)");
+  ok = ok && hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize(probe descs)");   // (pinned memory: the copy reads it when it runs, not when it is asked for)
+  for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags &= ~BROTLI_AMD_FLAG_PROBE;
+  ok = ok && hip_ok(hipMemsetAsync(b->d_queue, 0, sizeof(uint32_t) * 16, stream), "hipMemsetAsync(queue)");
+  ok = ok && hip_ok(brotli_amd_launch_decode(b->d_descs, b->d_status, n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena, b->d_dict, stream, (int)b->waves),
+                    "brotli_amd_decode_kernel launch (probe)");
+  ok = ok && hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(status)");
+  ok = ok && hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize(probe)");
+  if (!ok) return -1;
+  for (uint32_t i = 0; i < n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_PROBE) kind[i] = (uint8_t)(b->h_status[i].engine_commands & 7u);
+  return 0;
 }
 
 int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n) filled
@@ -218,15 +242,19 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   }
   bool engine_queue = false;
   static const uint32_t queue_max = getenv("BROTLI_AMD_ENGINE_QUEUE_MAX") ? (uint32_t)atoi(getenv("BROTLI_AMD_ENGINE_QUEUE_MAX")) : kEngineQueueMaxPerCu;  // (streams per CU)
+  std::vector<uint8_t> kind;
+  for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags &= ~(BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER);
   if (can16 && !no_wide && b->auto_arena && b->grid > b->cus && n <= queue_max * b->cus) {
-    uint64_t in_total = 0;
-    for (uint32_t i = 0; i < n; i++) in_total += b->h_descs[i].in_size;
-    if (in_total / n >= kEngineQueueMinBytes) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
+    // more streams than CUs, few enough for engine blocks to pay where the streams are the engines' kind: the device says which are
+    if (probe_streams(b, n, stream, kind) != 0) return -1;
+    uint64_t in_total = 0, in_engine = 0;
+    for (uint32_t i = 0; i < n; i++) { in_total += b->h_descs[i].in_size; if (kind[i] == 7u) in_engine += b->h_descs[i].in_size; }
+    if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
   }
   if (can16 && b->grid <= b->cus) { b->cur_arena = arena16; b->waves = 16; }
   engine_queue = engine_queue && b->waves == 16u;
-  for (uint32_t i = 0; i < n; i++)
-    b->h_descs[i].flags = engine_queue ? b->h_descs[i].flags | BROTLI_AMD_FLAG_ENGINE_ONLY : b->h_descs[i].flags & ~BROTLI_AMD_FLAG_ENGINE_ONLY;
+  if (engine_queue)   // (the engines' streams to the engine blocks; the others wait for the launch of small blocks behind it)
+    for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags |= kind[i] == 7u ? BROTLI_AMD_FLAG_ENGINE_ONLY : BROTLI_AMD_FLAG_DEFER;
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
@@ -274,7 +302,7 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
     else { level = 2; arena = b->max_arena; grid_max = b->retry_grid_max; waves = 4; last = true; }
     for (uint32_t j = 0; j < m; j++) {
       BrotliAmdStreamDesc d = b->h_descs[idx[j]];
-      d.flags = ((last ? d.flags & ~BROTLI_AMD_FLAG_NO_SPILL : d.flags) & ~BROTLI_AMD_FLAG_ENGINE_ONLY) | BROTLI_AMD_FLAG_RESUME;
+      d.flags = ((last ? d.flags & ~BROTLI_AMD_FLAG_NO_SPILL : d.flags) & ~(BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER)) | BROTLI_AMD_FLAG_RESUME;
       d.resume = b->h_status[idx[j]].resume;
       b->h_retry_descs[j] = d;
     }
@@ -357,7 +385,7 @@ int settle_output_limits(BrotliAmdBatch* b) {
     if (!b->h_retry_descs && run_retry_descs(b, 0, b->max_arena, b->retry_grid_max, 4) != 0) return -1;
     for (uint32_t j = 0; j < m; j++) {
       BrotliAmdStreamDesc d = b->h_descs[part[j]];
-      d.flags &= ~(BROTLI_AMD_FLAG_NO_SPILL | BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_RESUME);
+      d.flags &= ~(BROTLI_AMD_FLAG_NO_SPILL | BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER | BROTLI_AMD_FLAG_RESUME);
       d.out = b->d_settle + off[j]; d.out_cap = cap2s[j];
       b->h_retry_descs[j] = d;
     }

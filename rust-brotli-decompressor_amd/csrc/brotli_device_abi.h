@@ -22,7 +22,14 @@ extern "C" {
                                          // depend on context) ends the decode the same way, and the stream continues in a
                                          // launch of small blocks, several to a CU -- one wave decodes such a metablock
                                          // wherever it runs, so what counts for it is streams in flight
+#define BROTLI_AMD_FLAG_PROBE 128u       // nothing is decoded: the stream's header is read up to the literal context map of its first compressed
+                                         // metablock, and the status says what kind of stream this is (result BROTLI_AMD_RESULT_PROBE,
+                                         // engine_commands = bit 0: such a metablock exists, bit 1: its literals do not depend on context,
+                                         // bit 2: it is large enough for a command engine): the host picks the launch shape by it
+#define BROTLI_AMD_FLAG_DEFER 256u       // the stream is not this launch's: reported as BROTLI_AMD_RESULT_RETRY_ARENA at once (it is decoded, from
+                                         // its first byte, in the launch of small blocks that follows)
 #define BROTLI_AMD_RESULT_RETRY_ARENA 4  // (never reaches the caller of the C ABI)
+#define BROTLI_AMD_RESULT_PROBE 5        // (never reaches the caller of the C ABI)
 #define BROTLI_AMD_SPEC_SCRATCH 65536u   // bytes at the end of each block's global scratch that the helper waves use for
                                          // speculatively decoded literals (the table arena is the part in front of it)
 

@@ -61,6 +61,7 @@ constexpr int E_EXUBERANT_NIBBLE = -1, E_RESERVED = -2, E_EXUBERANT_META_NIBBLE 
               E_BLOCK_LENGTH_1 = -9, E_BLOCK_LENGTH_2 = -10, E_TRANSFORM = -11, E_DICTIONARY = -12, E_WINDOW_BITS = -13,
               E_PADDING_2 = -15, E_DISTANCE = -16, E_UNREACHABLE = -31;
 constexpr int E_RETRY_ARENA = 100;  // internal: see BROTLI_AMD_FLAG_NO_SPILL
+constexpr int E_PROBE = 101;        // internal: see BROTLI_AMD_FLAG_PROBE
 
 // ---- small constant tables (RFC 7932 sections 3.5, 4, 5, 6) ----
 // (decode.rs:801-853's three small tables -- kCodeLengthCodeOrder = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15},
@@ -4233,6 +4234,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
     }
     if (mid && (s.is_metadata || s.mlen == 0 || s.is_uncompressed)) return E_UNREACHABLE;  // (the resume block names a command inside a compressed metablock)
     if (!s.is_metadata && s.mlen != 0) {
+      if ((s.flags & BROTLI_AMD_FLAG_PROBE) && s.is_uncompressed) { s.engine_commands = 0u; return E_PROBE; }   // (a stored metablock first: no engine's stream)
       if (s.is_uncompressed) {
         TRY(copy_uncompressed(s));
       } else {
@@ -4262,6 +4264,19 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
           for (uint32_t k = 0; k < s.nbt0; k++) { uint32_t m = br.read(2); NEED_INPUT(br); s.ar.st8(s.ctx_modes + k, m); }
         }
         TRY(decode_context_map(s, s.nbt0 << 6, &s.num_lit_trees, &s.ctx_map));
+        if (s.flags & BROTLI_AMD_FLAG_PROBE) {
+          // what kind of stream is this?  (every literal block type with a constant context map: DetectTrivialLiteralBlockTypes,
+          // decode.rs:1525-1553 -- the command engines' kind)
+          bool ctx_never = true;
+          Arena ar_ = s.ar; ar_.uniformize();
+          const uint32_t nbt0 = rfl(s.nbt0), ctx_map = rfl(s.ctx_map);
+          for (uint32_t bt = 0; bt < nbt0; bt++) {
+            uint32_t mine = ar_.ld8_lane<false>(ctx_map + (bt << 6) + lane_id());
+            if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
+          }
+          s.engine_commands = 1u | (ctx_never ? 2u : 0u) | (rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN ? 4u : 0u);
+          return E_PROBE;
+        }
         uint32_t ndirect = s.num_direct - 16;
         uint32_t num_dist_codes = 16 + ndirect + ((s.large_window ? 62u : 24u) << (s.postfix_bits + 1));
         uint32_t max_dist_symbol = s.large_window ? max_distance_symbol(ndirect, s.postfix_bits) : num_dist_codes;
@@ -4378,6 +4393,16 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     if (queue[1] != 0u) idx = rfl(queue[16u + idx]);
     const BrotliAmdStreamDesc d = descs[idx];
     BrotliAmdStreamStatus* st = status + idx;
+    if (d.flags & BROTLI_AMD_FLAG_DEFER) {   // not this launch's stream (see the flag)
+      if (lane == 0) {
+        BrotliAmdResume z; z.bit_pos = 0; z.out_pos = 0; z.dist_rb[0] = z.dist_rb[1] = z.dist_rb[2] = z.dist_rb[3] = 0; z.dist_rb_idx = 0;
+        z.window_bits = 0; z.large_window = 0; z.rb_size_log2 = 0; z.is_last_done = 0; z.reserved = 0; z.mid_valid = 0;
+        st->result = BROTLI_AMD_RESULT_RETRY_ARENA; st->error_code = E_RETRY_ARENA; st->decoded_size = 0; st->consumed = 0; st->produced = 0;
+        st->num_metablocks = 0; st->spilled_metablocks = 0; st->num_commands = 0; st->engine_commands = 0;
+        st->peak_trees = 0; st->peak_map_bytes = 0; st->ring_bytes = 0; st->any_compressed = 0; st->resume = z;
+      }
+      continue;
+    }
 
     Stream s;
     s.ar.glb = as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block);
@@ -4447,7 +4472,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 
     // result mapping of the one-shot driver (decode.rs:2829-2916, 3382-3397; lib.rs:447-468)
     const bool over = s.br.over();
-    if (e != E_NEEDS_MORE_INPUT && e != E_BLOCK_LENGTH_1 && e != E_NEEDS_MORE_OUTPUT && e != E_RETRY_ARENA && over) e = E_NEEDS_MORE_INPUT;
+    if (e != E_NEEDS_MORE_INPUT && e != E_BLOCK_LENGTH_1 && e != E_NEEDS_MORE_OUTPUT && e != E_RETRY_ARENA && e != E_PROBE && over) e = E_NEEDS_MORE_INPUT;
     uint64_t decoded;
     if (e == E_SUCCESS || e == E_NEEDS_MORE_INPUT) decoded = s.P;          // everything produced is flushed
     else if (e == E_NEEDS_MORE_OUTPUT) decoded = s.out_cap;
@@ -4457,7 +4482,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       if (decoded > s.P) decoded = 0;
     }
     if (lane == 0) {
-      st->result = e == E_SUCCESS ? 1 : e == E_NEEDS_MORE_INPUT ? 2 : e == E_NEEDS_MORE_OUTPUT ? 3 : e == E_RETRY_ARENA ? BROTLI_AMD_RESULT_RETRY_ARENA : 0;
+      st->result = e == E_SUCCESS ? 1 : e == E_NEEDS_MORE_INPUT ? 2 : e == E_NEEDS_MORE_OUTPUT ? 3 : e == E_RETRY_ARENA ? BROTLI_AMD_RESULT_RETRY_ARENA : e == E_PROBE ? BROTLI_AMD_RESULT_PROBE : 0;
       st->error_code = e;
       st->decoded_size = decoded;
       uint64_t c = (s.br.pos() + 7) >> 3;

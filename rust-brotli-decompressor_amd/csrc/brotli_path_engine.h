@@ -2397,7 +2397,7 @@ pe_pass:
       if (idle < 256u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(127);
     }
     lds_acquire();
-    if (hc_ld(HC_SEQ) == seq_ + 1u && hc_ld(HC_KIND) == (PIPE ? (uint32_t)HK_PATH2 : (uint32_t)HK_PATH)) goto pe_again;
+    if (hc_ld(HC_SEQ) == seq_ + 1u && hc_ld(HC_KIND) == (PIPE ? (uint32_t)HK_PATH2 : PE_DICT ? (uint32_t)HK_PATHG : (uint32_t)HK_PATH)) goto pe_again;   // (this form of the engine again: the lean one and the general one are two functions)
     return seq_;
   }
 #ifdef BROTLI_AMD_PROFILE_SCAN

@@ -655,3 +655,55 @@ def test_batches_and_one_shot_calls_from_several_threads(pkg):
     for t in ts:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_the_device_says_which_streams_get_engine_blocks(pkg):
+    """More streams than CUs, few enough for blocks of sixteen waves to pay (round 5: a probe launch reads every stream's first
+    metablock header and the host routes by what it says -- engine-shaped streams to engine blocks, context-modelled ones to the
+    launch of small blocks behind it; round 4 guessed from the batch's size).  Three batches of 600 streams through the device-pointer
+    entry point: all of the metric's make-up (every stream through a command engine), all context-modelled text (none), and both
+    mixed -- every stream's status words against the oracle's and every output by SHA-256."""
+    import torch
+    gold = os.path.join(ROOT, "tests", "golden", "testdata")
+    alice = open(os.path.join(gold, "alice29.txt.compressed"), "rb").read()
+    a_info, a_exp = oracle.decode(alice, 200000, 1)
+    a_item = (alice, len(a_exp), hashlib.sha256(a_exp).hexdigest())
+    metric = _metric_streams(8, 1 << 20)
+
+    def run(items):
+        n = len(items)
+        in_off, out_off, a, o = [], [], 0, 0
+        for c, sz, _ in items:
+            in_off.append(a); out_off.append(o); a += (len(c) + 255) // 256 * 256; o += (sz + 255) // 256 * 256 + 256
+        host_in = bytearray(a)
+        for (c, _, _), off in zip(items, in_off):
+            host_in[off:off + len(c)] = c
+        d_in = torch.frombuffer(host_in, dtype=torch.uint8).cuda(); d_out = torch.zeros(o, dtype=torch.uint8, device="cuda")
+        b = pkg.Batch(n)
+        b.decode_device([d_in.data_ptr() + x for x in in_off], [len(c) for c, _, _ in items], [d_out.data_ptr() + x for x in out_off],
+                        [sz for _, sz, _ in items], pkg.FLAG_LARGE_WINDOW)
+        res = b.wait()
+        second = b.last_second_pass_count()
+        b.close()
+        host = d_out.cpu().numpy()
+        bad = [i for i, ((c, sz, sha), r, off) in enumerate(zip(items, res, out_off))
+               if r.result != 1 or r.decoded_size != sz or hashlib.sha256(host[off:off + sz].tobytes()).hexdigest() != sha]
+        assert not bad, (len(bad), bad[:5])
+        return res, second
+
+    # real text at -q 5 -- words of the static dictionary: a block's engine goes from its lean form to the general one and, with the
+    # block's next stream, back (round 5: the waves that stay inside the engine between invocations stayed in the wrong one)
+    ref = _enc()
+    lcet = open(os.path.join(gold, "lcet10.txt.compressed"), "rb").read()
+    _, lraw = oracle.decode(lcet, 1 << 20, 1)
+    l_item = (ref.encode(lraw, 5, 22), len(lraw), hashlib.sha256(lraw).hexdigest())
+    res, second = run([l_item if i % 2 else metric[i % 8] for i in range(520)])
+    assert second == 0 and all(r.engine_commands >= 0.9 * r.num_commands for r in res), (second, [(r.engine_commands, r.num_commands) for r in res[:4]])
+    res, second = run([metric[i % 8] for i in range(600)])
+    assert second == 0 and all(r.engine_commands >= 0.9 * r.num_commands for r in res), (second, [(r.engine_commands, r.num_commands) for r in res[:4]])
+    res, second = run([a_item] * 600)
+    assert second == 0 and all(r.num_commands == a_info.num_commands for r in res)   # (small blocks for all of them: nobody was sent back)
+    items = [metric[i % 8] if i % 3 else a_item for i in range(600)]
+    res, second = run(items)
+    assert second == 200, second   # (the texts: deferred to the launch of small blocks)
+    assert all(r.engine_commands >= 0.9 * r.num_commands for i, r in enumerate(res) if i % 3), [(i, r.engine_commands, r.num_commands) for i, r in enumerate(res[:6])]
