@@ -513,3 +513,34 @@ def test_literal_heavy_streams_of_random_makeup(pkg, seed):
         for cap in (len(raw), int(rng.integers(1, len(raw))), len(raw) + 100):
             datas.append(c); caps.append(cap)
     _check_against_oracle(pkg, datas, caps, 1, "random make-up")
+
+
+def test_prefix_code_headers_cut_at_every_byte_and_repeat_code_runs(pkg):
+    """The symbol code lengths of a prefix code are read sixty-four stream bits a step (round 5, read_symbol_lengths_wide: the chain of
+    code-length words by pointer doubling, repeat codes and code space by scans) -- same words, same order, same verdicts as the
+    reference's loop (decode.rs:661-797).  Streams whose headers exercise it: every fixture cut at EVERY byte of its first 700 (the input
+    ends inside the code-length code, inside a word, inside a repeat code's extra bits ...), and data whose alphabets make long runs of
+    repeat codes (sixteens behind sixteens, seventeens behind seventeens: the run length is a number in base four / eight)."""
+    import libbrotli_ref as ref
+    gold = os.path.join(ROOT, "tests", "golden", "testdata")
+    datas, caps = [], []
+    for name in ("alice29.txt.compressed", "asyoulik.txt.compressed", "mapsdatazrh.compressed", "ukkonooa.compressed", "compressed_file.compressed", "plrabn12.txt.compressed"):
+        if not os.path.exists(os.path.join(gold, name)):
+            continue
+        c = open(os.path.join(gold, name), "rb").read()
+        for cut in range(1, min(len(c), 700)):
+            datas.append(c[:cut]); caps.append(1 << 16)
+    if ref.encoder_available():
+        rnd = random.Random(77)
+        for k in range(24):
+            # few distinct byte values far apart: literal codes with long runs of zero lengths (seventeens), or many symbols of one
+            # length (sixteens); a sprinkling of others so that runs of different kinds meet
+            vals = rnd.sample(range(256), rnd.choice([2, 3, 5, 17, 40, 200, 256]))
+            raw = bytes(rnd.choice(vals) for _ in range(rnd.choice([300, 5000, 70000])))
+            c = ref.encode(raw + bytes(range(256)) * rnd.choice([0, 1]), rnd.choice([1, 5, 9, 11]), 18)
+            datas.append(c); caps.append(1 << 18)
+            for _ in range(6):
+                d = bytearray(c); pos = rnd.randrange(0, min(len(d), 200)); d[pos] ^= 1 << rnd.randrange(8)
+                datas.append(bytes(d)); caps.append(1 << 18)
+    for i in range(0, len(datas), 2000):
+        _check_against_oracle(pkg, datas[i:i + 2000], caps[i:i + 2000], 1, "headers")

@@ -27,15 +27,19 @@ python "$REPO/tools/rocpd_summary.py" $DB_T $DB_F $DB_W $DB_S $DB_M > "$OUT/summ
 python - "$WL" "$DB_T" "$DB_F" "$DB_W" > "$OUT/pmc.json" <<'EOF'
 import json, sqlite3, sys
 wl, dbt, dbf, dbw = sys.argv[1:5]
+# (the decode launches only: a batch of more streams than CUs is preceded by a probe launch of the same kernel that decodes nothing --
+# a few per cent of a decode launch's time and traffic; anything below half of the largest value is not a decode launch)
 def avg(db, counter):
     try:
-        r = sqlite3.connect(db).execute("select avg(value) from counters_collection where counter_name=? and kernel_name like 'brotli_amd_decode_kernel%'", (counter,)).fetchone()
-        return r[0]
+        v = [r[0] for r in sqlite3.connect(db).execute("select value from counters_collection where counter_name=? and kernel_name like 'brotli_amd_decode_kernel%'", (counter,))]
+        v = [x for x in v if x >= 0.5 * max(v)]
+        return sum(v) / len(v)
     except Exception:
         return None
 def kavg(db):
-    r = sqlite3.connect(db).execute("select avg(duration), count(*) from kernels where name like 'brotli_amd_decode_kernel%'").fetchone()
-    return r
+    v = [r[0] for r in sqlite3.connect(db).execute("select duration from kernels where name like 'brotli_amd_decode_kernel%'")]
+    v = [x for x in v if x >= 0.5 * max(v)]
+    return (sum(v) / len(v), len(v))
 f, w = avg(dbf, "FETCH_SIZE"), avg(dbw, "WRITE_SIZE")
 k = kavg(dbt)
 out = {"workload": wl, "kernel": "brotli_amd_decode_kernel",
