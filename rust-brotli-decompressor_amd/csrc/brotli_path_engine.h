@@ -57,7 +57,10 @@ constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this lon
 #endif
 constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this long from in front of the region are done by their command's lane (16-byte loads, 16 .. 64)
 static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
-constexpr uint32_t PE_RUN_MIN = 6000;             // literal runs from here on (about what a region's path holds) get regions of their own (2048 was tried: slower, C3 6.56 -> 6.75 ms:
+#ifndef BROTLI_AMD_PE_RUN_MIN
+#define BROTLI_AMD_PE_RUN_MIN 6000
+#endif
+constexpr uint32_t PE_RUN_MIN = BROTLI_AMD_PE_RUN_MIN;             // literal runs from here on (about what a region's path holds) get regions of their own (2048 was tried: slower, C3 6.56 -> 6.75 ms:
                                                   // every run ends the invocation)
 #ifndef BROTLI_AMD_PE_RUN_SB
 #define BROTLI_AMD_PE_RUN_SB 256
