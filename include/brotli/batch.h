@@ -79,6 +79,10 @@ BROTLI_DEC_API float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* batch);
 /* Streams the last BrotliAmdBatchWait had to continue in a second launch with a larger LDS arena (0 in the common case). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch);
 
+/* Blocks (CUs) that worked on each stream of the last launch: 1 as a rule; 2, 4 or 8 where the batch had fewer streams than half the
+ * device's CUs and each stream was given a gang of blocks (csrc/brotli_path_engine.h, PE_CFG_REMOTE; BROTLI_AMD_GANG=0 turns that off). */
+BROTLI_DEC_API uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* batch);
+
 /* Streaming (BrotliDecoderDecompressStream, decode.h): the commands the device has decoded for this stream in all the launches
  * of its calls together.  A call is a launch from the last command boundary reached, so this stays close to the stream's own
  * number of commands however the input is cut up; a test asserts that instead of timing calls. */

@@ -30,7 +30,7 @@ DECODE_H_SYMBOLS = [
 ]
 BATCH_H_SYMBOLS = [
     "BrotliAmdBatchCreate", "BrotliAmdBatchDestroy", "BrotliAmdBatchDecodeDevice", "BrotliAmdBatchRelaunch", "BrotliAmdBatchWait",
-    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
+    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdBatchLastGang", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
 ]
 
 
@@ -103,6 +103,9 @@ def load_library():
     L.BrotliAmdBatchLastKernelMs.argtypes = [vp]
     L.BrotliAmdBatchLastSecondPassCount.restype = ctypes.c_uint32
     L.BrotliAmdBatchLastSecondPassCount.argtypes = [vp]
+    if hasattr(L, "BrotliAmdBatchLastGang"):   # (libraries of earlier rounds, for A/B runs: tools/ab.sh)
+        L.BrotliAmdBatchLastGang.restype = ctypes.c_uint32
+        L.BrotliAmdBatchLastGang.argtypes = [vp]
     L.BrotliAmdLastError.restype = ctypes.c_char_p
     if hasattr(L, "BrotliAmdLastNote"):   # (an older build of the library, loaded through BROTLI_AMD_LIB for an A/B, has no such symbol)
         L.BrotliAmdLastNote.restype = ctypes.c_char_p
@@ -173,6 +176,10 @@ class Batch:
 
     def last_second_pass_count(self):
         return int(self._L.BrotliAmdBatchLastSecondPassCount(self._h))
+
+    def last_gang(self):
+        """blocks (CUs) a stream of the last launch: 1, or 2 / 4 / 8 where each stream had a gang of blocks"""
+        return int(self._L.BrotliAmdBatchLastGang(self._h)) if hasattr(self._L, "BrotliAmdBatchLastGang") else 1
 
     def decode_host(self, datas, out_caps, flags=FLAG_LARGE_WINDOW):
         """Host bytes in, (results, outputs) out: upload, decode, download."""

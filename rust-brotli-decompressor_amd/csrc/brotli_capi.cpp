@@ -136,6 +136,9 @@ struct BrotliAmdBatch {
   // blocks of sixteen waves with a command engine: the device's LDS holds one (decided at creation), nothing has refused one since
   bool engine_ok = false;
   uint8_t* d_settle = nullptr; size_t settle_cap = 0; uint32_t last_settle_count = 0;
+  // several CUs on one stream: the blocks of a gang in this launch (0: none) and the gangs' control blocks (brotli_device_abi.h)
+  uint32_t gang = 0, last_gang = 0;
+  uint8_t* d_gang = nullptr; size_t gang_cap = 0;
 };
 
 namespace {
@@ -152,6 +155,19 @@ bool ensure_scratch(BrotliAmdBatch* b, uint32_t grid) {
 int launch(BrotliAmdBatch* b, hipStream_t stream) {
   // queue header (pull counter, order flag) and, for batches of more streams than blocks, the order
   b->h_order[0] = 0; b->h_order[1] = b->ordered ? 1u : 0u;
+  for (int i = 2; i < 16; i++) b->h_order[i] = 0;
+  if (b->gang > 1u) {
+    const size_t need = (size_t)b->n * BROTLI_AMD_GANG_CTL_BYTES;
+    if (b->gang_cap < need) {
+      if (b->d_gang) (void)hipFree(b->d_gang);
+      b->d_gang = nullptr; b->gang_cap = 0;
+      if (!hip_ok(hipMalloc(&b->d_gang, need), "hipMalloc(gang control)")) return -1;
+      b->gang_cap = need;
+    }
+    if (!hip_ok(hipMemsetAsync(b->d_gang, 0, need, stream), "hipMemsetAsync(gang control)")) return -1;
+    b->h_order[2] = b->gang; b->h_order[4] = (uint32_t)(uintptr_t)b->d_gang; b->h_order[5] = (uint32_t)((uint64_t)(uintptr_t)b->d_gang >> 32);
+  }
+  b->last_gang = b->gang;
   if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
   hipError_t le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
@@ -163,6 +179,11 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
     g_last_note = std::string("engine blocks refused (") + hipGetErrorString(le) + "): eight-wave blocks from now on";   // (a note, not an error: the retry below decides)
     b->engine_ok = false;
     b->waves = 8;
+    if (b->gang > 1u) {   // (the gangs' helper blocks go with the engine blocks)
+      b->gang = 0; b->last_gang = 0; b->grid = std::min(b->n, b->grid);
+      b->h_order[2] = 0;
+      if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * 16, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
+    }
     for (uint32_t i = 0; i < b->n; i++) b->h_descs[i].flags &= ~(BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER);
     if (!hip_ok(hipMemcpyAsync(b->d_descs, b->h_descs, sizeof(BrotliAmdStreamDesc) * b->n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(descs)")) return -1;
     le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena, b->d_dict, stream, 8);
@@ -252,6 +273,17 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
   }
   if (can16 && b->grid <= b->cus) { b->cur_arena = arena16; b->waves = 16; }
+  // Fewer streams than half the CUs: GANGS of blocks, a CU each, on one stream -- its owner and one, three or seven helper blocks that take
+  // the path engine's regions in turns with it (csrc/brotli_path_engine.h, PE_CFG_REMOTE).  Eight streams' gangs are launched side by side,
+  // a gang's members eight block numbers apart (one XCD); streams beyond a multiple of eight leave their gangs' blocks without work.
+  const int gang_env = getenv("BROTLI_AMD_GANG") ? atoi(getenv("BROTLI_AMD_GANG")) : -1;   // (experiments: 0 or 1 none, 2 / 4 / 8 at most that many)
+  b->gang = 0;
+  if (b->waves == 16u && b->auto_arena && b->cur_arena <= 49152u && gang_env != 0 && gang_env != 1) {
+    const uint32_t groups = (n + 7u) / 8u;
+    uint32_t m = groups * 64u <= b->cus ? 8u : groups * 32u <= b->cus ? 4u : groups * 16u <= b->cus ? 2u : 0u;
+    if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
+    if (m > 1u) { b->gang = m; b->grid = groups * 8u * m; }
+  }
   engine_queue = engine_queue && b->waves == 16u;
   if (engine_queue)   // (the engines' streams to the engine blocks; the others wait for the launch of small blocks behind it)
     for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags |= kind[i] == 7u ? BROTLI_AMD_FLAG_ENGINE_ONLY : BROTLI_AMD_FLAG_DEFER;
@@ -467,6 +499,7 @@ extern "C" void BrotliAmdBatchDestroy(BrotliAmdBatch* b) {
   if (b->d_descs) (void)hipFree(b->d_descs);
   if (b->d_status) (void)hipFree(b->d_status);
   if (b->d_queue) (void)hipFree(b->d_queue);
+  if (b->d_gang) (void)hipFree(b->d_gang);
   if (b->d_scratch) (void)hipFree(b->d_scratch);
   if (b->d_retry_descs) (void)hipFree(b->d_retry_descs);
   if (b->d_retry_status) (void)hipFree(b->d_retry_status);
@@ -517,6 +550,15 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
   if (!hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * b->n, hipMemcpyDeviceToHost, b->last_stream), "hipMemcpyAsync(status)")) return -1;
   if (!hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize")) return -1;
+#ifdef BROTLI_AMD_GANG_STATS
+  if (b->last_gang > 1u && b->d_gang && getenv("BROTLI_AMD_GANG_STATS")) {   // (profile build: the first stream's gang)
+    unsigned long long st[40];
+    if (hipMemcpy(st, b->d_gang + 704, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "gang of %u: invocations %llu, regions arrived at %llu, of them not usable %llu (no tables %llu, short of the window %llu, too far into it %llu), rebuilt by a new plan %llu, tables built %llu; "
+              "ticks: owner waits for helpers to leave %llu, for the stream %llu (helpers %llu), for the output before %llu (+ acquire: %llu), at the end %llu; regions resolved %llu, declined %llu; owner inside the engine %llu (set-up %llu, its tables %llu, its regions' walk .. execute %llu), the releases behind a region's output %llu; invocations that took fewer than 64 commands %llu (none: %llu), commands in all %llu; from the stream's arrival, summed over the regions: walk done %llu, details %llu, resolve %llu, output complete %llu; from a publisher's clock to its reader's: the state %llu, the output word %llu (summed), regions that did not wait for the output before %llu; invocations that resolved no region %llu; regions that listed nothing %llu (first command's run >= 1024: %llu, runs summed %llu, no room to look %llu, listed before the cut %llu), entries that ran out of tries %llu\n",
+              b->last_gang, st[0], st[1], st[2], st[10], st[11], st[12], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[13], st[14], st[15], st[16], st[18], st[20], st[19], st[17], st[21], st[23], st[22], st[24], st[25], st[26], st[27], st[29], st[28], st[30], st[31], st[32], st[33], st[34], st[36], st[37], st[35]);
+  }
+#endif
   if (retry_with_larger_arenas(b) != 0) return -1;
   if (b->exact_limit && settle_output_limits(b) != 0) return -1;
   if (results) {
@@ -532,6 +574,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
 }
 
 extern "C" uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* b) { return b ? b->last_retry_count : 0; }
+extern "C" uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* b) { return b ? (b->last_gang > 1u ? b->last_gang : 1u) : 0; }
 
 extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
   if (!b || !b->launched) return 0.0f;

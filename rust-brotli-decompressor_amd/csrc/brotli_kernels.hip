@@ -1143,8 +1143,11 @@ __device__ __forceinline__ uint32_t dictionary_word_bytes(gcu8* dict, uint32_t o
 //   helper's answer, round moved.
 enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE = 5, HC_NW = 6, HC_OUT_LO = 7, HC_OUT_HI = 8, HC_CAPPED = 9, HC_FAILED = 10,
        HC_SCAN_BASE = 11 /* LDS base of the command engine (brotli_scan_engine.h); 0 = this block has none */, HC_NW_ALL = 12 /* waves in the block */,
-       HC_EXT_BASE = 13 /* LDS base of the command-record ring of the parse / copy split (SPX_BYTES, in the free tail of the table arena); 0 = this metablock has none */ };
-enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6, HK_PATH2 = 7, HK_PATHG = 8 };  // HC_KIND
+       HC_EXT_BASE = 13 /* LDS base of the command-record ring of the parse / copy split (SPX_BYTES, in the free tail of the table arena); 0 = this metablock has none */,
+       // a gang of blocks on one stream (see GC_* below): this block's number in it (0: the stream's owner), the gang's blocks, its control block in memory,
+       // the owner's count of the engine's invocations (a helper's: the last one it has seen), the bytes of the table arena in use
+       HC_GANG_ROLE = 14, HC_GANG_M = 15, HC_GANG_LO = 16, HC_GANG_HI = 17, HC_GANG_EPOCH = 18, HC_ARENA_TOP = 19 };
+enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6, HK_PATH2 = 7, HK_PATHG = 8, HK_PATHR = 9 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
        // with its own: round resolved, fell in (1/0), literals of that chain before it did, the helper's literals before
@@ -1161,6 +1164,45 @@ __device__ __forceinline__ uint32_t hw_ld(uint32_t slot, uint32_t k) { return rf
 __device__ __forceinline__ void hw_st(uint32_t slot, uint32_t k, uint32_t v) { if (lane_id() == 0) *reinterpret_cast<lds_vu32*>(&g_smem[slot + HL_CTL + 4u * k]) = v; }
 __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+
+// ---- Several CUs on one stream: the gang's control block in memory (one per stream of a gang launch; the host zeroes it) ----
+// A batch of fewer streams than half the CUs is launched as GANGS: the stream's owner -- the block that decodes it, as ever -- and up to
+// seven helper blocks, which do nothing but the path engine's regions in turns with it (brotli_path_engine.h, PE_CFG_REMOTE).  What they
+// tell each other goes through these words, every access an agent-scope atomic (it bypasses the CU's L1; the L2s of the chip's eight XCDs
+// are not coherent for plain accesses):
+//   JOINED   helpers that have started (the owner takes the gang or leaves it: a helper that is not running cannot be waited for)
+//   EPOCH    the engine's invocations so far, the owner's word: a helper waits for the next one; GC_QUIT: the stream is done
+//   READY    invocations the helpers have left, summed (the owner starts the next one when all of them have left the last)
+//   PLAN     where the regions' windows lie: generation << 48 | first region << 32 | its first bit; region k's window starts
+//            (k - first) strides behind it.  The engine whose turn it is writes a new one where the stream does not enter its window.
+//   STOP     epoch << 32 | regions resolved in all: the invocation is over
+//   EXEC     epoch << 32 | regions whose output is in memory
+//   STATE    the stream's state behind region k - 1's resolve: 26 granules of value | tag << 32, tag = epoch << 12 | k -- a granule is
+//            one eight-byte store and says itself whether it is the one waited for: no flag, no fence
+//   PARAMS, BR, ARENA   the invocation's parameters, the bit reader's words and the image of the owner's table arena (plain stores
+//            behind a release fence, in front of EPOCH; a helper's acquire fence stands behind its look at EPOCH)
+constexpr uint32_t GC_JOINED = 0, GC_EPOCH = 4, GC_READY = 8, GC_PLAN = 16, GC_STOP = 24, GC_EXEC = 32, GC_ARENA_BYTES = 40, GC_STATE = 64,
+                   GC_PARAMS = 512, GC_BR = 640, GC_ARENA = 1024, GC_ARENA_CAP = 48u << 10, GC_STRIDE = GC_ARENA + GC_ARENA_CAP;
+constexpr uint32_t GC_QUIT = 0xFFFFFFFFu, GC_STATE_WORDS = 26, GC_MAX_REGIONS = 4000;
+static_assert(GC_STRIDE == BROTLI_AMD_GANG_CTL_BYTES && GC_STATE + 8u * GC_STATE_WORDS <= GC_PARAMS, "the gang's control block");
+__device__ __forceinline__ gu8* gang_ctl() { return (gu8*)(uintptr_t)((uint64_t)hc_ld(HC_GANG_LO) | ((uint64_t)hc_ld(HC_GANG_HI) << 32)); }
+__device__ __forceinline__ uint32_t gang_ld32(gu8* gc, uint32_t off) { return __hip_atomic_load(reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(gc + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t gang_ld64(gu8* gc, uint32_t off) { return __hip_atomic_load(reinterpret_cast<__attribute__((address_space(1))) uint64_t*>(gc + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gang_st32(gu8* gc, uint32_t off, uint32_t v) { __hip_atomic_store(reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(gc + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gang_st64(gu8* gc, uint32_t off, uint64_t v) { __hip_atomic_store(reinterpret_cast<__attribute__((address_space(1))) uint64_t*>(gc + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t gang_add32(gu8* gc, uint32_t off, uint32_t v) { return __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(gc + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (-DBROTLI_AMD_GANG_STATS: counters of the gang's life in its control block, from GC_STATS on; the host prints them -- BrotliAmdBatchWait)
+constexpr uint32_t GC_STATS = 704;   // u64 x 40
+#ifdef BROTLI_AMD_GANG_STATS
+#define GANG_STAT(gc_, k_, v_) do { if (lane_id() == 0) __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(1))) unsigned long long*>((gc_) + GC_STATS + 8u * (k_)), (unsigned long long)(v_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define GANG_STAT(gc_, k_, v_) do { } while (0)
+#endif
+// (the stores so far have left this wave: what is stored next cannot overtake them)
+__device__ __forceinline__ void gang_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// plain stores of this CU (every wave has waited for its own) reach the other CUs / a look at another CU's word is followed by fresh data
+__device__ __forceinline__ void gang_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void gang_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 // walk over code lengths from bit `entry` of a window: which offsets start a symbol, and where the chain leaves it
 #define SPEC_WALK(Lw, entry, starts, woff) do { uint32_t t1_; \
@@ -1316,6 +1358,7 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
 namespace pe16 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }   // one engine of sixteen waves, the lean form: no words of the static dictionary
 namespace pe16g { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }  // ... the general form
 namespace pe8 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }    // two engines of eight, regions in turns
+namespace pe16r { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }  // one engine of sixteen a block, the blocks of a gang taking the regions in turns
 // which command engine blocks of sixteen waves use: 0 = the path engine where it applies (brotli_path_engine.h), 1 = the scan
 // engine only (experiments, A/B tests: BROTLI_AMD_ENGINE=scan)
 __device__ uint32_t g_engine_mode = 2;
@@ -1489,6 +1532,7 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     if (kind == HK_PATH) { seq = rfl(pe16::path_engine(me)); continue; }   // (back with the last request it answered: see there)
     if (kind == HK_PATHG) { seq = rfl(pe16g::path_engine(me)); continue; }
     if (kind == HK_PATH2) { seq = rfl(pe8::path_engine(me)); continue; }
+    if (kind == HK_PATHR) { seq = rfl(pe16r::path_engine(me)); continue; }
     if (kind == HK_SPLIT) {  // a context-modelled metablock: wave 1 copies (if asked to), wave 2 parses command records; the others go back to sleep
       if (rfl(me) == 1u && (g_engine_mode & 2u) == 0u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave();
       continue;
@@ -1962,6 +2006,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 #define PE_CFG_RBL 32768
 #define PE_CFG_PIPE 0
 #define PE_CFG_DICT 0
+#define PE_CFG_REMOTE 0
 #include "brotli_path_engine.h"
 #undef PE_CFG_NS
 #undef PE_CFG_DICT
@@ -1969,6 +2014,15 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 #define PE_CFG_DICT 1
 #include "brotli_path_engine.h"
 #undef PE_CFG_NS
+#undef PE_CFG_DICT
+#undef PE_CFG_REMOTE
+#define PE_CFG_NS pe16r
+#define PE_CFG_DICT 0
+#define PE_CFG_REMOTE 1
+#include "brotli_path_engine.h"
+#undef PE_CFG_NS
+#undef PE_CFG_REMOTE
+#define PE_CFG_REMOTE 0
 #undef PE_CFG_WAVES
 #undef PE_CFG_RBL
 #undef PE_CFG_PIPE
@@ -1984,6 +2038,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 #undef PE_CFG_RBL
 #undef PE_CFG_PIPE
 #undef PE_CFG_DICT
+#undef PE_CFG_REMOTE
 using pe16::PE_MIN_INPUT;
 
 // The pending copy of the lean loop lives in registers the compiler does not know about: v[120:123] (16 bytes per lane)
@@ -3322,6 +3377,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter; const uint64_t pp_start = __builtin_amdgcn_s_memtime(); bool pp_first = true; (void)pp_first;
 #endif
   bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
+  bool remote_off = false;          // ... the one-block form from here on, though the stream has a gang of blocks
   bool prefer_scan = false;         // ... or the scan engine: the path engine found its regions bound by their closure (see there)
   bool prefer_general = rfl(args->general_engine) != 0u;   // ... or the path engine's general form: the lean one has stopped in front of a dictionary reference in this stream
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
@@ -3384,7 +3440,25 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         sc_ctl_st(sb, SCC_DICT_LO, (uint32_t)(uintptr_t)dict); sc_ctl_st(sb, SCC_DICT_HI, (uint32_t)((uint64_t)(uintptr_t)dict >> 32));
         const bool use_pipe = use_path && (g_engine_mode & 8u) != 0u && !prefer_one_engine;   // (two engines of eight waves, regions in turns: BROTLI_AMD_ENGINE=path2 -- measured slower than one of sixteen, see DESIGN)
         const bool use_general = use_path && !use_pipe && prefer_general;
-        hc_st(HC_KIND, use_pipe ? (uint32_t)HK_PATH2 : use_general ? (uint32_t)HK_PATHG : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
+        // (the stream's owner in a gang of blocks: the gang's form of the engine -- not for a literal run that wants regions of its own, nor for
+        // words of the static dictionary: those are the one-block forms')
+        bool use_remote = use_path && !use_pipe && !use_general && !prefer_one_engine && !remote_off && hc_ld(HC_GANG_M) > 1u;
+        if (use_remote) {
+          const uint32_t ep = hc_ld(HC_GANG_EPOCH);
+          if (ep == 0u) {   // the first time: have the helpers all started?  (They do so with the owner, give or take a microsecond; a block that is not running cannot be waited for)
+            gu8* const gc = gang_ctl();
+            const uint32_t want = hc_ld(HC_GANG_M) - 1u;
+            uint32_t tries = 0;
+            while (gang_ld32(gc, GC_JOINED) < want && tries < 2048u) { __builtin_amdgcn_s_sleep(16); tries++; }
+            if (gang_ld32(gc, GC_JOINED) < want) {   // the stream stays this block's alone; a helper that turns up finds the gang dissolved
+              if (lane == 0) gang_st32(gc, GC_EPOCH, GC_QUIT);
+              hc_st(HC_GANG_M, 1u);
+              use_remote = false;
+            }
+          }
+          if (use_remote) hc_st(HC_GANG_EPOCH, ep + 1u);
+        }
+        hc_st(HC_KIND, use_remote ? (uint32_t)HK_PATHR : use_pipe ? (uint32_t)HK_PATH2 : use_general ? (uint32_t)HK_PATHG : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
 #ifdef BROTLI_AMD_PROFILE_SCAN
@@ -3393,7 +3467,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #ifdef BROTLI_AMD_PE_DEBUG
         if (blockIdx.x == 0 && lane == 0) printf("engine in: P %llu bl1 %u quota %u mlen %d commands so far %llu\n", (unsigned long long)P, bl1, quota, mlen, (unsigned long long)num_commands);
 #endif
-        const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_general ? rfl(pe16g::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+        const uint32_t took = use_remote ? rfl(pe16r::path_engine(0)) : use_pipe ? rfl(pe8::path_engine(0)) : use_general ? rfl(pe16g::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
 #ifdef BROTLI_AMD_PE_DEBUG
         if (blockIdx.x == 0 && lane == 0) printf("engine out: tick %llu took %u, P %llu form %u\n", (unsigned long long)__builtin_amdgcn_s_memtime(), took, (unsigned long long)(LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32)), LEAN_LD(L_SC_POS_HI));
 #endif
@@ -3409,6 +3483,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const uint32_t form_raw = LEAN_LD(L_SC_POS_HI), form = form_raw & 0xFFu;
         const bool declined = ((form_raw >> 8) & 1u) != 0u;
         if (((form_raw >> 10) & 1u) != 0u) prefer_general = true;   // (the lean form stopped in front of a dictionary reference)
+        if (((form_raw >> 11) & 1u) != 0u) remote_off = true;       // (a gang's regions were bound by their closure: the one-block form's for the rest of the metablock)
         if (((form_raw >> 9) & 1u) != 0u) prefer_scan = true;   // (the path engine's regions were bound by their closure: a stream of few literals -- the scan engine's from here on)   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
@@ -3425,7 +3500,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         lit_pos = P;
         force_checked = form == SCX_BEGIN ? 1u : 0u;  // (the command the engine stopped IN FRONT OF goes through the checked stages; one it stopped inside is on its way through them already)
         // (an invocation that got nowhere -- few commands AND few bytes: a long literal run is one command -- makes the next ones rarer)
-        if (declined) { prefer_one_engine = true; force_checked = 0u; }
+        if (declined) { prefer_one_engine = true; force_checked = 0u; if (use_remote && took == 0u) remote_off = true; }   // (a gang that met a long literal run first thing: a metablock of such runs, as a rule -- the one-block form's)
         else if (took < 64u && P - P_before < 4096u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
         insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
         distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
@@ -4337,6 +4412,16 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 #ifdef BROTLI_AMD_PROFILE_HDR
   const uint64_t hdr_prof_t0 = __builtin_amdgcn_s_memtime();
 #endif
+  // A gang launch (queue[2] blocks a stream, sixteen waves each; see GC_*): block b is member (b mod 8 gang) / 8 of the gang of stream
+  // (b / (8 gang)) 8 + b mod 8 -- the members of a gang are eight block numbers apart, which is how the hardware deals blocks to the same
+  // XCD (their L2 is one: what they hand each other does not cross the fabric; a matter of speed, not of correctness).  Member 0 owns the stream.
+  uint32_t gang_m = rfl(queue[2]), gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
+  if (gang_m > 1u && gang_m <= 8u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP) {
+    gang_role = (blockIdx.x % (8u * gang_m)) >> 3;
+    gang_stream = (blockIdx.x / (8u * gang_m)) * 8u + (blockIdx.x & 7u);
+    if (gang_stream >= n_streams) return;   // (the streams are not a multiple of eight: a gang without a stream)
+    gang_addr = ((uint64_t)rfl(queue[4]) | ((uint64_t)rfl(queue[5]) << 32)) + (uint64_t)gang_stream * GC_STRIDE;
+  } else gang_m = 1u;
   // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
     const uint32_t nw = blockDim.x >> 6, nr = nw < SPEC_MAX_WAVES ? nw : SPEC_MAX_WAVES;  // waves in the block, waves that take part in rounds
@@ -4347,10 +4432,19 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     if (threadIdx.x < 20u)
       lds_st32(LDS_HCTL + 4u * threadIdx.x, threadIdx.x == HC_KIND && nw < 2u ? (uint32_t)HK_NO_ROUNDS : threadIdx.x == HC_BASE ? slots :
                                             threadIdx.x == HC_NW ? nr : threadIdx.x == HC_NW_ALL ? nw :
-                                            threadIdx.x == HC_SCAN_BASE && nw == SC_WAVES ? behind : 0u);
+                                            threadIdx.x == HC_SCAN_BASE && nw == SC_WAVES ? behind :
+                                            threadIdx.x == HC_GANG_ROLE ? gang_role : threadIdx.x == HC_GANG_M ? gang_m :
+                                            threadIdx.x == HC_GANG_LO ? (uint32_t)gang_addr : threadIdx.x == HC_GANG_HI ? (uint32_t)(gang_addr >> 32) :
+                                            threadIdx.x == HC_ARENA_TOP ? lds_arena_bytes : 0u);
     if (nw >= 2u && threadIdx.x < nr * 16u) lds_st32(slots + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
   }  // (launched without helper waves: no rounds)
   __syncthreads();
+  if (gang_role != 0u) {   // a helper block of a gang: the path engine's regions of its owner's stream, nothing else (see there)
+    if ((uint32_t)(uintptr_t)g_dynamic_lds != 0u) return;   // (no LDS addressing: the owner finds the gang short of a block and goes on alone)
+    if (threadIdx.x == 0u) (void)gang_add32(gang_ctl(), GC_JOINED, 1u);
+    (void)pe16r::path_engine(rfl(threadIdx.x >> 6));
+    return;
+  }
   if (rfl(threadIdx.x >> 6) != 0u) {
     if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u)
       helper_wave(rfl(threadIdx.x >> 6), as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block + (scratch_per_block - BROTLI_AMD_SPEC_SCRATCH)));
@@ -4383,10 +4477,15 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
   if (lane < 26) bl = (uint32_t)kBlockLenBase[lane] | ((uint32_t)kBlockLenExtra[lane] << 16);
   lds_sync();
 
-  for (;;) {
+  for (uint32_t pulls = 0;; pulls++) {
     uint32_t idx = 0;
-    if (lane == 0) idx = atomicAdd(queue, 1u);
-    idx = rfl(idx);
+    if (gang_m > 1u) {   // (a gang's owner: its stream, and no other)
+      if (pulls != 0u) break;
+      idx = gang_stream;
+    } else {
+      if (lane == 0) idx = atomicAdd(queue, 1u);
+      idx = rfl(idx);
+    }
     if (idx >= n_streams) break;
     // (the host may give an order in which to take the streams -- longest first, so that the last blocks to finish do not
     // start a long stream when the others are done: queue[1] != 0, stream of the k-th pull in queue[16 + k])
@@ -4573,6 +4672,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
       printf("\nkernel ticks of block 0 in this launch: %llu; the path engine's regions so far (all launches): %llu\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - scan_prof_t0), eng); }
   }
 #endif
+  if (gang_m > 1u && lane == 0) gang_st32(gang_ctl(), GC_EPOCH, GC_QUIT);   // the stream is done: the gang's helper blocks may go
   // no more streams: the helper waves may go
   hc_st(HC_KIND, 2);
   lds_release();

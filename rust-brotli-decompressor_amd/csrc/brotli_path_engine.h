@@ -34,13 +34,20 @@
 // BYHAND: a cap was hit), and the walk starts at the stream's real position.
 // (no include guard: brotli_kernels.hip includes this file once per configuration -- PE_CFG_NS the namespace, PE_CFG_WAVES the
 // waves of one engine, PE_CFG_RBL its region in stream bits, PE_CFG_PIPE whether two engines of a block take turns)
-#if !defined(PE_CFG_NS) || !defined(PE_CFG_WAVES) || !defined(PE_CFG_RBL) || !defined(PE_CFG_PIPE) || !defined(PE_CFG_DICT)
+// PE_CFG_REMOTE (round 5): the engines that take a stream's regions in turns are BLOCKS -- a gang of up to eight, a CU each,
+// on one stream (see "several CUs on one stream" below); what they tell each other goes through memory.)
+#if !defined(PE_CFG_NS) || !defined(PE_CFG_WAVES) || !defined(PE_CFG_RBL) || !defined(PE_CFG_PIPE) || !defined(PE_CFG_DICT) || !defined(PE_CFG_REMOTE)
 #error "brotli_path_engine.h: configuration macros missing"
+#endif
+#if PE_CFG_PIPE && PE_CFG_REMOTE
+#error "brotli_path_engine.h: two engines a block or a gang of blocks, not both"
 #endif
 namespace PE_CFG_NS {
 constexpr uint32_t GW = PE_CFG_WAVES;             // waves of one engine
-constexpr bool PIPE = PE_CFG_PIPE != 0;           // two engines of GW waves a block, taking the stream's regions in turns
-static_assert(PIPE ? 2u * GW == SC_WAVES : GW == SC_WAVES, "engines and waves of a block");
+constexpr bool PIPE2 = PE_CFG_PIPE != 0;          // two engines of GW waves a block, taking the stream's regions in turns
+constexpr bool REMOTE = PE_CFG_REMOTE != 0;       // ... or one engine a block, and the blocks of a gang taking them in turns
+constexpr bool PIPE = PIPE2 || REMOTE;            // (either way: a region's tables are built before the stream's entry into it is known)
+static_assert(PIPE2 ? 2u * GW == SC_WAVES : GW == SC_WAVES, "engines and waves of a block");
 
 constexpr uint32_t PE_RBL = PE_CFG_RBL;           // stream bits per region (local bit 0 = the first bit of the region's first dword)
 constexpr uint32_t PE_CHUNKS = PE_RBL / 32;       // one lane per chunk of 32 bits: the whole block
@@ -70,6 +77,10 @@ constexpr uint32_t PE_RUN_SB = BROTLI_AMD_PE_RUN_SB;   // a long literal run's r
 constexpr uint32_t PE_RUN_RBL = 64u * GW * PE_RUN_SB;   // ... and the bits of such a region (no tables per bit: its input lies in the input's and J1's room)
 constexpr uint32_t PE_MIN_INPUT = 4096;           // stream bits that must be left for a region to be worth its set-up
 constexpr uint32_t PE_PIPE_MARGIN = 1024;          // two engines: a region's tables start this many bits in front of where the stream is expected to enter it
+#ifndef BROTLI_AMD_PE_REMOTE_MARGIN
+#define BROTLI_AMD_PE_REMOTE_MARGIN 1024
+#endif
+constexpr uint32_t PE_REMOTE_MARGIN = BROTLI_AMD_PE_REMOTE_MARGIN;   // a gang of blocks: the same margin between the windows of its plan
 constexpr uint32_t PE_PIPE_USEFUL = 4096;          // ... and are used if the stream enters them with at least this many bits to go
 constexpr uint32_t PE_PIPE_HAND = 48;              // ... and the walk evaluates this many states itself before the stream is on the path (commands without literals, one after the other)
 constexpr uint32_t PE_PIPE_DECLINE = 2500;         // ... and a literal run from here on is the one-engine form's (its regions hold 6656 path positions, these half)
@@ -137,11 +148,11 @@ constexpr uint32_t PE_SET_BYTES = PE_ANCH + 128 * 4;              // one engine'
 // most -- 45 bits beyond L, inside the six dwords (192 bits) of input that every region stages behind its last one.
 static_assert(15u + 62u + 96u <= 128u + 6u * 32u, "a record's reads stay inside the region's input slack");
 constexpr uint32_t PE_TD_ENTRIES = 1024;                          // (920 is the most a distance alphabet without large window takes; a large-window table that needs more keeps its metablock off the engine: td_ok)
-constexpr uint32_t PE_SHARED_CTL = PIPE ? 1024u : 0u;             // the shared control words (two engines)
-constexpr uint32_t PE_TD = PIPE ? PE_SHARED_CTL : PE_SET_BYTES;   // u16 per entry of the distance code's table: the same two levels, a leaf's value = bits of the whole distance code (symbol + extra)
+constexpr uint32_t PE_SHARED_CTL = PIPE2 ? 1024u : 0u;            // the shared control words (two engines)
+constexpr uint32_t PE_TD = PIPE2 ? PE_SHARED_CTL : PE_SET_BYTES;  // u16 per entry of the distance code's table: the same two levels, a leaf's value = bits of the whole distance code (symbol + extra)
 constexpr uint32_t PE_TC = PE_TD + PE_TD_ENTRIES * 2;             // u32 per command symbol: insert base | insert extra bits << 15 | copy extra bits << 20 | implicit distance << 25
-constexpr uint32_t PE_SET0 = PIPE ? PE_TC + 704 * 4 : 0u;         // the first engine's tables
-constexpr uint32_t PE_BYTES = PIPE ? PE_SET0 + 2u * PE_SET_BYTES : PE_TC + 704 * 4;
+constexpr uint32_t PE_SET0 = PIPE2 ? PE_TC + 704 * 4 : 0u;        // the first engine's tables
+constexpr uint32_t PE_BYTES = PIPE2 ? PE_SET0 + 2u * PE_SET_BYTES : PE_TC + 704 * 4;
 static_assert(PE_BYTES <= SC_BYTES, "the path engine lives in the scan engine's LDS");
 static_assert(PE_STATES * 2 <= PE_RBL + 64 && PE_WCAP * 2 <= PE_WSTB && PE_CMDS * 4 <= PE_CHUNKS * 4 && PE_STATES % 8 == 0, "overlays");
 static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR % 4 == 0 && PE_NEXT % 4 == 0 && PE_LIST % 4 == 0 && PE_TD % 4 == 0 && PE_TC % 4 == 0 && PE_SET0 % 16 == 0 && PE_SET_BYTES % 16 == 0, "alignment");
@@ -156,6 +167,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
        PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
+       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_BUILT = 158 /* ... whether its tables are built */,
        PEC_FIN = 156 /* a long literal run has ended in this region: its command's distance and copy are wave 0's, in place */,
        PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
        PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
@@ -170,7 +182,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
 // did, and tells the caller, who takes the general form (PE_CFG_DICT 1) for the rest of the stream.  A stream without such words -- the
 // metric's -- never runs the general form: what that form carries had cost it 4 % through the allocation of one very large function's
 // registers (128 a wave, and the function spills).
-#if PE_CFG_DICT && !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_NO_DICT)
+#if PE_CFG_DICT && !PE_CFG_PIPE && !PE_CFG_REMOTE && !defined(BROTLI_AMD_PE_NO_DICT)
 #define PE_DICT 1
 #else
 #define PE_DICT 0
@@ -673,7 +685,12 @@ namespace PE_CFG_NS {
 #else
 #define PE_BAR() __syncthreads()
 #endif
+#if PE_CFG_REMOTE
+__device__ __forceinline__ void pe_spin_check(uint32_t& spins) { if (++spins > (1u << 22)) __builtin_trap(); }   // (a gang's waits inside an invocation: some seconds)
+#define PE_SPIN_CHECK(s_) pe_spin_check(s_)
+#else
 #define PE_SPIN_CHECK(s_) do { } while (0)
+#endif
 #endif
 
 // One invocation: every wave of the block calls it (wave 0 from process_commands, the others from helper_wave).
@@ -724,15 +741,66 @@ __device__ __noinline__ void pe_dict_word(const uint32_t pbs, const uint32_t pb,
 __device__ __noinline__ uint32_t path_engine(const uint32_t me_) {
 pe_again:
   const uint32_t lane = lane_id();
-  const uint32_t eng = PIPE ? rfl(me_) / GW : 0u;                 // the engine this wave belongs to
-  const uint32_t me = PIPE ? rfl(me_) % GW : rfl(me_);            // ... and its number in it
-  const uint32_t T = PIPE ? threadIdx.x % (64u * GW) : threadIdx.x;
+  const uint32_t eng = PIPE2 ? rfl(me_) / GW : 0u;                // the engine this wave belongs to
+  const uint32_t me = PIPE2 ? rfl(me_) % GW : rfl(me_);           // ... and its number in it
+  const uint32_t T = PIPE2 ? threadIdx.x % (64u * GW) : threadIdx.x;
   const uint32_t pbs = hc_ld(HC_SCAN_BASE);                       // what the block's engines share
   const uint32_t pb = pbs + PE_SET0 + eng * PE_SET_BYTES;         // this engine's tables
   if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_NXOK, 0u); lds_st32(pb + PE_CTL + 4u * PEC_PDX, 0u); lds_st32(pb + PE_CTL + 4u * PEC_OVF, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DSEEN, 0u); }
   if (PIPE) {   // what the two engines tell each other starts from nothing
     if (threadIdx.x < 8u) lds_st32(pbs + PE_CTL + 4u * (PEC_RESOLVED + threadIdx.x), 0u);
     if (T == 0u) lds_st32(pb + PE_CTL + 4u * PEC_GBAR, 0u);
+  }
+  // ---- several CUs on one stream (PE_CFG_REMOTE; the control block's words: GC_* in brotli_kernels.hip) ----
+  // The blocks of a gang take the stream's regions in turns as the two engines of a block do -- region k is block k mod gang's --, each with
+  // the whole of its CU: the tables of a region (70 K clocks of the 130 K a region costs one CU) are built ahead by as many CUs as it takes,
+  // and the stream itself only waits for the walk, the details and the resolve of the region before (and the execute for the output of the
+  // region before).  The OWNER is the block that decodes the stream; it comes here from process_commands as ever and is member 0.  The HELPERS
+  // live in this function: they wait for the owner's next invocation (EPOCH), take its parameters and the image of its table arena, do their
+  // regions, say that they have left (READY) and wait again.
+  uint32_t role = 0, gang_m = 1, epoch = 0; gu8* gc = nullptr; (void)role; (void)gang_m; (void)epoch; (void)gc;
+  const uint64_t gs_t0 = __builtin_amdgcn_s_memtime(); (void)gs_t0;
+  if (REMOTE) {
+    role = hc_ld(HC_GANG_ROLE); gang_m = hc_ld(HC_GANG_M); gc = gang_ctl();
+    if (role == 0u) {
+      epoch = hc_ld(HC_GANG_EPOCH);
+      if (threadIdx.x == 0u) {   // the helpers have all left the invocation before (they read the image below when they enter one)
+        uint32_t spins = 0; (void)spins;
+        const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
+        while (gang_ld32(gc, GC_READY) != (gang_m - 1u) * (epoch - 1u)) { __builtin_amdgcn_s_sleep(8); PE_SPIN_CHECK(spins); }
+        GANG_STAT(gc, 0, 1); GANG_STAT(gc, 5, __builtin_amdgcn_s_memtime() - t0_);
+      }
+      __syncthreads();
+      const uint32_t ab = (hc_ld(HC_ARENA_TOP) + 15u) & ~15u;
+      for (uint32_t i = threadIdx.x << 4; i < ab; i += 64u * SC_WAVES * 16u)
+        *reinterpret_cast<gu32x4*>(gc + GC_ARENA + i) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[LDS_FIXED + i]);
+      if (threadIdx.x < 32u) *reinterpret_cast<gu32*>(gc + GC_PARAMS + 4u * threadIdx.x) = lds_ld32(pbs + PE_CTL + 4u * threadIdx.x);
+      else if (threadIdx.x < 40u) *reinterpret_cast<gu32*>(gc + GC_BR + 4u * (threadIdx.x - 32u)) = lds_ld32(LDS_BR + 4u * (threadIdx.x - 32u));
+      else if (threadIdx.x == 40u) *reinterpret_cast<gu32*>(gc + GC_ARENA_BYTES) = ab;
+      gang_drain();
+      __syncthreads();
+      if (threadIdx.x == 0u) { gang_release(); GANG_STAT(gc, 18, __builtin_amdgcn_s_memtime() - gs_t0); }   // (the state, the plan and EPOCH follow below, where wave 0 has put the state together)
+    } else {
+      if (threadIdx.x == 0u) {
+        const uint32_t last = *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_EPOCH]);
+        uint32_t e;
+        for (uint32_t idle = 0;; idle++) {   // (no cap: the owner may be busy with something else for as long as its stream takes)
+          e = gang_ld32(gc, GC_EPOCH);
+          if (e == GC_QUIT || e > last) break;
+          if (idle < 4096u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(127);
+        }
+        if (e != GC_QUIT) gang_acquire();
+        *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_EPOCH]) = e;
+      }
+      __syncthreads();
+      epoch = hc_ld(HC_GANG_EPOCH);
+      if (epoch == GC_QUIT) return 0u;
+      const uint32_t ab = *reinterpret_cast<gu32*>(gc + GC_ARENA_BYTES);
+      for (uint32_t i = threadIdx.x << 4; i < ab && i < GC_ARENA_CAP; i += 64u * SC_WAVES * 16u)
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(&g_smem[LDS_FIXED + i]) = *reinterpret_cast<gu32x4*>(gc + GC_ARENA + i);
+      if (threadIdx.x < 32u) lds_st32(pbs + PE_CTL + 4u * threadIdx.x, *reinterpret_cast<gu32*>(gc + GC_PARAMS + 4u * threadIdx.x));
+      else if (threadIdx.x < 40u) lds_st32(LDS_BR + 4u * (threadIdx.x - 32u), *reinterpret_cast<gu32*>(gc + GC_BR + 4u * (threadIdx.x - 32u)));
+    }
   }
   __syncthreads();  // the parameters are in place
 #ifdef BROTLI_AMD_PROFILE_SCAN
@@ -752,7 +820,7 @@ pe_again:
   else if (lane >= 32 && lane < 56) c.lut_vgpr = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
 
   // ---- wave 0: the stream's state (uniform), into its LDS words ----
-  if (me == 0) {
+  if (me == 0 && (!REMOTE || role == 0u)) {
     PeStream st;
     st.b = pe_ctl_ld(pbs, SCC_ENTRY);  // next command (bits from the engine's origin)
     st.P = (uint64_t)LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32);
@@ -767,6 +835,14 @@ pe_again:
     st.first = 1u;
     st.s_bits = 0u; st.s_cmds = 0u; st.s_lits = 0u; st.s_dsts = 0u;
     pe_st_store(pbs, st);
+    if (REMOTE) {   // the invocation is everybody's: the stream's state in front of region 0, the plan (from region 0 on, at the entry), then its number
+      lds_sync();
+      const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : 1u;
+      if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)(epoch << 12) << 32));
+      if (lane == 0u) gang_st64(gc, GC_PLAN, (uint64_t)st.b);
+      gang_drain();
+      if (lane == 0u) gang_st32(gc, GC_EPOCH, epoch);
+    }
   }
   // ---- the records' tables (see pe_eval_rec) ----
   for (uint32_t i = threadIdx.x; i < 704u; i += 64u * SC_WAVES) {
@@ -803,6 +879,7 @@ pe_again:
   uint32_t gb_target = 0; (void)gb_target;               // (two engines: this engine's barriers so far, times GW)
   uint32_t rseq = 0;                                     // regions of this invocation so far (the one at hand included)
   uint32_t kseq = 0; (void)kseq;                         // (two engines: the number of the region this engine is at)
+  uint64_t gs_arr = 0; (void)gs_arr;                     // (gang statistics: when the stream arrived at this engine's region)
 #ifdef BROTLI_AMD_PROFILE_REGIONS
   uint64_t rg_ts[10] = {}; uint64_t rg_prev_end = 0; uint64_t rg_rt[4] = {}; uint32_t rg_rn[4] = {};
 #define RG_STAMP(k) do { rg_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1102,7 +1179,7 @@ pe_again:
       }
       pe_st_store(pbs, st);
     }
-#if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_OLD_RUN_REGIONS)
+#if !PE_CFG_PIPE && !PE_CFG_REMOTE && !defined(BROTLI_AMD_PE_OLD_RUN_REGIONS)
     PE_BAR();   // (the first region's mode is wave 0's word)
     if (pe_ctl_ld(pb, PEC_MODE) != 0u) { c.L = pe_ctl_ld(pb, PEC_L); return run_region(); }
 #endif
@@ -1502,7 +1579,7 @@ pe_again:
         if (slot >= PE_WCAP) id = PEN_NONE;   // (no room for the entry's state: nothing listed, the checked loop's)
         else for (uint32_t tries = 0;; tries++) {
           if (lane == 0) lds_st16(pb + PE_WST + (slot << 1), desc);
-          if (tries >= PE_PIPE_HAND) { if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), PEN_BYHAND); break; }   // (the region ends in front of this state)
+          if (tries >= PE_PIPE_HAND) { if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), PEN_BYHAND); if (REMOTE) GANG_STAT(gc, 35, 1); break; }   // (the region ends in front of this state)
           const PeParse pr = pe_eval<false, false>(c, desc & 0x7FFFu, desc >> 15, true);
           const uint32_t cd = rfl(pr.code), nx = rfl(pr.next);
           const bool more = cd == 1u && slot + 1u < PE_WCAP;
@@ -1513,11 +1590,27 @@ pe_again:
         lds_sync();
       }
 #if !PE_CFG_PIPE && !defined(BROTLI_AMD_PE_NO_WALK_ASM)
-      {
+      bool walk_on = true;
+      if (REMOTE) {
+        // (a gang: the anchors up to the first one that stands on a state NEXT8 knows -- as a rule the first -- by the records, eight hops each)
+        while (id >= id_hand && id < PEN_FIRST_SPECIAL) {
+          uint32_t n8 = id;
+          for (uint32_t h = 0; h < PE_JUMP; h++) n8 = n8 < PEN_FIRST_SPECIAL ? rfl(lds_ld16(pb + PE_NEXT + (n8 << 1))) : (uint32_t)PEN_NONE;
+          if (n8 >= PEN_FIRST_SPECIAL || na >= (PE_CMDS - 64u) / PE_JUMP) { walk_on = false; break; }
+          if (lane == 0) {
+            *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + (na << 2)]) = id;
+            *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_NAPUB]) = na + 1u;
+          }
+          na++; id = n8;
+        }
+        if (id >= PEN_FIRST_SPECIAL) walk_on = false;
+      }
+      if (REMOTE) { id = rfl(id); na = rfl(na); }   // (uniform, and in scalar registers for what follows)
+      if (walk_on) {
         // The anchors by hand: one dependent LDS read an anchor is all the chain asks for, and the compiled loop wrapped it in
         // thirty-five instructions (the lane's own execution mask, the counter in a vector register): 330 clocks an anchor.
         // Here lane 0 alone: the next anchor's read is on its way before this one is stored and published.
-        uint32_t vr, va, vt; uint64_t sv; uint32_t n8s, ts, aa = pb + PE_ANCH;
+        uint32_t vr, va, vt; uint64_t sv; uint32_t n8s, ts, aa = pb + PE_ANCH + (na << 2);
         const uint32_t n8base = pb + PE_N8, pubaddr = pb + PE_CTL + 4u * PEC_NAPUB, cap = (PE_CMDS - 64u) / PE_JUMP;
         asm volatile(
           "s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\t"
@@ -1582,6 +1675,13 @@ pe_again:
         for (uint32_t q = 0; q < (m < 12u ? m + 1u : 12u); q++) printf("     list %u: %x\n", q, lds_ld16(pb + PE_LIST + (q << 1)));
       }
 #endif
+#ifdef BROTLI_AMD_GANG_STATS
+      if (REMOTE && m == 0u && lane == 0 && epoch < 400u) {
+        printf("gang: epoch %u region %u lists nothing: le %u L %u Lp %u Rn %u wn %u id %u id_hand %u desc %x; hand states:", epoch, kseq, le, c.L, c.Lp, c.Rn, wn, id, id_hand, desc);
+        for (uint32_t q = 0; q < 4u; q++) printf(" [%x -> %u]", lds_ld16(pb + PE_WST + ((wn + q) << 1)), lds_ld16(pb + PE_NEXT + ((PE_RANKS + wn + q) << 1)));
+        printf("\n");
+      }
+#endif
       pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
       lds_sync();
       pe_ctl_st(pb, PEC_WDONE, 1u);
@@ -1589,6 +1689,7 @@ pe_again:
       PE_COUNT(26, m); PE_COUNT(27, na);
     }
     PE_PROF(6);
+    if (REMOTE && me == 0) GANG_STAT(gc, 24, __builtin_amdgcn_s_memtime() - gs_arr);   // arrival .. walk done
     {
       const uint32_t k0 = bw << 6;
       uint32_t na_k, m_k;
@@ -1634,6 +1735,7 @@ pe_again:
     }
     PE_BAR();
     RG_STAMP(0);   // walk + details done
+    if (REMOTE && me == 0) GANG_STAT(gc, 25, __builtin_amdgcn_s_memtime() - gs_arr);   // .. details done
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
     PE_PROF(7);
     // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
@@ -1900,15 +2002,44 @@ pe_pass:
           uint32_t lo_, hi_;
           pe_bits64(pb, pbit, lo_, hi_);
           const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr);
-          if (rfl(h_.insert) >= PE_PIPE_DECLINE) { cont = false; pe_ctl_st(pbs, PEC_DECLINE, 1u); }
+          if (rfl(h_.insert) >= (REMOTE ? PE_RUN_MIN : PE_PIPE_DECLINE)) { cont = false; pe_ctl_st(pbs, PEC_DECLINE, 1u); }   // (a gang's regions are whole ones: what one of them holds, it takes)
         }
+        if (REMOTE && wn + 64u > PE_WCAP) {
+          // (a gang: the closure has filled its room -- a stretch of few literals; the one-block form halves its regions there and hands such
+          // streams to the scan engine, this form has no room left for the entry's states: the rest of the metablock is the one-block form's)
+          cont = false; pe_ctl_st(pbs, PEC_DECLINE, 3u);
+        }
+        if (REMOTE && m == 0u && pbit + 64u <= c.L) {
+          // (a gang: the region listed nothing -- as a rule its first command's literal run is more than what is left of the window holds: the
+          // one-block form's, which gives such a run regions of its own; an invocation that takes nothing and does not say why sends the stream
+          // through the one-wave loop for a while -- seen on a 64 MiB stream's seed: a tenth of the commands, two thirds of the time)
+          uint32_t lo_, hi_;
+          pe_bits64(pb, pbit, lo_, hi_);
+          const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr);
+          if (rfl(h_.insert) >= 1024u) pe_ctl_st(pbs, PEC_DECLINE, pe_ctl_ld(pbs, PEC_DECLINE) | 1u);
+          GANG_STAT(gc, 33, rfl(h_.insert) >= 1024u ? 1u : 0u); GANG_STAT(gc, 34, rfl(h_.insert));
+        }
+        if (REMOTE && m == 0u) { GANG_STAT(gc, 32, 1); GANG_STAT(gc, 36, pbit + 64u <= c.L ? 0u : 1u); GANG_STAT(gc, 37, pe_ctl_ld(pb, PEC_M)); }
 #ifdef BROTLI_AMD_PE_DEBUG
         if (PIPE && blockIdx.x == 0 && lane == 0) printf("   region %u: %u commands listed, %u executed, goes on at %u, cont %u, P now %llu ncmd %u\n", kseq, m, kp_total, sn.b, cont ? 1u : 0u, (unsigned long long)sn.P, sn.ncmd);
 #endif
+        if (REMOTE && kseq + 1u >= GC_MAX_REGIONS) cont = false;   // (the tags of the state's granules count regions in twelve bits)
         pe_ctl_st(pb, PEC_CONT, cont ? 1u : 0u);  // (a word of its own: wave 0 writes PEC_GO for the next region while the others may still be here)
         pe_st_store(pbs, sn);
         if (!PIPE) { lds_sync(); pe_ctl_st(pb, PEC_NXOK, rseq); }
-        if (PIPE) {
+        if (REMOTE) {
+          // the stream's state is the next region's from here on: granule by granule, each with the tag its reader waits for; the
+          // invocation's end in a word of its own behind them (whoever waits for a region that will not come looks at it)
+          pe_ctl_st(pb, PEC_MYNEXT, sn.b);
+          lds_sync();
+          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1);
+#ifdef BROTLI_AMD_GANG_STATS
+          if (lane == 0u) gang_st64(gc, 56u, __builtin_amdgcn_s_memtime());
+#endif
+          if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
+          if (!cont) { gang_drain(); if (lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
+        }
+        if (PIPE2) {
           pe_ctl_st(pb, PEC_MYNEXT, sn.b);
           // the stream's state is the next region's from here on; the invocation's end is everybody's to know first
           lds_sync();
@@ -1919,9 +2050,28 @@ pe_pass:
       }
     }
     PE_PROF(11);
+    if (REMOTE && me == 0) GANG_STAT(gc, 26, __builtin_amdgcn_s_memtime() - gs_arr);   // .. resolve done (wave 0 past the publish)
+    if (REMOTE && me == 0 && kseq != 0u) {
+      // (a gang: the word is another CU's; wave 0 looks at it, lets this CU forget what it has cached of the output, and tells the others)
+      uint32_t spins = 0; (void)spins;
+      const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
+      for (;;) {
+        const uint64_t ew = gang_ld64(gc, GC_EXEC);
+        if ((uint32_t)(ew >> 32) == epoch && (uint32_t)ew >= kseq) break;
+        __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
+      }
+      GANG_STAT(gc, 8, __builtin_amdgcn_s_memtime() - t0_);
+#ifdef BROTLI_AMD_GANG_STATS
+      { const uint64_t ts_ = gang_ld64(gc, 48u), now_ = __builtin_amdgcn_s_memtime(); GANG_STAT(gc, 28, now_ > ts_ ? now_ - ts_ : 0u); GANG_STAT(gc, 30, __builtin_amdgcn_s_memtime() - t0_ < 200u ? 1u : 0u); }
+#endif
+      gang_acquire();
+      GANG_STAT(gc, 9, __builtin_amdgcn_s_memtime() - t0_);
+      lds_sync();
+      pe_ctl_st(pbs, PEC_EXECUTED, kseq);
+    }
     if (PIPE) {
       // the region before's output is in memory before this one's copies read it (its engine says so)
-      uint32_t spins = 0;
+      uint32_t spins = 0; (void)spins;
       while (pe_ctl_ld(pbs, PEC_EXECUTED) < kseq) { __builtin_amdgcn_s_sleep(2); PE_SPIN_CHECK(spins); }
       PE_PROF(14);
     }
@@ -2251,10 +2401,15 @@ pe_pass:
     if (PIPE) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       PE_BAR();
-      if (T == 0u) { lds_sync(); pe_ctl_st(pbs, PEC_EXECUTED, kseq + 1u); }
+      if (PIPE2 && T == 0u) { lds_sync(); pe_ctl_st(pbs, PEC_EXECUTED, kseq + 1u); }
+      if (REMOTE && T == 0u) { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_; GANG_STAT(gc, 27, t0_ - gs_arr); gang_release();
+#ifdef BROTLI_AMD_GANG_STATS
+        gang_st64(gc, 48u, __builtin_amdgcn_s_memtime()); gang_drain();
+#endif
+        GANG_STAT(gc, 17, __builtin_amdgcn_s_memtime() - t0_); gang_st64(gc, GC_EXEC, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
     }
   };
-#if !PE_CFG_PIPE
+#if !PE_CFG_PIPE && !PE_CFG_REMOTE
   for (;;) {
     if (me == 0) {
       const PeStream st = pe_st_load(pbs);
@@ -2313,6 +2468,100 @@ pe_pass:
     rg_prev_end = __builtin_amdgcn_s_memtime(); rg_ts[4] = rg_ts[5] = 0;
 #endif
     if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
+  }
+#elif PE_CFG_REMOTE
+  // ---- a gang of blocks: the stream's regions in turns, as the two engines below, but as many regions ahead as the gang has blocks.  Where
+  // the windows lie is a PLAN everybody follows without asking: region k's starts (k - first) strides behind the plan's first bit (a stride is a
+  // region less a margin: a region's walk ends a command or two short of its window's end wherever it entered it).  The engine whose turn it
+  // is finds out whether the stream did enter its window; if not (the region before was cut short: its path's ranks or the closure's room
+  // ran out, a record hit a cap) it builds its tables once more where the stream is and writes a new plan from there -- the engines behind it,
+  // who look at the plan while they wait for the stream, build theirs once more too, side by side.
+  {
+    constexpr uint32_t STRIDE = PE_RBL - PE_REMOTE_MARGIN;
+    // (wave 0) region kseq's window by the plan: its tables' set-up, whether there is anything to build, the plan's generation
+    auto window_by_plan = [&](const uint64_t pl) {
+      const uint32_t k0_ = (uint32_t)(pl >> 32) & 0xFFFFu, base_ = (uint32_t)pl;
+      const uint64_t wb64 = (uint64_t)base_ + (kseq > k0_ ? (uint64_t)(kseq - k0_) * STRIDE : 0ull);
+      const uint32_t W = (uint32_t)((wb64 < (uint64_t)in_limit ? wb64 : (uint64_t)in_limit) >> 5);
+      const uint32_t avail = (W << 5) < in_limit ? in_limit - (W << 5) : 0u;
+      const bool buildable = td_ok && avail >= PE_MIN_INPUT && (uint32_t)(gang_ld64(gc, GC_STOP) >> 32) != epoch;
+      setup_tables(W, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
+      pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48));
+    };
+    for (kseq = role;; kseq += gang_m) {
+      if (me == 0) window_by_plan(gang_ld64(gc, GC_PLAN));
+      PE_BAR();
+      PE_PROF(15);   // (the window)
+      uint32_t plan;
+      for (;;) {
+        const bool built = pe_ctl_ld(pb, PEC_GO) != 0u;
+        if (built) { const uint64_t tb_ = __builtin_amdgcn_s_memtime(); (void)tb_; (void)build(); if (me == 0) { GANG_STAT(gc, 4, 1); if (role == 0u) GANG_STAT(gc, 20, __builtin_amdgcn_s_memtime() - tb_); } }
+        // -- the stream arrives (or the plan has changed, or the invocation is over) --
+        if (me == 0) {
+          const uint32_t mygen = pe_ctl_ld(pb, PEC_MYGEN), want = (epoch << 12) | kseq;
+          uint64_t v; uint32_t spins = 0; bool arrived, stopped, replanned;
+          const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
+          for (;;) {
+            v = gang_ld64(gc, lane < GC_STATE_WORDS ? GC_STATE + 8u * lane : lane == 32u ? GC_STOP : GC_PLAN);
+            arrived = __ballot(lane < GC_STATE_WORDS && (uint32_t)(v >> 32) == want) == ((1ull << GC_STATE_WORDS) - 1ull);
+            stopped = rdlane((uint32_t)(v >> 32), 32) == epoch;
+            replanned = (rdlane((uint32_t)(v >> 32), 33) >> 16) != mygen;
+            if (arrived || stopped || replanned) break;
+            __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
+          }
+          GANG_STAT(gc, role == 0u ? 6 : 7, __builtin_amdgcn_s_memtime() - t0_); gs_arr = __builtin_amdgcn_s_memtime();
+#ifdef BROTLI_AMD_GANG_STATS
+          if (arrived && !stopped && !replanned && kseq != 0u) { const uint64_t ts_ = gang_ld64(gc, 56u); GANG_STAT(gc, 29, gs_arr > ts_ ? gs_arr - ts_ : 0u); }
+#endif
+          plan = 2u;   // 0: the tables are the ones, 1: once more where the stream is, 2: the invocation is over, 3: once more by the new plan, then wait again
+          if (stopped) { }
+          else if (replanned) { GANG_STAT(gc, 3, 1); window_by_plan((uint64_t)rdlane((uint32_t)v, 33) | ((uint64_t)rdlane((uint32_t)(v >> 32), 33) << 32)); plan = 3u; }
+          else {
+            if (lane < 25u) lds_st32(pbs + PE_CTL + 4u * (PEC_STATE + lane), (uint32_t)v);   // the state into this engine's own words
+            lds_sync();
+            if ((rdlane((uint32_t)v, 25) & 1u) != 0u) {   // (the region before's resolve said that the stream goes on)
+              const PeStream st = pe_st_load(pbs);
+              const uint32_t avail = st.b < in_limit ? in_limit - ((st.b >> 5) << 5) : 0u;
+              const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && st.bl1 != 0u;
+              if (go) {
+                const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L);
+                const bool usable = built && st.b >= w0 && st.b + PE_PIPE_USEFUL <= w0 + wl;
+                plan = usable ? 0u : 1u;
+                GANG_STAT(gc, 1, 1);
+                if (!usable) {
+                  GANG_STAT(gc, 2, 1);
+                  if (!built) GANG_STAT(gc, 10, 1); else if (st.b < w0) GANG_STAT(gc, 11, 1); else GANG_STAT(gc, 12, 1);
+                  setup_tables(st.b >> 5, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
+                  if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)kseq << 32) | (uint64_t)st.b);
+                  gang_drain();
+                }
+              }
+            }
+            if (plan == 2u && lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)kseq);
+          }
+          pe_ctl_st(pb, PEC_PLAN, plan);
+        }
+        PE_BAR();
+        plan = pe_ctl_ld(pb, PEC_PLAN);
+        if (plan != 3u) break;
+      }
+      PE_PROF(16);   // (waiting for the stream)
+      if (plan == 2u) break;
+      if (plan == 1u) (void)build();
+      if (me == 0) {
+        const PeStream st = pe_st_load(pbs);
+        pe_ctl_st(pb, PEC_LE, st.b - (pe_ctl_ld(pb, PEC_LBDW) << 5));
+        pe_ctl_st(pb, PEC_MYENTRY, st.b); pe_ctl_st(pb, PEC_MYNEXT, st.b);
+        setup_walk(st.P);
+      }
+      PE_BAR();
+      le = pe_ctl_ld(pb, PEC_LE);
+      P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+      { const uint64_t tc_ = __builtin_amdgcn_s_memtime(); (void)tc_;
+        consume();
+        if (me == 0 && role == 0u) GANG_STAT(gc, 19, __builtin_amdgcn_s_memtime() - tc_); }
+      if (pe_ctl_ld(pb, PEC_CONT) == 0u) break;
+    }
   }
 #else
   // ---- two engines: the stream's regions in turns.  An engine builds the tables of its next region while the other one takes
@@ -2391,6 +2640,10 @@ pe_pass:
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t seq_ = hc_ld(HC_SEQ);   // (the request this invocation answers: the decoding wave posts the next one behind the barrier)
   __syncthreads();  // every store of the engine is in memory before the decoding wave goes on alone
+  if (REMOTE && role != 0u) {   // a helper block: it has left the invocation, and waits for the next one
+    if (threadIdx.x == 0u) gang_add32(gc, GC_READY, 1u);
+    goto pe_again;
+  }
   if (rfl(me_) != 0u) {
 #ifdef BROTLI_AMD_PE_NO_STAY   // (for A/B: every wave returns after every invocation, as in round 3)
     return seq_;
@@ -2400,15 +2653,38 @@ pe_pass:
       if (idle < 256u) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(127);
     }
     lds_acquire();
-    if (hc_ld(HC_SEQ) == seq_ + 1u && hc_ld(HC_KIND) == (PIPE ? (uint32_t)HK_PATH2 : PE_DICT ? (uint32_t)HK_PATHG : (uint32_t)HK_PATH)) goto pe_again;   // (this form of the engine again: the lean one and the general one are two functions)
+    if (hc_ld(HC_SEQ) == seq_ + 1u && hc_ld(HC_KIND) == (REMOTE ? (uint32_t)HK_PATHR : PIPE2 ? (uint32_t)HK_PATH2 : PE_DICT ? (uint32_t)HK_PATHG : (uint32_t)HK_PATH)) goto pe_again;   // (this form of the engine again: the lean one and the general one are two functions)
     return seq_;
   }
 #ifdef BROTLI_AMD_PROFILE_SCAN
   if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += pe_ctl_ld(pbs, PEC_STATE + 6); g_path_prof[33] += 1; }
 #endif
+  if (REMOTE) {
+    // (the owner of a gang) the invocation's end as the gang left it: the regions resolved in all, the stream's state behind the last of them
+    // -- whoever's it was --, and the last one's output in memory
+    uint32_t spins = 0; uint64_t sw_, v; (void)spins;
+    const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
+    for (;;) { sw_ = gang_ld64(gc, GC_STOP); if ((uint32_t)(sw_ >> 32) == epoch) break; __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins); }
+    const uint32_t Kr = (uint32_t)sw_, want = (epoch << 12) | Kr;
+    for (;;) {
+      v = gang_ld64(gc, GC_STATE + 8u * (lane < GC_STATE_WORDS ? lane : 0u));
+      if (__ballot(lane < GC_STATE_WORDS && (uint32_t)(v >> 32) == want) == ((1ull << GC_STATE_WORDS) - 1ull)) break;
+      __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
+    }
+    if (lane < 25u) lds_st32(pbs + PE_CTL + 4u * (PEC_STATE + lane), (uint32_t)v);
+    pe_ctl_st(pbs, PEC_DECLINE, (rdlane((uint32_t)v, 25) >> 1) & 3u);
+    if (Kr != 0u) {
+      for (;;) { const uint64_t ew = gang_ld64(gc, GC_EXEC); if ((uint32_t)(ew >> 32) == epoch && (uint32_t)ew >= Kr) break; __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins); }
+      gang_acquire();
+    }
+    GANG_STAT(gc, 31, Kr == 0u ? 1u : 0u);
+    GANG_STAT(gc, 13, __builtin_amdgcn_s_memtime() - t0_); GANG_STAT(gc, 16, __builtin_amdgcn_s_memtime() - gs_t0); GANG_STAT(gc, 14, Kr); GANG_STAT(gc, 15, rdlane((uint32_t)v, 25) >> 1 & 1u);
+    lds_sync();
+  }
   // ---- hand the stream back in front of the next command (LDS_LEAN, as the scan engine does) ----
   const PeStream st_ = pe_st_load(pbs);
   PeStream st = st_;
+  if (REMOTE) { GANG_STAT(gc, 21, st.ncmd < 64u ? 1u : 0u); GANG_STAT(gc, 22, st.ncmd); GANG_STAT(gc, 23, st.ncmd == 0u ? 1u : 0u); }
   if (st.run_on != 0u) {
     // inside a command whose literal run had regions of its own: the checked loop finishes its literals (what the limits kept
     // back, or none), its distance and its copy; the reference takes a command's whole insert length off when it reads the
@@ -2426,7 +2702,7 @@ pe_pass:
   }
   const bool pdx = PE_DICT && pe_ctl_ld(pb, PEC_PDX) != 0u;   // (behind the distance of a command whose literals are out: postReadDistance, decode.rs:2583)
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && pe_ctl_ld(pbs, PEC_DECLINE) != 0u ? 0x100u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && (pe_ctl_ld(pbs, PEC_DECLINE) & 1u) != 0u ? 0x100u : 0u) | (REMOTE && (pe_ctl_ld(pbs, PEC_DECLINE) & 2u) != 0u ? 0x800u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);

@@ -159,6 +159,7 @@ extern "C" {
     ) -> c_int;
     pub fn BrotliAmdBatchLastKernelMs(batch: *mut BrotliAmdBatch) -> f32;
     pub fn BrotliAmdBatchLastSecondPassCount(batch: *mut BrotliAmdBatch) -> u32;
+    pub fn BrotliAmdBatchLastGang(batch: *mut BrotliAmdBatch) -> u32;
     pub fn BrotliAmdLastError() -> *const c_char;
     pub fn BrotliAmdLastNote() -> *const c_char;
 }

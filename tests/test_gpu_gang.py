@@ -1,0 +1,138 @@
+"""Several CUs on one stream (needs a real MI355X): batches of fewer streams than half the device's CUs give every stream a GANG of
+blocks -- its owner and one, three or seven helper blocks that take the path engine's regions in turns with it
+(csrc/brotli_path_engine.h, PE_CFG_REMOTE; the words they exchange: GC_* in csrc/brotli_kernels.hip).
+
+What the reference does for one stream is one serial loop (src/decode.rs:2330-2744, ProcessCommandsInternal); whatever the number of
+blocks on a stream, its bytes and status words must be the oracle's."""
+import hashlib
+import os
+import random
+import sys
+
+import pytest
+
+import oracle_lib as oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, ROOT)
+
+
+def _w():
+    import workloads as w
+    if not w.encoder_available():
+        pytest.fail("libbrotlienc is not available: the GPU suite needs the encoder of the image for its synthetic streams")
+    return w
+
+
+def _decode(pkg, datas, caps, flags=1):
+    b = pkg.Batch(len(datas))
+    res, outs = b.decode_host(datas, caps, flags)
+    gang = b.last_gang()
+    b.close()
+    return res, outs, gang
+
+
+def _against_oracle(res, outs, datas, caps, flags=1):
+    bad = []
+    for i, (d, cap) in enumerate(zip(datas, caps)):
+        info, exp = oracle.decode(d, cap, flags)
+        r = res[i]
+        ok = (r.result, r.error_code, r.decoded_size, outs[i]) == (info.result, info.error_code, info.decoded_size, exp)
+        if ok and info.result == 1:
+            ok = r.consumed == info.consumed and r.num_commands == info.num_commands and r.num_metablocks == info.num_metablocks
+        if not ok:
+            bad.append((i, (r.result, r.error_code, r.decoded_size, r.consumed, r.num_commands), (info.result, info.error_code, info.decoded_size, info.consumed, info.num_commands), len(d), cap))
+    assert not bad, (len(bad), bad[:8])
+
+
+def _pool(w, rnd):
+    """streams of every kind the command loop knows, each with its raw size: the metric's make-up at several sizes and qualities, its
+    survey variant (a quarter seed), high-entropy literals (long literal runs: regions of their own, the one-block form's), real text at
+    -q 5 (words of the static dictionary), a context-modelled fixture (no engine at all), an executable (dozens of block types)"""
+    pool = []
+    for k, size in enumerate((256 << 10, 1 << 20, 1 << 20, 4 << 20)):
+        raw = w.long_backref_stream(7000 + k, size)
+        pool.append((w.brotli_compress(raw, rnd.choice([4, 5, 5, 9]), rnd.choice([18, 22, 22, 24])), len(raw)))
+    raw = w.long_backref_stream(7100, 2 << 20, seed_shift=2)   # (a quarter of it seed)
+    pool.append((w.brotli_compress(raw, 5, 22), len(raw)))
+    raw = w.high_entropy_stream(7200, 1 << 20)
+    pool.append((w.brotli_compress(raw, 5, 22), len(raw)))
+    gold = os.path.join(ROOT, "tests", "golden", "testdata")
+    alice = open(os.path.join(gold, "alice29.txt.compressed"), "rb").read()
+    info, text = oracle.decode(alice, 200000, 1)
+    assert info.result == 1
+    pool.append((alice, len(text)))
+    pool.append((w.brotli_compress(text, 5, 22), len(text)))
+    exe = open(sys.executable, "rb").read()[: 1 << 20]
+    pool.append((w.brotli_compress(exe, 5, 22), len(exe)))
+    return pool
+
+
+@pytest.mark.parametrize("n,blocks", [(1, 8), (3, 8), (8, 8), (9, 8), (32, 8), (33, 4), (64, 4), (65, 2), (128, 2), (129, 1)])
+def test_every_stream_of_a_small_batch_has_a_gang_of_blocks(pkg, n, blocks):
+    """n streams -- whole, with a buffer one byte short, truncated, with a flipped bit -- against the oracle; the host says how many blocks
+    each stream had (BrotliAmdBatchLastGang): eight up to 32 streams, four up to 64, two up to 128, one beyond"""
+    w = _w()
+    rnd = random.Random(20261001 + n)
+    pool = _pool(w, rnd)
+    datas, caps = [], []
+    for i in range(n):
+        c, size = pool[i % len(pool)] if i < len(pool) else rnd.choice(pool)
+        d, cap = c, size
+        k = rnd.random()
+        if i >= len(pool) and k < 0.15:
+            cap = rnd.choice([size - 1, size // 2, rnd.randrange(1, size)])
+        elif i >= len(pool) and k < 0.3:
+            d = c[: rnd.randrange(1, len(c))]
+        elif i >= len(pool) and k < 0.5:
+            t = bytearray(c)
+            t[rnd.randrange(len(t))] ^= 1 << rnd.randrange(8)
+            d = bytes(t)
+        datas.append(d)
+        caps.append(cap)
+    res, outs, gang = _decode(pkg, datas, caps)
+    assert gang == blocks, (n, gang)
+    _against_oracle(res, outs, datas, caps)
+
+
+def test_a_gang_and_one_block_agree_and_the_gang_takes_the_commands(pkg):
+    """the same eight streams by gangs of eight blocks and (BROTLI_AMD_GANG=0) by one block each: the same bytes and status words, and in both
+    runs the command engines take (nearly) all commands of the streams they are built for"""
+    w = _w()
+    us = w.make_streams("long_backref", 6, 4 << 20, 1000) + w.make_streams("survey_mix", 2, 4 << 20, 4000)
+    datas, caps = [c for c, _, _ in us], [sz for _, sz, _ in us]
+    old = os.environ.get("BROTLI_AMD_GANG")
+    try:
+        os.environ.pop("BROTLI_AMD_GANG", None)
+        res_g, outs_g, gang_g = _decode(pkg, datas, caps)
+        os.environ["BROTLI_AMD_GANG"] = "0"
+        res_1, outs_1, gang_1 = _decode(pkg, datas, caps)
+    finally:
+        if old is None:
+            os.environ.pop("BROTLI_AMD_GANG", None)
+        else:
+            os.environ["BROTLI_AMD_GANG"] = old
+    assert (gang_g, gang_1) == (8, 1)
+    for i, (_, sz, sha) in enumerate(us):
+        for r, o in ((res_g[i], outs_g[i]), (res_1[i], outs_1[i])):
+            assert (r.result, r.decoded_size) == (1, sz) and hashlib.sha256(o).hexdigest() == sha, i
+            assert r.engine_commands >= 0.99 * r.num_commands, (i, r.engine_commands, r.num_commands)
+        assert (res_g[i].consumed, res_g[i].num_commands, res_g[i].num_metablocks) == (res_1[i].consumed, res_1[i].num_commands, res_1[i].num_metablocks)
+
+
+def test_one_batch_object_through_gang_launches_and_others(pkg):
+    """one batch object, launches of 1, 200, 5 and 40 streams in turn (gangs of eight, none, eight, four): the gangs' control blocks are
+    the object's, zeroed before every gang launch"""
+    w = _w()
+    rnd = random.Random(77)
+    pool = _pool(w, rnd)
+    b = pkg.Batch(200)
+    for n, blocks in ((1, 8), (200, 1), (5, 8), (40, 4), (1, 8)):
+        picks = [pool[(i * 5 + n) % len(pool)] for i in range(n)]
+        datas, caps = [c for c, _ in picks], [sz for _, sz in picks]
+        res, outs = b.decode_host(datas, caps, 1)
+        assert b.last_gang() == blocks, (n, b.last_gang())
+        _against_oracle(res, outs, datas, caps)
+    b.close()

@@ -54,7 +54,13 @@ for seed in range(first, first + nseeds):
             a = rnd.randrange(0, len(d)); b_ = min(len(d), a + rnd.randrange(1, 64)); del d[a:b_]
         if k >= 0.15 and rnd.random() < 0.3: cap = rnd.randrange(1, n + 4096)  # (damage and a buffer that may be too small: the reference's verdict, batch.h)
         datas.append(bytes(d)); caps.append(cap)
-    b = pkg.Batch(len(datas)); res, outs = b.decode_host(datas, caps, 1); b.close()
+    # (FUZZ_BATCH: streams a launch -- up to 128 the host gives every stream a gang of blocks, csrc/brotli_path_engine.h PE_CFG_REMOTE; a seed's
+    # 200 streams then go through several launches of one batch object)
+    per = int(os.environ.get("FUZZ_BATCH", "200"))
+    b = pkg.Batch(min(per, len(datas))); res, outs, gangs = [], [], set()
+    for q in range(0, len(datas), per):
+        r_, o_ = b.decode_host(datas[q:q + per], caps[q:q + per], 1); res += r_; outs += o_; gangs.add(b.last_gang())
+    b.close()
     for i, (d, cap) in enumerate(zip(datas, caps)):
         info, exp = oracle.decode(d, cap, 1)
         r = res[i]
@@ -66,5 +72,5 @@ for seed in range(first, first + nseeds):
                       (info.result, info.error_code, info.decoded_size, info.consumed, info.num_commands), len(d), cap, flush=True)
                 open(os.path.join(ROOT, "gpurun_out", "fuzz_engine_bad_%d_%d.br" % (seed, i)), "wb").write(d)
     total += len(datas)
-    if seed % 10 == 0: print("seed", seed, "total", total, "bad", bad, "%.0fs" % (time.time() - t0), flush=True)
+    if seed % 10 == 0: print("seed", seed, "total", total, "bad", bad, "blocks a stream", sorted(gangs), "%.0fs" % (time.time() - t0), flush=True)
 print("done", total, "streams", bad, "mismatches", "%.0fs" % (time.time() - t0))
