@@ -1177,11 +1177,14 @@ __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_
 //            (k - first) strides behind it.  The engine whose turn it is writes a new one where the stream does not enter its window.
 //   STOP     epoch << 32 | regions resolved in all: the invocation is over
 //   EXEC     epoch << 32 | regions whose output is in memory
+//   ENTRY    bit << 0 | tag << 32: where the stream enters region k -- a granule as STATE's, written as soon as region k - 1's WALK knows where
+//            it ends: the walk and the details of region k need no more than that, and run while region k - 1 is still being resolved.  (It is
+//            what the stream does if all the commands region k - 1 listed go through; if its resolve finds otherwise, the invocation ends there.)
 //   STATE    the stream's state behind region k - 1's resolve: 26 granules of value | tag << 32, tag = epoch << 12 | k -- a granule is
 //            one eight-byte store and says itself whether it is the one waited for: no flag, no fence
 //   PARAMS, BR, ARENA   the invocation's parameters, the bit reader's words and the image of the owner's table arena (plain stores
 //            behind a release fence, in front of EPOCH; a helper's acquire fence stands behind its look at EPOCH)
-constexpr uint32_t GC_JOINED = 0, GC_EPOCH = 4, GC_READY = 8, GC_PLAN = 16, GC_STOP = 24, GC_EXEC = 32, GC_ARENA_BYTES = 40, GC_STATE = 64,
+constexpr uint32_t GC_JOINED = 0, GC_EPOCH = 4, GC_READY = 8, GC_PLAN = 16, GC_STOP = 24, GC_EXEC = 32, GC_ARENA_BYTES = 40, GC_ENTRY = 48, GC_STATE = 64,
                    GC_PARAMS = 512, GC_BR = 640, GC_ARENA = 1024, GC_ARENA_CAP = 48u << 10, GC_STRIDE = GC_ARENA + GC_ARENA_CAP;
 constexpr uint32_t GC_QUIT = 0xFFFFFFFFu, GC_STATE_WORDS = 26, GC_MAX_REGIONS = 4000;
 static_assert(GC_STRIDE == BROTLI_AMD_GANG_CTL_BYTES && GC_STATE + 8u * GC_STATE_WORDS <= GC_PARAMS, "the gang's control block");
@@ -3376,10 +3379,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #ifdef BROTLI_AMD_PROFILE_SCAN
   uint64_t pp_exit = 0, pp_enter = 0; (void)pp_enter; const uint64_t pp_start = __builtin_amdgcn_s_memtime(); bool pp_first = true; (void)pp_first;
 #endif
+  const uint32_t engine_hints = rfl(args->general_engine);   // (bit 0: the general form; bits 8 .. 15, 16 .. 23: the gang's penalty and the invocations it still sits out, see remote_off)
   bool prefer_one_engine = false;   // the next invocation of the path engine: its one-engine form (see `declined` below)
-  bool remote_off = false;          // ... the one-block form from here on, though the stream has a gang of blocks
+  // ... the one-block form though the stream has a gang of blocks: for the next invocations where the gang met a literal run that wants regions
+  // of its own first thing (it takes nothing then, and a region's tables of every block are lost: 8.1 against 5.8 ms on 4 MiB of high-entropy
+  // literals, all runs) -- one invocation the first time, twice as many every time it happens again before the gang has taken anything, up to 64;
+  // and for the rest of a metablock whose regions fill their closure's room (few literals: the one-block form halves its regions there, or hands
+  // the stream to the scan engine).  Both counts go with the stream from metablock to metablock (HotArgs::general_engine).
+  uint32_t remote_penalty = (engine_hints >> 8) & 0xFFu, remote_hold = (engine_hints >> 16) & 0xFFu;
+  bool remote_off = false;
   bool prefer_scan = false;         // ... or the scan engine: the path engine found its regions bound by their closure (see there)
-  bool prefer_general = rfl(args->general_engine) != 0u;   // ... or the path engine's general form: the lean one has stopped in front of a dictionary reference in this stream
+  bool prefer_general = (engine_hints & 1u) != 0u;   // ... or the path engine's general form: the lean one has stopped in front of a dictionary reference in this stream
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
   // ahead of this wave (rec_wave; the lean loop takes commands out of them); on request (BROTLI_AMD_ENGINE=split) wave 1 executes
   // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
@@ -3442,7 +3452,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const bool use_general = use_path && !use_pipe && prefer_general;
         // (the stream's owner in a gang of blocks: the gang's form of the engine -- not for a literal run that wants regions of its own, nor for
         // words of the static dictionary: those are the one-block forms')
-        bool use_remote = use_path && !use_pipe && !use_general && !prefer_one_engine && !remote_off && hc_ld(HC_GANG_M) > 1u;
+        const bool gang_here = use_path && !use_pipe && !use_general && hc_ld(HC_GANG_M) > 1u;
+        bool use_remote = gang_here && !prefer_one_engine && !remote_off && remote_hold == 0u;
+        if (gang_here && !use_remote && remote_hold != 0u) remote_hold--;
         if (use_remote) {
           const uint32_t ep = hc_ld(HC_GANG_EPOCH);
           if (ep == 0u) {   // the first time: have the helpers all started?  (They do so with the owner, give or take a microsecond; a block that is not running cannot be waited for)
@@ -3483,7 +3495,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const uint32_t form_raw = LEAN_LD(L_SC_POS_HI), form = form_raw & 0xFFu;
         const bool declined = ((form_raw >> 8) & 1u) != 0u;
         if (((form_raw >> 10) & 1u) != 0u) prefer_general = true;   // (the lean form stopped in front of a dictionary reference)
-        if (((form_raw >> 11) & 1u) != 0u) remote_off = true;       // (a gang's regions were bound by their closure: the one-block form's for the rest of the metablock)
+        if (use_remote && took >= 64u) remote_penalty = 0u;
+        if (((form_raw >> 11) & 1u) != 0u) remote_off = true;   // (a gang's regions were bound by their closure)
+        if (((form_raw >> 11) & 1u) != 0u || (use_remote && declined && took == 0u)) {   // (... or it met a long literal run first thing)
+          remote_penalty = remote_penalty == 0u ? 1u : remote_penalty >= 32u ? 64u : remote_penalty * 2u;
+          remote_hold = remote_penalty;
+        }
         if (((form_raw >> 9) & 1u) != 0u) prefer_scan = true;   // (the path engine's regions were bound by their closure: a stream of few literals -- the scan engine's from here on)   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
@@ -3500,13 +3517,14 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         lit_pos = P;
         force_checked = form == SCX_BEGIN ? 1u : 0u;  // (the command the engine stopped IN FRONT OF goes through the checked stages; one it stopped inside is on its way through them already)
         // (an invocation that got nowhere -- few commands AND few bytes: a long literal run is one command -- makes the next ones rarer)
-        if (declined) { prefer_one_engine = true; force_checked = 0u; if (use_remote && took == 0u) remote_off = true; }   // (a gang that met a long literal run first thing: a metablock of such runs, as a rule -- the one-block form's)
+        if (declined) { prefer_one_engine = true; force_checked = 0u; }
         else if (took < 64u && P - P_before < 4096u) { scan_fails = scan_fails < 6u ? scan_fails + 1u : 6u; force_checked = 8u << scan_fails; } else scan_fails = 0;
         insert_len = (int32_t)LEAN_LD(L_INSERT); copy_len = (int32_t)LEAN_LD(L_COPY);
         distance_code = (int32_t)LEAN_LD(L_DCODE); distance_context = LEAN_LD(L_DCTX); lits_left = (int32_t)LEAN_LD(L_LITS_LEFT);
         lds_sync();
         if (form == SCX_LITERALS_REST) { if (lits_left != 0) goto general_literals_rest; goto general_distance; }
         if (form == SCX_POST_DISTANCE) goto general_post_distance;
+        if (declined && use_remote) continue;   // (a gang stopped in front of a literal run that wants regions of its own: the one-block form's, at once -- not the one-wave loop's)
       }
      }
     }
@@ -4047,7 +4065,7 @@ done:
   args->P = P; args->next_boundary = next_boundary; args->mlen = mlen;
   args->d0 = d0; args->d1 = d1; args->d2 = d2; args->d3 = d3;
   args->num_commands = num_commands;
-  args->engine_commands = engine_commands; args->general_engine = prefer_general ? 1u : 0u;
+  args->engine_commands = engine_commands; args->general_engine = (prefer_general ? 1u : 0u) | (remote_penalty << 8) | (remote_hold << 16);
 #ifdef BROTLI_AMD_PROFILE
   if (lane == 0 && blockIdx.x == 0) printf("lean exits by stage: %u %u %u %u %u %u %u %u\n", prof_stage[0], prof_stage[1], prof_stage[2], prof_stage[3], prof_stage[4], prof_stage[5], prof_stage[6], prof_stage[7]);
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;

@@ -94,7 +94,11 @@ constexpr uint32_t PE_N8 = PE_J1F;                                // u16 per sta
 #ifndef BROTLI_AMD_PE_JUMP_LOG
 #define BROTLI_AMD_PE_JUMP_LOG 3
 #endif
-constexpr uint32_t PE_JUMP_LOG = BROTLI_AMD_PE_JUMP_LOG, PE_JUMP = 1u << PE_JUMP_LOG;  // commands a hop of the walk (8 or 16)
+#ifndef BROTLI_AMD_PE_REMOTE_JUMP_LOG
+#define BROTLI_AMD_PE_REMOTE_JUMP_LOG 4
+#endif
+// commands a hop of the walk (8 or 16; a gang of blocks: 16 -- there the walk is what the stream waits for, and one more doubling of the table is built ahead by somebody else)
+constexpr uint32_t PE_JUMP_LOG = PE_CFG_REMOTE ? BROTLI_AMD_PE_REMOTE_JUMP_LOG : BROTLI_AMD_PE_JUMP_LOG, PE_JUMP = 1u << PE_JUMP_LOG;
 static_assert(PE_JUMP_LOG == 3 || PE_JUMP_LOG == 4, "the walk's hop");
 constexpr uint32_t PE_STG = PE_J1F;                               // the region's output while it is put together (execute), where it fits: see PE_STG_CAP
 constexpr uint32_t PE_STG_CAP = PE_RBL;            // output bytes of a region that is put together in LDS and written out in one piece (0: never)
@@ -839,7 +843,7 @@ pe_again:
       lds_sync();
       const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : 1u;
       if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)(epoch << 12) << 32));
-      if (lane == 0u) gang_st64(gc, GC_PLAN, (uint64_t)st.b);
+      if (lane == 0u) { gang_st64(gc, GC_PLAN, (uint64_t)st.b); gang_st64(gc, GC_ENTRY, (uint64_t)st.b | ((uint64_t)(epoch << 12) << 32)); }
       gang_drain();
       if (lane == 0u) gang_st32(gc, GC_EPOCH, epoch);
     }
@@ -1553,6 +1557,38 @@ pe_again:
     PE_PROF(5);
     return 0u;
   };
+  // (a gang, wave 0) The stream's state as the region before's resolve left it -- or the word that it will not come: the invocation ended in front
+  // of this region (a limit cut the region before short of what its walk had listed: what was walked here was walked for nothing).  `walked`:
+  // the region has been walked from the entry its state should confirm; otherwise the region cannot be taken at all (no input left, no table
+  // for the distances) and the state is only waited for to say so: STOP counts the regions RESOLVED, and is written when that number is final --
+  // by the resolve that ends the invocation, or here, behind the state of the last region that was resolved.
+  auto full_arrival = [&](const bool walked) {
+    const uint32_t want = (epoch << 12) | kseq;
+    uint64_t v; uint32_t spins = 0; bool arrived, stopped; (void)spins;
+    const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
+    for (;;) {
+      v = gang_ld64(gc, lane < GC_STATE_WORDS ? GC_STATE + 8u * lane : GC_STOP);
+      arrived = __ballot(lane < GC_STATE_WORDS && (uint32_t)(v >> 32) == want) == ((1ull << GC_STATE_WORDS) - 1ull);
+      stopped = rdlane((uint32_t)(v >> 32), 32) == epoch && rdlane((uint32_t)v, 32) <= kseq;
+      if (arrived || stopped) break;
+      __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
+    }
+    GANG_STAT(gc, 39, __builtin_amdgcn_s_memtime() - t0_);
+    uint32_t ok_ = 0u;
+    if (arrived && (rdlane((uint32_t)v, 25) & 1u) != 0u) {   // (the region before's resolve said that the stream goes on)
+      if (lane < 25u) lds_st32(pbs + PE_CTL + 4u * (PEC_STATE + lane), (uint32_t)v);   // the state into this engine's own words
+      lds_sync();
+      const PeStream st = pe_st_load(pbs);
+      ok_ = (walked && st.b == pe_ctl_ld(pb, PEC_MYENTRY) && st.quota >= SC_MIN_QUOTA && st.bl1 != 0u) ? 1u : 0u;
+      pe_ctl_st(pb, PEC_P0_LO, (uint32_t)st.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(st.P >> 32));
+    }
+    if (ok_ == 0u) {
+      if (!arrived) GANG_STAT(gc, 32, 1); else if ((rdlane((uint32_t)v, 25) & 1u) == 0u) GANG_STAT(gc, 33, 1); else { const PeStream st = pe_st_load(pbs); if (st.b != pe_ctl_ld(pb, PEC_MYENTRY)) GANG_STAT(gc, 34, 1); else GANG_STAT(gc, 36, 1); }
+      if (arrived && lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)kseq);   // (the same word, if the resolve before has written it)
+      pe_ctl_st(pb, PEC_CONT, 0u);
+    }
+    pe_ctl_st(pb, PEC_PLAN, ok_ != 0u ? 0u : 2u);
+  };
   // ================= the stream's way through the region: walk, details, resolve, execute =================
   auto consume = [&]() {
     rseq++;
@@ -1567,6 +1603,7 @@ pe_again:
     const uint32_t bw = (me + GW - 1u) & (GW - 1u);  // this wave's batch (wave 0, which walks, gets the last one)
     uint32_t dr0 = 0, dr1 = 0, dr2 = 0, dr3 = 0;
     if (me == 0) {
+      if (REMOTE) GANG_STAT(gc, 28, __builtin_amdgcn_s_memtime() - gs_arr);   // arrival .. the walk's start
       __builtin_amdgcn_s_setprio(3);  // (the walk is the one chain everybody waits for: first in line on its SIMD)
       uint32_t id = PE_RANKS, na = 0;
       uint32_t id_hand = PEN_NONE;   // (two engines) the first of the states the walk added itself: NEXT8 does not know them
@@ -1576,10 +1613,19 @@ pe_again:
         // or the second).  They join the closure behind the ones the records put there.
         uint32_t slot = wn, desc = le | 0x8000u;
         id = PE_RANKS + slot; id_hand = id;
-        if (slot >= PE_WCAP) id = PEN_NONE;   // (no room for the entry's state: nothing listed, the checked loop's)
+        bool long_run = false;
+        if (REMOTE && le + 64u <= c.L) {
+          // (a gang: a first command with a literal run that wants regions of its own is not looked at any closer -- evaluated here, its run
+          // would be followed one code word after the other by this wave alone; nothing listed, and the resolve says why: see PEC_DECLINE)
+          uint32_t lo_, hi_;
+          pe_bits64(pb, le, lo_, hi_);
+          const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr);
+          long_run = rfl(h_.insert) >= PE_RUN_MIN;
+        }
+        if (slot >= PE_WCAP || long_run) id = PEN_NONE;   // (no room for the entry's state: nothing listed, the checked loop's)
         else for (uint32_t tries = 0;; tries++) {
           if (lane == 0) lds_st16(pb + PE_WST + (slot << 1), desc);
-          if (tries >= PE_PIPE_HAND) { if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), PEN_BYHAND); if (REMOTE) GANG_STAT(gc, 35, 1); break; }   // (the region ends in front of this state)
+          if (tries >= PE_PIPE_HAND) { if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), PEN_BYHAND); break; }   // (the region ends in front of this state)
           const PeParse pr = pe_eval<false, false>(c, desc & 0x7FFFu, desc >> 15, true);
           const uint32_t cd = rfl(pr.code), nx = rfl(pr.next);
           const bool more = cd == 1u && slot + 1u < PE_WCAP;
@@ -1606,6 +1652,7 @@ pe_again:
         if (id >= PEN_FIRST_SPECIAL) walk_on = false;
       }
       if (REMOTE) { id = rfl(id); na = rfl(na); }   // (uniform, and in scalar registers for what follows)
+      if (REMOTE) GANG_STAT(gc, 29, __builtin_amdgcn_s_memtime() - gs_arr);   // .. the entry's states and the first anchor
       if (walk_on) {
         // The anchors by hand: one dependent LDS read an anchor is all the chain asks for, and the compiled loop wrapped it in
         // thirty-five instructions (the lane's own execution mask, the counter in a vector register): 330 clocks an anchor.
@@ -1647,6 +1694,7 @@ pe_again:
       // commands on (the lanes side by side: a dozen dependent reads for all of them, where one command after the other by the
       // wave as a whole cost a third of the walk), the list's entries are theirs
       if (!PIPE) PE_PROF(15);   // (one engine: the anchors)
+      if (REMOTE) GANG_STAT(gc, 38, __builtin_amdgcn_s_memtime() - gs_arr);   // .. the anchors
       uint32_t m = PE_JUMP * na, desc;
       if (PIPE && id >= PEN_FIRST_SPECIAL) { desc = le | 0x8000u; if (lane == 0) lds_st16(pb + PE_LIST, desc); }   // (no room for the entry's state: nothing listed -- the list's closing entry says where the stream stands)
       else for (;;) {
@@ -1676,12 +1724,33 @@ pe_again:
       }
 #endif
 #ifdef BROTLI_AMD_GANG_STATS
-      if (REMOTE && m == 0u && lane == 0 && epoch < 400u) {
+      if (REMOTE && m == 0u && lane == 0 && epoch < 400u && blockDim.x == 1u) {   // (a look at the regions that list nothing: edit the condition)
         printf("gang: epoch %u region %u lists nothing: le %u L %u Lp %u Rn %u wn %u id %u id_hand %u desc %x; hand states:", epoch, kseq, le, c.L, c.Lp, c.Rn, wn, id, id_hand, desc);
         for (uint32_t q = 0; q < 4u; q++) printf(" [%x -> %u]", lds_ld16(pb + PE_WST + ((wn + q) << 1)), lds_ld16(pb + PE_NEXT + ((PE_RANKS + wn + q) << 1)));
         printf("\n");
       }
 #endif
+      if (REMOTE && m != 0u) {
+        // (a gang) where the stream goes on if every command listed goes through -- the next region's engine starts its walk from there while
+        // this region is resolved: the first bit of the command the list closes with (behind the distance code, if it starts with one)
+        lds_sync();
+        uint32_t dsc;
+        if (m >= PE_JUMP * na) dsc = rfl(lds_ld16(pb + PE_LIST + (m << 1)));
+        else {   // (the list's entries up to the last anchor are the details' to write: by the anchor and the records, as they do it)
+          uint32_t st_ = rfl(*reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_ANCH + ((m >> PE_JUMP_LOG) << 2)]));
+          for (uint32_t h = 0; h < (m & (PE_JUMP - 1u)); h++) st_ = rfl(lds_ld16(pb + PE_NEXT + (st_ << 1)));
+          dsc = rfl(st_ < PE_RANKS ? lds_ld16(pb + PE_POR + (st_ << 1)) : lds_ld16(pb + PE_WST + ((st_ - PE_RANKS) << 1)));
+        }
+        uint32_t nbit = dsc & 0x7FFFu;
+        if ((dsc >> 15) == 0u) {
+          uint32_t lo_, hi_;
+          pe_bits64(pb, nbit, lo_, hi_);
+          const ScDist d_ = sc_dist(lo_, hi_, c.dtree, c.postfix_bits, c.num_direct);
+          nbit += rfl(d_.bits);
+        }
+        if (lane == 0u) gang_st64(gc, GC_ENTRY, (uint64_t)((pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit) | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
+        pe_ctl_st(pb, PEC_MYNEXT, (pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit);
+      }
       pe_ctl_st(pb, PEC_M, m); pe_ctl_st(pb, PEC_NA, na);
       lds_sync();
       pe_ctl_st(pb, PEC_WDONE, 1u);
@@ -1736,6 +1805,12 @@ pe_again:
     PE_BAR();
     RG_STAMP(0);   // walk + details done
     if (REMOTE && me == 0) GANG_STAT(gc, 25, __builtin_amdgcn_s_memtime() - gs_arr);   // .. details done
+    if (REMOTE) {
+      if (me == 0) full_arrival(true);
+      PE_BAR();
+      if (pe_ctl_ld(pb, PEC_PLAN) == 2u) return;
+      P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+    }
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
     PE_PROF(7);
     // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
@@ -2017,9 +2092,9 @@ pe_pass:
           pe_bits64(pb, pbit, lo_, hi_);
           const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr);
           if (rfl(h_.insert) >= 1024u) pe_ctl_st(pbs, PEC_DECLINE, pe_ctl_ld(pbs, PEC_DECLINE) | 1u);
-          GANG_STAT(gc, 33, rfl(h_.insert) >= 1024u ? 1u : 0u); GANG_STAT(gc, 34, rfl(h_.insert));
         }
-        if (REMOTE && m == 0u) { GANG_STAT(gc, 32, 1); GANG_STAT(gc, 36, pbit + 64u <= c.L ? 0u : 1u); GANG_STAT(gc, 37, pe_ctl_ld(pb, PEC_M)); }
+        if (REMOTE && !cont) GANG_STAT(gc, 37, 1);
+        if (REMOTE && !cont && kp_total != m) GANG_STAT(gc, 35, 1);
 #ifdef BROTLI_AMD_PE_DEBUG
         if (PIPE && blockIdx.x == 0 && lane == 0) printf("   region %u: %u commands listed, %u executed, goes on at %u, cont %u, P now %llu ncmd %u\n", kseq, m, kp_total, sn.b, cont ? 1u : 0u, (unsigned long long)sn.P, sn.ncmd);
 #endif
@@ -2033,9 +2108,6 @@ pe_pass:
           pe_ctl_st(pb, PEC_MYNEXT, sn.b);
           lds_sync();
           const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1);
-#ifdef BROTLI_AMD_GANG_STATS
-          if (lane == 0u) gang_st64(gc, 56u, __builtin_amdgcn_s_memtime());
-#endif
           if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
           if (!cont) { gang_drain(); if (lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
         }
@@ -2061,9 +2133,7 @@ pe_pass:
         __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
       }
       GANG_STAT(gc, 8, __builtin_amdgcn_s_memtime() - t0_);
-#ifdef BROTLI_AMD_GANG_STATS
-      { const uint64_t ts_ = gang_ld64(gc, 48u), now_ = __builtin_amdgcn_s_memtime(); GANG_STAT(gc, 28, now_ > ts_ ? now_ - ts_ : 0u); GANG_STAT(gc, 30, __builtin_amdgcn_s_memtime() - t0_ < 200u ? 1u : 0u); }
-#endif
+      GANG_STAT(gc, 30, __builtin_amdgcn_s_memtime() - t0_ < 400u ? 1u : 0u);
       gang_acquire();
       GANG_STAT(gc, 9, __builtin_amdgcn_s_memtime() - t0_);
       lds_sync();
@@ -2403,10 +2473,7 @@ pe_pass:
       PE_BAR();
       if (PIPE2 && T == 0u) { lds_sync(); pe_ctl_st(pbs, PEC_EXECUTED, kseq + 1u); }
       if (REMOTE && T == 0u) { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_; GANG_STAT(gc, 27, t0_ - gs_arr); gang_release();
-#ifdef BROTLI_AMD_GANG_STATS
-        gang_st64(gc, 48u, __builtin_amdgcn_s_memtime()); gang_drain();
-#endif
-        GANG_STAT(gc, 17, __builtin_amdgcn_s_memtime() - t0_); gang_st64(gc, GC_EXEC, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
+ GANG_STAT(gc, 17, __builtin_amdgcn_s_memtime() - t0_); gang_st64(gc, GC_EXEC, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
     }
   };
 #if !PE_CFG_PIPE && !PE_CFG_REMOTE
@@ -2484,7 +2551,8 @@ pe_pass:
       const uint64_t wb64 = (uint64_t)base_ + (kseq > k0_ ? (uint64_t)(kseq - k0_) * STRIDE : 0ull);
       const uint32_t W = (uint32_t)((wb64 < (uint64_t)in_limit ? wb64 : (uint64_t)in_limit) >> 5);
       const uint32_t avail = (W << 5) < in_limit ? in_limit - (W << 5) : 0u;
-      const bool buildable = td_ok && avail >= PE_MIN_INPUT && (uint32_t)(gang_ld64(gc, GC_STOP) >> 32) != epoch;
+      const uint64_t sw_ = gang_ld64(gc, GC_STOP);
+      const bool buildable = td_ok && avail >= PE_MIN_INPUT && !((uint32_t)(sw_ >> 32) == epoch && (uint32_t)sw_ <= kseq);
       setup_tables(W, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
       pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48));
     };
@@ -2502,42 +2570,38 @@ pe_pass:
           uint64_t v; uint32_t spins = 0; bool arrived, stopped, replanned;
           const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
           for (;;) {
-            v = gang_ld64(gc, lane < GC_STATE_WORDS ? GC_STATE + 8u * lane : lane == 32u ? GC_STOP : GC_PLAN);
-            arrived = __ballot(lane < GC_STATE_WORDS && (uint32_t)(v >> 32) == want) == ((1ull << GC_STATE_WORDS) - 1ull);
-            stopped = rdlane((uint32_t)(v >> 32), 32) == epoch;
+            v = gang_ld64(gc, lane == 0u ? GC_ENTRY : lane == 32u ? GC_STOP : GC_PLAN);
+            arrived = rdlane((uint32_t)(v >> 32), 0) == want;
+            stopped = rdlane((uint32_t)(v >> 32), 32) == epoch && rdlane((uint32_t)v, 32) <= kseq;
             replanned = (rdlane((uint32_t)(v >> 32), 33) >> 16) != mygen;
             if (arrived || stopped || replanned) break;
             __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
           }
           GANG_STAT(gc, role == 0u ? 6 : 7, __builtin_amdgcn_s_memtime() - t0_); gs_arr = __builtin_amdgcn_s_memtime();
-#ifdef BROTLI_AMD_GANG_STATS
-          if (arrived && !stopped && !replanned && kseq != 0u) { const uint64_t ts_ = gang_ld64(gc, 56u); GANG_STAT(gc, 29, gs_arr > ts_ ? gs_arr - ts_ : 0u); }
-#endif
+
           plan = 2u;   // 0: the tables are the ones, 1: once more where the stream is, 2: the invocation is over, 3: once more by the new plan, then wait again
           if (stopped) { }
           else if (replanned) { GANG_STAT(gc, 3, 1); window_by_plan((uint64_t)rdlane((uint32_t)v, 33) | ((uint64_t)rdlane((uint32_t)(v >> 32), 33) << 32)); plan = 3u; }
           else {
-            if (lane < 25u) lds_st32(pbs + PE_CTL + 4u * (PEC_STATE + lane), (uint32_t)v);   // the state into this engine's own words
-            lds_sync();
-            if ((rdlane((uint32_t)v, 25) & 1u) != 0u) {   // (the region before's resolve said that the stream goes on)
-              const PeStream st = pe_st_load(pbs);
-              const uint32_t avail = st.b < in_limit ? in_limit - ((st.b >> 5) << 5) : 0u;
-              const bool go = td_ok && st.b < in_limit && avail >= PE_MIN_INPUT && st.quota >= SC_MIN_QUOTA && st.bl1 != 0u;
-              if (go) {
-                const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L);
-                const bool usable = built && st.b >= w0 && st.b + PE_PIPE_USEFUL <= w0 + wl;
-                plan = usable ? 0u : 1u;
-                GANG_STAT(gc, 1, 1);
-                if (!usable) {
-                  GANG_STAT(gc, 2, 1);
-                  if (!built) GANG_STAT(gc, 10, 1); else if (st.b < w0) GANG_STAT(gc, 11, 1); else GANG_STAT(gc, 12, 1);
-                  setup_tables(st.b >> 5, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
-                  if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)kseq << 32) | (uint64_t)st.b);
-                  gang_drain();
-                }
+            // (the bit the stream enters the region at: all the walk and the details ask for; its state comes behind the details -- see consume)
+            const uint32_t eb = rdlane((uint32_t)v, 0);
+            const uint32_t avail = eb < in_limit ? in_limit - ((eb >> 5) << 5) : 0u;
+            const bool go = td_ok && eb < in_limit && avail >= PE_MIN_INPUT;
+            if (go) {
+              const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L);
+              const bool usable = built && eb >= w0 && eb + PE_PIPE_USEFUL <= w0 + wl;
+              plan = usable ? 0u : 1u;
+              GANG_STAT(gc, 1, 1);
+              if (!usable) {
+                GANG_STAT(gc, 2, 1);
+                if (!built) GANG_STAT(gc, 10, 1); else if (eb < w0) GANG_STAT(gc, 11, 1); else GANG_STAT(gc, 12, 1);
+                setup_tables(eb >> 5, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
+                if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)kseq << 32) | (uint64_t)eb);
+                gang_drain();
               }
             }
-            if (plan == 2u && lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)kseq);
+            pe_ctl_st(pb, PEC_MYENTRY, eb);
+            if (plan == 2u) plan = 4u;   // (the region cannot be taken: the invocation ends in front of it -- said once the region before is resolved, see full_arrival)
           }
           pe_ctl_st(pb, PEC_PLAN, plan);
         }
@@ -2547,16 +2611,16 @@ pe_pass:
       }
       PE_PROF(16);   // (waiting for the stream)
       if (plan == 2u) break;
+      if (plan == 4u) { if (me == 0) full_arrival(false); PE_BAR(); break; }
       if (plan == 1u) (void)build();
       if (me == 0) {
-        const PeStream st = pe_st_load(pbs);
-        pe_ctl_st(pb, PEC_LE, st.b - (pe_ctl_ld(pb, PEC_LBDW) << 5));
-        pe_ctl_st(pb, PEC_MYENTRY, st.b); pe_ctl_st(pb, PEC_MYNEXT, st.b);
-        setup_walk(st.P);
+        const uint32_t eb = pe_ctl_ld(pb, PEC_MYENTRY);
+        pe_ctl_st(pb, PEC_LE, eb - (pe_ctl_ld(pb, PEC_LBDW) << 5));
+        pe_ctl_st(pb, PEC_MYNEXT, eb);
+        setup_walk(0ull);   // (where the region's output starts: with the stream's state, behind the details)
       }
       PE_BAR();
       le = pe_ctl_ld(pb, PEC_LE);
-      P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
       { const uint64_t tc_ = __builtin_amdgcn_s_memtime(); (void)tc_;
         consume();
         if (me == 0 && role == 0u) GANG_STAT(gc, 19, __builtin_amdgcn_s_memtime() - tc_); }
