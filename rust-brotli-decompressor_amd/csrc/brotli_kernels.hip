@@ -3384,8 +3384,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // ... the one-block form though the stream has a gang of blocks: for the next invocations where the gang met a literal run that wants regions
   // of its own first thing (it takes nothing then, and a region's tables of every block are lost: 8.1 against 5.8 ms on 4 MiB of high-entropy
   // literals, all runs) -- one invocation the first time, twice as many every time it happens again before the gang has taken anything, up to 64;
-  // and for the rest of a metablock whose regions fill their closure's room (few literals: the one-block form halves its regions there, or hands
-  // the stream to the scan engine).  Both counts go with the stream from metablock to metablock (HotArgs::general_engine).
+  // the same where its regions fill their closure's room (few literals: the one-block form halves its regions there, or hands the stream to the
+  // scan engine; sitting out the rest of the metablock instead left 18 % of a 1 GiB stream's commands to one block, three quarters of its time).
+  // Both counts go with the stream from metablock to metablock (HotArgs::general_engine).
   uint32_t remote_penalty = (engine_hints >> 8) & 0xFFu, remote_hold = (engine_hints >> 16) & 0xFFu;
   bool remote_off = false;
   bool prefer_scan = false;         // ... or the scan engine: the path engine found its regions bound by their closure (see there)
@@ -3468,7 +3469,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
               use_remote = false;
             }
           }
-          if (use_remote) hc_st(HC_GANG_EPOCH, ep + 1u);
         }
         hc_st(HC_KIND, use_remote ? (uint32_t)HK_PATHR : use_pipe ? (uint32_t)HK_PATH2 : use_general ? (uint32_t)HK_PATHG : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
@@ -3496,7 +3496,6 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const bool declined = ((form_raw >> 8) & 1u) != 0u;
         if (((form_raw >> 10) & 1u) != 0u) prefer_general = true;   // (the lean form stopped in front of a dictionary reference)
         if (use_remote && took >= 64u) remote_penalty = 0u;
-        if (((form_raw >> 11) & 1u) != 0u) remote_off = true;   // (a gang's regions were bound by their closure)
         if (((form_raw >> 11) & 1u) != 0u || (use_remote && declined && took == 0u)) {   // (... or it met a long literal run first thing)
           remote_penalty = remote_penalty == 0u ? 1u : remote_penalty >= 32u ? 64u : remote_penalty * 2u;
           remote_hold = remote_penalty;

@@ -171,7 +171,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
        PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
-       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_BUILT = 158 /* ... whether its tables are built */,
+       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_MYSHIFT = 138 /* ... and how often its regions are halved */, PEC_BUILT = 158 /* ... whether its tables are built */,
        PEC_FIN = 156 /* a long literal run has ended in this region: its command's distance and copy are wave 0's, in place */,
        PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
        PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
@@ -767,7 +767,7 @@ pe_again:
   if (REMOTE) {
     role = hc_ld(HC_GANG_ROLE); gang_m = hc_ld(HC_GANG_M); gc = gang_ctl();
     if (role == 0u) {
-      epoch = hc_ld(HC_GANG_EPOCH);
+      epoch = hc_ld(HC_GANG_EPOCH) + 1u;   // (the word is this invocation's once it is everybody's: see below)
       if (threadIdx.x == 0u) {   // the helpers have all left the invocation before (they read the image below when they enter one)
         uint32_t spins = 0; (void)spins;
         const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
@@ -839,7 +839,19 @@ pe_again:
     st.first = 1u;
     st.s_bits = 0u; st.s_cmds = 0u; st.s_lits = 0u; st.s_dsts = 0u;
     pe_st_store(pbs, st);
-    if (REMOTE) {   // the invocation is everybody's: the stream's state in front of region 0, the plan (from region 0 on, at the entry), then its number
+    bool long_first = false;
+    if (REMOTE && st.b + 64u <= in_limit) {
+      // (a gang) a first command whose literal run wants regions of its own is the one-block form's: seen here, in the stream's own bits,
+      // nobody else hears of the invocation -- it costs the owner a look, not every block a region's tables
+      const uint32_t d0_ = st.b >> 5, sh_ = st.b & 31u;
+      const uint32_t a0_ = d0_ < limit_dw ? in_dw[d0_] : 0u, a1_ = d0_ + 1u < limit_dw ? in_dw[d0_ + 1u] : 0u, a2_ = d0_ + 2u < limit_dw ? in_dw[d0_ + 2u] : 0u;
+      const ScHead h_ = sc_head(__builtin_amdgcn_alignbit(a1_, a0_, sh_), __builtin_amdgcn_alignbit(a2_, a1_, sh_), c.cmd_tree, c.lut_vgpr);
+      long_first = rfl(h_.insert) >= PE_RUN_MIN && rfl(h_.bits) != 0u;
+    }
+    if (REMOTE) pe_ctl_st(pb, PEC_PLAN, long_first ? 6u : 0u);
+    if (REMOTE && long_first) pe_ctl_st(pbs, PEC_DECLINE, 1u);
+    if (REMOTE && !long_first) {   // the invocation is everybody's: the stream's state in front of region 0, the plan (from region 0 on, at the entry), then its number
+      hc_st(HC_GANG_EPOCH, epoch);
       lds_sync();
       const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : 1u;
       if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)(epoch << 12) << 32));
@@ -1748,6 +1760,16 @@ pe_again:
           const ScDist d_ = sc_dist(lo_, hi_, c.dtree, c.postfix_bits, c.num_direct);
           nbit += rfl(d_.bits);
         }
+        {   // (regions that were halved take twice the bits again from the next one on where this one's closure is small: a new plan in front of the entry)
+          const uint32_t sh_ = pe_ctl_ld(pb, PEC_MYSHIFT);
+          if (sh_ != 0u && wn < PE_WCAP / 8u && kseq + 1u < GC_MAX_REGIONS) {
+            const uint64_t cur = gang_ld64(gc, GC_PLAN);
+            if ((uint32_t)(cur >> 48) == pe_ctl_ld(pb, PEC_MYGEN)) {   // (nobody has changed it since this engine's window was laid out)
+              if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((pe_ctl_ld(pb, PEC_MYGEN) + 1u) & 0xFFFFu) << 48) | ((uint64_t)(sh_ - 1u) << 44) | ((uint64_t)(kseq + 1u) << 32) | (uint64_t)((pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit));
+              gang_drain();
+            }
+          }
+        }
         if (lane == 0u) gang_st64(gc, GC_ENTRY, (uint64_t)((pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit) | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
         pe_ctl_st(pb, PEC_MYNEXT, (pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit);
       }
@@ -1975,13 +1997,13 @@ pe_pass:
         const uint64_t pk = st.P + rel + ins;
         const int32_t maxd = pk < (uint64_t)(uint32_t)st.max_backward ? (int32_t)pk : st.max_backward;
         if (PE_DICT) dictc = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd) & (uint32_t)!plainw);   // (`ok` so far: an active lane, its counts and its output -- the copy's length for the word's -- inside every limit)
-        if (!PE_DICT && !PIPE) dref = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd));
+        if (!PE_DICT && !PIPE2) dref = (bool)((uint32_t)ok & (uint32_t)(kind == SCK_EXPLICIT) & (uint32_t)(dist > maxd));
         ok = ok && (kind == SCK_NONE || plainw || (dist > 0 && dist <= maxd));
       }
       const uint64_t stopmask = __ballot(active && !ok);
       uint32_t kpb = stopmask ? (uint32_t)__builtin_ctzll(stopmask) : K;
       const uint64_t dictmask = PE_DICT ? __ballot(dictc) : 0ull;
-      const uint64_t drefmask = (!PE_DICT && !PIPE) ? __ballot(dref) : 0ull;
+      const uint64_t drefmask = (!PE_DICT && !PIPE2) ? __ballot(dref) : 0ull;
       if (PE_DICT && stopmask != 0ull && ((dictmask >> kpb) & 1ull) != 0ull) kpb++;   // (the pass ends BEHIND such a command's literals)
       if (mine && stopmask != 0ull && lane == 0) pe_atomic_min(pb + PE_CTL + 4u * PEC_KP, k0 + kpb);
       // a copy whose source reaches into the region's own output is done afterwards (bit 31 of w0); long items get a wave
@@ -2017,7 +2039,7 @@ pe_pass:
         const bool last = kp_total <= k0 + K;
         if (last) {
           const uint32_t kp = my_exec;
-          if (!PE_DICT && !PIPE && kp < 64u && ((drefmask >> kp) & 1ull) != 0ull) pe_ctl_st(pb, PEC_DSEEN, 1u);   // (the command the engine's part ends in front of)
+          if (!PE_DICT && !PIPE2 && kp < 64u && ((drefmask >> kp) & 1ull) != 0ull) pe_ctl_st(pb, PEC_DSEEN, 1u);   // (the command the engine's part ends in front of)
           // (PE_DICT: the pass's last command is one whose copy is a dictionary word -- wave 0's, behind the execute: its copy length
           // is not output of this pass, its distance not one for the ring, decode.rs:2643-2644)
           const bool dlast = PE_DICT && ((dictmask >> (kp - 1u)) & 1ull) != 0ull;
@@ -2107,7 +2129,7 @@ pe_pass:
           // invocation's end in a word of its own behind them (whoever waits for a region that will not come looks at it)
           pe_ctl_st(pb, PEC_MYNEXT, sn.b);
           lds_sync();
-          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1);
+          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1) | (pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 8u : 0u);
           if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
           if (!cont) { gang_drain(); if (lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
         }
@@ -2544,19 +2566,23 @@ pe_pass:
   // ran out, a record hit a cap) it builds its tables once more where the stream is and writes a new plan from there -- the engines behind it,
   // who look at the plan while they wait for the stream, build theirs once more too, side by side.
   {
-    constexpr uint32_t STRIDE = PE_RBL - PE_REMOTE_MARGIN;
+    // (the plan's word: generation << 48 | halvings << 44 | first region << 32 | its first bit.  Halvings: where a region's closure fills its room --
+    // a stretch of few literals --, the regions from there on take half the bits, and half again if need be, as the one-block form's do; back to
+    // twice the bits where the closure has become small)
     // (wave 0) region kseq's window by the plan: its tables' set-up, whether there is anything to build, the plan's generation
     auto window_by_plan = [&](const uint64_t pl) {
-      const uint32_t k0_ = (uint32_t)(pl >> 32) & 0xFFFFu, base_ = (uint32_t)pl;
-      const uint64_t wb64 = (uint64_t)base_ + (kseq > k0_ ? (uint64_t)(kseq - k0_) * STRIDE : 0ull);
+      const uint32_t k0_ = (uint32_t)(pl >> 32) & 0xFFFu, base_ = (uint32_t)pl, sh_ = (uint32_t)(pl >> 44) & 15u;
+      const uint32_t rbl_ = PE_RBL >> sh_, stride_ = rbl_ - PE_REMOTE_MARGIN;
+      const uint64_t wb64 = (uint64_t)base_ + (kseq > k0_ ? (uint64_t)(kseq - k0_) * stride_ : 0ull);
       const uint32_t W = (uint32_t)((wb64 < (uint64_t)in_limit ? wb64 : (uint64_t)in_limit) >> 5);
       const uint32_t avail = (W << 5) < in_limit ? in_limit - (W << 5) : 0u;
       const uint64_t sw_ = gang_ld64(gc, GC_STOP);
       const bool buildable = td_ok && avail >= PE_MIN_INPUT && !((uint32_t)(sw_ >> 32) == epoch && (uint32_t)sw_ <= kseq);
-      setup_tables(W, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
-      pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48));
+      setup_tables(W, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
+      pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48)); pe_ctl_st(pb, PEC_MYSHIFT, sh_);
     };
-    for (kseq = role;; kseq += gang_m) {
+    const bool alone = role == 0u && pe_ctl_ld(pb, PEC_PLAN) == 6u;   // (the owner has kept the invocation to itself: see `long_first`)
+    if (!alone) for (kseq = role;; kseq += gang_m) {
       if (me == 0) window_by_plan(gang_ld64(gc, GC_PLAN));
       PE_BAR();
       PE_PROF(15);   // (the window)
@@ -2588,15 +2614,16 @@ pe_pass:
             const uint32_t avail = eb < in_limit ? in_limit - ((eb >> 5) << 5) : 0u;
             const bool go = td_ok && eb < in_limit && avail >= PE_MIN_INPUT;
             if (go) {
-              const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L);
-              const bool usable = built && eb >= w0 && eb + PE_PIPE_USEFUL <= w0 + wl;
+              const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L), sh_ = pe_ctl_ld(pb, PEC_MYSHIFT), rbl_ = PE_RBL >> sh_;
+              const bool usable = built && eb >= w0 && eb + (PE_PIPE_USEFUL >> sh_) <= w0 + wl;
               plan = usable ? 0u : 1u;
               GANG_STAT(gc, 1, 1);
               if (!usable) {
                 GANG_STAT(gc, 2, 1);
                 if (!built) GANG_STAT(gc, 10, 1); else if (eb < w0) GANG_STAT(gc, 11, 1); else GANG_STAT(gc, 12, 1);
-                setup_tables(eb >> 5, 0u, avail < PE_RBL ? avail : PE_RBL, 0u, 0u);
-                if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)kseq << 32) | (uint64_t)eb);
+                setup_tables(eb >> 5, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
+                if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)sh_ << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
+                pe_ctl_st(pb, PEC_MYGEN, (mygen + 1u) & 0xFFFFu);
                 gang_drain();
               }
             }
@@ -2613,6 +2640,27 @@ pe_pass:
       if (plan == 2u) break;
       if (plan == 4u) { if (me == 0) full_arrival(false); PE_BAR(); break; }
       if (plan == 1u) (void)build();
+      // a region whose closure has filled its room: half the bits, for this one and the ones behind it -- a new plan; twice, if need be
+      for (uint32_t halvings = 0; halvings < 2u; halvings++) {
+        if (me == 0) {
+          const uint32_t sh_ = pe_ctl_ld(pb, PEC_MYSHIFT), eb = pe_ctl_ld(pb, PEC_MYENTRY);
+          const uint32_t avail = eb < in_limit ? in_limit - ((eb >> 5) << 5) : 0u;
+          uint32_t again = 0u;
+          if (wn + 64u > PE_WCAP && sh_ < 2u && pe_ctl_ld(pb, PEC_L) > (PE_RBL >> (sh_ + 1u))) {
+            const uint32_t rbl_ = PE_RBL >> (sh_ + 1u), g_ = (pe_ctl_ld(pb, PEC_MYGEN) + 1u) & 0xFFFFu;
+            setup_tables(eb >> 5, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
+            if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)g_ << 48) | ((uint64_t)(sh_ + 1u) << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
+            gang_drain();
+            pe_ctl_st(pb, PEC_MYGEN, g_); pe_ctl_st(pb, PEC_MYSHIFT, sh_ + 1u);
+            again = 1u;
+            GANG_STAT(gc, 12, 1);
+          }
+          pe_ctl_st(pb, PEC_PLAN, again != 0u ? 5u : 0u);
+        }
+        PE_BAR();
+        if (pe_ctl_ld(pb, PEC_PLAN) != 5u) break;
+        (void)build();
+      }
       if (me == 0) {
         const uint32_t eb = pe_ctl_ld(pb, PEC_MYENTRY);
         pe_ctl_st(pb, PEC_LE, eb - (pe_ctl_ld(pb, PEC_LBDW) << 5));
@@ -2723,7 +2771,7 @@ pe_pass:
 #ifdef BROTLI_AMD_PROFILE_SCAN
   if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 32; k++) if (k != 30) g_path_prof[k] += pp_acc[k]; g_path_prof[32] += pe_ctl_ld(pbs, PEC_STATE + 6); g_path_prof[33] += 1; }
 #endif
-  if (REMOTE) {
+  if (REMOTE && pe_ctl_ld(pb, PEC_PLAN) != 6u) {   // (6: the owner kept the invocation to itself)
     // (the owner of a gang) the invocation's end as the gang left it: the regions resolved in all, the stream's state behind the last of them
     // -- whoever's it was --, and the last one's output in memory
     uint32_t spins = 0; uint64_t sw_, v; (void)spins;
@@ -2737,6 +2785,7 @@ pe_pass:
     }
     if (lane < 25u) lds_st32(pbs + PE_CTL + 4u * (PEC_STATE + lane), (uint32_t)v);
     pe_ctl_st(pbs, PEC_DECLINE, (rdlane((uint32_t)v, 25) >> 1) & 3u);
+    pe_ctl_st(pb, PEC_DSEEN, Kr != 0u ? (rdlane((uint32_t)v, 25) >> 3) & 1u : 0u);   // (the engine's part ended in front of a dictionary reference: the general form's stream, as the lean form says it)
     if (Kr != 0u) {
       for (;;) { const uint64_t ew = gang_ld64(gc, GC_EXEC); if ((uint32_t)(ew >> 32) == epoch && (uint32_t)ew >= Kr) break; __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins); }
       gang_acquire();
@@ -2766,7 +2815,7 @@ pe_pass:
   }
   const bool pdx = PE_DICT && pe_ctl_ld(pb, PEC_PDX) != 0u;   // (behind the distance of a command whose literals are out: postReadDistance, decode.rs:2583)
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && (pe_ctl_ld(pbs, PEC_DECLINE) & 1u) != 0u ? 0x100u : 0u) | (REMOTE && (pe_ctl_ld(pbs, PEC_DECLINE) & 2u) != 0u ? 0x800u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && (pe_ctl_ld(pbs, PEC_DECLINE) & 1u) != 0u ? 0x100u : 0u) | (REMOTE && (pe_ctl_ld(pbs, PEC_DECLINE) & 2u) != 0u ? 0x800u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE2 && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);
