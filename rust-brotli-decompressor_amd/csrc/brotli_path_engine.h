@@ -171,7 +171,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
        PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
-       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_MYSHIFT = 138 /* ... and how often its regions are halved */, PEC_BUILT = 158 /* ... whether its tables are built */,
+       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_MYSHIFT = 138 /* ... and how often its regions are halved */, PEC_RELAX = 159 /* ... whether this engine's executes wait twice (see there): its own observation, kept from region to region */, PEC_LAG = 137 /* ... the bytes of the region before's output: what a copy may not read before that region's engine says they are there */, PEC_BUILT = 158 /* ... whether its tables are built */,
        PEC_FIN = 156 /* a long literal run has ended in this region: its command's distance and copy are wave 0's, in place */,
        PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
        PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
@@ -853,7 +853,7 @@ pe_again:
     if (REMOTE && !long_first) {   // the invocation is everybody's: the stream's state in front of region 0, the plan (from region 0 on, at the entry), then its number
       hc_st(HC_GANG_EPOCH, epoch);
       lds_sync();
-      const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : 1u;
+      const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : lane == 25u ? 1u : 0u;
       if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)(epoch << 12) << 32));
       if (lane == 0u) { gang_st64(gc, GC_PLAN, (uint64_t)st.b); gang_st64(gc, GC_ENTRY, (uint64_t)st.b | ((uint64_t)(epoch << 12) << 32)); }
       gang_drain();
@@ -1593,6 +1593,7 @@ pe_again:
       const PeStream st = pe_st_load(pbs);
       ok_ = (walked && st.b == pe_ctl_ld(pb, PEC_MYENTRY) && st.quota >= SC_MIN_QUOTA && st.bl1 != 0u) ? 1u : 0u;
       pe_ctl_st(pb, PEC_P0_LO, (uint32_t)st.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(st.P >> 32));
+      pe_ctl_st(pb, PEC_LAG, pe_ctl_ld(pb, PEC_RELAX) == 1u ? rdlane((uint32_t)v, 26) : 0u);
     }
     if (ok_ == 0u) {
       if (!arrived) GANG_STAT(gc, 32, 1); else if ((rdlane((uint32_t)v, 25) & 1u) == 0u) GANG_STAT(gc, 33, 1); else { const PeStream st = pe_st_load(pbs); if (st.b != pe_ctl_ld(pb, PEC_MYENTRY)) GANG_STAT(gc, 34, 1); else GANG_STAT(gc, 36, 1); }
@@ -2008,7 +2009,9 @@ pe_pass:
       if (mine && stopmask != 0ull && lane == 0) pe_atomic_min(pb + PE_CTL + 4u * PEC_KP, k0 + kpb);
       // a copy whose source reaches into the region's own output is done afterwards (bit 31 of w0); long items get a wave
       const uint32_t copy_x = (dictc || plainw) ? 0u : copy;   // (a dictionary word is no LZ77 copy: wave 0's behind the pass, or -- inside it -- an item of its own list)
-      const uint32_t dep = (copy_x != 0u && rel + ins + copy_x > (uint64_t)(uint32_t)dist) ? 1u : 0u;
+      // (a gang: a copy that reads the region BEFORE's output -- the last `lag` bytes in front of this region's -- waits with the copies that read
+      // this region's own: that region's engine may still be writing them.  What lies in front of that is there: see the execute's two waits.)
+      const uint32_t dep = (copy_x != 0u && rel + ins + copy_x + (REMOTE ? (uint64_t)pe_ctl_ld(pb, PEC_LAG) : 0ull) > (uint64_t)(uint32_t)dist) ? 1u : 0u;
       uint32_t uu = (r0 >> 15) & 255u; uu = uu < ins ? uu : ins;
       const bool bigc = (copy_x > PE_LANE_COPY && dep == 0u) || ins - uu > PE_LANE_LITS;
       const uint64_t dmk = __ballot(lane < kpb && dep != 0u), bmk = __ballot(lane < kpb && bigc), wmk = PE_DICT ? __ballot(lane < kpb && plainw) : 0ull;
@@ -2129,7 +2132,7 @@ pe_pass:
           // invocation's end in a word of its own behind them (whoever waits for a region that will not come looks at it)
           pe_ctl_st(pb, PEC_MYNEXT, sn.b);
           lds_sync();
-          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1) | (pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 8u : 0u);
+          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : lane == 25u ? (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1) | (pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 8u : 0u) : pe_ctl_ld(pb, PEC_OUTTOT);
           if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
           if (!cont) { gang_drain(); if (lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
         }
@@ -2145,19 +2148,33 @@ pe_pass:
     }
     PE_PROF(11);
     if (REMOTE && me == 0) GANG_STAT(gc, 26, __builtin_amdgcn_s_memtime() - gs_arr);   // .. resolve done (wave 0 past the publish)
-    if (REMOTE && me == 0 && kseq != 0u) {
-      // (a gang: the word is another CU's; wave 0 looks at it, lets this CU forget what it has cached of the output, and tells the others)
-      uint32_t spins = 0; (void)spins;
-      const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
+    // (a gang) Two waits for other CUs' output: here for the regions up to the one before the region before -- the literals, and the copies that
+    // read nothing younger, start at once --, and behind them for the region before, whose last bytes only the copies marked `dep` in the resolve
+    // read (with uniform distances a handful a region: they go with the copies that read this region's own output).  The word is another CU's:
+    // wave 0 looks at it, lets this CU forget what it has cached of the output, and tells the others.
+    // Which of the two it is, every engine decides for itself from what it has seen: two waits cost a second fence and put more copies on the
+    // slower road, and pay where the executes are what the stream waits for (many commands a region: +8 % on one stream of 64 MiB and more,
+    // -4 .. -10 % on batches of the metric's 4 MiB streams if it were the rule) -- an engine that has waited long for the region before's
+    // output waits twice from the next region on, one whose two waits were short goes back to one.  (Gangs of eight only: smaller ones wait for a
+    // block that is busy, not for a chain -- measured, two waits cost them 5 .. 8 %.)
+    auto await_output = [&](const uint32_t upto, const uint32_t stat) -> uint32_t {
+      uint32_t spins = 0; (void)spins; (void)stat;
+      const uint64_t t0_ = __builtin_amdgcn_s_memtime();
       for (;;) {
         const uint64_t ew = gang_ld64(gc, GC_EXEC);
-        if ((uint32_t)(ew >> 32) == epoch && (uint32_t)ew >= kseq) break;
+        if ((uint32_t)(ew >> 32) == epoch && (uint32_t)ew >= upto) break;
         __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
       }
-      GANG_STAT(gc, 8, __builtin_amdgcn_s_memtime() - t0_);
-      GANG_STAT(gc, 30, __builtin_amdgcn_s_memtime() - t0_ < 400u ? 1u : 0u);
+      const uint32_t waited = (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
+      GANG_STAT(gc, stat, waited);
       gang_acquire();
-      GANG_STAT(gc, 9, __builtin_amdgcn_s_memtime() - t0_);
+      return waited;
+    };
+    const bool relaxed = REMOTE && pe_ctl_ld(pb, PEC_LAG) != 0u;   // (the resolve marked the copies that read the region before's output)
+    uint32_t waited1 = 0; (void)waited1;
+    if (REMOTE && me == 0) {
+      if (relaxed) { if (kseq >= 2u) waited1 = await_output(kseq - 1u, 9u); }
+      else if (kseq != 0u) { waited1 = await_output(kseq, 8u); if (waited1 > 6000u && gang_m >= 8u) pe_ctl_st(pb, PEC_RELAX, 1u); GANG_STAT(gc, 30, 1); }
       lds_sync();
       pe_ctl_st(pbs, PEC_EXECUTED, kseq);
     }
@@ -2359,6 +2376,10 @@ pe_pass:
 #endif
       PE_PROF(9);
       RG_STAMP(3);   // (b) done (this wave's share)
+      if (REMOTE && me == 0 && kseq != 0u && relaxed) {   // (the region before's output: in front of the dependent copies' first barrier, and of the word that says this region's is there)
+        const uint32_t waited2 = await_output(kseq, 8u);
+        if (waited1 + waited2 < 1500u) pe_ctl_st(pb, PEC_RELAX, 0u);
+      }
       // (c) copies that read the region's own output.
       const uint32_t ndep = pe_ctl_ld(pb, PEC_ANYDEP);
       PE_COUNT(13, ndep);
@@ -2373,7 +2394,8 @@ pe_pass:
           const uint32_t cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
           const uint32_t dst = lds_ld32(pb + PE_OFF + (k << 2)) + (lds_ld32(ra + 4u) & 0xFFFFu);
           bool ready = dist >= cn && dist <= dst;  // (a source that begins in front of the region reads only what is complete)
-          if (dist >= cn) {
+          if (REMOTE && dist >= cn && dst + cn <= dist) ready = true;   // (a gang: a source that lies in the region before's output, whole: it builds on nothing of this region's)
+          else if (dist >= cn) {
             const uint32_t s_lo = dist <= dst ? dst - dist : 0u, s_hi = dst + cn - dist;  // the source's part inside the region
             // the first earlier dependent copy whose destination ends behind s_lo
             uint32_t lo_ = 0, hi_ = j;
