@@ -29,6 +29,10 @@
 extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
                                                uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
                                                uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int waves_per_block);
+// (the same kernel with the gang's form of the path engine in it: the launches that give every stream a gang of blocks -- csrc/brotli_kernels.hip, BROTLI_AMD_GANG_KERNEL)
+extern "C" hipError_t brotli_amd_launch_decode_gang(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
+                                                    uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
+                                                    uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int waves_per_block);
 extern "C" uint32_t brotli_amd_lds_fixed_bytes(void);
 extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves);
 extern "C" const uint8_t brotli_amd_dictionary[];  // dict_blob.c: data/dictionary.bin, 122784 bytes
@@ -170,8 +174,8 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   b->last_gang = b->gang;
   if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
-  hipError_t le = brotli_amd_launch_decode(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
-                                           b->d_dict, stream, (int)b->waves);
+  hipError_t le = (b->gang > 1u ? brotli_amd_launch_decode_gang : brotli_amd_launch_decode)(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
+                                                                                             b->d_dict, stream, (int)b->waves);
   if (b->waves == 16u && (le == hipErrorInvalidValue || le == hipErrorLaunchOutOfResources || le == hipErrorSharedObjectInitFailed || le == hipErrorInvalidConfiguration)) {
     // the device refused a block of sixteen waves with the engine's LDS although its properties allow one: this context goes
     // on with blocks of eight waves, and says so (BrotliAmdLastNote); streams are no longer sent back for engine blocks
@@ -290,7 +294,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
-  if (!ensure_scratch(b, b->grid)) return -1;
+  if (!ensure_scratch(b, b->gang > 1u ? n : b->grid)) return -1;   // (a gang's helper blocks have no scratch of their own: a slot per stream)
   // more streams than blocks: the blocks take them longest first (compressed size as the measure), so that no block starts
   // a long stream when the others are done
   static const bool no_order = getenv("BROTLI_AMD_NO_ORDER") != nullptr;  // (experiments)

@@ -1361,7 +1361,9 @@ __device__ __noinline__ uint32_t scan_engine(const uint32_t me_);
 namespace pe16 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }   // one engine of sixteen waves, the lean form: no words of the static dictionary
 namespace pe16g { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }  // ... the general form
 namespace pe8 { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }    // two engines of eight, regions in turns
+#ifdef BROTLI_AMD_GANG_KERNEL
 namespace pe16r { __device__ __noinline__ uint32_t path_engine(const uint32_t me_); }  // one engine of sixteen a block, the blocks of a gang taking the regions in turns
+#endif
 // which command engine blocks of sixteen waves use: 0 = the path engine where it applies (brotli_path_engine.h), 1 = the scan
 // engine only (experiments, A/B tests: BROTLI_AMD_ENGINE=scan)
 __device__ uint32_t g_engine_mode = 2;
@@ -1535,7 +1537,9 @@ __device__ __noinline__ void helper_wave(const uint32_t me /* 1 .. waves - 1 */,
     if (kind == HK_PATH) { seq = rfl(pe16::path_engine(me)); continue; }   // (back with the last request it answered: see there)
     if (kind == HK_PATHG) { seq = rfl(pe16g::path_engine(me)); continue; }
     if (kind == HK_PATH2) { seq = rfl(pe8::path_engine(me)); continue; }
+#ifdef BROTLI_AMD_GANG_KERNEL
     if (kind == HK_PATHR) { seq = rfl(pe16r::path_engine(me)); continue; }
+#endif
     if (kind == HK_SPLIT) {  // a context-modelled metablock: wave 1 copies (if asked to), wave 2 parses command records; the others go back to sleep
       if (rfl(me) == 1u && (g_engine_mode & 2u) == 0u) copier_wave(); else if (rfl(me) == 2u && hc_ld(HC_EXT_BASE) != 0u) rec_wave();
       continue;
@@ -2018,6 +2022,7 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 #include "brotli_path_engine.h"
 #undef PE_CFG_NS
 #undef PE_CFG_DICT
+#ifdef BROTLI_AMD_GANG_KERNEL
 #undef PE_CFG_REMOTE
 #define PE_CFG_NS pe16r
 #define PE_CFG_DICT 0
@@ -2026,6 +2031,9 @@ __device__ __noinline__ void spec_rounds(uint32_t tree_addr) {
 #undef PE_CFG_NS
 #undef PE_CFG_REMOTE
 #define PE_CFG_REMOTE 0
+#else
+#define PE_CFG_DICT 0
+#endif
 #undef PE_CFG_WAVES
 #undef PE_CFG_RBL
 #undef PE_CFG_PIPE
@@ -3453,7 +3461,11 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const bool use_general = use_path && !use_pipe && prefer_general;
         // (the stream's owner in a gang of blocks: the gang's form of the engine -- not for a literal run that wants regions of its own, nor for
         // words of the static dictionary: those are the one-block forms')
+#ifndef BROTLI_AMD_GANG_KERNEL   // (the kernel of the launches without gangs: see the end of this file)
+        const bool gang_here = false;
+#else
         const bool gang_here = use_path && !use_pipe && !use_general && hc_ld(HC_GANG_M) > 1u;
+#endif
         bool use_remote = gang_here && !prefer_one_engine && !remote_off && remote_hold == 0u;
         if (gang_here && !use_remote && remote_hold != 0u) remote_hold--;
         if (use_remote) {
@@ -3479,7 +3491,11 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
 #ifdef BROTLI_AMD_PE_DEBUG
         if (blockIdx.x == 0 && lane == 0) printf("engine in: P %llu bl1 %u quota %u mlen %d commands so far %llu\n", (unsigned long long)P, bl1, quota, mlen, (unsigned long long)num_commands);
 #endif
+#ifndef BROTLI_AMD_GANG_KERNEL
+        const uint32_t took = use_pipe ? rfl(pe8::path_engine(0)) : use_general ? rfl(pe16g::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+#else
         const uint32_t took = use_remote ? rfl(pe16r::path_engine(0)) : use_pipe ? rfl(pe8::path_engine(0)) : use_general ? rfl(pe16g::path_engine(0)) : use_path ? rfl(pe16::path_engine(0)) : rfl(scan_engine(0));
+#endif
 #ifdef BROTLI_AMD_PE_DEBUG
         if (blockIdx.x == 0 && lane == 0) printf("engine out: tick %llu took %u, P %llu form %u\n", (unsigned long long)__builtin_amdgcn_s_memtime(), took, (unsigned long long)(LEAN_LD(L_P_LO) | ((uint64_t)LEAN_LD(L_P_HI) << 32)), LEAN_LD(L_SC_POS_HI));
 #endif
@@ -4417,7 +4433,17 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 }  // namespace
 
 // One decoding wave (+ up to seven helper waves) per stream; persistent blocks pull stream indices from `queue`.
-extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(const BrotliAmdStreamDesc* __restrict__ descs,
+// This file compiles into two objects (Makefile): the kernel of the launches without gangs, and -- with -DBROTLI_AMD_GANG_KERNEL -- the kernel of the
+// gang launches, the only one that has the gang's form of the path engine in its call graph.  One kernel for both cost the metric 4.5 %
+// (6.39 -> 6.68 ms): a kernel's scratch is its deepest call chain's, 1408 bytes a lane without that form and 1828 with it.
+#ifdef BROTLI_AMD_GANG_KERNEL
+#define BROTLI_AMD_KERNEL brotli_amd_decode_gang_kernel
+#define BROTLI_AMD_LAUNCH brotli_amd_launch_decode_gang
+#else
+#define BROTLI_AMD_KERNEL brotli_amd_decode_kernel
+#define BROTLI_AMD_LAUNCH brotli_amd_launch_decode
+#endif
+extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const BrotliAmdStreamDesc* __restrict__ descs,
                                                                            BrotliAmdStreamStatus* __restrict__ status, uint32_t n_streams,
                                                                            uint32_t* __restrict__ queue, uint8_t* __restrict__ scratch,
                                                                            uint64_t scratch_per_block, uint32_t lds_arena_bytes,
@@ -4432,13 +4458,18 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
   // A gang launch (queue[2] blocks a stream, sixteen waves each; see GC_*): block b is member (b mod 8 gang) / 8 of the gang of stream
   // (b / (8 gang)) 8 + b mod 8 -- the members of a gang are eight block numbers apart, which is how the hardware deals blocks to the same
   // XCD (their L2 is one: what they hand each other does not cross the fabric; a matter of speed, not of correctness).  Member 0 owns the stream.
+#ifdef BROTLI_AMD_GANG_KERNEL
   uint32_t gang_m = rfl(queue[2]), gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
+#else
+  uint32_t gang_m = 1u, gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
+#endif
   if (gang_m > 1u && gang_m <= 8u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP) {
     gang_role = (blockIdx.x % (8u * gang_m)) >> 3;
     gang_stream = (blockIdx.x / (8u * gang_m)) * 8u + (blockIdx.x & 7u);
     if (gang_stream >= n_streams) return;   // (the streams are not a multiple of eight: a gang without a stream)
     gang_addr = ((uint64_t)rfl(queue[4]) | ((uint64_t)rfl(queue[5]) << 32)) + (uint64_t)gang_stream * GC_STRIDE;
   } else gang_m = 1u;
+  const uint32_t scratch_slot = gang_m > 1u ? gang_stream : blockIdx.x;   // (this block's part of `scratch`: a gang's helper blocks have none, its owner takes its stream's)
   // waves 1.. are helpers (see helper_wave); the mailbox is cleared before the waves part ways
   if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u) {
     const uint32_t nw = blockDim.x >> 6, nr = nw < SPEC_MAX_WAVES ? nw : SPEC_MAX_WAVES;  // waves in the block, waves that take part in rounds
@@ -4458,13 +4489,15 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
   __syncthreads();
   if (gang_role != 0u) {   // a helper block of a gang: the path engine's regions of its owner's stream, nothing else (see there)
     if ((uint32_t)(uintptr_t)g_dynamic_lds != 0u) return;   // (no LDS addressing: the owner finds the gang short of a block and goes on alone)
+#ifdef BROTLI_AMD_GANG_KERNEL
     if (threadIdx.x == 0u) (void)gang_add32(gang_ctl(), GC_JOINED, 1u);
     (void)pe16r::path_engine(rfl(threadIdx.x >> 6));
+#endif
     return;
   }
   if (rfl(threadIdx.x >> 6) != 0u) {
     if ((uint32_t)(uintptr_t)g_dynamic_lds == 0u)
-      helper_wave(rfl(threadIdx.x >> 6), as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block + (scratch_per_block - BROTLI_AMD_SPEC_SCRATCH)));
+      helper_wave(rfl(threadIdx.x >> 6), as_global<gu8>(scratch + (uint64_t)scratch_slot * scratch_per_block + (scratch_per_block - BROTLI_AMD_SPEC_SCRATCH)));
     return;
   }
   // the decoding wave is a chain of dependent instructions; the waves beside it on its SIMD (helpers of this and other blocks)
@@ -4521,7 +4554,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
     }
 
     Stream s;
-    s.ar.glb = as_global<gu8>(scratch + (uint64_t)blockIdx.x * scratch_per_block);
+    s.ar.glb = as_global<gu8>(scratch + (uint64_t)scratch_slot * scratch_per_block);
     s.ar.lds_limit = lds_arena_bytes;
     s.ar.top = 0;
     s.ar_end = (uint32_t)(scratch_per_block - BROTLI_AMD_SPEC_SCRATCH) & ~3u;
@@ -4697,9 +4730,9 @@ extern "C" __global__ __launch_bounds__(1024, 4) void brotli_amd_decode_kernel(c
 }
 
 extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves);
-extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
-                                               uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
-                                               uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves) {
+extern "C" hipError_t BROTLI_AMD_LAUNCH(const BrotliAmdStreamDesc* descs, BrotliAmdStreamStatus* status, uint32_t n_streams,
+                                        uint32_t* queue, uint8_t* scratch, uint64_t scratch_per_block, uint32_t grid,
+                                        uint32_t lds_arena_bytes, const uint8_t* dict, hipStream_t stream, int helper_waves) {
   if (n_streams == 0) return hipSuccess;
   static const bool no_helpers = getenv("BROTLI_AMD_NO_HELPERS") != nullptr;  // (experiments: one wave per block)
   // (sixteen waves: a block with the command engine; otherwise at most eight)
@@ -4722,15 +4755,16 @@ extern "C" hipError_t brotli_amd_launch_decode(const BrotliAmdStreamDesc* descs,
   // and launching is one critical section (the launch itself is asynchronous).
   static std::mutex launch_mutex;
   std::lock_guard<std::mutex> lock(launch_mutex);
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(brotli_amd_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(BROTLI_AMD_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (err != hipSuccess) return err;
   // Blocks of one wave where the caller wants more than four blocks per CU in flight (a CU's registers hold four
   // four-wave blocks): such batches gain more from streams in flight than from helper waves in long literal runs.
-  hipLaunchKernelGGL(brotli_amd_decode_kernel, dim3(grid), dim3(64u * waves), smem, stream, descs, status, n_streams, queue, scratch,
+  hipLaunchKernelGGL(BROTLI_AMD_KERNEL, dim3(grid), dim3(64u * waves), smem, stream, descs, status, n_streams, queue, scratch,
                      scratch_per_block, lds_arena_bytes, dict);
   return hipGetLastError();
 }
 
+#ifndef BROTLI_AMD_GANG_KERNEL   // (what follows exists once: in the object without the gang kernel)
 // Test hook (BrotliAmdDebugBuildTree, include/brotli/batch.h): the table builder alone.  One wave builds the two-level table of
 // `n_sym` code lengths (src/huffman/mod.rs:273-386) where a metablock's first table would lie and then decodes every fifteen-bit
 // value through it as read_symbol does: decoded[v] = symbol << 4 | code length.  The test compares that -- not the table's layout,
@@ -4766,3 +4800,4 @@ extern "C" uint32_t brotli_amd_lds_helper_bytes(uint32_t waves) {
   if (waves >= SC_WAVES) return SC_BYTES;  // (the rounds' slots lie inside the engine's rings)
   return waves > 1u ? waves * HL_SLOT : 0u;
 }
+#endif
