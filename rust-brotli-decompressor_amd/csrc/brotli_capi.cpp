@@ -170,6 +170,7 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
     }
     if (!hip_ok(hipMemsetAsync(b->d_gang, 0, need, stream), "hipMemsetAsync(gang control)")) return -1;
     b->h_order[2] = b->gang; b->h_order[4] = (uint32_t)(uintptr_t)b->d_gang; b->h_order[5] = (uint32_t)((uint64_t)(uintptr_t)b->d_gang >> 32);
+    b->h_order[6] = getenv("BROTLI_AMD_GANG_NO_HELPERS") != nullptr ? 1u : 0u;   // (tests: the helper blocks leave at once, the owners must find out and go on alone)
   }
   b->last_gang = b->gang;
   if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;

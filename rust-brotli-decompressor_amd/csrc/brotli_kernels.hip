@@ -3215,6 +3215,21 @@ struct HotArgs {
   uint64_t prof[6];
 };
 
+#ifdef BROTLI_AMD_GANG_KERNEL
+// What the gang made of an invocation: it sits out one invocation where it took nothing because it met a literal run that wants regions of its own first
+// thing or because its regions filled their closure's room, twice as many every time that happens again before it has taken anything, up to 64
+__device__ __noinline__ void gang_took(HotArgs* args, const uint32_t took, const uint32_t form_raw) {
+  const uint32_t counts = rfl(args->general_engine);
+  uint32_t pen = (counts >> 8) & 0xFFu, hold = 0u;
+  if (took >= 64u) pen = 0u;
+  if (((form_raw >> 11) & 1u) != 0u || (((form_raw >> 8) & 1u) != 0u && took == 0u)) {
+    pen = pen == 0u ? 1u : pen >= 32u ? 64u : pen * 2u;
+    hold = pen;
+  }
+  args->general_engine = (counts & 0xFFu) | (pen << 8) | (hold << 16);
+}
+#endif
+
 // src/decode.rs:2330-2744 with a flat output buffer.
 //  * literals are collected one per lane (v_writelane) and stored 64 at a time;
 //  * a copy of <= 64 bytes is split in two: its load is issued when the command is decoded, its store when the
@@ -3395,8 +3410,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // the same where its regions fill their closure's room (few literals: the one-block form halves its regions there, or hands the stream to the
   // scan engine; sitting out the rest of the metablock instead left 18 % of a 1 GiB stream's commands to one block, three quarters of its time).
   // Both counts go with the stream from metablock to metablock (HotArgs::general_engine).
-  uint32_t remote_penalty = (engine_hints >> 8) & 0xFFu, remote_hold = (engine_hints >> 16) & 0xFFu;
-  bool remote_off = false;
+  // (the counts and the two functions that keep them -- gang_wanted, gang_took -- are not this function's: what the gang asks of it lives in
+  // HotArgs, in words of the mailbox and in code of its own, because this function has no register to spare: with the counts in its registers and
+  // the decision in its body its frame was 432 bytes a lane where it is 128 without, and text through the gangs' kernel 8 % slower)
   bool prefer_scan = false;         // ... or the scan engine: the path engine found its regions bound by their closure (see there)
   bool prefer_general = (engine_hints & 1u) != 0u;   // ... or the path engine's general form: the lean one has stopped in front of a dictionary reference in this stream
   // ---- helper waves of a context-modelled metablock (LDS tables, a block of four or more waves): wave 2 parses command records
@@ -3462,26 +3478,17 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         // (the stream's owner in a gang of blocks: the gang's form of the engine -- not for a literal run that wants regions of its own, nor for
         // words of the static dictionary: those are the one-block forms')
 #ifndef BROTLI_AMD_GANG_KERNEL   // (the kernel of the launches without gangs: see the end of this file)
-        const bool gang_here = false;
+        const bool use_remote = false;
 #else
-        const bool gang_here = use_path && !use_pipe && !use_general && hc_ld(HC_GANG_M) > 1u;
-#endif
-        bool use_remote = gang_here && !prefer_one_engine && !remote_off && remote_hold == 0u;
-        if (gang_here && !use_remote && remote_hold != 0u) remote_hold--;
-        if (use_remote) {
-          const uint32_t ep = hc_ld(HC_GANG_EPOCH);
-          if (ep == 0u) {   // the first time: have the helpers all started?  (They do so with the owner, give or take a microsecond; a block that is not running cannot be waited for)
-            gu8* const gc = gang_ctl();
-            const uint32_t want = hc_ld(HC_GANG_M) - 1u;
-            uint32_t tries = 0;
-            while (gang_ld32(gc, GC_JOINED) < want && tries < 2048u) { __builtin_amdgcn_s_sleep(16); tries++; }
-            if (gang_ld32(gc, GC_JOINED) < want) {   // the stream stays this block's alone; a helper that turns up finds the gang dissolved
-              if (lane == 0) gang_st32(gc, GC_EPOCH, GC_QUIT);
-              hc_st(HC_GANG_M, 1u);
-              use_remote = false;
-            }
-          }
+        // (the counts looked at here, whether the helpers have all started by the engine itself the first time: a call in this place costs this
+        // function three hundred bytes of frame, and the spills around it every invocation)
+        bool use_remote = false;
+        if (use_path && !use_pipe && !use_general && hc_ld(HC_GANG_M) > 1u) {
+          const uint32_t counts = rfl(args->general_engine);
+          if (((counts >> 16) & 0xFFu) != 0u) args->general_engine = counts - (1u << 16);
+          else if (!prefer_one_engine) use_remote = true;
         }
+#endif
         hc_st(HC_KIND, use_remote ? (uint32_t)HK_PATHR : use_pipe ? (uint32_t)HK_PATH2 : use_general ? (uint32_t)HK_PATHG : use_path ? (uint32_t)HK_PATH : (uint32_t)HK_SCAN);
         lds_release();
         hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);  // the other waves of the block join (helper_wave)
@@ -3511,11 +3518,9 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         const uint32_t form_raw = LEAN_LD(L_SC_POS_HI), form = form_raw & 0xFFu;
         const bool declined = ((form_raw >> 8) & 1u) != 0u;
         if (((form_raw >> 10) & 1u) != 0u) prefer_general = true;   // (the lean form stopped in front of a dictionary reference)
-        if (use_remote && took >= 64u) remote_penalty = 0u;
-        if (((form_raw >> 11) & 1u) != 0u || (use_remote && declined && took == 0u)) {   // (... or it met a long literal run first thing)
-          remote_penalty = remote_penalty == 0u ? 1u : remote_penalty >= 32u ? 64u : remote_penalty * 2u;
-          remote_hold = remote_penalty;
-        }
+#ifdef BROTLI_AMD_GANG_KERNEL
+        if (use_remote) gang_took(args, took, form_raw);
+#endif
         if (((form_raw >> 9) & 1u) != 0u) prefer_scan = true;   // (the path engine's regions were bound by their closure: a stream of few literals -- the scan engine's from here on)   // (the two engines stopped in front of a literal run that wants regions of its own: the one-engine form's, at once)
         const uint64_t pos = origin + LEAN_LD(L_SC_POS_LO) - BitReader::skip_bits();
         if (lane == 0) { LEAN_ST(L_SPEC_LO, (uint32_t)rfl(args->spec_scratch)); LEAN_ST(L_SPEC_HI, (uint32_t)(rfl(args->spec_scratch) >> 32)); }
@@ -4080,7 +4085,7 @@ done:
   args->P = P; args->next_boundary = next_boundary; args->mlen = mlen;
   args->d0 = d0; args->d1 = d1; args->d2 = d2; args->d3 = d3;
   args->num_commands = num_commands;
-  args->engine_commands = engine_commands; args->general_engine = (prefer_general ? 1u : 0u) | (remote_penalty << 8) | (remote_hold << 16);
+  args->engine_commands = engine_commands; args->general_engine = (rfl(args->general_engine) & 0xFFFF00u) | (prefer_general ? 1u : 0u);
 #ifdef BROTLI_AMD_PROFILE
   if (lane == 0 && blockIdx.x == 0) printf("lean exits by stage: %u %u %u %u %u %u %u %u\n", prof_stage[0], prof_stage[1], prof_stage[2], prof_stage[3], prof_stage[4], prof_stage[5], prof_stage[6], prof_stage[7]);
   args->prof[0] = prof_cmd; args->prof[1] = prof_lit; args->prof[2] = prof_dist; args->prof[3] = prof_copy;
@@ -4489,6 +4494,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
   __syncthreads();
   if (gang_role != 0u) {   // a helper block of a gang: the path engine's regions of its owner's stream, nothing else (see there)
     if ((uint32_t)(uintptr_t)g_dynamic_lds != 0u) return;   // (no LDS addressing: the owner finds the gang short of a block and goes on alone)
+    if (queue[6] != 0u) return;   // (tests: helpers that never turn up -- BROTLI_AMD_GANG_NO_HELPERS --, as when the device has no CU for them)
 #ifdef BROTLI_AMD_GANG_KERNEL
     if (threadIdx.x == 0u) (void)gang_add32(gang_ctl(), GC_JOINED, 1u);
     (void)pe16r::path_engine(rfl(threadIdx.x >> 6));

@@ -768,6 +768,23 @@ pe_again:
     role = hc_ld(HC_GANG_ROLE); gang_m = hc_ld(HC_GANG_M); gc = gang_ctl();
     if (role == 0u) {
       epoch = hc_ld(HC_GANG_EPOCH) + 1u;   // (the word is this invocation's once it is everybody's: see below)
+      if (epoch == 1u) {
+        // the first time: have the helpers all started?  (They do so with the owner, give or take a microsecond; a block that is not running
+        // cannot be waited for: the stream stays this block's alone then -- the mailbox says so from here on --, and a helper that turns up
+        // finds the gang dissolved)
+        if (threadIdx.x == 0u) {
+          uint32_t tries = 0;
+          while (gang_ld32(gc, GC_JOINED) < gang_m - 1u && tries < 2048u) { __builtin_amdgcn_s_sleep(16); tries++; }
+          if (gang_ld32(gc, GC_JOINED) < gang_m - 1u) {
+            gang_st32(gc, GC_EPOCH, GC_QUIT);
+            *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_M]) = 1u;
+          }
+        }
+        __syncthreads();
+        gang_m = hc_ld(HC_GANG_M);
+      }
+    }
+    if (role == 0u && gang_m > 1u) {
       if (threadIdx.x == 0u) {   // the helpers have all left the invocation before (they read the image below when they enter one)
         uint32_t spins = 0; (void)spins;
         const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
@@ -784,7 +801,7 @@ pe_again:
       gang_drain();
       __syncthreads();
       if (threadIdx.x == 0u) { gang_release(); GANG_STAT(gc, 18, __builtin_amdgcn_s_memtime() - gs_t0); }   // (the state, the plan and EPOCH follow below, where wave 0 has put the state together)
-    } else {
+    } else if (role != 0u) {
       if (threadIdx.x == 0u) {
         const uint32_t last = *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_EPOCH]);
         uint32_t e;
@@ -848,6 +865,7 @@ pe_again:
       const ScHead h_ = sc_head(__builtin_amdgcn_alignbit(a1_, a0_, sh_), __builtin_amdgcn_alignbit(a2_, a1_, sh_), c.cmd_tree, c.lut_vgpr);
       long_first = rfl(h_.insert) >= PE_RUN_MIN && rfl(h_.bits) != 0u;
     }
+    if (REMOTE && gang_m <= 1u) long_first = true;   // (the gang is dissolved: the same way out)
     if (REMOTE) pe_ctl_st(pb, PEC_PLAN, long_first ? 6u : 0u);
     if (REMOTE && long_first) pe_ctl_st(pbs, PEC_DECLINE, 1u);
     if (REMOTE && !long_first) {   // the invocation is everybody's: the stream's state in front of region 0, the plan (from region 0 on, at the entry), then its number

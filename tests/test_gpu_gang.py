@@ -136,3 +136,24 @@ def test_one_batch_object_through_gang_launches_and_others(pkg):
         assert b.last_gang() == blocks, (n, b.last_gang())
         _against_oracle(res, outs, datas, caps)
     b.close()
+
+
+def test_helpers_that_never_turn_up(pkg):
+    """BROTLI_AMD_GANG_NO_HELPERS: the gangs' helper blocks leave at once, as blocks the device has no CU for would never start; the owners wait
+    for them once (a millisecond or two), dissolve their gangs and decode their streams alone -- same bytes, same status words"""
+    w = _w()
+    us = w.make_streams("long_backref", 3, 1 << 20, 1000)
+    datas, caps = [c for c, _, _ in us], [sz for _, sz, _ in us]
+    old = os.environ.get("BROTLI_AMD_GANG_NO_HELPERS")
+    try:
+        os.environ["BROTLI_AMD_GANG_NO_HELPERS"] = "1"
+        res, outs, gang = _decode(pkg, datas, caps)
+    finally:
+        if old is None:
+            os.environ.pop("BROTLI_AMD_GANG_NO_HELPERS", None)
+        else:
+            os.environ["BROTLI_AMD_GANG_NO_HELPERS"] = old
+    assert gang == 8
+    _against_oracle(res, outs, datas, caps)
+    for r in res:
+        assert r.engine_commands >= 0.9 * r.num_commands, (r.engine_commands, r.num_commands)
