@@ -1780,11 +1780,11 @@ pe_again:
           nbit += rfl(d_.bits);
         }
         {   // (regions that were halved take twice the bits again from the next one on where this one's closure is small: a new plan in front of the entry)
-          const uint32_t sh_ = pe_ctl_ld(pb, PEC_MYSHIFT);
+          const uint32_t shsc_ = pe_ctl_ld(pb, PEC_MYSHIFT), sh_ = shsc_ & 3u;
           if (sh_ != 0u && wn < PE_WCAP / 8u && kseq + 1u < GC_MAX_REGIONS) {
             const uint64_t cur = gang_ld64(gc, GC_PLAN);
             if ((uint32_t)(cur >> 48) == pe_ctl_ld(pb, PEC_MYGEN)) {   // (nobody has changed it since this engine's window was laid out)
-              if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((pe_ctl_ld(pb, PEC_MYGEN) + 1u) & 0xFFFFu) << 48) | ((uint64_t)(sh_ - 1u) << 44) | ((uint64_t)(kseq + 1u) << 32) | (uint64_t)((pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit));
+              if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((pe_ctl_ld(pb, PEC_MYGEN) + 1u) & 0xFFFFu) << 48) | ((uint64_t)(shsc_ - 1u) << 44) | ((uint64_t)(kseq + 1u) << 32) | (uint64_t)((pe_ctl_ld(pb, PEC_LBDW) << 5) + nbit));
               gang_drain();
             }
           }
@@ -2611,15 +2611,18 @@ pe_pass:
     // twice the bits where the closure has become small)
     // (wave 0) region kseq's window by the plan: its tables' set-up, whether there is anything to build, the plan's generation
     auto window_by_plan = [&](const uint64_t pl) {
-      const uint32_t k0_ = (uint32_t)(pl >> 32) & 0xFFFu, base_ = (uint32_t)pl, sh_ = (uint32_t)(pl >> 44) & 15u;
-      const uint32_t rbl_ = PE_RBL >> sh_, stride_ = rbl_ - PE_REMOTE_MARGIN;
+      // (bits 44, 45: the halvings; bits 46, 47: the stride in eighths less of a region less the margin -- where regions end short of their
+      // windows' ends, as the seed of the metric's streams does, whose path's ranks run out: 9 new plans a 4 MiB stream before, a region's
+      // tables of every block each)
+      const uint32_t k0_ = (uint32_t)(pl >> 32) & 0xFFFu, base_ = (uint32_t)pl, shsc_ = (uint32_t)(pl >> 44) & 15u, sh_ = shsc_ & 3u;
+      const uint32_t rbl_ = PE_RBL >> sh_, stride_ = ((rbl_ - PE_REMOTE_MARGIN) * (8u - (shsc_ >> 2))) >> 3;
       const uint64_t wb64 = (uint64_t)base_ + (kseq > k0_ ? (uint64_t)(kseq - k0_) * stride_ : 0ull);
       const uint32_t W = (uint32_t)((wb64 < (uint64_t)in_limit ? wb64 : (uint64_t)in_limit) >> 5);
       const uint32_t avail = (W << 5) < in_limit ? in_limit - (W << 5) : 0u;
       const uint64_t sw_ = gang_ld64(gc, GC_STOP);
       const bool buildable = td_ok && avail >= PE_MIN_INPUT && !((uint32_t)(sw_ >> 32) == epoch && (uint32_t)sw_ <= kseq);
       setup_tables(W, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
-      pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48)); pe_ctl_st(pb, PEC_MYSHIFT, sh_);
+      pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48)); pe_ctl_st(pb, PEC_MYSHIFT, shsc_);
     };
     const bool alone = role == 0u && pe_ctl_ld(pb, PEC_PLAN) == 6u;   // (the owner has kept the invocation to itself: see `long_first`)
     if (!alone) for (kseq = role;; kseq += gang_m) {
@@ -2654,7 +2657,7 @@ pe_pass:
             const uint32_t avail = eb < in_limit ? in_limit - ((eb >> 5) << 5) : 0u;
             const bool go = td_ok && eb < in_limit && avail >= PE_MIN_INPUT;
             if (go) {
-              const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L), sh_ = pe_ctl_ld(pb, PEC_MYSHIFT), rbl_ = PE_RBL >> sh_;
+              const uint32_t w0 = pe_ctl_ld(pb, PEC_LBDW) << 5, wl = pe_ctl_ld(pb, PEC_L), shsc_ = pe_ctl_ld(pb, PEC_MYSHIFT), sh_ = shsc_ & 3u, rbl_ = PE_RBL >> sh_;
               const bool usable = built && eb >= w0 && eb + (PE_PIPE_USEFUL >> sh_) <= w0 + wl;
               plan = usable ? 0u : 1u;
               GANG_STAT(gc, 1, 1);
@@ -2662,7 +2665,15 @@ pe_pass:
                 GANG_STAT(gc, 2, 1);
                 if (!built) GANG_STAT(gc, 10, 1); else if (eb < w0) GANG_STAT(gc, 11, 1); else GANG_STAT(gc, 12, 1);
                 setup_tables(eb >> 5, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
-                if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)sh_ << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
+                // (short of the window: the regions from here on a shorter stride -- what the region before did advance, in eighths)
+                uint32_t sc_ = shsc_ >> 2;
+                if (built && eb < w0) {
+                  const uint32_t full_ = rbl_ - PE_REMOTE_MARGIN, cur_ = (full_ * (8u - sc_)) >> 3, short_ = w0 - eb, adv_ = cur_ > short_ + 256u ? cur_ - short_ - 256u : 0u;
+                  while (sc_ < 3u && ((full_ * (8u - sc_)) >> 3) > adv_) sc_++;
+                }
+                const uint32_t nsh_ = sh_ | (sc_ << 2);
+                pe_ctl_st(pb, PEC_MYSHIFT, nsh_);
+                if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)((mygen + 1u) & 0xFFFFu) << 48) | ((uint64_t)nsh_ << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
                 pe_ctl_st(pb, PEC_MYGEN, (mygen + 1u) & 0xFFFFu);
                 gang_drain();
               }
@@ -2683,15 +2694,15 @@ pe_pass:
       // a region whose closure has filled its room: half the bits, for this one and the ones behind it -- a new plan; twice, if need be
       for (uint32_t halvings = 0; halvings < 2u; halvings++) {
         if (me == 0) {
-          const uint32_t sh_ = pe_ctl_ld(pb, PEC_MYSHIFT), eb = pe_ctl_ld(pb, PEC_MYENTRY);
+          const uint32_t shsc_ = pe_ctl_ld(pb, PEC_MYSHIFT), sh_ = shsc_ & 3u, eb = pe_ctl_ld(pb, PEC_MYENTRY);
           const uint32_t avail = eb < in_limit ? in_limit - ((eb >> 5) << 5) : 0u;
           uint32_t again = 0u;
           if (wn + 64u > PE_WCAP && sh_ < 2u && pe_ctl_ld(pb, PEC_L) > (PE_RBL >> (sh_ + 1u))) {
             const uint32_t rbl_ = PE_RBL >> (sh_ + 1u), g_ = (pe_ctl_ld(pb, PEC_MYGEN) + 1u) & 0xFFFFu;
             setup_tables(eb >> 5, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
-            if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)g_ << 48) | ((uint64_t)(sh_ + 1u) << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
+            if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)g_ << 48) | ((uint64_t)(shsc_ + 1u) << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
             gang_drain();
-            pe_ctl_st(pb, PEC_MYGEN, g_); pe_ctl_st(pb, PEC_MYSHIFT, sh_ + 1u);
+            pe_ctl_st(pb, PEC_MYGEN, g_); pe_ctl_st(pb, PEC_MYSHIFT, shsc_ + 1u);
             again = 1u;
             GANG_STAT(gc, 12, 1);
           }
