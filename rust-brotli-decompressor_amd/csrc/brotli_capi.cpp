@@ -560,7 +560,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
     unsigned long long st[40];
     if (hipMemcpy(st, b->d_gang + 704, sizeof st, hipMemcpyDeviceToHost) == hipSuccess)
       fprintf(stderr, "gang of %u: invocations %llu, regions arrived at %llu, of them not usable %llu (no tables %llu, short of the window %llu, too far into it %llu), rebuilt by a new plan %llu, tables built %llu; "
-              "ticks: owner waits for helpers to leave %llu, for the stream %llu (helpers %llu), for the output before %llu (+ acquire: %llu), at the end %llu; regions resolved %llu, declined %llu; owner inside the engine %llu (set-up %llu, its tables %llu, its regions' walk .. execute %llu), the releases behind a region's output %llu; invocations that took fewer than 64 commands %llu (none: %llu), commands in all %llu; from the stream's arrival, summed over the regions: walk done %llu, details %llu, resolve %llu, output complete %llu; (the walk's start %llu, the entry's states %llu, the anchors %llu); regions whose execute waited once %llu; invocations that resolved no region %llu; regions given up behind their details: the invocation had ended %llu, the region before said so %llu, the stream went on elsewhere %llu, no quota or commands left %llu; resolves that ended an invocation %llu (a limit cut the region: %llu); ticks waiting for the state behind the details %llu\n",
+              "ticks: owner waits for helpers to leave %llu, for the stream %llu (helpers %llu), for the region before's output %llu, for the regions' before that (executes that wait twice) %llu, at the end %llu; regions resolved %llu, declined %llu; owner inside the engine %llu (set-up %llu, its tables %llu, its regions' walk .. execute %llu), the releases behind a region's output %llu; invocations that took fewer than 64 commands %llu (none: %llu), commands in all %llu; from the stream's arrival, summed over the regions: walk done %llu, details %llu, resolve %llu, output complete %llu; (the walk's start %llu, the entry's states %llu, the anchors %llu); regions whose execute waited once %llu; invocations that resolved no region %llu; regions given up behind their details: the invocation had ended %llu, the region before said so %llu, the stream went on elsewhere %llu, no quota or commands left %llu; resolves that ended an invocation %llu (a limit cut the region: %llu); ticks waiting for the state behind the details %llu\n",
               b->last_gang, st[0], st[1], st[2], st[10], st[11], st[12], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[13], st[14], st[15], st[16], st[18], st[20], st[19], st[17], st[21], st[23], st[22], st[24], st[25], st[26], st[27], st[28], st[29], st[38], st[30], st[31], st[32], st[33], st[34], st[36], st[37], st[35], st[39]);
   }
 #endif
