@@ -690,7 +690,9 @@ namespace PE_CFG_NS {
 #define PE_BAR() __syncthreads()
 #endif
 #if PE_CFG_REMOTE
-__device__ __forceinline__ void pe_spin_check(uint32_t& spins) { if (++spins > (1u << 22)) __builtin_trap(); }   // (a gang's waits inside an invocation: some seconds)
+// (a gang's waits inside an invocation are for another block's work on one region -- whose output may be hundreds of megabytes of overlapping
+// copies: a minute or more of looking, not seconds, before the kernel is stopped rather than the machine)
+__device__ __forceinline__ void pe_spin_check(uint32_t& spins) { if (++spins > (1u << 26)) __builtin_trap(); }
 #define PE_SPIN_CHECK(s_) pe_spin_check(s_)
 #else
 #define PE_SPIN_CHECK(s_) do { } while (0)
