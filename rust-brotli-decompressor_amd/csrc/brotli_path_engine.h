@@ -2682,6 +2682,17 @@ pe_pass:
             }
             pe_ctl_st(pb, PEC_MYENTRY, eb);
             if (plan == 2u) plan = 4u;   // (the region cannot be taken: the invocation ends in front of it -- said once the region before is resolved, see full_arrival)
+            if (plan == 0u) {
+              // (the rule: the tables are the ones and their closure has room -- the walk's start words at once, one barrier between the stream's
+              // arrival and the walk instead of three: the walk is what the next region waits for)
+              const uint32_t shsc_ = pe_ctl_ld(pb, PEC_MYSHIFT), sh_ = shsc_ & 3u;
+              if (!(wn + 64u > PE_WCAP && sh_ < 2u && pe_ctl_ld(pb, PEC_L) > (PE_RBL >> (sh_ + 1u)))) {
+                pe_ctl_st(pb, PEC_LE, eb - (pe_ctl_ld(pb, PEC_LBDW) << 5));
+                pe_ctl_st(pb, PEC_MYNEXT, eb);
+                setup_walk(0ull);
+                plan = 7u;
+              }
+            }
           }
           pe_ctl_st(pb, PEC_PLAN, plan);
         }
@@ -2692,6 +2703,7 @@ pe_pass:
       PE_PROF(16);   // (waiting for the stream)
       if (plan == 2u) break;
       if (plan == 4u) { if (me == 0) full_arrival(false); PE_BAR(); break; }
+      if (plan != 7u) {
       if (plan == 1u) (void)build();
       // a region whose closure has filled its room: half the bits, for this one and the ones behind it -- a new plan; twice, if need be
       for (uint32_t halvings = 0; halvings < 2u; halvings++) {
@@ -2721,6 +2733,7 @@ pe_pass:
         setup_walk(0ull);   // (where the region's output starts: with the stream's state, behind the details)
       }
       PE_BAR();
+      }
       le = pe_ctl_ld(pb, PEC_LE);
       { const uint64_t tc_ = __builtin_amdgcn_s_memtime(); (void)tc_;
         consume();
