@@ -175,7 +175,8 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
   b->last_gang = b->gang;
   if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
   if (!hip_ok(hipEventRecord(b->ev0, stream), "hipEventRecord")) return -1;
-  hipError_t le = (b->gang > 1u ? brotli_amd_launch_decode_gang : brotli_amd_launch_decode)(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
+  static const bool gang_kernel_always = getenv("BROTLI_AMD_GANG_KERNEL_ALWAYS") != nullptr;   // (experiments: what the second kernel costs launches without gangs)
+  hipError_t le = (b->gang > 1u || gang_kernel_always ? brotli_amd_launch_decode_gang : brotli_amd_launch_decode)(b->d_descs, b->d_status, b->n, b->d_queue, b->d_scratch, kScratchPerBlock, b->grid, b->cur_arena,
                                                                                              b->d_dict, stream, (int)b->waves);
   if (b->waves == 16u && (le == hipErrorInvalidValue || le == hipErrorLaunchOutOfResources || le == hipErrorSharedObjectInitFailed || le == hipErrorInvalidConfiguration)) {
     // the device refused a block of sixteen waves with the engine's LDS although its properties allow one: this context goes

@@ -4440,7 +4440,8 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
 // One decoding wave (+ up to seven helper waves) per stream; persistent blocks pull stream indices from `queue`.
 // This file compiles into two objects (Makefile): the kernel of the launches without gangs, and -- with -DBROTLI_AMD_GANG_KERNEL -- the kernel of the
 // gang launches, the only one that has the gang's form of the path engine in its call graph.  One kernel for both cost the metric 4.5 %
-// (6.39 -> 6.68 ms): a kernel's scratch is its deepest call chain's, 1408 bytes a lane without that form and 1828 with it.
+// (6.39 -> 6.68 ms) while the gang's decision sat in process_commands' registers (see there); since it does not, the second kernel costs
+// launches without gangs nothing (BROTLI_AMD_GANG_KERNEL_ALWAYS=1 runs them through it) -- two objects all the same: insurance.
 #ifdef BROTLI_AMD_GANG_KERNEL
 #define BROTLI_AMD_KERNEL brotli_amd_decode_gang_kernel
 #define BROTLI_AMD_LAUNCH brotli_amd_launch_decode_gang
