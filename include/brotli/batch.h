@@ -80,7 +80,7 @@ BROTLI_DEC_API float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* batch);
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch);
 
 /* Blocks (CUs) that worked on each stream of the last launch: 1 as a rule; 2, 4 or 8 where the batch had fewer streams than half the
- * device's CUs and each stream was given a gang of blocks (csrc/brotli_path_engine.h, PE_CFG_REMOTE; BROTLI_AMD_GANG=0 turns that off). */
+ * device's CUs, at least one of them 64 KiB of compressed data or more, and each stream was given a gang of blocks (csrc/brotli_path_engine.h, PE_CFG_REMOTE; BROTLI_AMD_GANG=0 turns that off). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* batch);
 
 /* Streaming (BrotliDecoderDecompressStream, decode.h): the commands the device has decoded for this stream in all the launches

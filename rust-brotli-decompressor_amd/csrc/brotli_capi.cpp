@@ -284,7 +284,11 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   // a gang's members eight block numbers apart (one XCD); streams beyond a multiple of eight leave their gangs' blocks without work.
   const int gang_env = getenv("BROTLI_AMD_GANG") ? atoi(getenv("BROTLI_AMD_GANG")) : -1;   // (experiments: 0 or 1 none, 2 / 4 / 8 at most that many)
   b->gang = 0;
-  if (b->waves == 16u && b->auto_arena && b->cur_arena <= 49152u && gang_env != 0 && gang_env != 1) {
+  // (not for batches of small streams: a gang has something to divide from a dozen regions on -- 64 KiB of compressed data --, and costs a launch
+  // ten microseconds: its blocks' start, the control blocks' zeroing, the helpers' last look at the word that lets them go)
+  size_t largest_in = 0;
+  for (uint32_t i = 0; i < n; i++) largest_in = std::max<size_t>(largest_in, b->h_descs[i].in_size);
+  if (b->waves == 16u && b->auto_arena && b->cur_arena <= 49152u && gang_env != 0 && gang_env != 1 && largest_in >= 65536u) {
     const uint32_t groups = (n + 7u) / 8u;
     uint32_t m = groups * 64u <= b->cus ? 8u : groups * 32u <= b->cus ? 4u : groups * 16u <= b->cus ? 2u : 0u;
     if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;

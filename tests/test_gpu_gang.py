@@ -52,7 +52,7 @@ def _pool(w, rnd):
     survey variant (a quarter seed), high-entropy literals (long literal runs: regions of their own, the one-block form's), real text at
     -q 5 (words of the static dictionary), a context-modelled fixture (no engine at all), an executable (dozens of block types)"""
     pool = []
-    for k, size in enumerate((256 << 10, 1 << 20, 1 << 20, 4 << 20)):
+    for k, size in enumerate((4 << 20, 256 << 10, 1 << 20, 1 << 20)):   # (the first one large: a batch of small streams gets no gangs, see below)
         raw = w.long_backref_stream(7000 + k, size)
         pool.append((w.brotli_compress(raw, rnd.choice([4, 5, 5, 9]), rnd.choice([18, 22, 22, 24])), len(raw)))
     raw = w.long_backref_stream(7100, 2 << 20, seed_shift=2)   # (a quarter of it seed)
@@ -130,7 +130,7 @@ def test_one_batch_object_through_gang_launches_and_others(pkg):
     pool = _pool(w, rnd)
     b = pkg.Batch(200)
     for n, blocks in ((1, 8), (200, 1), (5, 8), (40, 4), (1, 8)):
-        picks = [pool[(i * 5 + n) % len(pool)] for i in range(n)]
+        picks = [pool[(i * 5) % len(pool)] for i in range(n)]   # (the first one the 4 MiB stream: see test_batches_of_small_streams_get_no_gangs)
         datas, caps = [c for c, _ in picks], [sz for _, sz in picks]
         res, outs = b.decode_host(datas, caps, 1)
         assert b.last_gang() == blocks, (n, b.last_gang())
@@ -157,3 +157,19 @@ def test_helpers_that_never_turn_up(pkg):
     _against_oracle(res, outs, datas, caps)
     for r in res:
         assert r.engine_commands >= 0.9 * r.num_commands, (r.engine_commands, r.num_commands)
+
+
+def test_batches_of_small_streams_get_no_gangs(pkg):
+    """a gang has something to divide from 64 KiB of compressed data on (a dozen regions) and costs a launch ten microseconds: batches whose
+    largest stream is smaller are launched with one block a stream, whatever their number; one large stream among them brings the gangs back"""
+    w = _w()
+    small = [w.brotli_compress(w.long_backref_stream(7300 + k, 128 << 10), 5, 22) for k in range(4)]
+    assert max(len(c) for c in small) < 65536
+    res, outs, gang = _decode(pkg, small, [128 << 10] * 4)
+    assert gang == 1
+    _against_oracle(res, outs, small, [128 << 10] * 4)
+    big = w.brotli_compress(w.long_backref_stream(7310, 2 << 20), 5, 22)
+    assert len(big) >= 65536
+    res, outs, gang = _decode(pkg, small + [big], [128 << 10] * 4 + [2 << 20])
+    assert gang == 8
+    _against_oracle(res, outs, small + [big], [128 << 10] * 4 + [2 << 20])
