@@ -770,7 +770,11 @@ pe_again:
     role = hc_ld(HC_GANG_ROLE); gang_m = hc_ld(HC_GANG_M); gc = gang_ctl();
     if (role == 0u) {
       epoch = hc_ld(HC_GANG_EPOCH) + 1u;   // (the word is this invocation's once it is everybody's: see below)
-      if (epoch == 1u) {
+      if (epoch >= (1u << 20) - 2u) {   // (the granules' tags hold twenty bits of it: a stream of a million invocations goes on without its gang)
+        if (threadIdx.x == 0u) { gang_st32(gc, GC_EPOCH, GC_QUIT); *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_M]) = 1u; }
+        __syncthreads();
+        gang_m = hc_ld(HC_GANG_M);
+      } else if (epoch == 1u) {
         // the first time: have the helpers all started?  (They do so with the owner, give or take a microsecond; a block that is not running
         // cannot be waited for: the stream stays this block's alone then -- the mailbox says so from here on --, and a helper that turns up
         // finds the gang dissolved)
