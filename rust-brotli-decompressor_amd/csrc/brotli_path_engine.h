@@ -1760,13 +1760,6 @@ pe_again:
         for (uint32_t q = 0; q < (m < 12u ? m + 1u : 12u); q++) printf("     list %u: %x\n", q, lds_ld16(pb + PE_LIST + (q << 1)));
       }
 #endif
-#ifdef BROTLI_AMD_GANG_STATS
-      if (REMOTE && m == 0u && lane == 0 && epoch < 400u && blockDim.x == 1u) {   // (a look at the regions that list nothing: edit the condition)
-        printf("gang: epoch %u region %u lists nothing: le %u L %u Lp %u Rn %u wn %u id %u id_hand %u desc %x; hand states:", epoch, kseq, le, c.L, c.Lp, c.Rn, wn, id, id_hand, desc);
-        for (uint32_t q = 0; q < 4u; q++) printf(" [%x -> %u]", lds_ld16(pb + PE_WST + ((wn + q) << 1)), lds_ld16(pb + PE_NEXT + ((PE_RANKS + wn + q) << 1)));
-        printf("\n");
-      }
-#endif
       if (REMOTE && m != 0u) {
         // (a gang) where the stream goes on if every command listed goes through -- the next region's engine starts its walk from there while
         // this region is resolved: the first bit of the command the list closes with (behind the distance code, if it starts with one)
