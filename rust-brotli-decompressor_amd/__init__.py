@@ -30,7 +30,7 @@ DECODE_H_SYMBOLS = [
 ]
 BATCH_H_SYMBOLS = [
     "BrotliAmdBatchCreate", "BrotliAmdBatchDestroy", "BrotliAmdBatchDecodeDevice", "BrotliAmdBatchRelaunch", "BrotliAmdBatchWait",
-    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdBatchLastGang", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
+    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdBatchLastGang", "BrotliAmdBatchLastPool", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
 ]
 
 
@@ -106,6 +106,9 @@ def load_library():
     if hasattr(L, "BrotliAmdBatchLastGang"):   # (libraries of earlier rounds, for A/B runs: tools/ab.sh)
         L.BrotliAmdBatchLastGang.restype = ctypes.c_uint32
         L.BrotliAmdBatchLastGang.argtypes = [vp]
+    if hasattr(L, "BrotliAmdBatchLastPool"):
+        L.BrotliAmdBatchLastPool.restype = ctypes.c_uint32
+        L.BrotliAmdBatchLastPool.argtypes = [vp]
     L.BrotliAmdLastError.restype = ctypes.c_char_p
     if hasattr(L, "BrotliAmdLastNote"):   # (an older build of the library, loaded through BROTLI_AMD_LIB for an A/B, has no such symbol)
         L.BrotliAmdLastNote.restype = ctypes.c_char_p
@@ -180,6 +183,10 @@ class Batch:
     def last_gang(self):
         """blocks (CUs) a stream of the last launch: 1, or 2 / 4 / 8 where each stream had a gang of blocks"""
         return int(self._L.BrotliAmdBatchLastGang(self._h)) if hasattr(self._L, "BrotliAmdBatchLastGang") else 1
+
+    def last_pool(self):
+        """whether the last launch was a pool: blocks without a stream of their own help the largest stream still being decoded"""
+        return bool(self._L.BrotliAmdBatchLastPool(self._h)) if hasattr(self._L, "BrotliAmdBatchLastPool") else False
 
     def decode_host(self, datas, out_caps, flags=FLAG_LARGE_WINDOW):
         """Host bytes in, (results, outputs) out: upload, decode, download."""

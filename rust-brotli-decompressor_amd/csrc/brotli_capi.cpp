@@ -170,7 +170,8 @@ int launch(BrotliAmdBatch* b, hipStream_t stream) {
     }
     if (!hip_ok(hipMemsetAsync(b->d_gang, 0, need, stream), "hipMemsetAsync(gang control)")) return -1;
     b->h_order[2] = b->gang; b->h_order[4] = (uint32_t)(uintptr_t)b->d_gang; b->h_order[5] = (uint32_t)((uint64_t)(uintptr_t)b->d_gang >> 32);
-    b->h_order[6] = getenv("BROTLI_AMD_GANG_NO_HELPERS") != nullptr ? 1u : 0u;   // (tests: the helper blocks leave at once, the owners must find out and go on alone)
+    b->h_order[6] = getenv("BROTLI_AMD_GANG_NO_HELPERS") != nullptr ? 1u : 0u;
+    b->h_order[8] = b->n;   // (a pool: the streams that are not done yet)   // (tests: the helper blocks leave at once, the owners must find out and go on alone)
   }
   b->last_gang = b->gang;
   if (!hip_ok(hipMemcpyAsync(b->d_queue, b->h_order, sizeof(uint32_t) * (b->ordered ? 16 + (size_t)b->n : 16), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(queue)")) return -1;
@@ -293,6 +294,19 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     uint32_t m = groups * 64u <= b->cus ? 8u : groups * 32u <= b->cus ? 4u : groups * 16u <= b->cus ? 2u : 0u;
     if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
     if (m > 1u) { b->gang = m; b->grid = groups * 8u * m; }
+    // More streams than half the CUs, at most as many as CUs, and of very different sizes (the largest more than twice the median): a POOL -- as
+    // many blocks as CUs; a block without a stream of its own (at once where there are fewer streams than CUs, else when its stream is done) joins
+    // the largest stream still being decoded (csrc/brotli_kernels.hip).  One stream of 64 MiB among 199 or 255 of 1 MiB: 127 -> 29 ms.  Not where
+    // the streams are of a size: they end within a few per cent of each other, and the control blocks' zeroing and the owners' looks at them cost
+    // what the last invocations' help brings (192 x 4 MiB +1 %, 250 x 4 MiB -4 %).
+    const bool no_pool = getenv("BROTLI_AMD_POOL") != nullptr && atoi(getenv("BROTLI_AMD_POOL")) == 0;   // (experiments, tests)
+    const bool force_pool = getenv("BROTLI_AMD_POOL") != nullptr && atoi(getenv("BROTLI_AMD_POOL")) == 2;
+    if (m == 0u && !no_pool && gang_env < 0 && n <= b->cus && b->grid <= b->cus) {
+      std::vector<size_t> sz(n);
+      for (uint32_t i = 0; i < n; i++) sz[i] = b->h_descs[i].in_size;
+      std::nth_element(sz.begin(), sz.begin() + n / 2, sz.end());
+      if (largest_in > 2u * sz[n / 2] || force_pool) { b->gang = 0x18u; b->grid = b->cus; }
+    }
   }
   engine_queue = engine_queue && b->waves == 16u;
   if (engine_queue)   // (the engines' streams to the engine blocks; the others wait for the launch of small blocks behind it)
@@ -300,7 +314,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
-  if (!ensure_scratch(b, b->gang > 1u ? n : b->grid)) return -1;   // (a gang's helper blocks have no scratch of their own: a slot per stream)
+  if (!ensure_scratch(b, b->gang > 1u && b->gang <= 8u ? n : b->grid)) return -1;   // (a gang's helper blocks have no scratch of their own: a slot per stream)
   // more streams than blocks: the blocks take them longest first (compressed size as the measure), so that no block starts
   // a long stream when the others are done
   static const bool no_order = getenv("BROTLI_AMD_NO_ORDER") != nullptr;  // (experiments)
@@ -584,7 +598,8 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
 }
 
 extern "C" uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* b) { return b ? b->last_retry_count : 0; }
-extern "C" uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* b) { return b ? (b->last_gang > 1u ? b->last_gang : 1u) : 0; }
+extern "C" uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* b) { return b ? (b->last_gang > 1u && b->last_gang <= 8u ? b->last_gang : 1u) : 0; }
+extern "C" uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* b) { return b && (b->last_gang & 0x10u) != 0u ? 1u : 0u; }
 
 extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
   if (!b || !b->launched) return 0.0f;

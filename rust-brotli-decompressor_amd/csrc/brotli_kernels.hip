@@ -1146,7 +1146,7 @@ enum { HC_SEQ = 0, HC_KIND = 1, HC_DW0 = 2, HC_SHIFT = 3, HC_TREE = 4, HC_BASE =
        HC_EXT_BASE = 13 /* LDS base of the command-record ring of the parse / copy split (SPX_BYTES, in the free tail of the table arena); 0 = this metablock has none */,
        // a gang of blocks on one stream (see GC_* below): this block's number in it (0: the stream's owner), the gang's blocks, its control block in memory,
        // the owner's count of the engine's invocations (a helper's: the last one it has seen), the bytes of the table arena in use
-       HC_GANG_ROLE = 14, HC_GANG_M = 15, HC_GANG_LO = 16, HC_GANG_HI = 17, HC_GANG_EPOCH = 18, HC_ARENA_TOP = 19 };
+       HC_GANG_ROLE = 14, HC_GANG_M = 15, HC_GANG_LO = 16, HC_GANG_HI = 17, HC_GANG_EPOCH = 18, HC_GANG_READY = 19 /* the owner's: what the control block's READY says when the helpers of every invocation so far have left */ };
 enum { HK_ROUND = 1, HK_EXIT = 2, HK_NO_ROUNDS = 3, HK_SCAN = 4, HK_PATH = 5, HK_SPLIT = 6, HK_PATH2 = 7, HK_PATHG = 8, HK_PATHR = 9 };  // HC_KIND
 enum { HW_DONE = 0, HW_N = 1, HW_EXIT = 2, HW_MVGO = 3, HW_MVSRC = 4, HW_MVDST_LO = 5, HW_MVDST_HI = 6, HW_MVN = 7, HW_MVDONE = 8,
        // a helper's own account of how the chain of the chunk before (entered where that chunk's chain ends) falls in
@@ -1184,7 +1184,7 @@ __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_
 //            one eight-byte store and says itself whether it is the one waited for: no flag, no fence
 //   PARAMS, BR, ARENA   the invocation's parameters, the bit reader's words and the image of the owner's table arena (plain stores
 //            behind a release fence, in front of EPOCH; a helper's acquire fence stands behind its look at EPOCH)
-constexpr uint32_t GC_JOINED = 0, GC_EPOCH = 4, GC_READY = 8, GC_PLAN = 16, GC_STOP = 24, GC_EXEC = 32, GC_ARENA_BYTES = 40, GC_ENTRY = 48, GC_STATE = 64,
+constexpr uint32_t GC_JOINED = 0, GC_EPOCH = 4, GC_READY = 8, GC_PLAN = 16, GC_STOP = 24, GC_EXEC = 32, GC_ARENA_BYTES = 40, GC_ENTRY = 48, GC_MEMBERS = 56 /* u64: invocation << 32 | blocks of its gang */, GC_STATE = 64,
                    GC_PARAMS = 512, GC_BR = 640, GC_ARENA = 1024, GC_ARENA_CAP = 48u << 10, GC_STRIDE = GC_ARENA + GC_ARENA_CAP;
 constexpr uint32_t GC_QUIT = 0xFFFFFFFFu, GC_STATE_WORDS = 27, GC_MAX_REGIONS = 4000;   // (the state's granules: 25 words of PeStream, the resolve's flags, the bytes its region put out)
 static_assert(GC_STRIDE == BROTLI_AMD_GANG_CTL_BYTES && GC_STATE + 8u * GC_STATE_WORDS <= GC_PARAMS, "the gang's control block");
@@ -3222,7 +3222,8 @@ __device__ __noinline__ void gang_took(HotArgs* args, const uint32_t took, const
   const uint32_t counts = rfl(args->general_engine);
   uint32_t pen = (counts >> 8) & 0xFFu, hold = 0u;
   if (took >= 64u) pen = 0u;
-  if (((form_raw >> 11) & 1u) != 0u || (((form_raw >> 8) & 1u) != 0u && took == 0u)) {
+  if (((form_raw >> 12) & 1u) != 0u) { }   // (a pool that has sent this stream nobody yet: nothing to learn from)
+  else if (((form_raw >> 11) & 1u) != 0u || (((form_raw >> 8) & 1u) != 0u && took == 0u)) {
     pen = pen == 0u ? 1u : pen >= 32u ? 64u : pen * 2u;
     hold = pen;
   }
@@ -4464,8 +4465,16 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
   // A gang launch (queue[2] blocks a stream, sixteen waves each; see GC_*): block b is member (b mod 8 gang) / 8 of the gang of stream
   // (b / (8 gang)) 8 + b mod 8 -- the members of a gang are eight block numbers apart, which is how the hardware deals blocks to the same
   // XCD (their L2 is one: what they hand each other does not cross the fabric; a matter of speed, not of correctness).  Member 0 owns the stream.
+// A POOL launch (queue[2] bit 4; as many blocks as CUs, at most as many streams): nobody is dealt to a gang.  Blocks take streams from the queue
+  // as ever; a block that finds the queue empty -- at once, where the batch has fewer streams than CUs; when its own stream is done, otherwise --
+  // joins the largest stream that is still being decoded and has fewer than seven helpers, for as long as that stream lasts, and then the next.
+  // A stream's gang is whoever has joined it when one of its invocations of the path engine starts (GC_JOINED, GC_MEMBERS).
 #ifdef BROTLI_AMD_GANG_KERNEL
   uint32_t gang_m = rfl(queue[2]), gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
+  const bool pool = (gang_m & 0x10u) != 0u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP;
+  const uint64_t pool_base = (uint64_t)rfl(queue[4]) | ((uint64_t)rfl(queue[5]) << 32);
+  if ((gang_m & 0x10u) != 0u) gang_m = 1u;
+  bool pool_open = false;   // (this block's stream has a control block that says it is being decoded)
 #else
   uint32_t gang_m = 1u, gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
 #endif
@@ -4489,7 +4498,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
                                             threadIdx.x == HC_SCAN_BASE && nw == SC_WAVES ? behind :
                                             threadIdx.x == HC_GANG_ROLE ? gang_role : threadIdx.x == HC_GANG_M ? gang_m :
                                             threadIdx.x == HC_GANG_LO ? (uint32_t)gang_addr : threadIdx.x == HC_GANG_HI ? (uint32_t)(gang_addr >> 32) :
-                                            threadIdx.x == HC_ARENA_TOP ? lds_arena_bytes : 0u);
+                                            0u);
     if (nw >= 2u && threadIdx.x < nr * 16u) lds_st32(slots + (threadIdx.x >> 4) * HL_SLOT + HL_CTL + 4u * (threadIdx.x & 15u), 0u);
   }  // (launched without helper waves: no rounds)
   __syncthreads();
@@ -4536,6 +4545,12 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
 
   for (uint32_t pulls = 0;; pulls++) {
     uint32_t idx = 0;
+#ifdef BROTLI_AMD_GANG_KERNEL
+    if (pool && pool_open) {   // (the stream before: done, whichever way its turn of this loop ended -- its helpers may go, the pool has one stream less)
+      if (lane == 0) { gang_st32(gang_ctl(), GC_EPOCH, GC_QUIT); (void)__hip_atomic_fetch_add(queue + 8, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      pool_open = false;
+    }
+#endif
     if (gang_m > 1u) {   // (a gang's owner: its stream, and no other)
       if (pulls != 0u) break;
       idx = gang_stream;
@@ -4547,6 +4562,15 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
     // (the host may give an order in which to take the streams -- longest first, so that the last blocks to finish do not
     // start a long stream when the others are done: queue[1] != 0, stream of the k-th pull in queue[16 + k])
     if (queue[1] != 0u) idx = rfl(queue[16u + idx]);
+#ifdef BROTLI_AMD_GANG_KERNEL
+    if (pool) {   // this block owns the stream: its control block, nobody's help yet
+      const uint64_t ca = pool_base + (uint64_t)idx * GC_STRIDE;
+      hc_st(HC_GANG_LO, (uint32_t)ca); hc_st(HC_GANG_HI, (uint32_t)(ca >> 32)); hc_st(HC_GANG_ROLE, 0u); hc_st(HC_GANG_M, 0x108u);
+      hc_st(HC_GANG_EPOCH, 0u); hc_st(HC_GANG_READY, 0u);
+      lds_sync();
+      pool_open = true;
+    }
+#endif
     const BrotliAmdStreamDesc d = descs[idx];
     BrotliAmdStreamStatus* st = status + idx;
     if (d.flags & BROTLI_AMD_FLAG_DEFER) {   // not this launch's stream (see the flag)
@@ -4730,6 +4754,42 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
   }
 #endif
   if (gang_m > 1u && lane == 0) gang_st32(gang_ctl(), GC_EPOCH, GC_QUIT);   // the stream is done: the gang's helper blocks may go
+#ifdef BROTLI_AMD_GANG_KERNEL
+  if (pool && queue[6] == 0u) {
+    // no stream of its own (any more): this block helps -- the largest stream that is being decoded, is large enough to have something to divide
+    // and has fewer than seven helpers; when that one is done, the next; until the pool has no stream left
+    for (;;) {
+      if (__hip_atomic_load(queue + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+      unsigned long long best = 0ull;   // size << 16 | stream + 1
+      for (uint32_t s_ = lane; s_ < n_streams; s_ += 64u) {
+        gu8* const c_ = (gu8*)(uintptr_t)(pool_base + (uint64_t)s_ * GC_STRIDE);
+        const uint32_t ep_ = gang_ld32(c_, GC_EPOCH), jn_ = gang_ld32(c_, GC_JOINED);
+        const uint64_t sz_ = descs[s_].in_size;
+        if (ep_ != GC_QUIT && jn_ < 7u && sz_ >= 65536ull && (descs[s_].flags & BROTLI_AMD_FLAG_DEFER) == 0u) {
+          const unsigned long long key_ = ((sz_ < (1ull << 40) ? sz_ : (1ull << 40) - 1ull) << 16) | (unsigned long long)(s_ + 1u);
+          best = key_ > best ? key_ : best;
+        }
+      }
+      for (int off_ = 32; off_ > 0; off_ >>= 1) { const unsigned long long o_ = __shfl_xor(best, off_); best = o_ > best ? o_ : best; }
+      best = (unsigned long long)rfl((uint32_t)best) | ((unsigned long long)rfl((uint32_t)(best >> 32)) << 32);
+      if (best == 0ull) { __builtin_amdgcn_s_sleep(127); continue; }
+      const uint32_t s_ = (uint32_t)(best & 0xFFFFull) - 1u;
+      gu8* const c_ = (gu8*)(uintptr_t)(pool_base + (uint64_t)s_ * GC_STRIDE);
+      const uint32_t last_ = gang_ld32(c_, GC_EPOCH);   // (read in front of the join: an invocation the owner starts behind the join is this block's too)
+      if (last_ == GC_QUIT) continue;
+      uint32_t j_ = 0;
+      if (lane == 0) j_ = gang_add32(c_, GC_JOINED, 1u);
+      j_ = rfl(j_);
+      if (j_ >= 7u) continue;   // (somebody else was faster: the count stays one too high, which the owner's cap of seven does not mind)
+      hc_st(HC_GANG_LO, (uint32_t)(uintptr_t)c_); hc_st(HC_GANG_HI, (uint32_t)((uint64_t)(uintptr_t)c_ >> 32)); hc_st(HC_GANG_ROLE, j_ + 1u); hc_st(HC_GANG_M, 0x108u);
+      hc_st(HC_GANG_EPOCH, last_);
+      hc_st(HC_KIND, (uint32_t)HK_PATHR);
+      lds_release();
+      hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);   // the other waves of the block join (helper_wave)
+      (void)pe16r::path_engine(0);          // ... and stay until the stream is done
+    }
+  }
+#endif
   // no more streams: the helper waves may go
   hc_st(HC_KIND, 2);
   lds_release();

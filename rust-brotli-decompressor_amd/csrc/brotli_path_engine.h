@@ -171,7 +171,7 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_STOP = 134 /* the invocation is over */, PEC_NFINAL = 135 /* regions whose window is final */, PEC_WINF = 136 /* + (region & 1): its first dword */,
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
        PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
-       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_MYSHIFT = 138 /* ... and how often its regions are halved */, PEC_RELAX = 159 /* ... whether this engine's executes wait twice (see there): its own observation, kept from region to region */, PEC_LAG = 137 /* ... the bytes of the region before's output: what a copy may not read before that region's engine says they are there */, PEC_BUILT = 158 /* ... whether its tables are built */,
+       PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_MYSHIFT = 138 /* ... and how often its regions are halved */, PEC_MEMBERS = 186 /* ... (a pool) the blocks of this invocation's gang */, PEC_NOHELP = 185 /* ... (a pool) the owner kept the invocation to itself because nobody has joined its stream */, PEC_RELAX = 159 /* ... whether this engine's executes wait twice (see there): its own observation, kept from region to region */, PEC_LAG = 137 /* ... the bytes of the region before's output: what a copy may not read before that region's engine says they are there */, PEC_BUILT = 158 /* ... whether its tables are built */,
        PEC_FIN = 156 /* a long literal run has ended in this region: its command's distance and copy are wave 0's, in place */,
        PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
        PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
@@ -767,14 +767,24 @@ pe_again:
   uint32_t role = 0, gang_m = 1, epoch = 0; gu8* gc = nullptr; (void)role; (void)gang_m; (void)epoch; (void)gc;
   const uint64_t gs_t0 = __builtin_amdgcn_s_memtime(); (void)gs_t0;
   if (REMOTE) {
-    role = hc_ld(HC_GANG_ROLE); gang_m = hc_ld(HC_GANG_M); gc = gang_ctl();
+    // (HC_GANG_M: the gang's blocks; bit 8: a POOL launch -- nobody is dealt to a gang, a block whose own stream is done joins a stream that is
+    // not, and a stream's gang is whoever has joined it when an invocation starts: see the kernel)
+    role = hc_ld(HC_GANG_ROLE); gang_m = hc_ld(HC_GANG_M) & 0xFFu; gc = gang_ctl();
+    const bool pool = (hc_ld(HC_GANG_M) >> 8) != 0u;
+    const uint32_t seq_in = hc_ld(HC_SEQ);   // (a pool's helper goes back to its block's mailbox when the stream it helped is done)
     if (role == 0u) {
       epoch = hc_ld(HC_GANG_EPOCH) + 1u;   // (the word is this invocation's once it is everybody's: see below)
+      if (pool && gang_m > 1u) {   // this invocation's gang: the helpers that have joined so far, seven at most; nobody: the one-block form's
+        // (ONE look for the whole block: helpers join while it is taken)
+        if (threadIdx.x == 0u) { const uint32_t joined = gang_ld32(gc, GC_JOINED); lds_st32(pbs + PE_CTL + 4u * PEC_MEMBERS, 1u + (joined < 7u ? joined : 7u)); }
+        __syncthreads();
+        gang_m = pe_ctl_ld(pbs, PEC_MEMBERS);
+      }
       if (epoch >= (1u << 20) - 2u) {   // (the granules' tags hold twenty bits of it: a stream of a million invocations goes on without its gang)
         if (threadIdx.x == 0u) { gang_st32(gc, GC_EPOCH, GC_QUIT); *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_M]) = 1u; }
         __syncthreads();
         gang_m = hc_ld(HC_GANG_M);
-      } else if (epoch == 1u) {
+      } else if (epoch == 1u && !pool) {
         // the first time: have the helpers all started?  (They do so with the owner, give or take a microsecond; a block that is not running
         // cannot be waited for: the stream stays this block's alone then -- the mailbox says so from here on --, and a helper that turns up
         // finds the gang dissolved)
@@ -794,34 +804,44 @@ pe_again:
       if (threadIdx.x == 0u) {   // the helpers have all left the invocation before (they read the image below when they enter one)
         uint32_t spins = 0; (void)spins;
         const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_;
-        while (gang_ld32(gc, GC_READY) != (gang_m - 1u) * (epoch - 1u)) { __builtin_amdgcn_s_sleep(8); PE_SPIN_CHECK(spins); }
+        const uint32_t expected = *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_READY]);   // (the helpers of every invocation so far, summed)
+        while (gang_ld32(gc, GC_READY) != expected) { __builtin_amdgcn_s_sleep(8); PE_SPIN_CHECK(spins); }
         GANG_STAT(gc, 0, 1); GANG_STAT(gc, 5, __builtin_amdgcn_s_memtime() - t0_);
       }
       __syncthreads();
-      const uint32_t ab = (hc_ld(HC_ARENA_TOP) + 15u) & ~15u;
+      const uint32_t ab = (pbs - LDS_FIXED + 15u) & ~15u;   // (the table arena lies between the fixed part and the engine's)
       for (uint32_t i = threadIdx.x << 4; i < ab; i += 64u * SC_WAVES * 16u)
         *reinterpret_cast<gu32x4*>(gc + GC_ARENA + i) = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(&g_smem[LDS_FIXED + i]);
       if (threadIdx.x < 32u) *reinterpret_cast<gu32*>(gc + GC_PARAMS + 4u * threadIdx.x) = lds_ld32(pbs + PE_CTL + 4u * threadIdx.x);
       else if (threadIdx.x < 40u) *reinterpret_cast<gu32*>(gc + GC_BR + 4u * (threadIdx.x - 32u)) = lds_ld32(LDS_BR + 4u * (threadIdx.x - 32u));
       else if (threadIdx.x == 40u) *reinterpret_cast<gu32*>(gc + GC_ARENA_BYTES) = ab;
+      else if (threadIdx.x == 41u) gang_st64(gc, GC_MEMBERS, ((uint64_t)epoch << 32) | (uint64_t)gang_m);   // (with the invocation it is for: a pool's late comer must not take the next one's for this one's)
       gang_drain();
       __syncthreads();
       if (threadIdx.x == 0u) { gang_release(); GANG_STAT(gc, 18, __builtin_amdgcn_s_memtime() - gs_t0); }   // (the state, the plan and EPOCH follow below, where wave 0 has put the state together)
     } else if (role != 0u) {
       if (threadIdx.x == 0u) {
-        const uint32_t last = *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_EPOCH]);
+        uint32_t last = *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_EPOCH]);
         uint32_t e;
         for (uint32_t idle = 0;; idle++) {   // (no cap: the owner may be busy with something else for as long as its stream takes)
           e = gang_ld32(gc, GC_EPOCH);
-          if (e == GC_QUIT || e > last) break;
+          if (e == GC_QUIT) break;
+          if (e > last) {
+            gang_acquire();
+            // (a pool: an invocation that started before the owner had seen this block join is not this block's; nor is one that is over --
+            // the word is the next one's already)
+            const uint64_t mw = gang_ld64(gc, GC_MEMBERS);
+            if ((uint32_t)(mw >> 32) == e && role < (uint32_t)mw) break;
+            last = e;
+          }
           if (idle < 4096u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(127);
         }
-        if (e != GC_QUIT) gang_acquire();
         *reinterpret_cast<lds_vu32*>(&g_smem[LDS_HCTL + 4u * HC_GANG_EPOCH]) = e;
       }
       __syncthreads();
       epoch = hc_ld(HC_GANG_EPOCH);
-      if (epoch == GC_QUIT) return 0u;
+      if (epoch == GC_QUIT) return seq_in;
+      gang_m = (uint32_t)gang_ld64(gc, GC_MEMBERS);
       const uint32_t ab = *reinterpret_cast<gu32*>(gc + GC_ARENA_BYTES);
       for (uint32_t i = threadIdx.x << 4; i < ab && i < GC_ARENA_CAP; i += 64u * SC_WAVES * 16u)
         *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(&g_smem[LDS_FIXED + i]) = *reinterpret_cast<gu32x4*>(gc + GC_ARENA + i);
@@ -871,11 +891,13 @@ pe_again:
       const ScHead h_ = sc_head(__builtin_amdgcn_alignbit(a1_, a0_, sh_), __builtin_amdgcn_alignbit(a2_, a1_, sh_), c.cmd_tree, c.lut_vgpr);
       long_first = rfl(h_.insert) >= PE_RUN_MIN && rfl(h_.bits) != 0u;
     }
-    if (REMOTE && gang_m <= 1u) long_first = true;   // (the gang is dissolved: the same way out)
+    if (REMOTE && gang_m <= 1u) long_first = true;   // (the gang is dissolved, or a pool has sent nobody yet: the same way out)
+    if (REMOTE) pe_ctl_st(pb, PEC_NOHELP, gang_m <= 1u && (hc_ld(HC_GANG_M) >> 8) != 0u ? 1u : 0u);
     if (REMOTE) pe_ctl_st(pb, PEC_PLAN, long_first ? 6u : 0u);
     if (REMOTE && long_first) pe_ctl_st(pbs, PEC_DECLINE, 1u);
     if (REMOTE && !long_first) {   // the invocation is everybody's: the stream's state in front of region 0, the plan (from region 0 on, at the entry), then its number
       hc_st(HC_GANG_EPOCH, epoch);
+      hc_st(HC_GANG_READY, hc_ld(HC_GANG_READY) + gang_m - 1u);   // (what READY says when this invocation's helpers have all left it)
       lds_sync();
       const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : lane == 25u ? 1u : 0u;
       if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)(epoch << 12) << 32));
@@ -2878,7 +2900,7 @@ pe_pass:
   }
   const bool pdx = PE_DICT && pe_ctl_ld(pb, PEC_PDX) != 0u;   // (behind the distance of a command whose literals are out: postReadDistance, decode.rs:2583)
   if (lane == 0) {
-    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && (pe_ctl_ld(pbs, PEC_DECLINE) & 1u) != 0u ? 0x100u : 0u) | (REMOTE && (pe_ctl_ld(pbs, PEC_DECLINE) & 2u) != 0u ? 0x800u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE2 && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
+    LEAN_ST(L_SC_POS_LO, st.b); LEAN_ST(L_SC_POS_HI, pdx ? (uint32_t)SCX_POST_DISTANCE : (uint32_t)SCX_BEGIN | (PIPE && (pe_ctl_ld(pbs, PEC_DECLINE) & 1u) != 0u ? 0x100u : 0u) | (REMOTE && (pe_ctl_ld(pbs, PEC_DECLINE) & 2u) != 0u ? 0x800u : 0u) | (REMOTE && pe_ctl_ld(pb, PEC_PLAN) == 6u && pe_ctl_ld(pb, PEC_NOHELP) != 0u ? 0x1000u : 0u) | (!PIPE && pe_ctl_ld(pb, PEC_OVF) >= 3u ? 0x200u : 0u) | (!PIPE2 && !PE_DICT && pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 0x400u : 0u));
     LEAN_ST(L_P_LO, (uint32_t)st.P); LEAN_ST(L_P_HI, (uint32_t)(st.P >> 32)); LEAN_ST(L_QUOTA, st.quota); LEAN_ST(L_MLEN, st.mlen);
     LEAN_ST(L_BL0, st.bl0); LEAN_ST(L_BL1, st.bl1); LEAN_ST(L_BL2, st.bl2);
     LEAN_ST(L_D0, st.d0); LEAN_ST(L_D1, st.d1); LEAN_ST(L_D2, st.d2); LEAN_ST(L_D3, st.d3); LEAN_ST(L_NCMD_LO, st.ncmd);

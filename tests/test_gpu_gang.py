@@ -173,3 +173,49 @@ def test_batches_of_small_streams_get_no_gangs(pkg):
     res, outs, gang = _decode(pkg, small + [big], [128 << 10] * 4 + [2 << 20])
     assert gang == 8
     _against_oracle(res, outs, small + [big], [128 << 10] * 4 + [2 << 20])
+
+
+def test_a_pool_of_blocks_helps_the_streams_that_last(pkg):
+    """more streams than half the CUs, fewer than CUs, one of them sixteen times the others: a pool launch -- the blocks without a stream of their
+    own join the streams still being decoded, the large one first (BrotliAmdBatchLastPool) -- against the oracle, damaged streams among them;
+    the same with BROTLI_AMD_POOL=0 (no pool): the same bytes and status words"""
+    w = _w()
+    rnd = random.Random(4242)
+    big_raw = w.long_backref_stream(7400, 16 << 20)
+    big = w.brotli_compress(big_raw, 5, 22)
+    smalls = [(w.brotli_compress(w.long_backref_stream(7410 + k, 1 << 20), 5, 22), 1 << 20) for k in range(6)]
+    datas, caps = [big], [len(big_raw)]
+    for i in range(149):
+        c, sz = smalls[i % len(smalls)]
+        d, cap = c, sz
+        k = rnd.random()
+        if k < 0.1:
+            d = c[: rnd.randrange(1, len(c))]
+        elif k < 0.2:
+            t = bytearray(c)
+            t[rnd.randrange(len(t))] ^= 1 << rnd.randrange(8)
+            d = bytes(t)
+        elif k < 0.3:
+            cap = rnd.randrange(1, sz)
+        datas.append(d)
+        caps.append(cap)
+    b = pkg.Batch(len(datas))
+    res, outs = b.decode_host(datas, caps, 1)
+    assert b.last_pool() and b.last_gang() == 1
+    _against_oracle(res, outs, datas, caps)
+    assert res[0].engine_commands >= 0.99 * res[0].num_commands
+    old = os.environ.get("BROTLI_AMD_POOL")
+    try:
+        os.environ["BROTLI_AMD_POOL"] = "0"
+        b2 = pkg.Batch(len(datas))
+        res2, outs2 = b2.decode_host(datas, caps, 1)
+        assert not b2.last_pool()
+        b2.close()
+    finally:
+        if old is None:
+            os.environ.pop("BROTLI_AMD_POOL", None)
+        else:
+            os.environ["BROTLI_AMD_POOL"] = old
+    b.close()
+    assert [(r.result, r.error_code, r.decoded_size, r.consumed, r.num_commands) for r in res] == [(r.result, r.error_code, r.decoded_size, r.consumed, r.num_commands) for r in res2]
+    assert outs == outs2
