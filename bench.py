@@ -78,6 +78,12 @@ def build_workload(name, n_unique=None):
     if m or not w.encoder_available():
         n = int(m.group(1)) if m else 1024
         return "%d x alice29.txt.compressed (reference fixture, wbits 22)" % n, w.fixture_streams("alice29.txt.compressed"), n
+    m = re.fullmatch(r"longbackrefmix_(\d+)", name)   # one 64 MiB stream among n - 1 of 1 MiB: a pool of blocks
+    if m:
+        n = int(m.group(1))
+        big = w.make_streams("long_backref", 1, 64 << 20, 1000)
+        small = w.make_streams("long_backref", 8, 1 << 20, 3000)
+        return ("1 x 65536 KiB + %d x 1024 KiB streams, wbits 22, brotli -q5, long back-references" % (n - 1)), big + [small[i % 8] for i in range(n - 1)], n
     m = re.fullmatch(r"(longbackref|highentropy|surveymix)(?:q(\d+))?_(\d+)x(\d+)(KiB|MiB)", name)
     if not m:
         raise SystemExit("unknown workload " + name)
@@ -127,6 +133,7 @@ class DeviceJob:
         if not self.indices:
             self.second_pass = 0
             self.blocks_per_stream = 1
+            self.pool = False
             self.num_commands = self.engine_commands = 0
             return []
         self.batch.decode_device(self.in_ptrs, self.sizes, self.out_ptrs, self.caps, self.pkg.FLAG_LARGE_WINDOW, self.stream)
@@ -135,6 +142,7 @@ class DeviceJob:
         # second, large-arena launch (reported so that it cannot go unnoticed; then the whole submit + wait is timed).
         self.second_pass = self.batch.last_second_pass_count()
         self.blocks_per_stream = self.batch.last_gang()   # (1, or 2 / 4 / 8: a gang of blocks on every stream of a small batch)
+        self.pool = self.batch.last_pool()                # (blocks without a stream of their own help the largest stream still being decoded)
         self.num_commands = sum(int(r.num_commands) for r in res)
         self.engine_commands = sum(int(r.engine_commands) for r in res)
         bad = [j for j, r in enumerate(res) if r.result != 1 or r.decoded_size != self.caps[j]]
@@ -224,6 +232,8 @@ def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None, cpu_bud
     out = {"id": name, "n": n, "D": job.raw_total, "C": job.comp_total, "MBps": round(job.raw_total * steps / elapsed / 1e6, 1), "kernel_ms": rl["kernel_ms"],
            "frac": rl["frac"], "dfrac": rl["decompressed_frac"], "traffic": traffic, "Mcmd_s": round(cr["commands_per_s"] / 1e6, 1), "B_cmd": cr["bytes_per_command"],
            "eng": cr["engine_commands_share"], "pass2": job.second_pass, "cus": job.blocks_per_stream}
+    if job.pool:
+        out["pool"] = 1
     job.close()
     if cpu_budget_s:  # the CPU path beside it: the oracle on all host threads and on one, a bounded sample of this leg's streams
         try:
@@ -391,7 +401,7 @@ def main():
             "config": {"workload": label, "streams_per_gpu": per_gpu, "streams_total": n_total, "decompressed_bytes_per_gpu": job.raw_total,
                        "compressed_bytes_per_gpu": job.comp_total,
                        "parallelism": "independent streams, LPT partition over %d GPU(s) (sharding.py), no data-path collective" % world,
-                       "second_pass_streams": job.second_pass, "blocks_per_stream": job.blocks_per_stream},
+                       "second_pass_streams": job.second_pass, "blocks_per_stream": job.blocks_per_stream, "pool_of_blocks": bool(job.pool)},
             "roofline": roofline(job.comp_total, job.raw_total, mean_kernel_ms, traffic),
         }
         out["roofline"]["traffic_source"] = traffic_source
@@ -433,7 +443,7 @@ def main():
             if w.encoder_available():
                 legs += [("longbackref_512x4MiB", 3, None), ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None), ("longbackref_4096x1MiB", 3, None),
                          ("recompressed:lcet10.txt.compressedq5x1024", 3, None), ("recompressed:lcet10.txt.compressedq5x256", 3, None),
-                         ("surveymix_256x4MiB", 5, None), ("longbackref_32x4MiB", 5, None), ("longbackref_1x64MiB", 3, 1)]
+                         ("surveymix_256x4MiB", 5, None), ("longbackref_32x4MiB", 5, None), ("longbackrefmix_200", 3, None), ("longbackref_1x64MiB", 3, 1)]
                 if os.environ.get("BROTLI_BENCH_NO_1GIB") is None:
                     legs.append(("longbackref_1x1024MiB", 1, 1))  # BASELINE config 3 as written: ONE stream of 1 GiB
                 legs.append(("highentropy_256x4MiB", 5, None))
@@ -447,7 +457,7 @@ def main():
                                    "1x64MiB the same at 64 MiB; surveymix = SURVEY 8(a1)'s make-up, a quarter of each stream Zipf seed; 512x4MiB = the metric's streams twice; q9 = the metric's data at -q9; "
                                    "1024x1MiB = its make-up in 1 MiB streams (four a CU: engine blocks, the device's choice), 4096x1MiB = sixteen a CU (one-wave blocks: streams in flight); recompressed:lcet10 = real text at -q5, 256 / 1024 copies); n streams, D / C bytes out / in, MBps decompressed whole job, "
                                    "frac = (C+D)/t/8 TB/s, dfrac = D/t/8 TB/s, traffic = HBM bytes a launch from profiles/pmc_r*_<id>.json (null: no PMC pass committed), Mcmd_s = million commands/s, "
-                                   "B_cmd bytes a command, eng = share of commands a command engine took, pass2 = streams that needed a second launch, cus = blocks (CUs) that worked on each stream (batches of up to half the CUs' streams: gangs of 8 / 4 / 2; 32x4MiB = 32 of the metric's streams, eight blocks each), cpu = [oracle MB/s on all host threads, on 1 thread, threads]")
+                                   "B_cmd bytes a command, eng = share of commands a command engine took, pass2 = streams that needed a second launch, cus = blocks (CUs) that worked on each stream (batches of up to half the CUs' streams: gangs of 8 / 4 / 2; 32x4MiB = 32 of the metric's streams, eight blocks each; mix_200 = one 64 MiB stream among 199 of 1 MiB, a POOL launch: blocks without a stream of their own help the largest stream still being decoded), cpu = [oracle MB/s on all host threads, on 1 thread, threads]")
             out["extra_configs"] = extra
     if rank == 0:
         print(json.dumps(out))
