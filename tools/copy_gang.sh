@@ -2,7 +2,7 @@
 # tools/copy_gang.sh <tag>: what tools/gang_run.sh left under gpurun_out/ into profiles/ (the tracked copies the design cites)
 TAG=${1:-r05}
 cd "$(dirname "$0")/.."
-for WL in longbackref_1x1024MiB longbackref_1x64MiB longbackref_32x4MiB; do
+for WL in longbackref_1x1024MiB longbackref_1x64MiB longbackref_32x4MiB longbackrefmix_200; do
   cp gpurun_out/prof_${TAG}_$WL/summary.txt profiles/${TAG}_bench_$WL.txt
   cp gpurun_out/prof_${TAG}_$WL/pmc.json profiles/pmc_${TAG}_$WL.json
 done
