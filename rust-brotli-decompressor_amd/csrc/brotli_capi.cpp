@@ -305,7 +305,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
       std::vector<size_t> sz(n);
       for (uint32_t i = 0; i < n; i++) sz[i] = b->h_descs[i].in_size;
       std::nth_element(sz.begin(), sz.begin() + n / 2, sz.end());
-      if (largest_in > 2u * sz[n / 2] || force_pool) { b->gang = 0x18u; b->grid = b->cus; }
+      if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || force_pool) { b->gang = 0x18u; b->grid = b->cus; }   // (a long pole worth the launch's extra ten microseconds: a millisecond and more alone)
     }
   }
   engine_queue = engine_queue && b->waves == 16u;
