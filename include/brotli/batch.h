@@ -83,7 +83,7 @@ BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch)
  * device's CUs, at least one of them 64 KiB of compressed data or more, and each stream was given a gang of blocks (csrc/brotli_path_engine.h, PE_CFG_REMOTE; BROTLI_AMD_GANG=0 turns that off). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* batch);
 
-/* 1 where the last launch was a POOL: more streams than half the device's CUs and at most as many as CUs (fewer, or of very different sizes) --
+/* 1 where the last launch was a POOL: more than 32 streams, at most as many as CUs, of very different sizes (the largest more than twice the median) --
  * every block that has no stream of its own, at once or when its stream is done, joins the largest stream still being decoded
  * (BROTLI_AMD_POOL=0 turns that off).  BrotliAmdBatchLastGang says 1 for such a launch: a stream's helpers come and go. */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* batch);

@@ -294,18 +294,20 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     uint32_t m = groups * 64u <= b->cus ? 8u : groups * 32u <= b->cus ? 4u : groups * 16u <= b->cus ? 2u : 0u;
     if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
     if (m > 1u) { b->gang = m; b->grid = groups * 8u * m; }
-    // More streams than half the CUs, at most as many as CUs, and of very different sizes (the largest more than twice the median): a POOL -- as
+    // At most as many streams as CUs, and of very different sizes (the largest more than twice the median): a POOL -- as
     // many blocks as CUs; a block without a stream of its own (at once where there are fewer streams than CUs, else when its stream is done) joins
     // the largest stream still being decoded (csrc/brotli_kernels.hip).  One stream of 64 MiB among 199 or 255 of 1 MiB: 127 -> 29 ms.  Not where
     // the streams are of a size: they end within a few per cent of each other, and the control blocks' zeroing and the owners' looks at them cost
     // what the last invocations' help brings (192 x 4 MiB +1 %, 250 x 4 MiB -4 %).
     const bool no_pool = getenv("BROTLI_AMD_POOL") != nullptr && atoi(getenv("BROTLI_AMD_POOL")) == 0;   // (experiments, tests)
     const bool force_pool = getenv("BROTLI_AMD_POOL") != nullptr && atoi(getenv("BROTLI_AMD_POOL")) == 2;
-    if (m == 0u && !no_pool && gang_env < 0 && n <= b->cus && b->grid <= b->cus) {
+    // (... and fewer streams than that whose sizes differ, where the batch's gangs would be of four or two blocks: the long one gets seven helpers
+    // from the start instead of three or one -- one 64 MiB stream among 39 / 99 of 1 MiB: 43.5 / 76.7 -> 28.7 ms)
+    if (m != 8u && !no_pool && gang_env < 0 && n <= b->cus && std::min(n, b->grid_max) <= b->cus) {
       std::vector<size_t> sz(n);
       for (uint32_t i = 0; i < n; i++) sz[i] = b->h_descs[i].in_size;
       std::nth_element(sz.begin(), sz.begin() + n / 2, sz.end());
-      if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || force_pool) { b->gang = 0x18u; b->grid = b->cus; }   // (a long pole worth the launch's extra ten microseconds: a millisecond and more alone)
+      if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || (force_pool && m == 0u)) { b->gang = 0x18u; b->grid = b->cus; }   // (a long pole worth the launch's extra ten microseconds: a millisecond and more alone)
     }
   }
   engine_queue = engine_queue && b->waves == 16u;

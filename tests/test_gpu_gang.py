@@ -70,10 +70,11 @@ def _pool(w, rnd):
     return pool
 
 
-@pytest.mark.parametrize("n,blocks", [(1, 8), (3, 8), (8, 8), (9, 8), (32, 8), (33, 4), (64, 4), (65, 2), (128, 2), (129, 1)])
+@pytest.mark.parametrize("n,blocks", [(1, 8), (3, 8), (8, 8), (9, 8), (32, 8), (33, 0), (64, 0), (65, 0), (128, 0), (129, 0)])
 def test_every_stream_of_a_small_batch_has_a_gang_of_blocks(pkg, n, blocks):
-    """n streams -- whole, with a buffer one byte short, truncated, with a flipped bit -- against the oracle; the host says how many blocks
-    each stream had (BrotliAmdBatchLastGang): eight up to 32 streams, four up to 64, two up to 128, one beyond"""
+    """n streams of very different sizes -- whole, with a buffer one byte short, truncated, with a flipped bit -- against the oracle; the host says
+    how many blocks each stream had (BrotliAmdBatchLastGang): eight up to 32 streams; beyond that such a batch is a POOL (blocks 0 here:
+    BrotliAmdBatchLastPool) -- the blocks without a stream of their own help the largest streams still being decoded"""
     w = _w()
     rnd = random.Random(20261001 + n)
     pool = _pool(w, rnd)
@@ -92,9 +93,27 @@ def test_every_stream_of_a_small_batch_has_a_gang_of_blocks(pkg, n, blocks):
             d = bytes(t)
         datas.append(d)
         caps.append(cap)
-    res, outs, gang = _decode(pkg, datas, caps)
-    assert gang == blocks, (n, gang)
+    b = pkg.Batch(len(datas))
+    res, outs = b.decode_host(datas, caps, 1)
+    gang, pool = b.last_gang(), b.last_pool()
+    b.close()
+    assert (gang, pool) == ((blocks, False) if blocks else (1, True)), (n, gang, pool)
     _against_oracle(res, outs, datas, caps)
+
+
+@pytest.mark.parametrize("n,blocks", [(33, 4), (64, 4), (65, 2), (128, 2), (129, 1)])
+def test_batches_of_equal_streams_get_gangs_of_four_and_two(pkg, n, blocks):
+    """streams of a size: four blocks a stream up to 64 streams, two up to 128, one beyond (no pool: they end together)"""
+    w = _w()
+    us = w.make_streams("long_backref", 4, 1 << 20, 1000)
+    datas, caps = [us[i % 4][0] for i in range(n)], [us[i % 4][1] for i in range(n)]
+    b = pkg.Batch(n)
+    res, outs = b.decode_host(datas, caps, 1)
+    gang, pool = b.last_gang(), b.last_pool()
+    b.close()
+    assert (gang, pool) == (blocks, False), (n, gang, pool)
+    for i, (r, o) in enumerate(zip(res, outs)):
+        assert r.result == 1 and hashlib.sha256(o).hexdigest() == us[i % 4][2], i
 
 
 def test_a_gang_and_one_block_agree_and_the_gang_takes_the_commands(pkg):
@@ -123,17 +142,17 @@ def test_a_gang_and_one_block_agree_and_the_gang_takes_the_commands(pkg):
 
 
 def test_one_batch_object_through_gang_launches_and_others(pkg):
-    """one batch object, launches of 1, 200, 5 and 40 streams in turn (gangs of eight, none, eight, four): the gangs' control blocks are
-    the object's, zeroed before every gang launch"""
+    """one batch object, launches of 1, 200, 5 and 40 streams in turn (gangs of eight, a pool, eight, a pool): the gangs' control blocks are
+    the object's, zeroed before every launch that has any"""
     w = _w()
     rnd = random.Random(77)
     pool = _pool(w, rnd)
     b = pkg.Batch(200)
-    for n, blocks in ((1, 8), (200, 1), (5, 8), (40, 4), (1, 8)):
+    for n, blocks in ((1, 8), (200, 0), (5, 8), (40, 0), (1, 8)):   # (0: a pool -- streams of very different sizes, more than 32 of them)
         picks = [pool[(i * 5) % len(pool)] for i in range(n)]   # (the first one the 4 MiB stream: see test_batches_of_small_streams_get_no_gangs)
         datas, caps = [c for c, _ in picks], [sz for _, sz in picks]
         res, outs = b.decode_host(datas, caps, 1)
-        assert b.last_gang() == blocks, (n, b.last_gang())
+        assert (b.last_gang(), b.last_pool()) == ((blocks, False) if blocks else (1, True)), (n, b.last_gang(), b.last_pool())
         _against_oracle(res, outs, datas, caps)
     b.close()
 
