@@ -4772,7 +4772,7 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
       }
       for (int off_ = 32; off_ > 0; off_ >>= 1) { const unsigned long long o_ = __shfl_xor(best, off_); best = o_ > best ? o_ : best; }
       best = (unsigned long long)rfl((uint32_t)best) | ((unsigned long long)rfl((uint32_t)(best >> 32)) << 32);
-      if (best == 0ull) { __builtin_amdgcn_s_sleep(127); continue; }
+      if (best == 0ull) break;   // (nobody to join, and there never will be: streams only end and helpers only join -- no block keeps looking while the last streams are decoded)
       const uint32_t s_ = (uint32_t)(best & 0xFFFFull) - 1u;
       gu8* const c_ = (gu8*)(uintptr_t)(pool_base + (uint64_t)s_ * GC_STRIDE);
       const uint32_t last_ = gang_ld32(c_, GC_EPOCH);   // (read in front of the join: an invocation the owner starts behind the join is this block's too)
