@@ -34,6 +34,10 @@
 //     source and destination are far enough apart), overlapping copies as pattern fills.
 // What bounds it is the instruction issue rate of one wave (about one instruction per 8 clocks): see DESIGN.md.
 // Blocks are persistent: each pulls stream indices from an atomic queue until the batch is empty.
+// Blocks of sixteen waves put all of them on their stream's commands where the metablock allows it (the command engines:
+// brotli_scan_engine.h, brotli_path_engine.h), and -- round 5 -- batches of few streams put SEVERAL BLOCKS on a stream: gangs of
+// blocks that take the path engine's regions in turns, dealt at the launch or, in a pool, joining the streams that last (GC_*
+// below, the kernel at the end of this file).
 //
 // Roofline that bounds it: HBM traffic is (compressed bytes read + decompressed bytes written); there is no
 // dense contraction, MFMA is not used.  See DESIGN.md.
