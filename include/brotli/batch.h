@@ -88,6 +88,11 @@ BROTLI_DEC_API uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* batch);
  * (BROTLI_AMD_POOL=0 turns that off).  BrotliAmdBatchLastGang says 1 for such a launch: a stream's helpers come and go. */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* batch);
 
+/* Test hook (no device needed): what a launch of n streams of these compressed sizes gets on a device of `cus` compute units -- 0 one block a
+ * stream, 2 / 4 / 8 gangs of that many blocks a stream, 0x18 a pool -- and its number of blocks in *grid.  gang_env / pool_env: the values of
+ * BROTLI_AMD_GANG / BROTLI_AMD_POOL, -1 where unset. */
+BROTLI_DEC_API uint32_t BrotliAmdDebugPlanGangs(uint32_t n, uint32_t cus, const size_t* in_sizes, int gang_env, int pool_env, uint32_t* grid);
+
 /* Streaming (BrotliDecoderDecompressStream, decode.h): the commands the device has decoded for this stream in all the launches
  * of its calls together.  A call is a launch from the last command boundary reached, so this stays close to the stream's own
  * number of commands however the input is cut up; a test asserts that instead of timing calls. */

@@ -231,6 +231,38 @@ int probe_streams(BrotliAmdBatch* b, uint32_t n, hipStream_t stream, std::vector
   return 0;
 }
 
+// Several blocks on a stream (csrc/brotli_path_engine.h, PE_CFG_REMOTE): what a launch of sixteen-wave blocks, one a stream, gets on top.
+// Returns 0 (nothing), 2 / 4 / 8 (GANGS: that many blocks a stream, dealt at the launch -- its owner and one, three or seven helper blocks that take
+// the path engine's regions in turns with it; eight streams' gangs side by side, a gang's members eight block numbers apart: one XCD; streams beyond a
+// multiple of eight leave their gangs' blocks without work) or 0x18 (a POOL: as many blocks as CUs; a block without a stream of its own -- at once where
+// there are fewer streams than CUs, else when its stream is done -- joins the largest stream still being decoded), and the launch's blocks in *grid.
+//   * Not for batches of small streams: a gang has something to divide from a dozen regions on -- 64 KiB of compressed data --, and costs a launch ten
+//     microseconds (its blocks' start, the control blocks' zeroing, the helpers' last look at the word that lets them go).
+//   * Gangs of eight up to an eighth of the CUs' streams, of four up to a quarter, of two up to half.
+//   * A pool where the sizes differ -- the largest more than twice the median, and a long pole worth it: 256 KiB compressed, a millisecond and more
+//     alone -- and the gangs would be of four or two blocks or none: the long one gets seven helpers (one 64 MiB stream among 39 / 99 / 199 of 1 MiB:
+//     43.5 / 76.7 / 127.6 -> 29 ms).  Not where the streams are of a size: they end within a few per cent of each other, and the control blocks'
+//     zeroing and the owners' looks at them cost what the last invocations' help brings (a pool forced on 192 x 4 MiB: +1 %, on 250 x 4 MiB: -4 %).
+// gang_env: BROTLI_AMD_GANG (-1 unset; 0, 1: nothing at all; 2, 4, 8: gangs of at most that many, no pool); pool_env: BROTLI_AMD_POOL (-1 unset; 0: no
+// pool; 2: a pool whatever the sizes where there would be no gangs).  A pure function of its arguments: BrotliAmdDebugPlanGangs, tests/test_host_logic.
+uint32_t plan_gangs(uint32_t n, uint32_t cus, const size_t* in_sizes, int gang_env, int pool_env, uint32_t* grid) {
+  if (n == 0u || n > cus || gang_env == 0 || gang_env == 1) return 0u;
+  size_t largest_in = 0;
+  for (uint32_t i = 0; i < n; i++) largest_in = std::max<size_t>(largest_in, in_sizes[i]);
+  if (largest_in < 65536u) return 0u;
+  uint32_t gang = 0u;
+  const uint32_t groups = (n + 7u) / 8u;
+  uint32_t m = groups * 64u <= cus ? 8u : groups * 32u <= cus ? 4u : groups * 16u <= cus ? 2u : 0u;
+  if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
+  if (m > 1u) { gang = m; *grid = groups * 8u * m; }
+  if (m != 8u && pool_env != 0 && gang_env < 0) {
+    std::vector<size_t> sz(in_sizes, in_sizes + n);
+    std::nth_element(sz.begin(), sz.begin() + n / 2, sz.end());
+    if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || (pool_env == 2 && m == 0u)) { gang = 0x18u; *grid = cus; }
+  }
+  return gang;
+}
+
 int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n) filled
   if (n == 0) { b->n = 0; b->launched = false; return 0; }
   if (!hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
@@ -284,31 +316,14 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   // the path engine's regions in turns with it (csrc/brotli_path_engine.h, PE_CFG_REMOTE).  Eight streams' gangs are launched side by side,
   // a gang's members eight block numbers apart (one XCD); streams beyond a multiple of eight leave their gangs' blocks without work.
   const int gang_env = getenv("BROTLI_AMD_GANG") ? atoi(getenv("BROTLI_AMD_GANG")) : -1;   // (experiments: 0 or 1 none, 2 / 4 / 8 at most that many)
+  const int pool_env = getenv("BROTLI_AMD_POOL") ? atoi(getenv("BROTLI_AMD_POOL")) : -1;   // (experiments, tests: 0 no pool, 2 a pool whatever the sizes)
   b->gang = 0;
-  // (not for batches of small streams: a gang has something to divide from a dozen regions on -- 64 KiB of compressed data --, and costs a launch
-  // ten microseconds: its blocks' start, the control blocks' zeroing, the helpers' last look at the word that lets them go)
-  size_t largest_in = 0;
-  for (uint32_t i = 0; i < n; i++) largest_in = std::max<size_t>(largest_in, b->h_descs[i].in_size);
-  if (b->waves == 16u && b->auto_arena && b->cur_arena <= 49152u && gang_env != 0 && gang_env != 1 && largest_in >= 65536u) {
-    const uint32_t groups = (n + 7u) / 8u;
-    uint32_t m = groups * 64u <= b->cus ? 8u : groups * 32u <= b->cus ? 4u : groups * 16u <= b->cus ? 2u : 0u;
-    if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
-    if (m > 1u) { b->gang = m; b->grid = groups * 8u * m; }
-    // At most as many streams as CUs, and of very different sizes (the largest more than twice the median): a POOL -- as
-    // many blocks as CUs; a block without a stream of its own (at once where there are fewer streams than CUs, else when its stream is done) joins
-    // the largest stream still being decoded (csrc/brotli_kernels.hip).  One stream of 64 MiB among 199 or 255 of 1 MiB: 127 -> 29 ms.  Not where
-    // the streams are of a size: they end within a few per cent of each other, and the control blocks' zeroing and the owners' looks at them cost
-    // what the last invocations' help brings (192 x 4 MiB +1 %, 250 x 4 MiB -4 %).
-    const bool no_pool = getenv("BROTLI_AMD_POOL") != nullptr && atoi(getenv("BROTLI_AMD_POOL")) == 0;   // (experiments, tests)
-    const bool force_pool = getenv("BROTLI_AMD_POOL") != nullptr && atoi(getenv("BROTLI_AMD_POOL")) == 2;
-    // (... and fewer streams than that whose sizes differ, where the batch's gangs would be of four or two blocks: the long one gets seven helpers
-    // from the start instead of three or one -- one 64 MiB stream among 39 / 99 of 1 MiB: 43.5 / 76.7 -> 28.7 ms)
-    if (m != 8u && !no_pool && gang_env < 0 && n <= b->cus && std::min(n, b->grid_max) <= b->cus) {
-      std::vector<size_t> sz(n);
-      for (uint32_t i = 0; i < n; i++) sz[i] = b->h_descs[i].in_size;
-      std::nth_element(sz.begin(), sz.begin() + n / 2, sz.end());
-      if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || (force_pool && m == 0u)) { b->gang = 0x18u; b->grid = b->cus; }   // (a long pole worth the launch's extra ten microseconds: a millisecond and more alone)
-    }
+  if (b->waves == 16u && b->auto_arena && b->cur_arena <= 49152u && n <= b->cus) {
+    std::vector<size_t> sz(n);
+    for (uint32_t i = 0; i < n; i++) sz[i] = b->h_descs[i].in_size;
+    uint32_t grid = b->grid;
+    b->gang = plan_gangs(n, b->cus, sz.data(), gang_env, pool_env, &grid);
+    b->grid = grid;
   }
   engine_queue = engine_queue && b->waves == 16u;
   if (engine_queue)   // (the engines' streams to the engine blocks; the others wait for the launch of small blocks behind it)
@@ -601,6 +616,12 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
 
 extern "C" uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* b) { return b ? b->last_retry_count : 0; }
 extern "C" uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* b) { return b ? (b->last_gang > 1u && b->last_gang <= 8u ? b->last_gang : 1u) : 0; }
+extern "C" uint32_t BrotliAmdDebugPlanGangs(uint32_t n, uint32_t cus, const size_t* in_sizes, int gang_env, int pool_env, uint32_t* grid) {
+  uint32_t g = n;
+  const uint32_t r = (n != 0u && in_sizes != nullptr) ? plan_gangs(n, cus, in_sizes, gang_env, pool_env, &g) : 0u;
+  if (grid) *grid = g;
+  return r;
+}
 extern "C" uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* b) { return b && (b->last_gang & 0x10u) != 0u ? 1u : 0u; }
 
 extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {

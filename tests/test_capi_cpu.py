@@ -82,3 +82,51 @@ def test_fails_loudly_without_a_device(lib):
     assert b"HIP" in info.error
     with pytest.raises(RuntimeError):
         pkg.Batch(4)
+
+
+def _plan(lib, sizes, cus=256, gang_env=-1, pool_env=-1):
+    lib.BrotliAmdDebugPlanGangs.restype = ctypes.c_uint32
+    lib.BrotliAmdDebugPlanGangs.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    arr = (ctypes.c_size_t * len(sizes))(*sizes)
+    grid = ctypes.c_uint32(0)
+    kind = lib.BrotliAmdDebugPlanGangs(len(sizes), cus, arr, gang_env, pool_env, ctypes.byref(grid))
+    return kind, grid.value
+
+
+def test_how_many_blocks_a_stream_gets(lib):
+    """the host's plan for several blocks on a stream (csrc/brotli_capi.cpp: plan_gangs), a pure function of the batch's compressed
+    sizes and the device's CUs: gangs of 8 / 4 / 2 blocks a stream for batches of equal streams up to an eighth / a quarter / half the CUs'
+    number, a pool (0x18) where more than 32 streams differ widely in size, nothing for small streams or where the environment says so"""
+    MB = 400_000   # (a 4 MiB stream of the metric's, compressed)
+    assert _plan(lib, [MB]) == (8, 64)                    # one stream: a gang of eight, eight streams' worth of blocks
+    assert _plan(lib, [MB] * 8) == (8, 64)
+    assert _plan(lib, [MB] * 9) == (8, 128)
+    assert _plan(lib, [MB] * 32) == (8, 256)
+    assert _plan(lib, [MB] * 33) == (4, 160)
+    assert _plan(lib, [MB] * 64) == (4, 256)
+    assert _plan(lib, [MB] * 65) == (2, 144)
+    assert _plan(lib, [MB] * 128) == (2, 256)
+    assert _plan(lib, [MB] * 129) == (0, 129)             # one block a stream, as many blocks as streams
+    assert _plan(lib, [MB] * 256) == (0, 256)
+    assert _plan(lib, [MB] * 257) == (0, 257)             # (more streams than CUs: not this function's)
+    # small streams: nothing to divide
+    assert _plan(lib, [60_000] * 8) == (0, 8)
+    assert _plan(lib, [60_000] * 7 + [70_000]) == (8, 64)
+    # very different sizes: a pool from 33 streams on (up to 32 every stream has eight blocks anyway), as many blocks as CUs
+    big = 8_000_000
+    assert _plan(lib, [big] + [100_000] * 31) == (8, 256)
+    assert _plan(lib, [big] + [100_000] * 39) == (0x18, 256)
+    assert _plan(lib, [big] + [100_000] * 199) == (0x18, 256)
+    assert _plan(lib, [big] + [100_000] * 255) == (0x18, 256)
+    assert _plan(lib, [big] + [100_000] * 255, cus=304) == (0x18, 304)
+    assert _plan(lib, [200_000] + [60_000] * 99) == (2, 208)   # (the long one is no long pole: under 256 KiB compressed)
+    assert _plan(lib, [MB] * 100 + [2 * MB]) == (2, 208)       # (not more than twice the median)
+    # the environment: BROTLI_AMD_GANG=0 nothing, =2 / 4 gangs of at most that many and no pool; BROTLI_AMD_POOL=0 no pool, =2 a pool whatever the sizes
+    assert _plan(lib, [MB] * 8, gang_env=0) == (0, 8)
+    assert _plan(lib, [MB] * 8, gang_env=1) == (0, 8)
+    assert _plan(lib, [MB] * 8, gang_env=4) == (4, 32)
+    assert _plan(lib, [big] + [100_000] * 199, gang_env=8) == (0, 200)
+    assert _plan(lib, [big] + [100_000] * 199, pool_env=0) == (0, 200)
+    assert _plan(lib, [big] + [100_000] * 39, pool_env=0) == (4, 160)
+    assert _plan(lib, [MB] * 200, pool_env=2) == (0x18, 256)
+    assert _plan(lib, [MB] * 100, pool_env=2) == (2, 208)      # (where there are gangs, a forced pool does not replace them)
