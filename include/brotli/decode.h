@@ -127,8 +127,11 @@ BROTLI_DEC_API BrotliDecoderReturnInfo BrotliDecoderDecompressPrealloc(size_t en
                                                                        HuffmanCode* scratch_hc_buffer);
 
 /* ffi/mod.rs:390 -> decode.h:278.  total_out may be NULL; input is never over-consumed on SUCCESS.
- * While output the decoder owes does not fit *available_out, a call consumes no input and returns NEEDS_MORE_OUTPUT
- * (decode.rs:2835-2846).  Cost model of this implementation: the compressed bytes of a call are copied to the device
+ * A call whose input ends inside the stream writes what fits *available_out, takes ALL of its input and returns
+ * NEEDS_MORE_INPUT; what did not fit stays with the decoder and goes out with later calls (decode.rs:2835-2846).  Output the
+ * decoder OWES -- at the end of the stream, in front of an error, or a whole window's worth not yet taken (the reference's
+ * full ring buffer, decode.rs:1693-1738) -- comes first: while it does not fit, a call consumes no further input and returns
+ * NEEDS_MORE_OUTPUT.  Cost model of this implementation: the compressed bytes of a call are copied to the device
  * and a kernel is launched that goes on where the call before got to: it parses the header of the metablock in
  * flight again (prefix codes are not kept between launches) and continues from the last command boundary that launch
  * reached, like the reference's resumable state.  A call costs a launch (about a millisecond) plus its bytes; an

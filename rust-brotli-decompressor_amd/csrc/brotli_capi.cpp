@@ -1165,19 +1165,25 @@ extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState*
     s->error_code = BROTLI_DECODER_ERROR_INVALID_ARGUMENTS;
     return BROTLI_DECODER_RESULT_ERROR;
   }
-  // Output the decoder still owes comes first, and while it does not fit no input is consumed: a caller that sees
-  // NEEDS_MORE_OUTPUT finds its input where it left it (decode.rs:2835-2846; bit_reader/mod.rs:295-306).
+  // Output the decoder OWES comes first, and while it does not fit no input is consumed (a caller that sees
+  // NEEDS_MORE_OUTPUT finds its input where it left it: bit_reader/mod.rs:295-306).  Owed is what the reference has to write
+  // before it decodes on: the end of the stream (decode.rs:3382-3397), the bytes in front of a fatal error, and a full ring
+  // buffer (decode.rs:1693-1738) -- this decoder keeps no ring, so "a window's worth not yet taken" stands for that.  What a
+  // call that ended in NEEDS_MORE_INPUT had no room for is NOT owed: the reference wrote what fitted, took the call's input
+  // and kept the rest for later calls (decode.rs:2835-2846), and so does this.
   if (s->outq_len != s->outq_off) {
-    size_t n0 = hand_over(s, *next_out, *available_out);
-    *next_out += n0; *available_out -= n0;
-    if (s->outq_len != s->outq_off) {
-      if (total_out) *total_out = (size_t)s->total_out;
-      s->error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT;
-      return BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT;
+    const uint64_t ring = (s->have_resume && s->resume.window_bits) ? (1ull << s->resume.window_bits) : ~0ull;
+    if (s->finished || s->pending_error || (uint64_t)(s->outq_len - s->outq_off) >= ring) {
+      size_t n0 = hand_over(s, *next_out, *available_out);
+      *next_out += n0; *available_out -= n0;
+      if (s->outq_len != s->outq_off) {
+        if (total_out) *total_out = (size_t)s->total_out;
+        s->error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT;
+        return BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT;
+      }
     }
   }
   const size_t given = *available_in;
-  bool new_input = false;
   if (!s->finished && !s->pending_error && given) {
     DeviceGuard guard;
     // lazily bind to the current device
@@ -1198,7 +1204,6 @@ extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState*
     s->d_in_len += given;
     *next_in += given; *available_in = 0;
     s->used = true;
-    new_input = true;
     BrotliAmdStreamStatus st;
     if (int e = decode_pass(s, &st)) {
       if (e == 2) { s->error_code = BROTLI_DECODER_ERROR_ALLOC_RING_BUFFER_2; return BROTLI_DECODER_RESULT_ERROR; }
@@ -1218,11 +1223,10 @@ extern "C" BrotliDecoderResult BrotliDecoderDecompressStream(BrotliDecoderState*
       return BROTLI_DECODER_RESULT_ERROR;
     }
   }
-  (void)new_input;
   size_t n = hand_over(s, *next_out, *available_out);
   *next_out += n; *available_out -= n;
   if (total_out) *total_out = (size_t)s->total_out;
-  if (s->outq_len != s->outq_off) { s->error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT; return BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT; }
+  if (s->outq_len != s->outq_off && (s->finished || s->pending_error)) { s->error_code = BROTLI_DECODER_NEEDS_MORE_OUTPUT; return BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT; }
   if (s->pending_error) { s->error_code = s->pending_error; return BROTLI_DECODER_RESULT_ERROR; }
   if (s->finished) { s->error_code = BROTLI_DECODER_SUCCESS; return BROTLI_DECODER_RESULT_SUCCESS; }
   s->error_code = BROTLI_DECODER_NEEDS_MORE_INPUT;

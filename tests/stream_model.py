@@ -118,20 +118,6 @@ class ReferenceStream:
         return RESULT_NEEDS_MORE_INPUT, avail_in, produced
 
 
-def checkpoints(seq):
-    """What a caller knows whenever the decoder asks for more input or is done: {bytes consumed so far: (result, bytes
-    produced so far)}, the last word for every amount of input (calls that only hand over owed output in between do not
-    show).  Two decoders that differ only in HOW they hand over output a call had no room for -- the reference writes what
-    fits and says NEEDS_MORE_INPUT, keeping the rest for the next call; this implementation says NEEDS_MORE_OUTPUT until
-    the output is taken -- have the same checkpoints."""
-    cp, c, p = {}, 0, 0
-    for result, used, got in seq:
-        c += used; p += got
-        if result != RESULT_NEEDS_MORE_OUTPUT:
-            cp[c] = (result, p)
-    return cp
-
-
 def run_schedule(step, data: bytes, in_chunk: int, out_chunk: int, max_calls=2000000, drain=False):
     """The loop of the reference's decompress_internal (src/bin/integration_tests.rs:122-216) around `step(pending bytes,
     out_chunk) -> (result, consumed, produced)`: new input only on NEEDS_MORE_INPUT with nothing pending.

@@ -31,6 +31,10 @@ def _stream_decode(pkg, data, in_chunk, out_chunk, large_window=False, max_calls
     while True:
         if not pending and result == pkg.RESULT_NEEDS_MORE_INPUT:
             if pos >= len(data):
+                if calls and got:   # (a cut stream: what earlier calls had no room for still goes out, decode.rs:2835-2846)
+                    result, used, got = st.decompress_stream(b"", out_chunk)
+                    out += got; calls += 1
+                    continue
                 break
             pending = data[pos:pos + in_chunk]
             pos += len(pending)
@@ -298,9 +302,10 @@ def test_less_common_entry_points(pkg):
     assert hashlib.sha256(got).hexdigest() == sha
 
 
-def test_output_owed_stops_input(pkg):
-    """While the decoder owes output that does not fit, calls consume no input (decode.rs:2835-2846): the caller finds
-    its bytes where it left them and is told NEEDS_MORE_OUTPUT."""
+def test_output_that_does_not_fit(pkg):
+    """decode.rs:2835-2846: a call whose input ends inside the stream writes what fits, takes all of its input and answers
+    NEEDS_MORE_INPUT; the rest goes out with later calls.  At the end of the stream the output is OWED (decode.rs:3382-3397):
+    NEEDS_MORE_OUTPUT, and bytes offered behind the end of the stream stay with the caller."""
     import ctypes
     L = pkg.load_library()
     data, sha = _data("alice29.txt.compressed"), MANIFEST["alice29.txt.compressed"]["sha256"]
@@ -309,29 +314,36 @@ def test_output_owed_stops_input(pkg):
     L.BrotliDecoderDestroyInstance.argtypes = [ctypes.c_void_p]
     L.BrotliDecoderDecompressStreaming.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     st = L.BrotliDecoderCreateInstance(None, None, None)
-    half = len(data) // 2
+    third = len(data) // 3
     obuf = ctypes.create_string_buffer(1000)
-    ain, aout = ctypes.c_size_t(half), ctypes.c_size_t(1000)
-    r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), data[:half], ctypes.byref(aout), obuf)
-    assert r == 3 and ain.value == 0 and aout.value == 0  # the first half is taken, more output than fits is owed
-    got = bytearray(obuf.raw[:1000])
-    rest = data[half:]
-    for _ in range(3):  # the second half is offered while output is still owed: none of it is consumed
+    got = bytearray()
+    for piece in (data[:third], data[third:2 * third]):
+        ain, aout = ctypes.c_size_t(len(piece)), ctypes.c_size_t(1000)
+        r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), piece, ctypes.byref(aout), obuf)
+        assert r == 2 and ain.value == 0 and aout.value == 0  # the piece is taken, 1000 bytes of what it held are written
+        got += obuf.raw[:1000]
+    ain, aout = ctypes.c_size_t(0), ctypes.c_size_t(1000)   # no input: what there is goes on coming
+    r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), b"", ctypes.byref(aout), obuf)
+    assert r == 2 and aout.value == 0
+    got += obuf.raw[:1000]
+    rest = data[2 * third:] + b"trailing"
+    ain, aout = ctypes.c_size_t(len(rest)), ctypes.c_size_t(1000)
+    r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), rest, ctypes.byref(aout), obuf)
+    assert r == 3 and ain.value == len(b"trailing") and aout.value == 0  # the stream's end: the output is owed now
+    got += obuf.raw[:1000]
+    rest = rest[len(rest) - ain.value:]
+    for _ in range(3):  # while it is owed nothing more is consumed
         ain, aout = ctypes.c_size_t(len(rest)), ctypes.c_size_t(1000)
         r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), rest, ctypes.byref(aout), obuf)
         assert r == 3 and ain.value == len(rest) and aout.value == 0
         got += obuf.raw[:1000]
     big = ctypes.create_string_buffer(1 << 20)
-    while True:
-        ain, aout = ctypes.c_size_t(len(rest)), ctypes.c_size_t(len(big))
-        r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), rest, ctypes.byref(aout), big)
-        rest = rest[len(rest) - ain.value:]
-        got += big.raw[:len(big) - aout.value]
-        assert r != 0
-        if r == 1:
-            break
+    ain, aout = ctypes.c_size_t(len(rest)), ctypes.c_size_t(len(big))
+    r = L.BrotliDecoderDecompressStreaming(st, ctypes.byref(ain), rest, ctypes.byref(aout), big)
+    got += big.raw[:len(big) - aout.value]
+    assert r == 1 and ain.value == len(rest)
     L.BrotliDecoderDestroyInstance(st)
-    assert hashlib.sha256(got).hexdigest() == sha and rest == b""
+    assert hashlib.sha256(got).hexdigest() == sha
 
 
 def test_streaming_memory_stays_bounded(pkg):

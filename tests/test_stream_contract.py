@@ -4,7 +4,9 @@
 tests/stream_model.py restates the reference's resumable driver (src/decode.rs:2779-2911) on top of the oracle's trace.  The
 Rust reference cannot be run here; what pins the model is Google's libbrotlidec 1.0.9 -- the C decoder whose driver the
 reference's is a line-by-line port of -- fed the same schedules (CPU, below), on streams that fit the ring buffer under both
-decoders' sizing rules.  The GPU test compares the product with the model and spells out where the product differs on purpose."""
+decoders' sizing rules.  The GPU tests compare the product with the model: call for call on streams that fit their ring buffer;
+on streams that wrap it, every byte, the totals and the final result (this decoder keeps no ring: where inside such a stream a
+NEEDS_MORE_OUTPUT falls is its own)."""
 import os
 
 import pytest
@@ -86,14 +88,10 @@ def _product_seq(pkg, data, ic, oc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunks", CHUNKINGS)
 def test_streaming_calls_against_the_model(pkg, chunks):
-    """The product, call by call, against the reference's contract.  Streams that fit their ring buffer (every one here).
-    Whenever the product asks for more input or reports the end it has consumed and delivered exactly what the reference
-    has consumed and delivered everything the reference has decoded by then (stream_model.checkpoints), and no call
-    delivers more than its buffer or consumes more than it was given.  The one
-    documented difference (include/brotli/decode.h): output a call had no room for.  The reference writes what fits and
-    answers NEEDS_MORE_INPUT, keeping the rest for the next call; the product answers NEEDS_MORE_OUTPUT, consuming nothing,
-    until the output is taken -- so a caller that stops feeding at the end of its input still gets every byte.  Where no
-    such overflow happens the two sequences are identical, call for call (asserted)."""
+    """The product, call by call, against the reference's contract (src/decode.rs:2779-2911), on streams that fit their ring
+    buffer (every one here), whole and cut short: every call returns the (result, consumed, produced) the model returns --
+    including the calls whose output has no room: what fits is written, the call's input is taken, the answer is
+    NEEDS_MORE_INPUT (decode.rs:2835-2846), and the rest goes out with the calls that follow."""
     ic, oc = chunks
     names = SMALL + (BIG if ic > 1 and oc > 1 else BIG[:1] if (ic, oc) != (1, 1) else [])
     for name in names:
@@ -101,22 +99,9 @@ def test_streaming_calls_against_the_model(pkg, chunks):
         for d in (data, data[: max(1, len(data) * 2 // 3)]):
             got, out = _product_seq(pkg, d, ic, oc)
             m = sm.ReferenceStream(d)
-            decoded, overflow = {}, [False]
-
-            def mstep(pending, cap):
-                r = m.call(len(pending), cap)
-                if r[0] != sm.RESULT_NEEDS_MORE_OUTPUT:
-                    decoded[m.fed] = (r[0], m.P)
-                    overflow[0] = overflow[0] or m.delivered < m.P
-                return r
-            want = sm.run_schedule(mstep, d, ic, oc, drain=True)
-            # whenever the product asks for more input (or is done) it has consumed what the reference has and delivered
-            # everything the reference has DECODED by then
-            assert sm.checkpoints(got) == decoded, (name, len(d), chunks)
-            assert all(g[2] <= oc for g in got)
+            want = sm.run_schedule(lambda pending, cap: m.call(len(pending), cap), d, ic, oc, drain=True)
+            assert got == want, (name, len(d), chunks, next((i, g, w) for i, (g, w) in enumerate(zip(got + [None], want + [None])) if g != w))
             assert out == oracle.decode(d, 1 << 22, 1)[1]
-            if not overflow[0]:
-                assert got == want, (name, len(d), chunks, next((i, g, w) for i, (g, w) in enumerate(zip(got + [None], want + [None])) if g != w))
 
 
 @pytest.mark.gpu
