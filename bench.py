@@ -132,12 +132,14 @@ class DeviceJob:
         """First decode + bit-exact check against the regenerated raw data (SHA-256 per stream) -> status rows"""
         if not self.indices:
             self.second_pass = 0
+            self.probe_ms = 0.0
             self.blocks_per_stream = 1
             self.pool = False
             self.num_commands = self.engine_commands = 0
             return []
         self.batch.decode_device(self.in_ptrs, self.sizes, self.out_ptrs, self.caps, self.pkg.FLAG_LARGE_WINDOW, self.stream)
         res = self.batch.wait()
+        self.probe_ms = self.batch.last_probe_ms()   # (batch.h: what the call spent asking the device what kind the streams are; relaunches never probe)
         # The timed region re-runs the (first-pass) kernel only: it is the whole job as long as no stream needed the
         # second, large-arena launch (reported so that it cannot go unnoticed; then the whole submit + wait is timed).
         self.second_pass = self.batch.last_second_pass_count()
@@ -178,6 +180,17 @@ class DeviceJob:
         self.batch.relaunch(self.stream)
         # HIP events recorded around the launch on the launch stream; reading them waits for this step only
         return self.batch.last_kernel_ms()
+
+    def call_ms(self):
+        """one whole call as a caller makes it -- BrotliAmdBatchDecodeDevice + BrotliAmdBatchWait, host clock -- beside the kernel time of the
+        timed relaunches (the probe's answer is kept with the batch object: its cost, paid once, is `probe_ms`)"""
+        if not self.indices:
+            return 0.0
+        self.torch.cuda.synchronize()
+        ts = time.perf_counter()
+        self.batch.decode_device(self.in_ptrs, self.sizes, self.out_ptrs, self.caps, self.pkg.FLAG_LARGE_WINDOW, self.stream)
+        self.batch.wait()
+        return (time.perf_counter() - ts) * 1e3
 
     def close(self):
         self.batch.close()
@@ -234,6 +247,9 @@ def time_single_gpu(pkg, torch, dev, name, steps, warmup, n_unique=None, cpu_bud
            "eng": cr["engine_commands_share"], "pass2": job.second_pass, "cus": job.blocks_per_stream}
     if job.pool:
         out["pool"] = 1
+    out["call_ms"] = round(min(job.call_ms() for _ in range(2)), 3)
+    if job.probe_ms:
+        out["probe_ms"] = round(job.probe_ms, 3)
     job.close()
     if cpu_budget_s:  # the CPU path beside it: the oracle on all host threads and on one, a bounded sample of this leg's streams
         try:

@@ -58,6 +58,11 @@ BROTLI_DEC_API void BrotliAmdBatchDestroy(BrotliAmdBatch* batch);
 /* Decodes n streams whose compressed bytes and output buffers already live in DEVICE memory.
  * d_in[i]/d_out[i] are device pointers (any alignment).  The launch is asynchronous on hip_stream
  * (a hipStream_t, NULL = default stream); call BrotliAmdBatchWait before reading results.
+ * One case is NOT asynchronous: a batch of more streams than the device has compute units and at most four times as many, of a mean
+ * compressed size of 8 KiB or more, is PROBED first -- a short launch that reads every stream's header and tells the host which streams
+ * the command engines can take -- and the call waits on hip_stream for its answer (some tens of microseconds of kernel; it cannot be
+ * captured into a graph).  The answer is kept with the batch object: the same descriptors again (pointers, sizes, flags) are not probed
+ * again, and BrotliAmdBatchRelaunch never probes.  BrotliAmdBatchLastProbeMs says what the last call spent there.
  * Returns 0 on success, a negative value if the arguments or the device are unusable. */
 BROTLI_DEC_API int BrotliAmdBatchDecodeDevice(BrotliAmdBatch* batch, uint32_t n, const void* const* d_in, const size_t* in_sizes,
                                              void* const* d_out, const size_t* out_caps, uint32_t flags, void* hip_stream);
@@ -75,6 +80,9 @@ BROTLI_DEC_API int BrotliAmdBatchDecodeHost(BrotliAmdBatch* batch, uint32_t n, c
 
 /* Milliseconds the last launch spent in the decode kernel (HIP events on the launch stream). */
 BROTLI_DEC_API float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* batch);
+
+/* Host milliseconds the last BrotliAmdBatchDecodeDevice / DecodeHost call spent in the probe launch and its wait (0: no probe). */
+BROTLI_DEC_API float BrotliAmdBatchLastProbeMs(BrotliAmdBatch* batch);
 
 /* Streams the last BrotliAmdBatchWait had to continue in a second launch with a larger LDS arena (0 in the common case). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch);

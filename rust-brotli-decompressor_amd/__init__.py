@@ -30,7 +30,7 @@ DECODE_H_SYMBOLS = [
 ]
 BATCH_H_SYMBOLS = [
     "BrotliAmdBatchCreate", "BrotliAmdBatchDestroy", "BrotliAmdBatchDecodeDevice", "BrotliAmdBatchRelaunch", "BrotliAmdBatchWait",
-    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdBatchLastGang", "BrotliAmdBatchLastPool", "BrotliAmdDebugPlanGangs", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
+    "BrotliAmdBatchDecodeHost", "BrotliAmdBatchLastKernelMs", "BrotliAmdBatchLastSecondPassCount", "BrotliAmdBatchLastGang", "BrotliAmdBatchLastPool", "BrotliAmdBatchLastProbeMs", "BrotliAmdDebugPlanGangs", "BrotliAmdLastError", "BrotliAmdLastNote", "BrotliAmdDebugBuildTree", "BrotliAmdDecoderDeviceCommands",
 ]
 
 
@@ -106,6 +106,9 @@ def load_library():
     if hasattr(L, "BrotliAmdBatchLastGang"):   # (libraries of earlier rounds, for A/B runs: tools/ab.sh)
         L.BrotliAmdBatchLastGang.restype = ctypes.c_uint32
         L.BrotliAmdBatchLastGang.argtypes = [vp]
+    if hasattr(L, "BrotliAmdBatchLastProbeMs"):
+        L.BrotliAmdBatchLastProbeMs.restype = ctypes.c_float
+        L.BrotliAmdBatchLastProbeMs.argtypes = [vp]
     if hasattr(L, "BrotliAmdBatchLastPool"):
         L.BrotliAmdBatchLastPool.restype = ctypes.c_uint32
         L.BrotliAmdBatchLastPool.argtypes = [vp]
@@ -183,6 +186,10 @@ class Batch:
     def last_gang(self):
         """blocks (CUs) a stream of the last launch: 1, or 2 / 4 / 8 where each stream had a gang of blocks"""
         return int(self._L.BrotliAmdBatchLastGang(self._h)) if hasattr(self._L, "BrotliAmdBatchLastGang") else 1
+
+    def last_probe_ms(self):
+        """host milliseconds the last decode call spent asking the device what kind the batch's streams are (batch.h; 0: no probe)"""
+        return float(self._L.BrotliAmdBatchLastProbeMs(self._h)) if hasattr(self._L, "BrotliAmdBatchLastProbeMs") else 0.0
 
     def last_pool(self):
         """whether the last launch was a pool: blocks without a stream of their own help the largest stream still being decoded"""

@@ -19,7 +19,9 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "brotli/batch.h"
@@ -52,6 +54,7 @@ thread_local std::string g_last_note;   // what a call did differently without f
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
 static const bool g_engine_wanted = getenv("BROTLI_AMD_NO_SCAN") == nullptr;  // (whether a device can hold such a block is decided per batch context, at its creation)
+constexpr uint64_t kProbeMinMeanBytes = 8192;     // mean compressed size of a batch from which the device is asked what kind its streams are (submit())
 constexpr uint32_t kEngineQueueMaxPerCu = 4;      // streams per CU up to which blocks of sixteen waves, one a CU, take a batch's streams one after the other -- where the
                                                   // DEVICE says they are a command engine's kind (probe_streams); beyond, streams in flight beat the engine (2048 x 1 MiB of the
                                                   // metric's make-up: 220 GB/s eight to a CU in one-wave blocks, 151 through engine blocks)
@@ -143,6 +146,8 @@ struct BrotliAmdBatch {
   // several CUs on one stream: the blocks of a gang in this launch (0: none) and the gangs' control blocks (brotli_device_abi.h)
   uint32_t gang = 0, last_gang = 0;
   uint8_t* d_gang = nullptr; size_t gang_cap = 0;
+  // the probe's answers for the batch it was asked about (probe_streams): the same descriptors again are not probed again
+  std::vector<uint8_t> probe_kind; uint64_t probe_key = 0; float last_probe_ms = 0.0f;
 };
 
 namespace {
@@ -304,12 +309,27 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   static const uint32_t queue_max = getenv("BROTLI_AMD_ENGINE_QUEUE_MAX") ? (uint32_t)atoi(getenv("BROTLI_AMD_ENGINE_QUEUE_MAX")) : kEngineQueueMaxPerCu;  // (streams per CU)
   std::vector<uint8_t> kind;
   for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags &= ~(BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER);
+  b->last_probe_ms = 0.0f;
   if (can16 && !no_wide && b->auto_arena && b->grid > b->cus && n <= queue_max * b->cus) {
-    // more streams than CUs, few enough for engine blocks to pay where the streams are the engines' kind: the device says which are
-    if (probe_streams(b, n, stream, kind) != 0) return -1;
-    uint64_t in_total = 0, in_engine = 0;
-    for (uint32_t i = 0; i < n; i++) { in_total += b->h_descs[i].in_size; if (kind[i] == 7u) in_engine += b->h_descs[i].in_size; }
-    if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
+    // more streams than CUs, few enough for engine blocks to pay where the streams are the engines' kind: the device says which are.
+    // Not for batches of small streams (a mean of less than 8 KiB compressed: an engine has nothing to spread out, and the probe -- a
+    // launch and a wait on the caller's stream -- would cost such a batch more than its decode), and not twice for the same descriptors.
+    uint64_t in_total = 0, in_engine = 0, key = 0xcbf29ce484222325ull ^ n;
+    for (uint32_t i = 0; i < n; i++) {
+      in_total += b->h_descs[i].in_size;
+      for (uint64_t v : {(uint64_t)(uintptr_t)b->h_descs[i].in, (uint64_t)b->h_descs[i].in_size, (uint64_t)b->h_descs[i].flags}) key = (key ^ v) * 0x100000001b3ull;
+    }
+    if (in_total >= (uint64_t)n * kProbeMinMeanBytes) {
+      if (b->probe_kind.size() == n && b->probe_key == key) kind = b->probe_kind;
+      else {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (probe_streams(b, n, stream, kind) != 0) return -1;
+        b->last_probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        b->probe_kind = kind; b->probe_key = key;
+      }
+      for (uint32_t i = 0; i < n; i++) if (kind[i] == 7u) in_engine += b->h_descs[i].in_size;
+      if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
+    }
   }
   if (can16 && b->grid <= b->cus) { b->cur_arena = arena16; b->waves = 16; }
   // Fewer streams than half the CUs: GANGS of blocks, a CU each, on one stream -- its owner and one, three or seven helper blocks that take
@@ -331,7 +351,9 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   // where a larger arena exists, tables that do not fit this one are a reason to come back, not to spill
   if (b->cur_arena < b->max_arena)
     for (uint32_t i = 0; i < n; i++) if (!(b->h_descs[i].flags & BROTLI_AMD_BATCH_SPILL_IN_PLACE)) b->h_descs[i].flags |= BROTLI_AMD_FLAG_NO_SPILL;
-  if (!ensure_scratch(b, b->gang > 1u && b->gang <= 8u ? n : b->grid)) return -1;   // (a gang's helper blocks have no scratch of their own: a slot per stream)
+  // (a gang's helper blocks have no scratch of their own -- a slot per stream --, but a launch whose kernel decides against gangs after all
+  // (fewer waves than sixteen: BROTLI_AMD_LAUNCH experiments) indexes the scratch by block: there is a slot for every block as well)
+  if (!ensure_scratch(b, std::max(n, b->grid))) return -1;
   // more streams than blocks: the blocks take them longest first (compressed size as the measure), so that no block starts
   // a long stream when the others are done
   static const bool no_order = getenv("BROTLI_AMD_NO_ORDER") != nullptr;  // (experiments)
@@ -370,6 +392,14 @@ int retry_with_larger_arenas(BrotliAmdBatch* b) {
     if (!b->h_retry_descs && run_retry_descs(b, 0, b->max_arena, b->retry_grid_max, 4) != 0) return -1;  // (allocates the pass's buffers)
     // shape of this pass
     uint32_t arena, grid_max; int waves; bool last;
+    bool deferred = false;   // streams an engine launch sent back unread (BROTLI_AMD_FLAG_DEFER): the launch of small blocks they were promised
+    if (pass == 0) for (uint32_t j = 0; j < m && !deferred; j++) deferred = (b->h_descs[idx[j]].flags & BROTLI_AMD_FLAG_DEFER) != 0u;
+    if (deferred) {   // the shape submit() gives a batch of m streams without engine blocks: several blocks a CU, streams in flight
+      const uint32_t per_cu = (uint32_t)std::min<size_t>(b->per_cu_cap, ((size_t)m + b->cus - 1) / b->cus);
+      if (per_cu > 4u && small_arena(b, per_cu) != 0u && small_arena(b, per_cu) < b->lds_arena) { level = per_cu; arena = small_arena(b, per_cu); grid_max = b->cus * per_cu; waves = 1; }
+      else { level = 4; arena = b->lds_arena; grid_max = b->grid_max; waves = 4; }
+      last = false;
+    } else
     if (level > 8u && small_arena(b, 8) > b->cur_arena) { level = 8; arena = small_arena(b, 8); grid_max = b->cus * 8u; waves = 1; last = false; }
     else if (level > 4u && b->lds_arena > b->cur_arena) { level = 4; arena = b->lds_arena; grid_max = b->grid_max; waves = 4; last = false; }
     else { level = 2; arena = b->max_arena; grid_max = b->retry_grid_max; waves = 4; last = true; }
@@ -622,6 +652,7 @@ extern "C" uint32_t BrotliAmdDebugPlanGangs(uint32_t n, uint32_t cus, const size
   if (grid) *grid = g;
   return r;
 }
+extern "C" float BrotliAmdBatchLastProbeMs(BrotliAmdBatch* b) { return b ? b->last_probe_ms : 0.0f; }
 extern "C" uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* b) { return b && (b->last_gang & 0x10u) != 0u ? 1u : 0u; }
 
 extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
@@ -657,18 +688,20 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
     if (!hip_ok(hipMalloc(&b->d_stage_out, out_total), "hipMalloc(output arena)")) return -1;
     b->stage_out_cap = out_total;
   }
-  // pinned staging on the host (kept with the batch object) and a stream for the transfers
+  // pinned staging on the host (kept with the batch object) and a stream for the transfers; where the host has no pinned memory to give,
+  // the transfers go stream by stream from and to the caller's own (pageable) buffers
+  bool pinned = true;
   if (in_total > b->pin_in_cap) {
     if (b->h_pin_in) (void)hipHostFree(b->h_pin_in);
     b->h_pin_in = nullptr; b->pin_in_cap = 0;
-    if (!hip_ok(hipHostMalloc(&b->h_pin_in, in_total, hipHostMallocDefault), "hipHostMalloc(input staging)")) return -1;
-    b->pin_in_cap = in_total;
+    if (hipHostMalloc(&b->h_pin_in, in_total, hipHostMallocDefault) == hipSuccess) b->pin_in_cap = in_total;
+    else { (void)hipGetLastError(); b->h_pin_in = nullptr; pinned = false; }
   }
-  if (out_total > b->pin_out_cap) {
+  if (pinned && out_total > b->pin_out_cap) {
     if (b->h_pin_out) (void)hipHostFree(b->h_pin_out);
     b->h_pin_out = nullptr; b->pin_out_cap = 0;
-    if (!hip_ok(hipHostMalloc(&b->h_pin_out, out_total, hipHostMallocDefault), "hipHostMalloc(output staging)")) return -1;
-    b->pin_out_cap = out_total;
+    if (hipHostMalloc(&b->h_pin_out, out_total, hipHostMallocDefault) == hipSuccess) b->pin_out_cap = out_total;
+    else { (void)hipGetLastError(); b->h_pin_out = nullptr; pinned = false; }
   }
   if (!b->copy_stream && !hip_ok(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking), "hipStreamCreate")) return -1;
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -681,13 +714,17 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
     for (unsigned t = 0; t < nt && i0 < hi; t++) {
       uint32_t i1 = i0; size_t acc = 0;
       while (i1 < hi && (acc < per || t + 1 == nt)) acc += one(i1++, false);
-      ts.emplace_back([=, &one]() { for (uint32_t i = i0; i < i1; i++) (void)one(i, true); });
+      try { ts.emplace_back([=, &one]() { for (uint32_t i = i0; i < i1; i++) (void)one(i, true); }); }
+      catch (const std::system_error&) { for (uint32_t i = i0; i < i1; i++) (void)one(i, true); }   // (no thread to be had: this one does the part)
       i0 = i1;
     }
     for (auto& t : ts) t.join();
   };
   // upload: the inputs packed into pinned memory by several threads, piece by piece, each piece's transfer behind it
-  {
+  if (!pinned) {
+    for (uint32_t i = 0; i < n; i++)
+      if (in_sizes[i] && !hip_ok(hipMemcpyAsync(b->d_stage_in + in_off[i], in[i], in_sizes[i], hipMemcpyHostToDevice, b->copy_stream), "hipMemcpyAsync(input)")) return -1;
+  } else {
     uint32_t lo = 0;
     while (lo < n) {
       uint32_t hi = lo; size_t acc = 0;
@@ -713,17 +750,29 @@ extern "C" int BrotliAmdBatchDecodeHost(BrotliAmdBatch* b, uint32_t n, const uin
   if (BrotliAmdBatchWait(b, results) != 0) return -1;
   // download: pieces of about 32 MiB into pinned memory, the copies into the caller's buffers (several threads) side by side with the
   // next piece's transfer
-  {
+  if (!pinned) {
+    for (uint32_t i = 0; i < n; i++) {
+      const size_t got = (size_t)std::min<uint64_t>(results[i].decoded_size, out_caps[i]);
+      if (got && !hip_ok(hipMemcpyAsync(out[i], b->d_stage_out + out_off[i], got, hipMemcpyDeviceToHost, b->copy_stream), "hipMemcpyAsync(output)")) return -1;
+    }
+    if (!hip_ok(hipStreamSynchronize(b->copy_stream), "hipStreamSynchronize(download)")) return -1;
+  } else {
     std::vector<std::pair<uint32_t, uint32_t>> pieces; std::vector<hipEvent_t> evs;
     uint32_t lo = 0;
     bool ok = true;
+    const auto got_of = [&](uint32_t i) { return (size_t)std::min<uint64_t>(results[i].decoded_size, out_caps[i]); };
     while (lo < n && ok) {
       uint32_t hi = lo; size_t acc = 0;
-      while (hi < n && acc < ((size_t)32 << 20)) { acc += (size_t)std::min<uint64_t>(results[hi].decoded_size, out_caps[hi]); hi++; }
-      const size_t o0 = out_off[lo];
-      const size_t last = (size_t)std::min<uint64_t>(results[hi - 1].decoded_size, out_caps[hi - 1]);
-      const size_t o1 = out_off[hi - 1] + last;
-      if (o1 > o0) ok = hip_ok(hipMemcpyAsync(b->h_pin_out + o0, b->d_stage_out + o0, o1 - o0, hipMemcpyDeviceToHost, b->copy_stream), "hipMemcpyAsync(output)");
+      while (hi < n && acc < ((size_t)32 << 20)) { acc += got_of(hi); hi++; }
+      // a transfer per run of streams that filled their slots (the rule); a stream that stopped short of its slot ends a run, so that a
+      // failed stream with a large buffer costs its decoded bytes, not its capacity
+      for (uint32_t r0 = lo; r0 < hi && ok; ) {
+        uint32_t r1 = r0;
+        while (r1 + 1 < hi && got_of(r1) + 4096 >= out_caps[r1]) r1++;
+        const size_t o0 = out_off[r0], o1 = out_off[r1] + got_of(r1);
+        if (o1 > o0) ok = hip_ok(hipMemcpyAsync(b->h_pin_out + o0, b->d_stage_out + o0, o1 - o0, hipMemcpyDeviceToHost, b->copy_stream), "hipMemcpyAsync(output)");
+        r0 = r1 + 1;
+      }
       hipEvent_t ev = nullptr;
       ok = ok && hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate") && hip_ok(hipEventRecord(ev, b->copy_stream), "hipEventRecord");
       evs.push_back(ev); pieces.emplace_back(lo, hi);

@@ -161,6 +161,7 @@ extern "C" {
     pub fn BrotliAmdBatchLastSecondPassCount(batch: *mut BrotliAmdBatch) -> u32;
     pub fn BrotliAmdBatchLastGang(batch: *mut BrotliAmdBatch) -> u32;
     pub fn BrotliAmdBatchLastPool(batch: *mut BrotliAmdBatch) -> u32;
+    pub fn BrotliAmdBatchLastProbeMs(batch: *mut BrotliAmdBatch) -> f32;
     pub fn BrotliAmdLastError() -> *const c_char;
     pub fn BrotliAmdLastNote() -> *const c_char;
 }
