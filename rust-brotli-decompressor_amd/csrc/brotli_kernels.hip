@@ -250,6 +250,23 @@ struct BitReader {
     chunk_base = next_dw;
     while (issued_half <= a + 2u) { dma_half(issued_half); issued_half++; }  // slots of pieces below a - 1 are dead
   }
+  // ... to [next_dw - 2, next_dw + 62): the two dwords in front of next_dw may still be in buf, and a reader that goes by its POSITION
+  // (the hand-written run of lean_rec_commands: bits into the window) wants them in the window too.  (Piece a - 1 of the ring is still
+  // there: see above.)
+  __device__ __forceinline__ void rebase_back2() {
+    const uint32_t a = next_dw >> 6;
+    while (issued_half <= a + 1u) { dma_half(issued_half); issued_half++; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t first = next_dw >= 2u ? next_dw - 2u : 0u;
+    uint32_t j = first + lane_id();
+    uint32_t v = lds_ld32(LDS_INWIN + ((j & 255u) << 2));
+    const uint32_t ndw = n_dw();
+    v = j < ndw ? v : 0u;
+    if (j == ndw - 1u) v &= tail_mask();
+    cur = v;
+    chunk_base = first;
+    while (issued_half <= a + 2u) { dma_half(issued_half); issued_half++; }
+  }
   __device__ __forceinline__ void seek(uint64_t bit_pos) {
     uint64_t abs = bit_pos + skip_bits();
     uint32_t dw = (uint32_t)(abs >> 5);
@@ -1430,7 +1447,8 @@ constexpr uint32_t SPX_BYTES = SPX_CTL_BYTES + SPX_POS * 8u;
 enum { XW_FRONT = 0 /* u64: positions below are written (low), for parameter epoch (high) */, XW_POS = 2 /* the parser's position (lags) */,
        XW_EPOCH = 3, XW_STOP = 4, XW_ORIGIN_DW = 5, XW_LIMIT = 6, XW_CMD_TREE = 7, XW_DT0 = 8, XW_POSTFIX = 12, XW_NUM_DIRECT = 13,
        XW_DICT_LO = 14, XW_DICT_HI = 15 /* the static dictionary (device address) */, XW_WORDS = 16 };
-enum { XR_VALID = 1u << 23, XR_LITERALS = 1u << 24, XR_IMPLICIT = 1u << 25, XR_DCTX_SHIFT = 26, XR_SHORT = 1u << 28 };
+enum : uint32_t { XR_VALID = 1u << 23, XR_LITERALS = 1u << 24, XR_IMPLICIT = 1u << 25, XR_DCTX_SHIFT = 26, XR_SHORT = 1u << 28,
+       XR_NOT_RUN = 1u << 31 /* not a record the hand-written run takes: not valid, or a copy of more than 63 bytes (its tests are one sign test) */ };
 __device__ __noinline__ void rec_wave();
 
 // Wave 1 of the block while the decoding wave parses a context-modelled metablock.
@@ -2406,6 +2424,7 @@ __device__ __noinline__ void rec_wave() {
     valid = valid && bits <= 63u;  // (all of the command inside the lane's 64 bits; 63: the parser shifts its 64-bit buffer by that much)
     w0 |= (bits & 127u) << 16;
     if (valid) w0 |= XR_VALID;
+    if (!valid || h.copy > 63u) w0 |= XR_NOT_RUN;
     *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[ring + ((p & (SPX_POS - 1u)) << 3)]) = ((uint64_t)w1 << 32) | w0;
     F += 64u;
     lds_release();
@@ -2416,364 +2435,23 @@ __device__ __noinline__ void rec_wave() {
 }
 
 // ===================================== record lean loop =====================================
-// The plain commands of a context-modelled metablock out of their records, in hand-written scalar code (what the compiler makes of
-// the same loop is three times as long: see DESIGN 2d).  One iteration = one command of the plain kind, taken whole:
+// The plain commands of a context-modelled metablock out of their records, in hand-written scalar code: LEAN_REC_RUN_ASM, generated by
+// tools/gen_rec_asm.py into brotli_rec_run_asm.h (that file says what the loop does and why it is laid out as it is: a lone wave pays 13
+// clocks for a branch it does not take and 26 - 29 for one it takes, tools/ubench/branch.hip).  One iteration = one command of the plain kind:
 //   * WITHOUT literals: a short LZ77 copy that does not repeat itself, clear of every limit, all of it out of the record at the reader's
 //     position -- distance (explicit, implicit, or a ring code: decode.rs:2017-2049), counts, the reader moved on by the record's bits;
 //   * WITH literals (round 6; decode.rs:2463-2551): at most sixteen, the tree of each by the two bytes before it (the context tables and
 //     the map in registers: three v_readlane), then the distance code behind them (decode.rs:2066-2131: ring codes and the codes of the
 //     plain alphabet with their extra bits out of a lane table) and the same plain copy.  Nothing of such a command is COMMITTED before
-//     all of it is known to be plain: the reader and the context bytes are kept and put back where anything else turns up -- a word of the
-//     static dictionary, a copy that repeats itself, a distance code beyond the lane table, a count that has run out -- and the
-//     compiled loop below takes that command from its first bit.
+//     all of it is known to be plain: where anything else turns up -- a word of the static dictionary, a copy that repeats itself, a
+//     distance code beyond the lane table, a count that has run out -- the reader's position has not moved, the context bytes are put
+//     back, and the compiled loop below takes that command from its first bit.
 // The copy in flight (its bytes on their way into v124) is stored when the next command comes by, a command's literals with it in one
 // store: lanes below pn the copy's bytes, the literals behind them.  The record of the next command is asked for before the memory
 // pipe is waited for.  Leaves in front of the first command that is anything else, with nothing of it touched; bit 0 of `ok` then says
-// whether rx / ry hold that command's record, bit 1 whether p1 / p2 are the two bytes before P.  P < 2^32 in here.
-// s[98:99] = the reader's 64-bit buffer (an operand's halves cannot be named); temporaries s78 .. s97, v117 .. v119.
-#define LRA_NEED32(L) \
-  "s_cmp_ge_u32 %[cnt], 32\n\t" \
-  "s_cbranch_scc1 " #L "f\n\t" \
-  "s_sub_u32 s96, %[ndw], %[cb]\n\t" \
-  "s_mov_b32 s97, 0\n\t" \
-  "v_readlane_b32 s96, %[cur], s96\n\t" \
-  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
-  "s_lshl_b64 s[96:97], s[96:97], %[cnt]\n\t" \
-  "s_add_u32 %[cnt], %[cnt], 32\n\t" \
-  "s_or_b64 s[98:99], s[98:99], s[96:97]\n" \
-  #L ":\n\t"
-/* the reader moves on by s95 bits (<= 64) */
-#define LRA_ADVANCE(L1, L2) \
-  "s_cmp_le_u32 s95, %[cnt]\n\t" \
-  "s_cbranch_scc1 " #L2 "f\n\t" \
-  "s_sub_u32 s95, s95, %[cnt]\n\t" \
-  "s_cmp_lt_u32 s95, 32\n\t" \
-  "s_cbranch_scc1 " #L1 "f\n\t" \
-  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
-  "s_sub_u32 s95, s95, 32\n" \
-  #L1 ":\n\t" \
-  "s_sub_u32 s96, %[ndw], %[cb]\n\t" \
-  "s_mov_b32 s97, 0\n\t" \
-  "v_readlane_b32 s96, %[cur], s96\n\t" \
-  "s_add_u32 %[ndw], %[ndw], 1\n\t" \
-  "s_mov_b32 %[cnt], 32\n\t" \
-  "s_mov_b64 s[98:99], s[96:97]\n" \
-  #L2 ":\n\t" \
-  "s_lshr_b64 s[98:99], s[98:99], s95\n\t" \
-  "s_sub_u32 %[cnt], %[cnt], s95\n\t"
-/* the symbol at the reader's position by the two-level table at LDS address s87 (read_symbol<true>) -> s85, its bits taken; at least 32 bits in the buffer */
-#define LRA_SYMBOL(L) \
-  "s_and_b32 s85, s98, 0xff\n\t" \
-  "s_lshl_b32 s85, s85, 1\n\t" \
-  "s_add_u32 s85, s85, s87\n\t" \
-  "v_mov_b32 v117, s85\n\t" \
-  "ds_read_u16 v118, v117\n\t" \
-  "s_waitcnt lgkmcnt(0)\n\t" \
-  "v_readfirstlane_b32 s85, v118\n\t" \
-  "s_and_b32 s86, s85, 15\n\t" \
-  "s_lshr_b32 s85, s85, 4\n\t" \
-  "s_cmp_le_u32 s86, 8\n\t" \
-  "s_cbranch_scc1 " #L "f\n\t" \
-  "s_sub_u32 s86, s86, 8\n\t" \
-  "s_lshr_b32 s88, s98, 8\n\t" \
-  "s_bfm_b32 s96, s86, 0\n\t" \
-  "s_and_b32 s88, s88, s96\n\t" \
-  "s_add_u32 s85, s85, s88\n\t" \
-  "s_lshl_b32 s85, s85, 1\n\t" \
-  "s_add_u32 s85, s85, s87\n\t" \
-  "v_mov_b32 v117, s85\n\t" \
-  "ds_read_u16 v118, v117\n\t" \
-  "s_waitcnt lgkmcnt(0)\n\t" \
-  "v_readfirstlane_b32 s85, v118\n\t" \
-  "s_and_b32 s86, s85, 15\n\t" \
-  "s_add_u32 s86, s86, 8\n\t" \
-  "s_lshr_b32 s85, s85, 4\n" \
-  #L ":\n\t" \
-  "s_lshr_b64 s[98:99], s[98:99], s86\n\t" \
-  "s_sub_u32 %[cnt], %[cnt], s86\n\t"
-/* a ring code s85 = 1 .. 15 -> distance s93 (TakeDistanceFromRingBuffer, decode.rs:2017-2049), pushed */
-#define LRA_RING(CODE, L, END) \
-  "s_lshl_b32 s95, " CODE ", 1\n\t" \
-  "s_lshr_b32 s96, 0xaaafff1b, s95\n\t" \
-  "s_and_b32 s96, s96, 3\n\t"                   /* 3 - (how far back) */ \
-  "s_mov_b32 s93, %[d3]\n\t" \
-  "s_cmp_eq_u32 s96, 1\n\t" \
-  "s_cselect_b32 s93, %[d2], s93\n\t" \
-  "s_cmp_eq_u32 s96, 2\n\t" \
-  "s_cselect_b32 s93, %[d1], s93\n\t" \
-  "s_cmp_eq_u32 s96, 3\n\t" \
-  "s_cselect_b32 s93, %[d0], s93\n\t" \
-  "s_lshr_b32 s97, 0xfa5fa500, s95\n\t" \
-  "s_and_b32 s97, s97, 3\n\t" \
-  "s_mov_b32 s94, 1\n\t" \
-  "s_bitcmp1_b32 " CODE ", 0\n\t" \
-  "s_cbranch_scc1 " #L "f\n\t" \
-  "s_sub_i32 s93, s93, s97\n\t" \
-  "s_cmp_gt_i32 s93, 0\n\t" \
-  "s_cselect_b32 s93, s93, 0x7fffffff\n\t" \
-  "s_branch " #END "f\n" \
-  #L ":\n\t" \
-  "s_add_i32 s93, s93, s97\n"
-/* the next command's record, if wave 2 has written it (and wave 2 is told where the reader is every 128 bits: it stays less than a lap ahead of that) */
-#define LRA_REQUEST(L1, L2) \
-  "s_lshl_b32 s95, %[ndw], 5\n\t" \
-  "s_sub_u32 s95, s95, %[cnt]\n\t" \
-  "s_sub_u32 s95, s95, %[org]\n\t" \
-  "s_andn2_b32 %[ok], %[ok], 3\n\t" \
-  "s_sub_u32 s96, s95, %[said]\n\t" \
-  "s_cmp_lt_u32 s96, 128\n\t" \
-  "s_cbranch_scc1 " #L1 "f\n\t" \
-  "s_mov_b32 %[said], s95\n\t" \
-  "v_readlane_b32 s96, %[params], 5\n\t"        /* (lane 5: where that word lies) */ \
-  "v_mov_b32 v118, s95\n\t" \
-  "v_mov_b32 v117, s96\n\t" \
-  "ds_write_b32 v117, v118\n" \
-  #L1 ":\n\t" \
-  "s_cmp_ge_u32 s95, %[front]\n\t" \
-  "s_cbranch_scc1 " #L2 "f\n\t" \
-  "s_and_b32 s95, s95, 0x3ff\n\t" \
-  "s_lshl_b32 s95, s95, 3\n\t" \
-  "s_add_u32 s95, s95, %[xring]\n\t" \
-  "v_mov_b32 %[rx], s95\n\t" \
-  "s_or_b32 %[ok], %[ok], 1\n\t" \
-  "ds_read_b32 %[ry], %[rx] offset:4\n\t" \
-  "ds_read_b32 %[rx], %[rx]\n" \
-  #L2 ":\n\t"
-#define LEAN_REC_RUN_ASM \
-  "s_mov_b64 s[98:99], %[buf]\n" \
-  "1:\n\t" \
-  "s_bitcmp0_b32 %[ok], 0\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_waitcnt lgkmcnt(0)\n\t" \
-  "v_readfirstlane_b32 s90, %[rx]\n\t" \
-  "v_readfirstlane_b32 s91, %[ry]\n\t" \
-  "s_bitcmp0_b32 s90, 23\n\t"                   /* valid */ \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_eq_u32 %[bl1], 0\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_ge_u32 %[ndw], %[lim]\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_bitcmp1_b32 s90, 24\n\t"                   /* literals */ \
-  "s_cbranch_scc1 100f\n\t" \
-  "s_and_b32 s92, s90, 0xffff\n\t"              /* s92 = copy length */ \
-  "s_mov_b32 s93, %[d0]\n\t"                    /* s93 = distance, s94 = pushed onto the ring? */ \
-  "s_mov_b32 s94, 0\n\t" \
-  "s_bitcmp1_b32 s90, 25\n\t"                   /* implicit: the last distance */ \
-  "s_cbranch_scc1 3f\n\t" \
-  "s_cmp_eq_u32 %[bl2], 0\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_bitcmp1_b32 s90, 28\n\t" \
-  "s_cbranch_scc1 2f\n\t" \
-  "s_mov_b32 s93, s91\n\t"                      /* explicit */ \
-  "s_mov_b32 s94, 1\n\t" \
-  "s_branch 3f\n" \
-  "2:\n\t"                                      /* ring code s91 = 0 .. 15 */ \
-  "s_cmp_eq_u32 s91, 0\n\t" \
-  "s_cbranch_scc1 3f\n\t" \
-  LRA_RING("s91", 21, 3) \
-  "3:\n\t"                                      /* the plain copy?  0 < distance <= min(P, max_backward), length <= 64, <= distance, < quota */ \
-  "s_min_u32 s95, %[P], %[maxb]\n\t" \
-  "s_cmp_le_i32 s93, 0\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_gt_u32 s93, s95\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_gt_u32 s92, 64\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_lt_u32 s93, s92\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_ge_u32 s92, %[quota]\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_bfe_u32 s95, s90, 0x10019\n\t"             /* counts: an explicit distance takes one of its block */ \
-  "s_xor_b32 s95, s95, 1\n\t" \
-  "s_sub_u32 %[bl2], %[bl2], s95\n\t" \
-  "s_sub_u32 %[bl1], %[bl1], 1\n\t" \
-  "s_cmp_eq_u32 s94, 0\n\t" \
-  "s_cbranch_scc1 4f\n\t" \
-  "s_mov_b32 %[d3], %[d2]\n\t" \
-  "s_mov_b32 %[d2], %[d1]\n\t" \
-  "s_mov_b32 %[d1], %[d0]\n\t" \
-  "s_mov_b32 %[d0], s93\n" \
-  "4:\n\t"                                      /* the reader moves on by the command's bits (<= 64) */ \
-  "s_bfe_u32 s95, s90, 0x70010\n\t" \
-  LRA_ADVANCE(41, 5) \
-  LRA_NEED32(7)                                 /* at least 32 bits in the buffer */ \
-  LRA_REQUEST(71, 8) \
-  "s_cmp_eq_u32 %[pn], 0\n\t"                   /* the copy in flight goes to memory */ \
-  "s_cbranch_scc1 6f\n\t" \
-  "s_sub_u32 s96, %[P], %[pn]\n\t" \
-  "s_add_u32 s96, %[outlo], s96\n\t" \
-  "s_addc_u32 s97, %[outhi], 0\n\t" \
-  "s_sub_u32 s95, 64, %[pn]\n\t" \
-  "s_waitcnt vmcnt(0)\n\t" \
-  "s_lshr_b64 exec, -1, s95\n\t" \
-  "global_store_byte %[lane], v124, s[96:97]\n\t" \
-  "s_mov_b64 exec, -1\n" \
-  "6:\n\t"                                      /* this one's load */ \
-  "s_add_u32 s96, %[outlo], %[P]\n\t" \
-  "s_addc_u32 s97, %[outhi], 0\n\t" \
-  "s_sub_u32 s96, s96, s93\n\t" \
-  "s_subb_u32 s97, s97, 0\n\t" \
-  "s_sub_u32 s95, 64, s92\n\t" \
-  "s_lshr_b64 exec, -1, s95\n\t" \
-  "global_load_ubyte v124, %[lane], s[96:97]\n\t" \
-  "s_mov_b64 exec, -1\n\t" \
-  "s_mov_b32 %[pn], s92\n\t" \
-  "s_add_u32 %[P], %[P], s92\n\t" \
-  "s_sub_u32 %[quota], %[quota], s92\n\t" \
-  "s_branch 1b\n" \
-  /* ---- a command with literals: s91 = their number ---- */ \
-  "100:\n\t" \
-  "s_cmp_gt_u32 s91, 16\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_ge_u32 s91, %[quota]\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_cmp_gt_u32 s91, %[bl0]\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "s_add_u32 s89, s91, %[pn]\n\t"               /* lanes of the store: the copy in flight and the literals behind it */ \
-  "s_cmp_gt_u32 s89, 64\n\t" \
-  "s_cbranch_scc1 9f\n\t" \
-  "v_writelane_b32 v116, s98, 0\n\t"            /* what is put back if the command turns out not to be plain (lanes of v116: scalar registers are scarce here) */ \
-  "v_writelane_b32 v116, s99, 1\n\t" \
-  "v_writelane_b32 v116, %[cnt], 2\n\t" \
-  "v_writelane_b32 v116, %[ndw], 3\n\t" \
-  "v_writelane_b32 v116, %[p1], 4\n\t" \
-  "v_writelane_b32 v116, %[p2], 5\n\t" \
-  "s_bfe_u32 s95, s90, 0x70010\n\t"             /* the head's bits */ \
-  LRA_ADVANCE(101, 102) \
-  "s_bitcmp1_b32 %[ok], 1\n\t"                  /* the two bytes before P: in p1 / p2, or the tail of the copy in flight */ \
-  "s_cbranch_scc1 103f\n\t" \
-  "s_cmp_lt_u32 %[pn], 2\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_waitcnt vmcnt(0)\n\t" \
-  "s_sub_u32 s96, %[pn], 1\n\t" \
-  "s_sub_u32 s97, %[pn], 2\n\t" \
-  "v_readlane_b32 %[p1], v124, s96\n\t" \
-  "v_readlane_b32 %[p2], v124, s97\n" \
-  "103:\n\t" \
-  "s_mov_b32 s84, %[pn]\n"                      /* the lane of the next literal */ \
-  "104:\n\t" \
-  "s_mov_b32 s87, %[littree]\n\t" \
-  "s_cmp_lg_u32 %[trivial], 0\n\t" \
-  "s_cbranch_scc1 105f\n\t" \
-  "s_lshr_b32 s85, %[p1], 2\n\t"                /* context = lut0[p1] | lut1[p2] (four bytes a lane), tree = map[context] */ \
-  "s_lshr_b32 s86, %[p2], 2\n\t" \
-  "v_readlane_b32 s85, %[lut0], s85\n\t" \
-  "v_readlane_b32 s86, %[lut1], s86\n\t" \
-  "s_lshl_b32 s87, %[p1], 3\n\t" \
-  "s_lshl_b32 s88, %[p2], 3\n\t" \
-  "s_lshr_b32 s85, s85, s87\n\t" \
-  "s_lshr_b32 s86, s86, s88\n\t" \
-  "s_or_b32 s85, s85, s86\n\t" \
-  "s_and_b32 s85, s85, 0xff\n\t" \
-  "v_readlane_b32 s87, %[ctxtree], s85\n" \
-  "105:\n\t" \
-  LRA_NEED32(106) \
-  LRA_SYMBOL(107) \
-  "s_mov_b32 %[p2], %[p1]\n\t" \
-  "s_mov_b32 %[p1], s85\n\t" \
-  "s_mov_b32 m0, s84\n\t" \
-  "s_nop 0\n\t" \
-  "v_writelane_b32 v119, s85, m0\n\t" \
-  "s_add_u32 s84, s84, 1\n\t" \
-  "s_cmp_lt_u32 s84, s89\n\t" \
-  "s_cbranch_scc1 104b\n\t" \
-  /* the distance behind them */ \
-  "s_mov_b32 s93, %[d0]\n\t" \
-  "s_mov_b32 s94, 0\n\t" \
-  "s_bitcmp1_b32 s90, 25\n\t" \
-  "s_cbranch_scc1 130f\n\t" \
-  "s_cmp_eq_u32 %[bl2], 0\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_bfe_u32 s85, s90, 0x2001a\n\t"             /* the distance context picks the code */ \
-  "v_readlane_b32 s87, %[params], s85\n\t"      /* (lanes 0 .. 3 of the parameters: the four contexts' tables) */ \
-  LRA_NEED32(111) \
-  LRA_SYMBOL(112) \
-  "s_cmp_eq_u32 s85, 0\n\t" \
-  "s_cbranch_scc1 130f\n\t" \
-  "s_cmp_ge_u32 s85, 16\n\t" \
-  "s_cbranch_scc1 120f\n\t" \
-  LRA_RING("s85", 113, 130) \
-  "s_branch 130f\n" \
-  "120:\n\t"                                    /* a code of the plain alphabet: base and number of extra bits out of the lane table */ \
-  "v_readlane_b32 s86, %[params], 4\n\t"        /* (lane 4: whether the lane table is the alphabet's) */ \
-  "s_cmp_eq_u32 s86, 0\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_cmp_ge_u32 s85, 64\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "v_readlane_b32 s85, %[dlut], s85\n\t" \
-  "s_and_b32 s86, s85, 31\n\t" \
-  "s_lshr_b32 s93, s85, 5\n\t" \
-  LRA_NEED32(121) \
-  "s_bfm_b32 s96, s86, 0\n\t" \
-  "s_and_b32 s96, s98, s96\n\t" \
-  "s_add_u32 s93, s93, s96\n\t" \
-  "s_lshr_b64 s[98:99], s[98:99], s86\n\t" \
-  "s_sub_u32 %[cnt], %[cnt], s86\n\t" \
-  "s_mov_b32 s94, 1\n" \
-  "130:\n\t"                                    /* the plain copy, from behind the literals? */ \
-  "s_and_b32 s92, s90, 0xffff\n\t" \
-  "s_add_u32 s88, %[P], s91\n\t" \
-  "s_min_u32 s95, s88, %[maxb]\n\t" \
-  "s_cmp_le_i32 s93, 0\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_cmp_gt_u32 s93, s95\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_cmp_gt_u32 s92, 64\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_cmp_lt_u32 s93, s92\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  "s_sub_u32 s96, %[quota], s91\n\t" \
-  "s_cmp_ge_u32 s92, s96\n\t" \
-  "s_cbranch_scc1 190f\n\t" \
-  /* it is: the counts, the ring */ \
-  "s_sub_u32 %[quota], s96, s92\n\t" \
-  "s_sub_u32 %[bl0], %[bl0], s91\n\t" \
-  "s_bfe_u32 s95, s90, 0x10019\n\t" \
-  "s_xor_b32 s95, s95, 1\n\t" \
-  "s_sub_u32 %[bl2], %[bl2], s95\n\t" \
-  "s_sub_u32 %[bl1], %[bl1], 1\n\t" \
-  "s_cmp_eq_u32 s94, 0\n\t" \
-  "s_cbranch_scc1 131f\n\t" \
-  "s_mov_b32 %[d3], %[d2]\n\t" \
-  "s_mov_b32 %[d2], %[d1]\n\t" \
-  "s_mov_b32 %[d1], %[d0]\n\t" \
-  "s_mov_b32 %[d0], s93\n" \
-  "131:\n\t" \
-  LRA_NEED32(132) \
-  /* one store: the copy in flight (lanes below pn, its bytes have arrived) and the literals behind it */ \
-  "s_sub_u32 s96, %[P], %[pn]\n\t" \
-  "s_add_u32 s96, %[outlo], s96\n\t" \
-  "s_addc_u32 s97, %[outhi], 0\n\t" \
-  "s_bfm_b64 vcc, %[pn], 0\n\t"                 /* (pn <= 63 here) */ \
-  "s_sub_u32 s95, 64, s89\n\t" \
-  "s_waitcnt vmcnt(0)\n\t" \
-  "v_cndmask_b32 v118, v119, v124, vcc\n\t" \
-  "s_lshr_b64 exec, -1, s95\n\t" \
-  "global_store_byte %[lane], v118, s[96:97]\n\t" \
-  /* this copy's load */ \
-  "s_add_u32 s96, %[outlo], s88\n\t" \
-  "s_addc_u32 s97, %[outhi], 0\n\t" \
-  "s_sub_u32 s96, s96, s93\n\t" \
-  "s_subb_u32 s97, s97, 0\n\t" \
-  "s_sub_u32 s95, 64, s92\n\t" \
-  "s_lshr_b64 exec, -1, s95\n\t" \
-  "global_load_ubyte v124, %[lane], s[96:97]\n\t" \
-  "s_mov_b64 exec, -1\n\t" \
-  "s_mov_b32 %[pn], s92\n\t" \
-  "s_add_u32 %[P], s88, s92\n\t" \
-  LRA_REQUEST(133, 134) \
-  "s_branch 1b\n" \
-  "190:\n\t"                                    /* not a plain command after all: as if nothing of it had been read */ \
-  "v_readlane_b32 s98, v116, 0\n\t" \
-  "v_readlane_b32 s99, v116, 1\n\t" \
-  "v_readlane_b32 %[cnt], v116, 2\n\t" \
-  "v_readlane_b32 %[ndw], v116, 3\n\t" \
-  "v_readlane_b32 %[p1], v116, 4\n\t" \
-  "v_readlane_b32 %[p2], v116, 5\n" \
-  "9:\n\t" \
-  "s_mov_b64 %[buf], s[98:99]\n\t" \
-  "s_waitcnt lgkmcnt(0)\n"
-static_assert(XR_VALID == 0x800000u && XR_LITERALS == 0x1000000u && XR_IMPLICIT == (1u << 25) && XR_DCTX_SHIFT == 26 && XR_SHORT == (1u << 28) && SPX_POS == 1024u, "LEAN_REC_RUN_ASM spells these out");
+// whether rx / ry hold that command's record, bit 1 whether p1 / p2 are the two bytes before P.  P < 2^32 in here; copies of at most 63 bytes.
+#include "brotli_rec_run_asm.h"
+static_assert(XR_VALID == 0x800000u && XR_LITERALS == 0x1000000u && XR_IMPLICIT == (1u << 25) && XR_DCTX_SHIFT == 26 && XR_SHORT == (1u << 28) && XR_NOT_RUN == (1u << 31) && SPX_POS == 1024u, "LEAN_REC_RUN_ASM spells these out");
 
 // The lean loop of a context-modelled metablock whose command records are there (rec_wave): nothing of a command's head is
 // parsed here, and a command without literals is not parsed at all -- copy length, distance and the bits to skip come out of
@@ -2803,7 +2481,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
   uint32_t dlut;
   {
     const uint32_t dv = (lane - 16u) & 63u, nb = (dv >> 1) + 1u;
-    dlut = nb | ((((2u + (dv & 1u)) << nb) - 3u) << 5);  // distance = ((2 + (dv & 1)) << nb) - 4 + bits + 1
+    dlut = dlut_ok ? nb | ((((2u + (dv & 1u)) << nb) - 3u) << 5) : 0u;  // distance = ((2 + (dv & 1)) << nb) - 4 + bits + 1   (all zero where the alphabet is another: the run looks at the entry)
   }
   // (a command is begun at most fifty dwords into the register window, and no command of the plain path reads more than thirteen:
   // the window only moves between two commands)
@@ -2880,15 +2558,17 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
   bool rec_ok = request();
   static const bool no_run_asm = false;
   const uint32_t ctx_tree_abs = ctx_tree_v + LDS_FIXED;   // (the run's literals: a context's tree as an address)
-  // what the run reads once a command at most, a lane each: the four distance contexts' tables, whether the lane table of distance codes is the alphabet's, XW_POS
-  const uint32_t run_params = lane == 0u ? LDS_FIXED + dt0 : lane == 1u ? LDS_FIXED + dt1 : lane == 2u ? LDS_FIXED + dt2 : lane == 3u ? LDS_FIXED + dt3 : lane == 4u ? (dlut_ok ? 1u : 0u) : xb + 4u * (uint32_t)XW_POS;
+  // what the run reads once a command at most, a lane each: the four distance contexts' tables (lanes 0 .. 3), XW_POS (lane 5)
+  const uint32_t run_params = lane == 0u ? LDS_FIXED + dt0 : lane == 1u ? LDS_FIXED + dt1 : lane == 2u ? LDS_FIXED + dt2 : lane == 3u ? LDS_FIXED + dt3 : xb + 4u * (uint32_t)XW_POS;
 
 #ifdef BROTLI_AMD_PROFILE_SPLIT
   uint64_t lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lap_t = __builtin_amdgcn_s_memtime(); const uint64_t lap_t0 = lap_t; uint32_t n_run = 0, n_lit = 0, n_nolit = 0, n_word = 0;
 #endif
   for (;;) {
     if (bl1 == 0 || br.next_dw >= safe_dw) break;
-    if (br.next_dw >= win_end) { br.rebase(); win_end = br.chunk_base + 50u; }  // (the only place the window moves: between two commands)
+    // (the only place the window moves: between two commands.  The run goes by the reader's position in window bits: the window starts
+    // in front of whatever the bit buffer still holds)
+    if (br.next_dw >= win_end || (br.next_dw - br.chunk_base) * 32u < br.cnt) { br.rebase_back2(); win_end = br.chunk_base + 50u; }
     SPLIT_LAP(0);
     if (rec_ok && !no_run_asm && P + (uint64_t)quota <= 0xFFFFFFFFull && front_c <= 0x40000000u) {   // (the run keeps the output position in 32 bits and moves it by at most `quota`: ADVICE round 3)
       // ---- a run of commands without literals (see LEAN_REC_RUN_ASM) ----
@@ -2904,8 +2584,8 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
             [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
             [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits), [front] "s"(rfl(front_c)),
             [littree] "s"(rfl(LDS_FIXED + lit_tree)), [trivial] "s"(rfl(trivial))
-          : "memory", "vcc", "scc", "m0", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
-            "v116", "v117", "v118", "v119", "v124");
+          : "memory", "vcc", "scc", "m0", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+            "v117", "v118", "v119", "v124");
       ncmd += bl1_0 - bl1; mlen -= (int32_t)(quota0 - quota);   // (a command of the run takes one of the command block's count, and from the quota what it takes from the metablock)
       SPLIT_LAP(1);
 #ifdef BROTLI_AMD_PROFILE_SPLIT
@@ -3026,7 +2706,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     // finish it from the distance on (the ring and the copy's counts are untouched) ----
     SPLIT_LAP(5);
     const uint32_t max_distance = P < (uint64_t)max_backward ? (uint32_t)P : max_backward;
-    const bool plain = dist > 0 && (uint32_t)dist <= max_distance && n <= 64u && (uint32_t)dist >= n && n < quota;
+    const bool plain = dist > 0 && (uint32_t)dist <= max_distance && n <= 63u && (uint32_t)dist >= n && n < quota;   // (63: the hand-written run makes a copy's lanes with s_bfm_b64)
     bool word = false;
     WordShape w = {};
     uint32_t word_offset = 0;

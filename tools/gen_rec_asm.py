@@ -1,0 +1,502 @@
+#!/usr/bin/env python3
+"""Writes rust-brotli-decompressor_amd/csrc/brotli_rec_run_asm.h: LEAN_REC_RUN_ASM, the hand-written loop over the plain commands of a
+context-modelled metablock (lean_rec_commands in brotli_kernels.hip; reference: src/decode.rs:2359-2726 for the path it takes --
+ReadCommand's result out of wave 2's records, the literals of decode.rs:2463-2551, ReadDistance of decode.rs:2066-2131 with the ring of
+decode.rs:2017-2049, the copy of decode.rs:2641-2680).
+
+Why a generator: the loop is written for the cost of a LONE wave on gfx950 (tools/ubench/branch.hip, s_memtime ticks): a scalar
+instruction 5 - 7, a conditional branch that is not taken 13, one that is taken 26 - 29, a v_readlane whose result the next instruction
+needs 25, an LDS round trip (v_mov, ds_read, s_waitcnt, v_readfirstlane) 70.  So: the common way through a command falls through every
+branch -- everything else (ring codes, implicit distances, second-level table entries, refills of the bit buffer, telling wave 2 where the
+reader is) lies OUT OF LINE behind a branch taken only then and branches back --, checks are folded into one sign test where that is
+cheaper than a branch each, and the blocks that appear several times (a symbol of a two-level table, the plain-copy test) are instantiated
+with labels of their own.  Local labels are numbers handed out here.
+
+Registers inside the asm (all clobbered): s80 / s81 p2 / p1 as they were (a command with literals that is not plain after all puts them
+back), s82 RB = (bits of the window's first dword) - (bits of the records' origin), s83 LIMM1 = the last window bit a command may begin at,
+s84 POS = the reader's position in window bits, s85 .. s89 and s95 .. s97 scratch, s90 / s91 the record, s92 copy length, s93 distance,
+s94 the distance block's count behind this command, s[98:99] the bit buffer of a command with literals; v116 .. v119 scratch, v124 the copy
+in flight.  %[cnt] and %[ndw] are the buffer's count and the next WINDOW dword inside a command with literals; they and %[buf] are made
+from POS on the way out, whatever happened."""
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_label = [200]
+
+
+def L():
+    _label[0] += 1
+    return str(_label[0])
+
+
+class Asm:
+    def __init__(self):
+        self.main, self.ool = [], []   # the straight way; the blocks out of line (emitted behind the loop)
+
+    def m(self, text, comment=None):
+        for line in text.strip().split("\n"):
+            self.main.append((line.strip(), comment)); comment = None
+
+    def o(self, text, comment=None):
+        for line in text.strip().split("\n"):
+            self.ool.append((line.strip(), comment)); comment = None
+
+
+def plain_test(p, q):
+    """s95 < 0 unless: 0 < distance s93 <= min(P, max_backward), copy length s92 <= min(63, distance, quota - 1)   (p: the output position, q: the quota, in front of the copy)"""
+    return f"""
+s_min_u32 s95, {p}, %[maxb]
+s_sub_u32 s95, s95, s93
+s_sub_u32 s96, s93, 1
+s_or_b32 s95, s95, s96
+s_min_u32 s96, s93, 63
+s_sub_u32 s97, {q}, 1
+s_min_u32 s96, s96, s97
+s_sub_u32 s96, s96, s92
+s_or_b32 s95, s95, s96"""
+
+
+def ring(code):
+    """a ring code 1 .. 15 -> s93 (TakeDistanceFromRingBuffer, decode.rs:2017-2049); scratch s95 .. s97"""
+    a, b = L(), L()
+    return f"""
+s_lshl_b32 s95, {code}, 1
+s_lshr_b32 s96, 0xaaafff1b, s95
+s_and_b32 s96, s96, 3
+s_mov_b32 s93, %[d3]
+s_cmp_eq_u32 s96, 1
+s_cselect_b32 s93, %[d2], s93
+s_cmp_eq_u32 s96, 2
+s_cselect_b32 s93, %[d1], s93
+s_cmp_eq_u32 s96, 3
+s_cselect_b32 s93, %[d0], s93
+s_lshr_b32 s97, 0xfa5fa500, s95
+s_and_b32 s97, s97, 3
+s_bitcmp1_b32 {code}, 0
+s_cbranch_scc1 {a}f
+s_sub_i32 s93, s93, s97
+s_cmp_gt_i32 s93, 0
+s_cselect_b32 s93, s93, 0x7fffffff
+s_branch {b}f
+{a}:
+s_add_i32 s93, s93, s97
+{b}:"""
+
+
+PUSH = """
+s_mov_b32 %[d3], %[d2]
+s_mov_b32 %[d2], %[d1]
+s_mov_b32 %[d1], %[d0]
+s_mov_b32 %[d0], s93"""
+
+
+def symbol(A, need):
+    """the symbol at the buffer's low end by the two-level table at LDS address s87 -> s86, its bits taken (read_symbol<true>); refill and
+    second level out of line.  `need`: bits the buffer must hold (15: a code word)"""
+    refill, back1, second, back2 = L(), L(), L(), L()
+    A.m(f"""
+s_cmp_lt_u32 %[cnt], {need}
+s_cbranch_scc1 {refill}f
+{back1}:
+s_and_b32 s86, s98, 0xff
+s_lshl_b32 s86, s86, 1
+s_add_u32 s86, s86, s87
+v_mov_b32 v117, s86
+ds_read_u16 v118, v117
+s_waitcnt lgkmcnt(0)
+v_readfirstlane_b32 s86, v118
+s_and_b32 s88, s86, 15
+s_lshr_b32 s86, s86, 4
+s_cmp_gt_u32 s88, 8
+s_cbranch_scc1 {second}f
+{back2}:
+s_lshr_b64 s[98:99], s[98:99], s88
+s_sub_u32 %[cnt], %[cnt], s88""")
+    A.o(f"""
+{refill}:
+v_readlane_b32 s96, %[cur], %[ndw]
+s_mov_b32 s97, 0
+s_add_u32 %[ndw], %[ndw], 1
+s_lshl_b64 s[96:97], s[96:97], %[cnt]
+s_add_u32 %[cnt], %[cnt], 32
+s_or_b64 s[98:99], s[98:99], s[96:97]
+s_branch {back1}b
+{second}:
+s_sub_u32 s88, s88, 8
+s_lshr_b32 s96, s98, 8
+s_bfm_b32 s97, s88, 0
+s_and_b32 s96, s96, s97
+s_add_u32 s86, s86, s96
+s_lshl_b32 s86, s86, 1
+s_add_u32 s86, s86, s87
+v_mov_b32 v117, s86
+ds_read_u16 v118, v117
+s_waitcnt lgkmcnt(0)
+v_readfirstlane_b32 s86, v118
+s_and_b32 s88, s86, 15
+s_add_u32 s88, s88, 8
+s_lshr_b32 s86, s86, 4
+s_branch {back2}b""")
+
+
+def request_and_copy(A, p_expr_regs):
+    """behind a command: the next command's record asked for (if wave 2 has written it: bit 0 of ok), the copy in flight -- and, behind a command
+    with literals, its literals: v118 / s89 lanes -- stored, this command's load issued, the loop closed.  p_expr_regs: (register that holds the
+    output position in front of this command's copy, lanes of the store register or None)"""
+    pcopy, merged = p_expr_regs
+    tell, back = L(), L()
+    norec = L()
+    A.m(f"""
+s_add_u32 s95, s84, s82
+s_andn2_b32 %[ok], %[ok], 3
+s_sub_u32 s96, s95, %[said]
+s_cmp_ge_u32 s96, 128
+s_cbranch_scc1 {tell}f
+{back}:
+s_cmp_ge_u32 s95, %[front]
+s_cbranch_scc1 {norec}f
+s_and_b32 s95, s95, 0x3ff
+s_lshl_b32 s95, s95, 3
+s_add_u32 s95, s95, %[xring]
+v_mov_b32 %[rx], s95
+s_or_b32 %[ok], %[ok], 1
+ds_read_b32 %[ry], %[rx] offset:4
+ds_read_b32 %[rx], %[rx]
+{norec}:""", "the next command's record, asked for before the memory pipe is waited for")
+    A.o(f"""
+{tell}:
+s_mov_b32 %[said], s95
+v_readlane_b32 s96, %[params], 5
+v_mov_b32 v118, s95
+v_mov_b32 v117, s96
+ds_write_b32 v117, v118
+s_branch {back}b""", "wave 2 is told where the reader is every 128 bits: it stays less than a lap ahead of that")
+    A.m("""
+s_sub_u32 s96, %[P], %[pn]
+s_add_u32 s96, %[outlo], s96
+s_addc_u32 s97, %[outhi], 0
+s_waitcnt vmcnt(0)""", "the copy in flight goes to memory (no lanes: no store)")
+    if merged:
+        A.m("""
+s_bfm_b64 vcc, %[pn], 0
+s_bfm_b64 exec, s89, 0
+v_cndmask_b32 v118, v119, v124, vcc
+global_store_byte %[lane], v118, s[96:97]""", "... and the literals behind it with it: lanes below pn the copy's bytes")
+    else:
+        A.m("""
+s_bfm_b64 exec, %[pn], 0
+global_store_byte %[lane], v124, s[96:97]""")
+    A.m(f"""
+s_add_u32 s96, %[outlo], {pcopy}
+s_addc_u32 s97, %[outhi], 0
+s_sub_u32 s96, s96, s93
+s_subb_u32 s97, s97, 0
+s_bfm_b64 exec, s92, 0
+global_load_ubyte v124, %[lane], s[96:97]
+s_mov_b64 exec, -1
+s_mov_b32 %[pn], s92
+s_add_u32 %[P], {pcopy}, s92
+s_bitcmp1_b32 %[ok], 0
+s_cbranch_scc1 1b
+s_branch 90f""", "this one's load (its bytes stay in v124 until the next command comes by)")
+
+
+def literal_loop(A, trivial):
+    top = L()
+    A.m(f"{top}:")
+    if not trivial:
+        A.m("""
+s_lshr_b32 s86, %[p1], 2
+s_lshr_b32 s87, %[p2], 2
+v_readlane_b32 s86, %[lut0], s86
+v_readlane_b32 s87, %[lut1], s87
+s_lshl_b32 s88, %[p1], 3
+s_lshl_b32 s96, %[p2], 3
+s_lshr_b32 s86, s86, s88
+s_lshr_b32 s87, s87, s96
+s_or_b32 s86, s86, s87
+s_and_b32 s86, s86, 0xff
+v_readlane_b32 s87, %[ctxtree], s86""", "context = lut0[p1] | lut1[p2] (four bytes a lane), its tree out of the map")
+    else:
+        A.m("s_mov_b32 s87, %[littree]")
+    symbol(A, 15)
+    A.m(f"""
+s_mov_b32 %[p2], %[p1]
+s_mov_b32 %[p1], s86
+s_mov_b32 m0, s85
+s_add_u32 s85, s85, 1
+v_writelane_b32 v119, s86, m0
+s_cmp_lt_u32 s85, s89
+s_cbranch_scc1 {top}b""")
+
+
+def build():
+    A = Asm()
+    # ---------------- entry ----------------
+    A.m("""
+s_bitcmp0_b32 %[ok], 0
+s_cbranch_scc1 99f
+s_sub_u32 s84, %[ndw], %[cb]
+s_lshl_b32 s84, s84, 5
+s_sub_u32 s84, s84, %[cnt]
+s_sub_u32 s83, %[lim], %[cb]
+s_sub_u32 s83, s83, 2
+s_lshl_b32 s83, s83, 5
+s_sub_u32 s83, s83, 1
+s_lshl_b32 s82, %[cb], 5
+s_sub_u32 s82, s82, %[org]""", "POS, LIMM1 (signed: a window that has no room left says so), RB")
+    # ---------------- top of the loop ----------------
+    A.m("""
+1:
+s_waitcnt lgkmcnt(0)
+v_readfirstlane_b32 s90, %[rx]
+v_readfirstlane_b32 s91, %[ry]
+s_sub_u32 s95, %[bl1], 1
+s_sub_u32 s96, s83, s84
+s_or_b32 s95, s95, s96
+s_or_b32 s95, s95, s90
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 90f
+s_bitcmp1_b32 s90, 24
+s_cbranch_scc1 100f""", "one sign test: a command block's count that has run out, a window without room, a record that says 'not for this loop' (bit 31)")
+    # ---------------- a command without literals, explicit distance (the common kind) ----------------
+    kinds = L()
+    A.m(f"""
+s_and_b32 s92, s90, 0xffff
+s_and_b32 s95, s90, 0x12000000
+s_mov_b32 s93, s91
+s_cmp_lg_u32 s95, 0
+s_cbranch_scc1 {kinds}f
+s_sub_u32 s94, %[bl2], 1""", "copy length; an implicit distance or a ring code: out of line; the explicit distance takes one of its block's count")
+    A.m(plain_test("%[P]", "%[quota]"))
+    A.m("""
+s_or_b32 s95, s95, s94
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 90f
+s_mov_b32 %[bl2], s94""")
+    A.m(PUSH)
+    A.m("""
+3:
+s_sub_u32 %[bl1], %[bl1], 1
+s_sub_u32 %[quota], %[quota], s92
+s_bfe_u32 s95, s90, 0x70010
+s_add_u32 s84, s84, s95""", "counts; the reader moves on by the record's bits")
+    request_and_copy(A, ("%[P]", None))
+    # the other kinds of distance of a command without literals
+    short, zero = L(), L()
+    A.o(f"""
+{kinds}:
+s_bitcmp1_b32 s90, 25
+s_cbranch_scc0 {short}f
+s_mov_b32 s93, %[d0]""", "implicit: the last distance, nothing pushed, no count")
+    A.o(plain_test("%[P]", "%[quota]"))
+    A.o(f"""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 90f
+s_branch 3b
+{short}:
+s_cmp_eq_u32 %[bl2], 0
+s_cbranch_scc1 90f
+s_cmp_eq_u32 s91, 0
+s_cbranch_scc1 {zero}f""", "a ring code s91 = 0 .. 15")
+    A.o(ring("s91"))
+    A.o(plain_test("%[P]", "%[quota]"))
+    A.o("""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 90f
+s_sub_u32 %[bl2], %[bl2], 1""")
+    A.o(PUSH)
+    A.o(f"""
+s_branch 3b
+{zero}:
+s_mov_b32 s93, %[d0]""")
+    A.o(plain_test("%[P]", "%[quota]"))
+    A.o("""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 90f
+s_sub_u32 %[bl2], %[bl2], 1
+s_branch 3b""")
+    # ---------------- a command with literals: s91 = their number ----------------
+    have_ctx, triv = L(), L()
+    A.m(f"""
+100:
+s_cmp_gt_u32 s91, 16
+s_cbranch_scc1 90f
+s_cmp_ge_u32 s91, %[quota]
+s_cbranch_scc1 90f
+s_cmp_gt_u32 s91, %[bl0]
+s_cbranch_scc1 90f
+s_add_u32 s89, s91, %[pn]
+s_cmp_gt_u32 s89, 63
+s_cbranch_scc1 90f
+s_mov_b32 s81, %[p1]
+s_mov_b32 s80, %[p2]
+s_bitcmp1_b32 %[ok], 1
+s_cbranch_scc1 {have_ctx}f
+s_cmp_lt_u32 %[pn], 2
+s_cbranch_scc1 90f
+s_sub_u32 s96, %[pn], 1
+s_sub_u32 s97, %[pn], 2
+s_waitcnt vmcnt(0)
+v_readlane_b32 %[p1], v124, s96
+v_readlane_b32 %[p2], v124, s97
+{have_ctx}:
+s_bfe_u32 s95, s90, 0x70010
+s_add_u32 s85, s84, s95
+s_lshr_b32 s86, s85, 5
+s_add_u32 s87, s86, 1
+v_readlane_b32 s96, %[cur], s86
+v_readlane_b32 s97, %[cur], s87
+s_and_b32 s88, s85, 31
+s_add_u32 %[ndw], s86, 2
+s_lshr_b64 s[98:99], s[96:97], s88
+s_sub_u32 %[cnt], 64, s88
+s_mov_b32 s85, %[pn]
+s_cmp_lg_u32 %[trivial], 0
+s_cbranch_scc1 {triv}f""", "s89 = lanes of the store (the copy in flight and the literals behind it); the two bytes before P: in p1 / p2 or the tail of the copy in flight; the bit buffer from behind the head's bits on; s85 = the lane of the next literal")
+    literal_loop(A, False)
+    dist = L()
+    A.m(f"{dist}:")
+    A.o(f"{triv}:")
+    # the trivial loop lives out of line: emit it into ool by swapping buffers
+    main_keep, ool_keep = A.main, A.ool
+    A.main, A.ool = [], []
+    literal_loop(A, True)
+    A.m(f"s_branch {dist}b")
+    ool_keep.extend(A.main); ool_keep.extend(A.ool)   # (the loop, then what lies out of line of IT: its labels are looked for forward)
+    A.main, A.ool = main_keep, ool_keep
+    # the distance behind the literals
+    implicit, small, join = L(), L(), L()
+    extra_refill, extra_back = L(), L()
+    A.m(f"""
+s_bitcmp1_b32 s90, 25
+s_cbranch_scc1 {implicit}f
+s_cmp_eq_u32 %[bl2], 0
+s_cbranch_scc1 190f
+s_bfe_u32 s86, s90, 0x2001a
+s_sub_u32 s94, %[bl2], 1
+v_readlane_b32 s87, %[params], s86""", "the distance code: its context picks the table (lanes 0 .. 3 of the parameters)")
+    symbol(A, 15)
+    A.m(f"""
+s_cmp_lt_u32 s86, 16
+s_cbranch_scc1 {small}f
+s_cmp_ge_u32 s86, 64
+s_cbranch_scc1 190f
+v_readlane_b32 s86, %[dlut], s86
+s_cmp_lt_u32 %[cnt], 24
+s_cbranch_scc1 {extra_refill}f
+{extra_back}:
+s_cmp_eq_u32 s86, 0
+s_cbranch_scc1 190f
+s_and_b32 s88, s86, 31
+s_lshr_b32 s93, s86, 5
+s_bfm_b32 s96, s88, 0
+s_and_b32 s96, s98, s96
+s_add_u32 s93, s93, s96
+s_lshr_b64 s[98:99], s[98:99], s88
+s_sub_u32 %[cnt], %[cnt], s88
+s_and_b32 s92, s90, 0xffff
+s_add_u32 s85, %[P], s91
+s_sub_u32 s88, %[quota], s91""", "a code of the plain alphabet: base and number of extra bits out of the lane table (all zero where the alphabet is another)")
+    A.m(plain_test("s85", "s88"))
+    A.m("""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 190f
+s_mov_b32 %[bl2], s94""")
+    A.m(PUSH)
+    A.m(f"""
+{join}:
+s_sub_u32 %[quota], s88, s92
+s_sub_u32 %[bl0], %[bl0], s91
+s_sub_u32 %[bl1], %[bl1], 1
+s_lshl_b32 s95, %[ndw], 5
+s_sub_u32 s84, s95, %[cnt]""", "it is a plain command: the counts, the reader's position")
+    request_and_copy(A, ("s85", True))
+    A.o(f"""
+{extra_refill}:
+v_readlane_b32 s96, %[cur], %[ndw]
+s_mov_b32 s97, 0
+s_add_u32 %[ndw], %[ndw], 1
+s_lshl_b64 s[96:97], s[96:97], %[cnt]
+s_add_u32 %[cnt], %[cnt], 32
+s_or_b64 s[98:99], s[98:99], s[96:97]
+s_branch {extra_back}b""")
+    # implicit distance / ring codes behind literals
+    A.o(f"""
+{implicit}:
+s_mov_b32 s93, %[d0]
+s_and_b32 s92, s90, 0xffff
+s_add_u32 s85, %[P], s91
+s_sub_u32 s88, %[quota], s91""")
+    A.o(plain_test("s85", "s88"))
+    zero2 = L()
+    A.o(f"""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 190f
+s_branch {join}b
+{small}:
+s_and_b32 s92, s90, 0xffff
+s_add_u32 s85, %[P], s91
+s_sub_u32 s88, %[quota], s91
+s_cmp_eq_u32 s86, 0
+s_cbranch_scc1 {zero2}f""")
+    A.o(ring("s86"))
+    A.o(plain_test("s85", "s88"))
+    A.o("""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 190f
+s_mov_b32 %[bl2], s94""")
+    A.o(PUSH)
+    A.o(f"""
+s_branch {join}b
+{zero2}:
+s_mov_b32 s93, %[d0]""")
+    A.o(plain_test("s85", "s88"))
+    A.o(f"""
+s_cmp_lt_i32 s95, 0
+s_cbranch_scc1 190f
+s_mov_b32 %[bl2], s94
+s_branch {join}b""")
+    # ---------------- the ways out ----------------
+    tail = """
+190:
+s_mov_b32 %[p1], s81
+s_mov_b32 %[p2], s80
+90:
+s_lshr_b32 s95, s84, 5
+s_add_u32 s85, s95, 1
+v_readlane_b32 s96, %[cur], s95
+v_readlane_b32 s97, %[cur], s85
+s_and_b32 s85, s84, 31
+s_add_u32 %[ndw], s95, %[cb]
+s_lshr_b64 s[98:99], s[96:97], s85
+s_sub_u32 %[cnt], 64, s85
+s_add_u32 %[ndw], %[ndw], 2
+s_cmp_eq_u32 s85, 0
+s_cselect_b32 %[cnt], 32, %[cnt]
+s_cselect_b32 s99, 0, s99
+s_cselect_b32 s96, 1, 0
+s_sub_u32 %[ndw], %[ndw], s96
+s_mov_b64 %[buf], s[98:99]
+99:
+s_waitcnt lgkmcnt(0)"""
+    lines = A.main + A.ool + [(t.strip(), None) for t in tail.strip().split("\n")]
+    return lines
+
+
+def main():
+    lines = build()
+    out = ["// GENERATED by tools/gen_rec_asm.py -- do not edit; see that file for what the loop does, why it is laid out like this and which registers it keeps.",
+           "#define LEAN_REC_RUN_ASM \\"]
+    for i, (text, comment) in enumerate(lines):
+        sep = "\\n" if text.endswith(":") else "\\n\\t"
+        c = ("  /* " + comment + " */") if comment else ""
+        out.append('  "%s%s"%s \\' % (text, sep, c))
+    out[-1] = out[-1][:-2]
+    path = os.path.join(ROOT, "rust-brotli-decompressor_amd", "csrc", "brotli_rec_run_asm.h")
+    open(path, "w").write("\n".join(out) + "\n")
+    print("wrote", path, len(lines), "lines")
+
+
+if __name__ == "__main__":
+    main()
