@@ -2450,7 +2450,15 @@ __device__ __noinline__ void rec_wave() {
 // store: lanes below pn the copy's bytes, the literals behind them.  The record of the next command is asked for before the memory
 // pipe is waited for.  Leaves in front of the first command that is anything else, with nothing of it touched; bit 0 of `ok` then says
 // whether rx / ry hold that command's record, bit 1 whether p1 / p2 are the two bytes before P.  P < 2^32 in here; copies of at most 63 bytes.
+#ifdef BROTLI_AMD_PROFILE_RUN_WAIT   // (tools/gen_rec_asm.py --profile-wait: s_memtime around the run's waits for the memory pipe; with -DBROTLI_AMD_PROFILE_SPLIT)
+#include "brotli_rec_run_asm_wait.h"
+#define LRA_WAIT_OPERAND , [wacc] "+s"(run_wait)
+#define LRA_WAIT_CLOBBERS "s74", "s75", "s76", "s77", "s78", "s79",
+#else
 #include "brotli_rec_run_asm.h"
+#define LRA_WAIT_OPERAND
+#define LRA_WAIT_CLOBBERS
+#endif
 static_assert(XR_VALID == 0x800000u && XR_LITERALS == 0x1000000u && XR_IMPLICIT == (1u << 25) && XR_DCTX_SHIFT == 26 && XR_SHORT == (1u << 28) && XR_NOT_RUN == (1u << 31) && SPX_POS == 1024u, "LEAN_REC_RUN_ASM spells these out");
 
 // The lean loop of a context-modelled metablock whose command records are there (rec_wave): nothing of a command's head is
@@ -2558,8 +2566,14 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
   bool rec_ok = request();
   static const bool no_run_asm = false;
   const uint32_t ctx_tree_abs = ctx_tree_v + LDS_FIXED;   // (the run's literals: a context's tree as an address)
-  // what the run reads once a command at most, a lane each: the four distance contexts' tables (lanes 0 .. 3), XW_POS (lane 5)
-  const uint32_t run_params = lane == 0u ? LDS_FIXED + dt0 : lane == 1u ? LDS_FIXED + dt1 : lane == 2u ? LDS_FIXED + dt2 : lane == 3u ? LDS_FIXED + dt3 : xb + 4u * (uint32_t)XW_POS;
+#ifdef BROTLI_AMD_PROFILE_RUN_WAIT
+  uint64_t run_wait = 0;
+#endif
+  // what the run reads once a command at most, a lane each: the four distance contexts' tables (lanes 0 .. 3), XW_POS (lane 5), the static dictionary's address (lanes 6, 7)
+  const uint32_t run_params = lane == 0u ? LDS_FIXED + dt0 : lane == 1u ? LDS_FIXED + dt1 : lane == 2u ? LDS_FIXED + dt2 : lane == 3u ? LDS_FIXED + dt3 :
+                              lane == 6u ? sp_ld(xb, XW_DICT_LO) : lane == 7u ? sp_ld(xb, XW_DICT_HI) : xb + 4u * (uint32_t)XW_POS;
+  // ... and of a word of the static dictionary as it stands (transform 0), by its length: where the words of that length begin | the bits of their index << 24
+  const uint32_t run_wtab = lane >= 4u && lane <= 24u ? kDictOffsetsByLength[lane] | ((uint32_t)kDictSizeBitsByLength[lane] << 24) : 0u;
 
 #ifdef BROTLI_AMD_PROFILE_SPLIT
   uint64_t lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lap_t = __builtin_amdgcn_s_memtime(); const uint64_t lap_t0 = lap_t; uint32_t n_run = 0, n_lit = 0, n_nolit = 0, n_word = 0;
@@ -2579,12 +2593,12 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
       asm volatile(LEAN_REC_RUN_ASM
           : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [bl0] "+s"(bl0s), [bl1] "+s"(bl1), [bl2] "+s"(bl2),
             [d0] "+s"(d0), [d1] "+s"(d1), [d2] "+s"(d2), [d3] "+s"(d3), [P] "+s"(P32), [quota] "+s"(quota), [pn] "+s"(pend_n),
-            [ok] "+s"(ok), [p1] "+s"(p1s), [p2] "+s"(p2s), [said] "+s"(saids), [rx] "+v"(rx), [ry] "+v"(ry)
-          : [cur] "v"(br.cur), [lane] "v"(lane), [lut0] "v"(lut0v), [lut1] "v"(lut1v), [ctxtree] "v"(ctx_tree_abs), [dlut] "v"(dlut), [params] "v"(run_params),
+            [ok] "+s"(ok), [p1] "+s"(p1s), [p2] "+s"(p2s), [said] "+s"(saids), [rx] "+v"(rx), [ry] "+v"(ry) LRA_WAIT_OPERAND
+          : [cur] "v"(br.cur), [lane] "v"(lane), [lut0] "v"(lut0v), [lut1] "v"(lut1v), [ctxtree] "v"(ctx_tree_abs), [dlut] "v"(dlut), [params] "v"(run_params), [wtab] "v"(run_wtab),
             [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
             [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits), [front] "s"(rfl(front_c)),
             [littree] "s"(rfl(LDS_FIXED + lit_tree)), [trivial] "s"(rfl(trivial))
-          : "memory", "vcc", "scc", "m0", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
+          : "memory", "vcc", "scc", "m0", LRA_WAIT_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
             "v117", "v118", "v119", "v124");
       ncmd += bl1_0 - bl1; mlen -= (int32_t)(quota0 - quota);   // (a command of the run takes one of the command block's count, and from the quota what it takes from the metablock)
       SPLIT_LAP(1);
@@ -2754,6 +2768,9 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
   }
 #ifdef BROTLI_AMD_PROFILE_SPLIT
   if (blockIdx.x == 0 && lane == 0) { for (int k = 0; k < 7; k++) g_split_prof[24 + k] += lap_acc[k]; g_split_prof[32] += n_run; g_split_prof[33] += n_lit; g_split_prof[34] += n_nolit; g_split_prof[35] += n_word; g_split_prof[36] += ncmd; g_split_prof[37] += 1; g_split_prof[38] += __builtin_amdgcn_s_memtime() - lap_t0; }
+#ifdef BROTLI_AMD_PROFILE_RUN_WAIT
+  if (blockIdx.x == 0 && lane == 0) g_split_prof[39] += run_wait;
+#endif
 #endif
   if (!ctx_regs && pend_n >= 2u) { p1 = pend_byte(pend_n - 1u); p2 = pend_byte(pend_n - 2u); ctx_regs = true; }
   flush();
@@ -4609,6 +4626,8 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
            "head + context bytes %llu, literals %llu, distance %llu, counts + literal store %llu, copy / word + next record %llu\n",
            g_split_prof[37], g_split_prof[36], g_split_prof[32], g_split_prof[33], g_split_prof[34], g_split_prof[35], g_split_prof[38],
            g_split_prof[24], g_split_prof[25], g_split_prof[26], g_split_prof[27], g_split_prof[28], g_split_prof[29], g_split_prof[30]);
+  if (blockIdx.x == 0 && lane_id() == 0 && g_split_prof[39] != 0)
+    printf("record loop: %llu ticks between the s_memtime pairs around the runs' waits for the memory pipe (an empty pair costs what tools/ubench says)\n", g_split_prof[39]);
 #endif
 #ifdef BROTLI_AMD_PROFILE_SPEC
   if (blockIdx.x == 0 && lane_id() == 0)

@@ -19,6 +19,19 @@ s94 the distance block's count behind this command, s[98:99] the bit buffer of a
 in flight.  %[cnt] and %[ndw] are the buffer's count and the next WINDOW dword inside a command with literals; they and %[buf] are made
 from POS on the way out, whatever happened."""
 import os
+import sys
+
+PROFILE_WAIT = "--profile-wait" in sys.argv   # s_memtime around every wait for the memory pipe, summed into %[wacc] (a 64-bit "+s" operand; -DBROTLI_AMD_PROFILE_RUN_WAIT)
+VMWAIT = """
+s_memtime s[76:77]
+s_waitcnt lgkmcnt(0)
+s_waitcnt vmcnt(0)
+s_memtime s[74:75]
+s_waitcnt lgkmcnt(0)
+s_sub_u32 s74, s74, s76
+s_subb_u32 s75, s75, s77
+s_add_u32 s78, s78, s74
+s_addc_u32 s79, s79, s75""" if PROFILE_WAIT else "s_waitcnt vmcnt(0)"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _label = [200]
@@ -83,6 +96,40 @@ s_add_i32 s93, s93, s97
 {b}:"""
 
 
+def word_test(p, q, fail, src_lo, src_hi):
+    """The command is not a plain copy.  A word of the static dictionary as it stands (decode.rs:2593-2640 with transform 0: every word of the
+    reference's alice29 is one)?  distance s93 beyond min(P, max_backward), 4 <= length s92 <= 24, (distance - max_distance - 1) >> bits[length] == 0,
+    length < quota, the distance block's count s94 there -> its address in {src_lo}:{src_hi}; anything else: {fail}.  (p, q as plain_test; lane n of
+    %[wtab]: kDictOffsetsByLength[n] | kDictSizeBitsByLength[n] << 24; lanes 6 / 7 of the parameters: the dictionary's address)"""
+    return f"""
+s_min_u32 s95, {p}, %[maxb]
+s_cmp_le_u32 s93, s95
+s_cbranch_scc1 {fail}f
+s_cmp_gt_u32 s93, 0x7ffffffc
+s_cbranch_scc1 {fail}f
+s_sub_u32 s96, s92, 4
+s_cmp_gt_u32 s96, 20
+s_cbranch_scc1 {fail}f
+s_cmp_ge_u32 s92, {q}
+s_cbranch_scc1 {fail}f
+s_cmp_lt_i32 s94, 0
+s_cbranch_scc1 {fail}f
+v_readlane_b32 s96, %[wtab], s92
+s_sub_u32 s95, s93, s95
+s_sub_u32 s95, s95, 1
+s_lshr_b32 s97, s96, 24
+s_lshr_b32 s97, s95, s97
+s_cmp_lg_u32 s97, 0
+s_cbranch_scc1 {fail}f
+s_and_b32 s96, s96, 0xffffff
+s_mul_i32 s95, s95, s92
+s_add_u32 s96, s96, s95
+v_readlane_b32 {src_lo}, %[params], 6
+v_readlane_b32 {src_hi}, %[params], 7
+s_add_u32 {src_lo}, {src_lo}, s96
+s_addc_u32 {src_hi}, {src_hi}, 0"""
+
+
 PUSH = """
 s_mov_b32 %[d3], %[d2]
 s_mov_b32 %[d2], %[d1]
@@ -142,8 +189,9 @@ s_branch {back2}b""")
 def request_and_copy(A, p_expr_regs):
     """behind a command: the next command's record asked for (if wave 2 has written it: bit 0 of ok), the copy in flight -- and, behind a command
     with literals, its literals: v118 / s89 lanes -- stored, this command's load issued, the loop closed.  p_expr_regs: (register that holds the
-    output position in front of this command's copy, lanes of the store register or None)"""
-    pcopy, merged = p_expr_regs
+    output position in front of this command's copy, lanes of the store register or None, the register pair that holds the address of the copy's source --
+    in the output, or in the static dictionary)"""
+    pcopy, merged, src = p_expr_regs
     tell, back = L(), L()
     norec = L()
     A.m(f"""
@@ -175,7 +223,7 @@ s_branch {back}b""", "wave 2 is told where the reader is every 128 bits: it stay
 s_sub_u32 s96, %[P], %[pn]
 s_add_u32 s96, %[outlo], s96
 s_addc_u32 s97, %[outhi], 0
-s_waitcnt vmcnt(0)""", "the copy in flight goes to memory (no lanes: no store)")
+""" + VMWAIT, "the copy in flight goes to memory (no lanes: no store)")
     if merged:
         A.m("""
 s_bfm_b64 vcc, %[pn], 0
@@ -187,12 +235,8 @@ global_store_byte %[lane], v118, s[96:97]""", "... and the literals behind it wi
 s_bfm_b64 exec, %[pn], 0
 global_store_byte %[lane], v124, s[96:97]""")
     A.m(f"""
-s_add_u32 s96, %[outlo], {pcopy}
-s_addc_u32 s97, %[outhi], 0
-s_sub_u32 s96, s96, s93
-s_subb_u32 s97, s97, 0
 s_bfm_b64 exec, s92, 0
-global_load_ubyte v124, %[lane], s[96:97]
+global_load_ubyte v124, %[lane], {src}
 s_mov_b64 exec, -1
 s_mov_b32 %[pn], s92
 s_add_u32 %[P], {pcopy}, s92
@@ -233,6 +277,8 @@ s_cbranch_scc1 {top}b""")
 def build():
     A = Asm()
     # ---------------- entry ----------------
+    if PROFILE_WAIT:
+        A.m("s_mov_b64 s[78:79], %[wacc]")
     A.m("""
 s_bitcmp0_b32 %[ok], 0
 s_cbranch_scc1 99f
@@ -269,19 +315,30 @@ s_cmp_lg_u32 s95, 0
 s_cbranch_scc1 {kinds}f
 s_sub_u32 s94, %[bl2], 1""", "copy length; an implicit distance or a ring code: out of line; the explicit distance takes one of its block's count")
     A.m(plain_test("%[P]", "%[quota]"))
-    A.m("""
+    word = L()
+    A.m(f"""
 s_or_b32 s95, s95, s94
 s_cmp_lt_i32 s95, 0
-s_cbranch_scc1 90f
+s_cbranch_scc1 {word}f
 s_mov_b32 %[bl2], s94""")
     A.m(PUSH)
     A.m("""
 3:
+s_add_u32 s88, %[outlo], %[P]
+s_addc_u32 s89, %[outhi], 0
+s_sub_u32 s88, s88, s93
+s_subb_u32 s89, s89, 0
+4:
 s_sub_u32 %[bl1], %[bl1], 1
 s_sub_u32 %[quota], %[quota], s92
 s_bfe_u32 s95, s90, 0x70010
-s_add_u32 s84, s84, s95""", "counts; the reader moves on by the record's bits")
-    request_and_copy(A, ("%[P]", None))
+s_add_u32 s84, s84, s95""", "the copy's source; counts; the reader moves on by the record's bits")
+    request_and_copy(A, ("%[P]", None, "s[88:89]"))
+    A.o(f"{word}:")
+    A.o(word_test("%[P]", "%[quota]", "90", "s88", "s89"))
+    A.o("""
+s_mov_b32 %[bl2], s94
+s_branch 4b""", "a word: the distance's count, nothing pushed (decode.rs:2643-2644)")
     # the other kinds of distance of a command without literals
     short, zero = L(), L()
     A.o(f"""
@@ -337,7 +394,7 @@ s_cmp_lt_u32 %[pn], 2
 s_cbranch_scc1 90f
 s_sub_u32 s96, %[pn], 1
 s_sub_u32 s97, %[pn], 2
-s_waitcnt vmcnt(0)
+{VMWAIT}
 v_readlane_b32 %[p1], v124, s96
 v_readlane_b32 %[p2], v124, s97
 {have_ctx}:
@@ -399,19 +456,30 @@ s_and_b32 s92, s90, 0xffff
 s_add_u32 s85, %[P], s91
 s_sub_u32 s88, %[quota], s91""", "a code of the plain alphabet: base and number of extra bits out of the lane table (all zero where the alphabet is another)")
     A.m(plain_test("s85", "s88"))
-    A.m("""
+    word2, join2 = L(), L()
+    A.m(f"""
 s_cmp_lt_i32 s95, 0
-s_cbranch_scc1 190f
+s_cbranch_scc1 {word2}f
 s_mov_b32 %[bl2], s94""")
     A.m(PUSH)
     A.m(f"""
 {join}:
+s_add_u32 s86, %[outlo], s85
+s_addc_u32 s87, %[outhi], 0
+s_sub_u32 s86, s86, s93
+s_subb_u32 s87, s87, 0
+{join2}:
 s_sub_u32 %[quota], s88, s92
 s_sub_u32 %[bl0], %[bl0], s91
 s_sub_u32 %[bl1], %[bl1], 1
 s_lshl_b32 s95, %[ndw], 5
-s_sub_u32 s84, s95, %[cnt]""", "it is a plain command: the counts, the reader's position")
-    request_and_copy(A, ("s85", True))
+s_sub_u32 s84, s95, %[cnt]""", "it is a plain command: the copy's source, the counts, the reader's position")
+    request_and_copy(A, ("s85", True, "s[86:87]"))
+    A.o(f"{word2}:")
+    A.o(word_test("s85", "s88", "190", "s86", "s87"))
+    A.o(f"""
+s_mov_b32 %[bl2], s94
+s_branch {join2}b""")
     A.o(f"""
 {extra_refill}:
 v_readlane_b32 s96, %[cur], %[ndw]
@@ -479,7 +547,7 @@ s_cselect_b32 s96, 1, 0
 s_sub_u32 %[ndw], %[ndw], s96
 s_mov_b64 %[buf], s[98:99]
 99:
-s_waitcnt lgkmcnt(0)"""
+s_waitcnt lgkmcnt(0)""" + ("\ns_mov_b64 %[wacc], s[78:79]" if PROFILE_WAIT else "")
     lines = A.main + A.ool + [(t.strip(), None) for t in tail.strip().split("\n")]
     return lines
 
@@ -493,7 +561,7 @@ def main():
         c = ("  /* " + comment + " */") if comment else ""
         out.append('  "%s%s"%s \\' % (text, sep, c))
     out[-1] = out[-1][:-2]
-    path = os.path.join(ROOT, "rust-brotli-decompressor_amd", "csrc", "brotli_rec_run_asm.h")
+    path = os.path.join(ROOT, "rust-brotli-decompressor_amd", "csrc", "brotli_rec_run_asm_wait.h" if PROFILE_WAIT else "brotli_rec_run_asm.h")
     open(path, "w").write("\n".join(out) + "\n")
     print("wrote", path, len(lines), "lines")
 
