@@ -2569,9 +2569,10 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
 #ifdef BROTLI_AMD_PROFILE_RUN_WAIT
   uint64_t run_wait = 0;
 #endif
-  // what the run reads once a command at most, a lane each: the four distance contexts' tables (lanes 0 .. 3), XW_POS (lane 5), the static dictionary's address (lanes 6, 7)
+  // what the run reads once a command at most, a lane each: the four distance contexts' tables (lanes 0 .. 3), XW_POS (lane 5), the static dictionary's address (lanes 6, 7), XW_FRONT and the codes' epoch (lanes 8, 9)
   const uint32_t run_params = lane == 0u ? LDS_FIXED + dt0 : lane == 1u ? LDS_FIXED + dt1 : lane == 2u ? LDS_FIXED + dt2 : lane == 3u ? LDS_FIXED + dt3 :
-                              lane == 6u ? sp_ld(xb, XW_DICT_LO) : lane == 7u ? sp_ld(xb, XW_DICT_HI) : xb + 4u * (uint32_t)XW_POS;
+                              lane == 6u ? sp_ld(xb, XW_DICT_LO) : lane == 7u ? sp_ld(xb, XW_DICT_HI) : lane == 8u ? xb + 4u * (uint32_t)XW_FRONT : lane == 9u ? my_epoch :
+                              xb + 4u * (uint32_t)XW_POS;
   // ... and of a word of the static dictionary as it stands (transform 0), by its length: where the words of that length begin | the bits of their index << 24
   const uint32_t run_wtab = lane >= 4u && lane <= 24u ? kDictOffsetsByLength[lane] | ((uint32_t)kDictSizeBitsByLength[lane] << 24) : 0u;
 
@@ -2587,26 +2588,26 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     if (rec_ok && !no_run_asm && P + (uint64_t)quota <= 0xFFFFFFFFull && front_c <= 0x40000000u) {   // (the run keeps the output position in 32 bits and moves it by at most `quota`: ADVICE round 3)
       // ---- a run of commands without literals (see LEAN_REC_RUN_ASM) ----
       uint32_t ok = rfl(1u | (ctx_regs ? 2u : 0u)), rx = rec_v.x, ry = rec_v.y, P32 = rfl((uint32_t)P);   // (the copy in flight lies at P - pend_n)
-      uint32_t p1s = rfl(p1), p2s = rfl(p2), saids = rfl(pos_said), bl0s = rfl(bl0);
+      uint32_t p1s = rfl(p1), p2s = rfl(p2), saids = rfl(pos_said), bl0s = rfl(bl0), fronts = rfl(front_c);
       const uint32_t lim = rfl(safe_dw < win_end ? safe_dw : win_end);  // (rfl: scalar registers for the "s" operands)
       const uint32_t ncmd0 = ncmd, bl1_0 = bl1, quota0 = quota; (void)ncmd0;
       asm volatile(LEAN_REC_RUN_ASM
           : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [bl0] "+s"(bl0s), [bl1] "+s"(bl1), [bl2] "+s"(bl2),
             [d0] "+s"(d0), [d1] "+s"(d1), [d2] "+s"(d2), [d3] "+s"(d3), [P] "+s"(P32), [quota] "+s"(quota), [pn] "+s"(pend_n),
-            [ok] "+s"(ok), [p1] "+s"(p1s), [p2] "+s"(p2s), [said] "+s"(saids), [rx] "+v"(rx), [ry] "+v"(ry) LRA_WAIT_OPERAND
+            [ok] "+s"(ok), [p1] "+s"(p1s), [p2] "+s"(p2s), [said] "+s"(saids), [front] "+s"(fronts), [rx] "+v"(rx), [ry] "+v"(ry) LRA_WAIT_OPERAND
           : [cur] "v"(br.cur), [lane] "v"(lane), [lut0] "v"(lut0v), [lut1] "v"(lut1v), [ctxtree] "v"(ctx_tree_abs), [dlut] "v"(dlut), [params] "v"(run_params), [wtab] "v"(run_wtab),
             [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
-            [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits), [front] "s"(rfl(front_c)),
+            [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits),
             [littree] "s"(rfl(LDS_FIXED + lit_tree)), [trivial] "s"(rfl(trivial))
           : "memory", "vcc", "scc", "m0", LRA_WAIT_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
-            "v117", "v118", "v119", "v124");
+            "v116", "v117", "v118", "v119", "v124");
       ncmd += bl1_0 - bl1; mlen -= (int32_t)(quota0 - quota);   // (a command of the run takes one of the command block's count, and from the quota what it takes from the metablock)
       SPLIT_LAP(1);
 #ifdef BROTLI_AMD_PROFILE_SPLIT
       n_run += ncmd - ncmd0;
 #endif
       P = P32; pend_pos = (uint64_t)rfl(P32 - pend_n);
-      p1 = p1s; p2 = p2s; pos_said = saids; bl0 = bl0s;
+      p1 = p1s; p2 = p2s; pos_said = saids; bl0 = bl0s; front_c = fronts;
       rec_v.x = rx; rec_v.y = ry; rec_ok = (ok & 1u) != 0u;
       ctx_regs = (ok & 2u) != 0u;  // (after a command of the run: the two bytes before P are the tail of the copy in flight)
       if (bl1 == 0 || br.next_dw >= safe_dw) break;

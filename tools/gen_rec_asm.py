@@ -161,6 +161,8 @@ s_lshr_b64 s[98:99], s[98:99], s88
 s_sub_u32 %[cnt], %[cnt], s88""")
     A.o(f"""
 {refill}:
+s_cmp_gt_u32 %[ndw], 63
+s_cbranch_scc1 190f
 v_readlane_b32 s96, %[cur], %[ndw]
 s_mov_b32 s97, 0
 s_add_u32 %[ndw], %[ndw], 1
@@ -193,7 +195,7 @@ def request_and_copy(A, p_expr_regs):
     in the output, or in the static dictionary)"""
     pcopy, merged, src = p_expr_regs
     tell, back = L(), L()
-    norec = L()
+    norec, look, have = L(), L(), L()
     A.m(f"""
 s_add_u32 s95, s84, s82
 s_andn2_b32 %[ok], %[ok], 3
@@ -202,7 +204,8 @@ s_cmp_ge_u32 s96, 128
 s_cbranch_scc1 {tell}f
 {back}:
 s_cmp_ge_u32 s95, %[front]
-s_cbranch_scc1 {norec}f
+s_cbranch_scc1 {look}f
+{have}:
 s_and_b32 s95, s95, 0x3ff
 s_lshl_b32 s95, s95, 3
 s_add_u32 s95, s95, %[xring]
@@ -219,6 +222,21 @@ v_mov_b32 v118, s95
 v_mov_b32 v117, s96
 ds_write_b32 v117, v118
 s_branch {back}b""", "wave 2 is told where the reader is every 128 bits: it stays less than a lap ahead of that")
+    A.o(f"""
+{look}:
+v_readlane_b32 s96, %[params], 8
+v_mov_b32 v118, s96
+ds_read_b64 v[116:117], v118
+s_waitcnt lgkmcnt(0)
+v_readfirstlane_b32 s96, v116
+v_readfirstlane_b32 s97, v117
+v_readlane_b32 s94, %[params], 9
+s_cmp_lg_u32 s97, s94
+s_cbranch_scc1 {norec}b
+s_mov_b32 %[front], s96
+s_cmp_lt_u32 s95, s96
+s_cbranch_scc1 {have}b
+s_branch {norec}b""", "the reader has reached the frontier it knew: where wave 2 has got to by now (XW_FRONT: positions below are written | the codes' epoch << 32)")
     A.m("""
 s_sub_u32 s96, %[P], %[pn]
 s_add_u32 s96, %[outlo], s96
@@ -245,33 +263,44 @@ s_cbranch_scc1 1b
 s_branch 90f""", "this one's load (its bytes stay in v124 until the next command comes by)")
 
 
-def literal_loop(A, trivial):
-    top = L()
-    A.m(f"{top}:")
-    if not trivial:
-        A.m("""
-s_lshr_b32 s86, %[p1], 2
-s_lshr_b32 s87, %[p2], 2
+def literal_loop(A, trivial, done):
+    """the command's literals, two a round: the first takes the older context byte's register, the second the other one's -- the bytes do not
+    move from register to register, and a round's first literal falls through its test.  A run that ends with a round's first literal swaps the two
+    (out of line).  Ends at `done`."""
+    top, odd = L(), L()
+
+    def one(last, second, test):
+        if not trivial:
+            A.m(f"""
+s_lshr_b32 s86, {last}, 2
+s_lshr_b32 s87, {second}, 2
 v_readlane_b32 s86, %[lut0], s86
 v_readlane_b32 s87, %[lut1], s87
-s_lshl_b32 s88, %[p1], 3
-s_lshl_b32 s96, %[p2], 3
+s_lshl_b32 s88, {last}, 3
+s_lshl_b32 s96, {second}, 3
 s_lshr_b32 s86, s86, s88
 s_lshr_b32 s87, s87, s96
 s_or_b32 s86, s86, s87
 s_and_b32 s86, s86, 0xff
-v_readlane_b32 s87, %[ctxtree], s86""", "context = lut0[p1] | lut1[p2] (four bytes a lane), its tree out of the map")
-    else:
-        A.m("s_mov_b32 s87, %[littree]")
-    symbol(A, 15)
-    A.m(f"""
-s_mov_b32 %[p2], %[p1]
-s_mov_b32 %[p1], s86
+v_readlane_b32 s87, %[ctxtree], s86""", "context = lut0[the byte before] | lut1[the one before that] (four bytes a lane), its tree out of the map")
+        else:
+            A.m("s_mov_b32 s87, %[littree]")
+        symbol(A, 15)
+        A.m(f"""
+s_mov_b32 {second}, s86
 s_mov_b32 m0, s85
 s_add_u32 s85, s85, 1
 v_writelane_b32 v119, s86, m0
-s_cmp_lt_u32 s85, s89
-s_cbranch_scc1 {top}b""")
+{test}""")
+    A.m(f"{top}:")
+    one("%[p1]", "%[p2]", f"s_cmp_ge_u32 s85, s89\ns_cbranch_scc1 {odd}f")
+    one("%[p2]", "%[p1]", f"s_cmp_lt_u32 s85, s89\ns_cbranch_scc1 {top}b")
+    A.o(f"""
+{odd}:
+s_mov_b32 s86, %[p1]
+s_mov_b32 %[p1], %[p2]
+s_mov_b32 %[p2], s86
+s_branch {done}""")
 
 
 def build():
@@ -374,18 +403,14 @@ s_cbranch_scc1 90f
 s_sub_u32 %[bl2], %[bl2], 1
 s_branch 3b""")
     # ---------------- a command with literals: s91 = their number ----------------
-    have_ctx, triv = L(), L()
+    have_ctx, triv, long, long_back = L(), L(), L(), L()
     A.m(f"""
 100:
-s_cmp_gt_u32 s91, 16
-s_cbranch_scc1 90f
 s_cmp_ge_u32 s91, %[quota]
 s_cbranch_scc1 90f
 s_cmp_gt_u32 s91, %[bl0]
 s_cbranch_scc1 90f
 s_add_u32 s89, s91, %[pn]
-s_cmp_gt_u32 s89, 63
-s_cbranch_scc1 90f
 s_mov_b32 s81, %[p1]
 s_mov_b32 s80, %[p2]
 s_bitcmp1_b32 %[ok], 1
@@ -398,6 +423,9 @@ s_sub_u32 s97, %[pn], 2
 v_readlane_b32 %[p1], v124, s96
 v_readlane_b32 %[p2], v124, s97
 {have_ctx}:
+s_cmp_gt_u32 s89, 63
+s_cbranch_scc1 {long}f
+{long_back}:
 s_bfe_u32 s95, s90, 0x70010
 s_add_u32 s85, s84, s95
 s_lshr_b32 s86, s85, 5
@@ -411,14 +439,33 @@ s_sub_u32 %[cnt], 64, s88
 s_mov_b32 s85, %[pn]
 s_cmp_lg_u32 %[trivial], 0
 s_cbranch_scc1 {triv}f""", "s89 = lanes of the store (the copy in flight and the literals behind it); the two bytes before P: in p1 / p2 or the tail of the copy in flight; the bit buffer from behind the head's bits on; s85 = the lane of the next literal")
-    literal_loop(A, False)
+    A.o(f"""
+{long}:
+s_cmp_gt_u32 s91, 63
+s_cbranch_scc1 190f
+s_cmp_eq_u32 %[pn], 0
+s_cbranch_scc1 190f
+s_sub_u32 s96, %[P], %[pn]
+s_add_u32 s96, %[outlo], s96
+s_addc_u32 s97, %[outhi], 0
+s_waitcnt vmcnt(0)
+s_bfm_b64 exec, %[pn], 0
+global_store_byte %[lane], v124, s[96:97]
+s_mov_b64 exec, -1
+s_mov_b32 %[pn], 0
+s_mov_b32 s89, s91
+s_or_b32 %[ok], %[ok], 2
+s_mov_b32 s81, %[p1]
+s_mov_b32 s80, %[p2]
+s_branch {long_back}b""", "more literals than fit one store behind the copy in flight: that copy goes to memory first (its last two bytes are in p1 / p2 by now, and stay the context whatever becomes of this command)")
     dist = L()
+    literal_loop(A, False, dist + "b")
     A.m(f"{dist}:")
     A.o(f"{triv}:")
     # the trivial loop lives out of line: emit it into ool by swapping buffers
     main_keep, ool_keep = A.main, A.ool
     A.main, A.ool = [], []
-    literal_loop(A, True)
+    literal_loop(A, True, dist + "b")
     A.m(f"s_branch {dist}b")
     ool_keep.extend(A.main); ool_keep.extend(A.ool)   # (the loop, then what lies out of line of IT: its labels are looked for forward)
     A.main, A.ool = main_keep, ool_keep
@@ -482,6 +529,8 @@ s_mov_b32 %[bl2], s94
 s_branch {join2}b""")
     A.o(f"""
 {extra_refill}:
+s_cmp_gt_u32 %[ndw], 63
+s_cbranch_scc1 190f
 v_readlane_b32 s96, %[cur], %[ndw]
 s_mov_b32 s97, 0
 s_add_u32 %[ndw], %[ndw], 1
