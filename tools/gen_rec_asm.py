@@ -189,16 +189,39 @@ s_branch {back2}b""")
 
 
 def request_and_copy(A, p_expr_regs):
-    """behind a command: the next command's record asked for (if wave 2 has written it: bit 0 of ok), the copy in flight -- and, behind a command
-    with literals, its literals: v118 / s89 lanes -- stored, this command's load issued, the loop closed.  p_expr_regs: (register that holds the
-    output position in front of this command's copy, lanes of the store register or None, the register pair that holds the address of the copy's source --
-    in the output, or in the static dictionary)"""
+    """behind a command: the next command's record asked for, the copy in flight -- and, behind a command with literals, its literals: v118 /
+    s89 lanes -- stored, this command's load issued, the loop closed.  Where wave 2 has not written that record yet (rare) the same store and load
+    lie out of line and end the run with bit 0 of ok cleared.  p_expr_regs: (register that holds the output position in front of this command's copy,
+    lanes of the store register or None, the register pair that holds the address of the copy's source -- in the output, or in the static dictionary)"""
     pcopy, merged, src = p_expr_regs
     tell, back = L(), L()
     norec, look, have = L(), L(), L()
+
+    def store_and_load():
+        t = """
+s_sub_u32 s96, %[P], %[pn]
+s_add_u32 s96, %[outlo], s96
+s_addc_u32 s97, %[outhi], 0
+""" + VMWAIT
+        if merged:
+            t += """
+s_bfm_b64 vcc, %[pn], 0
+s_bfm_b64 exec, s89, 0
+v_cndmask_b32 v118, v119, v124, vcc
+global_store_byte %[lane], v118, s[96:97]"""
+        else:
+            t += """
+s_bfm_b64 exec, %[pn], 0
+global_store_byte %[lane], v124, s[96:97]"""
+        return t + f"""
+s_bfm_b64 exec, s92, 0
+global_load_ubyte v124, %[lane], {src}
+s_mov_b64 exec, -1
+s_mov_b32 %[pn], s92
+s_add_u32 %[P], {pcopy}, s92"""
     A.m(f"""
 s_add_u32 s95, s84, s82
-s_andn2_b32 %[ok], %[ok], 3
+s_andn2_b32 %[ok], %[ok], 2
 s_sub_u32 s96, s95, %[said]
 s_cmp_ge_u32 s96, 128
 s_cbranch_scc1 {tell}f
@@ -210,10 +233,10 @@ s_and_b32 s95, s95, 0x3ff
 s_lshl_b32 s95, s95, 3
 s_add_u32 s95, s95, %[xring]
 v_mov_b32 %[rx], s95
-s_or_b32 %[ok], %[ok], 1
 ds_read_b32 %[ry], %[rx] offset:4
-ds_read_b32 %[rx], %[rx]
-{norec}:""", "the next command's record, asked for before the memory pipe is waited for")
+ds_read_b32 %[rx], %[rx]""", "the two bytes before P are the copy's from here on; the next command's record, asked for before the memory pipe is waited for")
+    A.m(store_and_load(), "the copy in flight goes to memory (no lanes: no store; behind literals: they go with it, lanes below pn the copy's bytes); this one's load (its bytes stay in v124 until the next command comes by)")
+    A.m("s_branch 1b")
     A.o(f"""
 {tell}:
 s_mov_b32 %[said], s95
@@ -232,35 +255,14 @@ v_readfirstlane_b32 s96, v116
 v_readfirstlane_b32 s97, v117
 v_readlane_b32 s94, %[params], 9
 s_cmp_lg_u32 s97, s94
-s_cbranch_scc1 {norec}b
+s_cbranch_scc1 {norec}f
 s_mov_b32 %[front], s96
 s_cmp_lt_u32 s95, s96
 s_cbranch_scc1 {have}b
-s_branch {norec}b""", "the reader has reached the frontier it knew: where wave 2 has got to by now (XW_FRONT: positions below are written | the codes' epoch << 32)")
-    A.m("""
-s_sub_u32 s96, %[P], %[pn]
-s_add_u32 s96, %[outlo], s96
-s_addc_u32 s97, %[outhi], 0
-""" + VMWAIT, "the copy in flight goes to memory (no lanes: no store)")
-    if merged:
-        A.m("""
-s_bfm_b64 vcc, %[pn], 0
-s_bfm_b64 exec, s89, 0
-v_cndmask_b32 v118, v119, v124, vcc
-global_store_byte %[lane], v118, s[96:97]""", "... and the literals behind it with it: lanes below pn the copy's bytes")
-    else:
-        A.m("""
-s_bfm_b64 exec, %[pn], 0
-global_store_byte %[lane], v124, s[96:97]""")
-    A.m(f"""
-s_bfm_b64 exec, s92, 0
-global_load_ubyte v124, %[lane], {src}
-s_mov_b64 exec, -1
-s_mov_b32 %[pn], s92
-s_add_u32 %[P], {pcopy}, s92
-s_bitcmp1_b32 %[ok], 0
-s_cbranch_scc1 1b
-s_branch 90f""", "this one's load (its bytes stay in v124 until the next command comes by)")
+{norec}:
+s_andn2_b32 %[ok], %[ok], 1""", "the reader has reached the frontier it knew: where wave 2 has got to by now (XW_FRONT: positions below are written | the codes' epoch << 32); not there yet: the run ends behind this command")
+    A.o(store_and_load())
+    A.o("s_branch 90f")
 
 
 def literal_loop(A, trivial, done):
@@ -403,7 +405,7 @@ s_cbranch_scc1 90f
 s_sub_u32 %[bl2], %[bl2], 1
 s_branch 3b""")
     # ---------------- a command with literals: s91 = their number ----------------
-    have_ctx, triv, long, long_back = L(), L(), L(), L()
+    have_ctx, triv, long, long_back, keep_ctx = L(), L(), L(), L(), L()
     A.m(f"""
 100:
 s_cmp_ge_u32 s91, %[quota]
@@ -411,10 +413,8 @@ s_cbranch_scc1 90f
 s_cmp_gt_u32 s91, %[bl0]
 s_cbranch_scc1 90f
 s_add_u32 s89, s91, %[pn]
-s_mov_b32 s81, %[p1]
-s_mov_b32 s80, %[p2]
 s_bitcmp1_b32 %[ok], 1
-s_cbranch_scc1 {have_ctx}f
+s_cbranch_scc1 {keep_ctx}f
 s_cmp_lt_u32 %[pn], 2
 s_cbranch_scc1 90f
 s_sub_u32 s96, %[pn], 1
@@ -439,6 +439,11 @@ s_sub_u32 %[cnt], 64, s88
 s_mov_b32 s85, %[pn]
 s_cmp_lg_u32 %[trivial], 0
 s_cbranch_scc1 {triv}f""", "s89 = lanes of the store (the copy in flight and the literals behind it); the two bytes before P: in p1 / p2 or the tail of the copy in flight; the bit buffer from behind the head's bits on; s85 = the lane of the next literal")
+    A.o(f"""
+{keep_ctx}:
+s_mov_b32 s81, %[p1]
+s_mov_b32 s80, %[p2]
+s_branch {have_ctx}b""", "p1 / p2 are the two bytes before P already: kept, for a command that is not plain after all (where they are not, what a roll-back puts into them does not matter)")
     A.o(f"""
 {long}:
 s_cmp_gt_u32 s91, 63
