@@ -21,7 +21,11 @@ def run(data, pieces, out_chunk):
     out = bytearray(); pos = 0; k = 0; pending = b""; result = 2; calls = 0
     while True:
         if not pending and result == 2:
-            if pos >= len(data): break
+            if pos >= len(data):
+                if calls and got:   # (the input has run out inside the stream: what earlier calls had no room for still goes out, decode.rs:2835-2846)
+                    result, used, got = st.decompress_stream(b"", out_chunk); out += got; calls += 1
+                    continue
+                break
             n = pieces[k % len(pieces)]; k += 1
             pending = data[pos:pos + n]; pos += len(pending)
         result, used, got = st.decompress_stream(pending, out_chunk)
