@@ -413,6 +413,16 @@ s_cbranch_scc1 90f
 s_cmp_gt_u32 s91, %[bl0]
 s_cbranch_scc1 90f
 s_add_u32 s89, s91, %[pn]
+s_bfe_u32 s95, s90, 0x70010
+s_add_u32 s85, s84, s95
+s_lshr_b32 s86, s85, 5
+s_add_u32 s87, s86, 1
+v_readlane_b32 s96, %[cur], s86
+v_readlane_b32 s97, %[cur], s87
+s_and_b32 s88, s85, 31
+s_add_u32 %[ndw], s86, 2
+s_lshr_b64 s[98:99], s[96:97], s88
+s_sub_u32 %[cnt], 64, s88
 s_bitcmp1_b32 %[ok], 1
 s_cbranch_scc1 {keep_ctx}f
 s_cmp_lt_u32 %[pn], 2
@@ -426,19 +436,9 @@ v_readlane_b32 %[p2], v124, s97
 s_cmp_gt_u32 s89, 63
 s_cbranch_scc1 {long}f
 {long_back}:
-s_bfe_u32 s95, s90, 0x70010
-s_add_u32 s85, s84, s95
-s_lshr_b32 s86, s85, 5
-s_add_u32 s87, s86, 1
-v_readlane_b32 s96, %[cur], s86
-v_readlane_b32 s97, %[cur], s87
-s_and_b32 s88, s85, 31
-s_add_u32 %[ndw], s86, 2
-s_lshr_b64 s[98:99], s[96:97], s88
-s_sub_u32 %[cnt], 64, s88
 s_mov_b32 s85, %[pn]
 s_cmp_lg_u32 %[trivial], 0
-s_cbranch_scc1 {triv}f""", "s89 = lanes of the store (the copy in flight and the literals behind it); the two bytes before P: in p1 / p2 or the tail of the copy in flight; the bit buffer from behind the head's bits on; s85 = the lane of the next literal")
+s_cbranch_scc1 {triv}f""", "s89 = lanes of the store (the copy in flight and the literals behind it); the bit buffer from behind the head's bits on (made BEFORE the copy in flight is waited for: its last two bytes are the context); the two bytes before P: in p1 / p2 or that copy's tail; s85 = the lane of the next literal")
     A.o(f"""
 {keep_ctx}:
 s_mov_b32 s81, %[p1]
