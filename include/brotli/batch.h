@@ -87,7 +87,7 @@ BROTLI_DEC_API float BrotliAmdBatchLastProbeMs(BrotliAmdBatch* batch);
 /* Streams the last BrotliAmdBatchWait had to continue in a second launch with a larger LDS arena (0 in the common case). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* batch);
 
-/* Blocks (CUs) that worked on each stream of the last launch: 1 as a rule; 2, 4 or 8 where the batch had fewer streams than half the
+/* Blocks (CUs) that worked on each stream of the last launch: 1 as a rule; 2, 4, 8 or 16 where the batch had fewer streams than half the
  * device's CUs, at least one of them 64 KiB of compressed data or more, and each stream was given a gang of blocks (csrc/brotli_path_engine.h, PE_CFG_REMOTE; BROTLI_AMD_GANG=0 turns that off). */
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* batch);
 
@@ -97,7 +97,7 @@ BROTLI_DEC_API uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* batch);
 BROTLI_DEC_API uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* batch);
 
 /* Test hook (no device needed): what a launch of n streams of these compressed sizes gets on a device of `cus` compute units -- 0 one block a
- * stream, 2 / 4 / 8 gangs of that many blocks a stream, 0x18 a pool -- and its number of blocks in *grid.  gang_env / pool_env: the values of
+ * stream, 2 / 4 / 8 / 16 gangs of that many blocks a stream, 0x108 a pool -- and its number of blocks in *grid.  gang_env / pool_env: the values of
  * BROTLI_AMD_GANG / BROTLI_AMD_POOL, -1 where unset. */
 BROTLI_DEC_API uint32_t BrotliAmdDebugPlanGangs(uint32_t n, uint32_t cus, const size_t* in_sizes, int gang_env, int pool_env, uint32_t* grid);
 

@@ -54,6 +54,8 @@ thread_local std::string g_last_note;   // what a call did differently without f
 // Blocks of sixteen waves with the command engine (csrc/brotli_scan_engine.h) for batches of at most one stream per CU;
 // BROTLI_AMD_NO_SCAN=1 keeps the launch shapes without it (experiments, A/B measurements).
 static const bool g_engine_wanted = getenv("BROTLI_AMD_NO_SCAN") == nullptr;  // (whether a device can hold such a block is decided per batch context, at its creation)
+constexpr size_t kGang16MinBytes = (size_t)2 << 20;   // compressed bytes of a batch's largest stream from which a gang is sixteen blocks (plan_gangs)
+constexpr uint32_t kGangPool = BROTLI_AMD_GANG_POOL_FLAG | 8u;   // plan_gangs' word for a pool launch (queue[2])
 constexpr uint64_t kProbeMinMeanBytes = 8192;     // mean compressed size of a batch from which the device is asked what kind its streams are (submit())
 constexpr uint32_t kEngineQueueMaxPerCu = 4;      // streams per CU up to which blocks of sixteen waves, one a CU, take a batch's streams one after the other -- where the
                                                   // DEVICE says they are a command engine's kind (probe_streams); beyond, streams in flight beat the engine (2048 x 1 MiB of the
@@ -237,13 +239,15 @@ int probe_streams(BrotliAmdBatch* b, uint32_t n, hipStream_t stream, std::vector
 }
 
 // Several blocks on a stream (csrc/brotli_path_engine.h, PE_CFG_REMOTE): what a launch of sixteen-wave blocks, one a stream, gets on top.
-// Returns 0 (nothing), 2 / 4 / 8 (GANGS: that many blocks a stream, dealt at the launch -- its owner and one, three or seven helper blocks that take
+// Returns 0 (nothing), 2 / 4 / 8 / 16 (GANGS: that many blocks a stream, dealt at the launch -- its owner and one, three or seven helper blocks that take
 // the path engine's regions in turns with it; eight streams' gangs side by side, a gang's members eight block numbers apart: one XCD; streams beyond a
-// multiple of eight leave their gangs' blocks without work) or 0x18 (a POOL: as many blocks as CUs; a block without a stream of its own -- at once where
+// multiple of eight leave their gangs' blocks without work) or 0x108 (a POOL: as many blocks as CUs; a block without a stream of its own -- at once where
 // there are fewer streams than CUs, else when its stream is done -- joins the largest stream still being decoded), and the launch's blocks in *grid.
 //   * Not for batches of small streams: a gang has something to divide from a dozen regions on -- 64 KiB of compressed data --, and costs a launch ten
 //     microseconds (its blocks' start, the control blocks' zeroing, the helpers' last look at the word that lets them go).
-//   * Gangs of eight up to an eighth of the CUs' streams, of four up to a quarter, of two up to half.
+//   * Gangs of eight up to an eighth of the CUs' streams, of four up to a quarter, of two up to half; of SIXTEEN up to a sixteenth where a stream is long
+//     (kGang16MinBytes compressed: eight blocks on one long stream are busy building and consuming, not waiting -- one 64 MiB stream 26.6 -> 24.3 ms,
+//     one of 1 GiB 387 -> 356 ms; streams of the metric's 4 MiB gain nothing: their invocations are a dozen regions).
 //   * A pool where the sizes differ -- the largest more than twice the median, and a long pole worth it: 256 KiB compressed, a millisecond and more
 //     alone -- and the gangs would be of four or two blocks or none: the long one gets seven helpers (one 64 MiB stream among 39 / 99 / 199 of 1 MiB:
 //     43.5 / 76.7 / 127.6 -> 29 ms).  Not where the streams are of a size: they end within a few per cent of each other, and the control blocks'
@@ -258,12 +262,16 @@ uint32_t plan_gangs(uint32_t n, uint32_t cus, const size_t* in_sizes, int gang_e
   uint32_t gang = 0u;
   const uint32_t groups = (n + 7u) / 8u;
   uint32_t m = groups * 64u <= cus ? 8u : groups * 32u <= cus ? 4u : groups * 16u <= cus ? 2u : 0u;
-  if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
+  // (round 6) sixteen blocks a stream where the device has them and a stream is long enough to keep them busy -- 2 MiB compressed, a few hundred regions:
+  // eight blocks on one long stream are BUSY (96 % of the launch building their windows' tables and taking their regions through), not waiting for one another
+  if (m == 8u && groups * 128u <= cus && largest_in >= kGang16MinBytes) m = 16u;
+  if (gang_env > 1 && m > (uint32_t)gang_env) m = gang_env >= 16 ? 16u : gang_env >= 8 ? 8u : gang_env >= 4 ? 4u : 2u;
+  if (gang_env == 16 && groups * 128u <= cus) m = 16u;   // (experiments: sixteen whatever the sizes)
   if (m > 1u) { gang = m; *grid = groups * 8u * m; }
-  if (m != 8u && pool_env != 0 && gang_env < 0) {
+  if (m < 8u && pool_env != 0 && gang_env < 0) {
     std::vector<size_t> sz(in_sizes, in_sizes + n);
     std::nth_element(sz.begin(), sz.begin() + n / 2, sz.end());
-    if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || (pool_env == 2 && m == 0u)) { gang = 0x18u; *grid = cus; }
+    if ((largest_in > 2u * sz[n / 2] && largest_in >= (256u << 10)) || (pool_env == 2 && m == 0u)) { gang = kGangPool; *grid = cus; }
   }
   return gang;
 }
@@ -645,7 +653,7 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
 }
 
 extern "C" uint32_t BrotliAmdBatchLastSecondPassCount(BrotliAmdBatch* b) { return b ? b->last_retry_count : 0; }
-extern "C" uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* b) { return b ? (b->last_gang > 1u && b->last_gang <= 8u ? b->last_gang : 1u) : 0; }
+extern "C" uint32_t BrotliAmdBatchLastGang(BrotliAmdBatch* b) { return b ? (b->last_gang > 1u && b->last_gang <= 16u ? b->last_gang : 1u) : 0; }
 extern "C" uint32_t BrotliAmdDebugPlanGangs(uint32_t n, uint32_t cus, const size_t* in_sizes, int gang_env, int pool_env, uint32_t* grid) {
   uint32_t g = n;
   const uint32_t r = (n != 0u && in_sizes != nullptr) ? plan_gangs(n, cus, in_sizes, gang_env, pool_env, &g) : 0u;
@@ -653,7 +661,7 @@ extern "C" uint32_t BrotliAmdDebugPlanGangs(uint32_t n, uint32_t cus, const size
   return r;
 }
 extern "C" float BrotliAmdBatchLastProbeMs(BrotliAmdBatch* b) { return b ? b->last_probe_ms : 0.0f; }
-extern "C" uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* b) { return b && (b->last_gang & 0x10u) != 0u ? 1u : 0u; }
+extern "C" uint32_t BrotliAmdBatchLastPool(BrotliAmdBatch* b) { return b && (b->last_gang & BROTLI_AMD_GANG_POOL_FLAG) != 0u ? 1u : 0u; }
 
 extern "C" float BrotliAmdBatchLastKernelMs(BrotliAmdBatch* b) {
   if (!b || !b->launched) return 0.0f;

@@ -30,6 +30,7 @@ extern "C" {
                                          // its first byte, in the launch of small blocks that follows)
 #define BROTLI_AMD_RESULT_RETRY_ARENA 4  // (never reaches the caller of the C ABI)
 #define BROTLI_AMD_RESULT_PROBE 5        // (never reaches the caller of the C ABI)
+#define BROTLI_AMD_GANG_POOL_FLAG 0x100u  // queue[2] of a POOL launch (with 8 in the low bits: the blocks a stream may gather); a gang launch: 2, 4, 8 or 16 blocks a stream
 #define BROTLI_AMD_GANG_CTL_BYTES 50176u // a gang's control block in memory, one per stream of a gang launch (brotli_kernels.hip: GC_*): queue[2] = blocks of a
                                          // gang (0 or 1: none), queue[4], queue[5] = the address of the first stream's block, the host zeroes them before the launch
 #define BROTLI_AMD_SPEC_SCRATCH 65536u   // bytes at the end of each block's global scratch that the helper waves use for

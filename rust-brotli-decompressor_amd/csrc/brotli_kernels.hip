@@ -4386,20 +4386,20 @@ extern "C" __global__ __launch_bounds__(1024, 4) void BROTLI_AMD_KERNEL(const Br
   // A gang launch (queue[2] blocks a stream, sixteen waves each; see GC_*): block b is member (b mod 8 gang) / 8 of the gang of stream
   // (b / (8 gang)) 8 + b mod 8 -- the members of a gang are eight block numbers apart, which is how the hardware deals blocks to the same
   // XCD (their L2 is one: what they hand each other does not cross the fabric; a matter of speed, not of correctness).  Member 0 owns the stream.
-// A POOL launch (queue[2] bit 4; as many blocks as CUs, at most as many streams): nobody is dealt to a gang.  Blocks take streams from the queue
+// A POOL launch (queue[2] bit 8, BROTLI_AMD_GANG_POOL_FLAG; as many blocks as CUs, at most as many streams): nobody is dealt to a gang.  Blocks take streams from the queue
   // as ever; a block that finds the queue empty -- at once, where the batch has fewer streams than CUs; when its own stream is done, otherwise --
   // joins the largest stream that is still being decoded and has fewer than seven helpers, for as long as that stream lasts, and then the next.
   // A stream's gang is whoever has joined it when one of its invocations of the path engine starts (GC_JOINED, GC_MEMBERS).
 #ifdef BROTLI_AMD_GANG_KERNEL
   uint32_t gang_m = rfl(queue[2]), gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
-  const bool pool = (gang_m & 0x10u) != 0u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP;
+  const bool pool = (gang_m & BROTLI_AMD_GANG_POOL_FLAG) != 0u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP;
   const uint64_t pool_base = (uint64_t)rfl(queue[4]) | ((uint64_t)rfl(queue[5]) << 32);
-  if ((gang_m & 0x10u) != 0u) gang_m = 1u;
+  if ((gang_m & BROTLI_AMD_GANG_POOL_FLAG) != 0u) gang_m = 1u;
   bool pool_open = false;   // (this block's stream has a control block that says it is being decoded)
 #else
   uint32_t gang_m = 1u, gang_role = 0, gang_stream = 0; uint64_t gang_addr = 0;
 #endif
-  if (gang_m > 1u && gang_m <= 8u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP) {
+  if (gang_m > 1u && gang_m <= 16u && blockDim.x == 64u * SC_WAVES && lds_arena_bytes <= GC_ARENA_CAP) {
     gang_role = (blockIdx.x % (8u * gang_m)) >> 3;
     gang_stream = (blockIdx.x / (8u * gang_m)) * 8u + (blockIdx.x & 7u);
     if (gang_stream >= n_streams) return;   // (the streams are not a multiple of eight: a gang without a stream)

@@ -80,6 +80,15 @@ constexpr uint32_t PE_PIPE_MARGIN = 1024;          // two engines: a region's ta
 #ifndef BROTLI_AMD_PE_REMOTE_MARGIN
 #define BROTLI_AMD_PE_REMOTE_MARGIN 1024
 #endif
+#ifndef BROTLI_AMD_PE_SEEDS
+#define BROTLI_AMD_PE_SEEDS 384
+#endif
+#ifndef BROTLI_AMD_PE_SEED_BACK
+#define BROTLI_AMD_PE_SEED_BACK 448
+#endif
+constexpr uint32_t PE_SEEDS = BROTLI_AMD_PE_SEEDS;          // a gang: entry seeds of a window built ahead of the stream (PEC_SEEDLO): this many bit positions ...
+constexpr uint32_t PE_SEED_BACK = BROTLI_AMD_PE_SEED_BACK;  // ... from this far in front of where a stream that ran the region before to its end would enter
+static_assert(!PE_CFG_REMOTE || PE_SEEDS <= 64u * PE_CFG_WAVES, "a thread a seed");
 constexpr uint32_t PE_REMOTE_MARGIN = BROTLI_AMD_PE_REMOTE_MARGIN;   // a gang of blocks: the same margin between the windows of its plan
 constexpr uint32_t PE_PIPE_USEFUL = 4096;          // ... and are used if the stream enters them with at least this many bits to go
 constexpr uint32_t PE_PIPE_HAND = 48;              // ... and the walk evaluates this many states itself before the stream is on the path (commands without literals, one after the other)
@@ -172,6 +181,8 @@ enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN 
        PEC_DECLINE = 139 /* the next command's literal run wants regions of its own: the one-engine form's */, PEC_PLAN = 140 /* (an engine's own word) what to do with the tables it built */, PEC_MYENTRY = 141 /* ... where the stream entered its region */, PEC_MYNEXT = 142 /* ... and where it left it */,
        PEC_BIGNEXT = 143 /* the execute's items that get a wave: handed out so far */, PEC_NXOK = 144 /* the number of the region whose PEC_CONT / PEC_NEXT_LBDW are there */ , PEC_KS = 145 /* the pass's first command (passes: see PE_DICT) */, PEC_DICTK = 146 /* the command whose copy is a word of the static dictionary, its literals out: its index, distance, copy length */, PEC_DICTD = 147, PEC_DICTN = 148, PEC_AGAIN = 149, PEC_PDX = 150 /* the invocation ends behind that command's distance (SCX_POST_DISTANCE) */, PEC_OVF = 151 /* regions of this invocation whose closure all but filled its room */,
        PEC_MYGEN = 157 /* (a gang) the generation of the plan this engine's window follows */, PEC_MYSHIFT = 138 /* ... and how often its regions are halved */, PEC_MEMBERS = 186 /* ... (a pool) the blocks of this invocation's gang */, PEC_NOHELP = 185 /* ... (a pool) the owner kept the invocation to itself because nobody has joined its stream */, PEC_RELAX = 159 /* ... whether this engine's executes wait twice (see there): its own observation, kept from region to region */, PEC_LAG = 137 /* ... the bytes of the region before's output: what a copy may not read before that region's engine says they are there */, PEC_BUILT = 158 /* ... whether its tables are built */,
+       PEC_SEEDLO = 190 /* (a gang) the window's ENTRY SEEDS: the states 'a command starts at bit PEC_SEEDLO + i', i < PEC_SEEDN, are closure states 1 + i -- evaluated with the
+                            tables, ahead of the stream, so that the walk finds the state the stream enters in among them instead of evaluating it itself (see the walk) */, PEC_SEEDN = 191,
        PEC_FIN = 156 /* a long literal run has ended in this region: its command's distance and copy are wave 0's, in place */,
        PEC_DSEEN = 155 /* (lean form) the engine's part ended in front of a dictionary reference: the general form's stream */,
        PEC_DCAND = 152 /* (PE_DICT) a command of the pass may be a word of the static dictionary */, PEC_NWORD = 153 /* ... words the pass puts out */, PEC_WNEXT = 154 /* ... handed out so far */ };
@@ -954,6 +965,11 @@ pe_again:
     pe_ctl_st(pb, PEC_WN, 1u); pe_ctl_st(pb, PEC_ON, 0u); pe_ctl_st(pb, PEC_NEXTRANK, 0u); pe_ctl_st(pb, PEC_TAILN, 0u); pe_ctl_st(pb, PEC_TAILNEXT, 0u); pe_ctl_st(pb, PEC_READY, 0u); pe_ctl_st(pb, PEC_TMIN, PE_CHUNKS);
     pe_ctl_st(pb, PEC_CHG, 0u); pe_ctl_st(pb, PEC_CHG + 1, 0u); pe_ctl_st(pb, PEC_CHG + 2, 0u);
     pe_ctl_st(pb, PEC_MODE, mode); pe_ctl_st(pb, PEC_ENT, ent_);
+    if (REMOTE) pe_ctl_st(pb, PEC_SEEDN, 0u);
+  };
+  // (a gang, wave 0, behind setup_tables) entry seeds: n states from bit lo_ on (see PEC_SEEDLO)
+  auto seed_entries = [&](const uint32_t lo_, const uint32_t n_) {
+    pe_ctl_st(pb, PEC_SEEDLO, lo_); pe_ctl_st(pb, PEC_SEEDN, n_); pe_ctl_st(pb, PEC_WN, 1u + n_);
   };
   // ... and what the walk and what follows it start from: where the region's output begins, nothing published yet
   auto setup_walk = [&](const uint64_t P_) {
@@ -1392,6 +1408,8 @@ pe_again:
       }
     }
     if (T == 0u) lds_st16(pb + PE_WST, le | 0x8000u);  // the closure's first state: a command starts at the entry (lane 0 evaluates it)
+    const uint32_t seed_n = REMOTE ? pe_ctl_ld(pb, PEC_SEEDN) : 0u;
+    if (REMOTE && T < seed_n) lds_st16(pb + PE_WST + ((1u + T) << 1), (pe_ctl_ld(pb, PEC_SEEDLO) + T) | 0x8000u);   // ... and the entry seeds behind it
     if (T == 1u) lds_st16(pb + PE_NEXT + (PE_STATES << 1), PEN_NONE);  // (NEXT8's sentinel)
     {
       const uint32_t lim = c.L > 16u ? c.L - 16u : 0u, cut = tmin << 5;
@@ -1480,6 +1498,7 @@ pe_again:
               base += (uint32_t)__popcll(nm[t]);
               bool take = (bool)((uint32_t)!has[t] & (uint32_t)(rr < limit));
               uint32_t idv = rr;
+              if (REMOTE && source == 0u && rr >= c.Rn) idv = PE_RANKS + 1u + (rr - c.Rn);   // (behind the path positions: the entry seeds, closure states 1 ..)
               if (source == 1u) { idv = lds_ld16(pb + PE_TAILQ + ((take ? rr : 0u) << 1)); take = (bool)((uint32_t)take & (uint32_t)(idv < PEN_FIRST_SPECIAL)); }
               const uint32_t idc = take ? idv : 0u;
               const uint32_t stv = lds_ld16(pb + (idc < PE_RANKS ? PE_POR + (idc << 1) : PE_WST + ((idc - PE_RANKS) << 1)));
@@ -1544,7 +1563,7 @@ pe_again:
 #ifndef BROTLI_AMD_PE_BULK_NS
 #define BROTLI_AMD_PE_BULK_NS 2
 #endif
-    records_loop(std::integral_constant<uint32_t, BROTLI_AMD_PE_BULK_NS>{}, 0u, c.Rn);
+    records_loop(std::integral_constant<uint32_t, BROTLI_AMD_PE_BULK_NS>{}, 0u, c.Rn + seed_n);
     PE_BAR();
     {
       const uint32_t tail_n = pe_ctl_ld(pb, PEC_TAILN) < PE_TAILCAP ? pe_ctl_ld(pb, PEC_TAILN) : PE_TAILCAP;
@@ -1681,7 +1700,16 @@ pe_again:
           const ScHead h_ = sc_head(lo_, hi_, c.cmd_tree, c.lut_vgpr);
           long_run = rfl(h_.insert) >= PE_RUN_MIN;
         }
-        if (slot >= PE_WCAP || long_run) id = PEN_NONE;   // (no room for the entry's state: nothing listed, the checked loop's)
+        bool seeded = false;
+        if (REMOTE && !long_run) {   // (a gang) the state the stream enters in is one of the window's entry seeds: its record is there, and NEXT8 knows it
+          const uint32_t sn_ = pe_ctl_ld(pb, PEC_SEEDN), off_ = le - pe_ctl_ld(pb, PEC_SEEDLO);
+          if (off_ < sn_) { id = PE_RANKS + 1u + off_; id_hand = PEN_NONE; seeded = true; }
+#ifdef BROTLI_AMD_SEED_DEBUG
+          if (lane == 0 && kseq < 400u) printf("seed: region %u role %u le %u lo %u n %u hit %d L %u\n", kseq, role, le, pe_ctl_ld(pb, PEC_SEEDLO), sn_, (int)seeded, c.L);
+#endif
+        }
+        if (seeded) { }
+        else if (slot >= PE_WCAP || long_run) id = PEN_NONE;   // (no room for the entry's state: nothing listed, the checked loop's)
         else for (uint32_t tries = 0;; tries++) {
           if (lane == 0) lds_st16(pb + PE_WST + (slot << 1), desc);
           if (tries >= PE_PIPE_HAND) { if (lane == 0) lds_st16(pb + PE_NEXT + ((PE_RANKS + slot) << 1), PEN_BYHAND); break; }   // (the region ends in front of this state)
@@ -2643,6 +2671,10 @@ pe_pass:
       const uint64_t sw_ = gang_ld64(gc, GC_STOP);
       const bool buildable = td_ok && avail >= PE_MIN_INPUT && !((uint32_t)(sw_ >> 32) == epoch && (uint32_t)sw_ <= kseq);
       setup_tables(W, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
+      // (entry seeds: a region's walk ends a command or two short of bit L - 128 of its window, and the next window starts a stride behind this one's
+      // start: the stream enters it that far short of rbl - stride -- PE_SEEDS bits around that.  The plan's first region starts where the stream is)
+      if (kseq > k0_) { const uint32_t e0_ = rbl_ - stride_; seed_entries(e0_ > PE_SEED_BACK ? e0_ - PE_SEED_BACK : 0u, PE_SEEDS); }
+      else seed_entries(0u, 32u);
       pe_ctl_st(pb, PEC_GO, buildable ? 1u : 0u); pe_ctl_st(pb, PEC_MYGEN, (uint32_t)(pl >> 48)); pe_ctl_st(pb, PEC_MYSHIFT, shsc_);
     };
     const bool alone = role == 0u && pe_ctl_ld(pb, PEC_PLAN) == 6u;   // (the owner has kept the invocation to itself: see `long_first`)
@@ -2686,6 +2718,7 @@ pe_pass:
                 GANG_STAT(gc, 2, 1);
                 if (!built) GANG_STAT(gc, 10, 1); else if (eb < w0) GANG_STAT(gc, 11, 1); else GANG_STAT(gc, 12, 1);
                 setup_tables(eb >> 5, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
+                seed_entries(0u, 32u);   // (the window starts at the entry's dword)
                 // (short of the window: the regions from here on a shorter stride -- what the region before did advance, in eighths)
                 uint32_t sc_ = shsc_ >> 2;
                 if (built && eb < w0) {
@@ -2733,6 +2766,7 @@ pe_pass:
           if (wn + 64u > PE_WCAP && sh_ < 2u && pe_ctl_ld(pb, PEC_L) > (PE_RBL >> (sh_ + 1u))) {
             const uint32_t rbl_ = PE_RBL >> (sh_ + 1u), g_ = (pe_ctl_ld(pb, PEC_MYGEN) + 1u) & 0xFFFFu;
             setup_tables(eb >> 5, 0u, avail < rbl_ ? avail : rbl_, 0u, 0u);
+            seed_entries(0u, 32u);
             if (lane == 0u) gang_st64(gc, GC_PLAN, ((uint64_t)g_ << 48) | ((uint64_t)(shsc_ + 1u) << 44) | ((uint64_t)kseq << 32) | (uint64_t)eb);
             gang_drain();
             pe_ctl_st(pb, PEC_MYGEN, g_); pe_ctl_st(pb, PEC_MYSHIFT, shsc_ + 1u);

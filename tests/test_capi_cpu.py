@@ -96,7 +96,8 @@ def _plan(lib, sizes, cus=256, gang_env=-1, pool_env=-1):
 def test_how_many_blocks_a_stream_gets(lib):
     """the host's plan for several blocks on a stream (csrc/brotli_capi.cpp: plan_gangs), a pure function of the batch's compressed
     sizes and the device's CUs: gangs of 8 / 4 / 2 blocks a stream for batches of equal streams up to an eighth / a quarter / half the CUs'
-    number, a pool (0x18) where more than 32 streams differ widely in size, nothing for small streams or where the environment says so"""
+    number (sixteen where the device has them and a stream is long: 2 MiB compressed), a pool (0x108) where more than 32 streams differ widely in
+    size, nothing for small streams or where the environment says so"""
     MB = 400_000   # (a 4 MiB stream of the metric's, compressed)
     assert _plan(lib, [MB]) == (8, 64)                    # one stream: a gang of eight, eight streams' worth of blocks
     assert _plan(lib, [MB] * 8) == (8, 64)
@@ -109,16 +110,23 @@ def test_how_many_blocks_a_stream_gets(lib):
     assert _plan(lib, [MB] * 129) == (0, 129)             # one block a stream, as many blocks as streams
     assert _plan(lib, [MB] * 256) == (0, 256)
     assert _plan(lib, [MB] * 257) == (0, 257)             # (more streams than CUs: not this function's)
+    # long streams, few enough for sixteen blocks each (round 6: eight blocks on one long stream are busy, not waiting for one another)
+    assert _plan(lib, [8_000_000]) == (16, 128)
+    assert _plan(lib, [8_000_000] * 16) == (16, 256)
+    assert _plan(lib, [8_000_000] * 17) == (8, 192)
+    assert _plan(lib, [8_000_000], cus=120) == (8, 64)
+    assert _plan(lib, [8_000_000], gang_env=8) == (8, 64)
+    assert _plan(lib, [MB], gang_env=16) == (16, 128)
     # small streams: nothing to divide
     assert _plan(lib, [60_000] * 8) == (0, 8)
     assert _plan(lib, [60_000] * 7 + [70_000]) == (8, 64)
     # very different sizes: a pool from 33 streams on (up to 32 every stream has eight blocks anyway), as many blocks as CUs
     big = 8_000_000
     assert _plan(lib, [big] + [100_000] * 31) == (8, 256)
-    assert _plan(lib, [big] + [100_000] * 39) == (0x18, 256)
-    assert _plan(lib, [big] + [100_000] * 199) == (0x18, 256)
-    assert _plan(lib, [big] + [100_000] * 255) == (0x18, 256)
-    assert _plan(lib, [big] + [100_000] * 255, cus=304) == (0x18, 304)
+    assert _plan(lib, [big] + [100_000] * 39) == (0x108, 256)
+    assert _plan(lib, [big] + [100_000] * 199) == (0x108, 256)
+    assert _plan(lib, [big] + [100_000] * 255) == (0x108, 256)
+    assert _plan(lib, [big] + [100_000] * 255, cus=304) == (0x108, 304)
     assert _plan(lib, [200_000] + [60_000] * 99) == (2, 208)   # (the long one is no long pole: under 256 KiB compressed)
     assert _plan(lib, [MB] * 100 + [2 * MB]) == (2, 208)       # (not more than twice the median)
     # the environment: BROTLI_AMD_GANG=0 nothing, =2 / 4 gangs of at most that many and no pool; BROTLI_AMD_POOL=0 no pool, =2 a pool whatever the sizes
@@ -128,5 +136,5 @@ def test_how_many_blocks_a_stream_gets(lib):
     assert _plan(lib, [big] + [100_000] * 199, gang_env=8) == (0, 200)
     assert _plan(lib, [big] + [100_000] * 199, pool_env=0) == (0, 200)
     assert _plan(lib, [big] + [100_000] * 39, pool_env=0) == (4, 160)
-    assert _plan(lib, [MB] * 200, pool_env=2) == (0x18, 256)
+    assert _plan(lib, [MB] * 200, pool_env=2) == (0x108, 256)
     assert _plan(lib, [MB] * 100, pool_env=2) == (2, 208)      # (where there are gangs, a forced pool does not replace them)
