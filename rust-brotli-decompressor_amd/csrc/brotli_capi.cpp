@@ -330,6 +330,7 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
     if (in_total >= (uint64_t)n * kProbeMinMeanBytes) {
       if (b->probe_kind.size() == n && b->probe_key == key) kind = b->probe_kind;
       else {
+        if (!ensure_scratch(b, b->grid)) return -1;   // (a batch object's first launch allocates its blocks' scratch: not the probe's time)
         const auto t0 = std::chrono::steady_clock::now();
         if (probe_streams(b, n, stream, kind) != 0) return -1;
         b->last_probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
