@@ -2575,6 +2575,8 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
                               xb + 4u * (uint32_t)XW_POS;
   // ... and of a word of the static dictionary as it stands (transform 0), by its length: where the words of that length begin | the bits of their index << 24
   const uint32_t run_wtab = lane >= 4u && lane <= 24u ? kDictOffsetsByLength[lane] | ((uint32_t)kDictSizeBitsByLength[lane] << 24) : 0u;
+  // ... and of a copy that repeats itself, by its distance d: 65536 / d + 1 (lane * that >> 16 = lane / d: the copy's byte i is byte i mod d of its source)
+  const uint32_t run_mtab = lane != 0u ? 65536u / lane + 1u : 0u;
 
 #ifdef BROTLI_AMD_PROFILE_SPLIT
   uint64_t lap_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lap_t = __builtin_amdgcn_s_memtime(); const uint64_t lap_t0 = lap_t; uint32_t n_run = 0, n_lit = 0, n_nolit = 0, n_word = 0;
@@ -2595,12 +2597,12 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
           : [buf] "+s"(br.buf), [cnt] "+s"(br.cnt), [ndw] "+s"(br.next_dw), [bl0] "+s"(bl0s), [bl1] "+s"(bl1), [bl2] "+s"(bl2),
             [d0] "+s"(d0), [d1] "+s"(d1), [d2] "+s"(d2), [d3] "+s"(d3), [P] "+s"(P32), [quota] "+s"(quota), [pn] "+s"(pend_n),
             [ok] "+s"(ok), [p1] "+s"(p1s), [p2] "+s"(p2s), [said] "+s"(saids), [front] "+s"(fronts), [rx] "+v"(rx), [ry] "+v"(ry) LRA_WAIT_OPERAND
-          : [cur] "v"(br.cur), [lane] "v"(lane), [lut0] "v"(lut0v), [lut1] "v"(lut1v), [ctxtree] "v"(ctx_tree_abs), [dlut] "v"(dlut), [params] "v"(run_params), [wtab] "v"(run_wtab),
+          : [cur] "v"(br.cur), [lane] "v"(lane), [lut0] "v"(lut0v), [lut1] "v"(lut1v), [ctxtree] "v"(ctx_tree_abs), [dlut] "v"(dlut), [params] "v"(run_params), [wtab] "v"(run_wtab), [mtab] "v"(run_mtab),
             [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
             [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits),
             [littree] "s"(rfl(LDS_FIXED + lit_tree)), [trivial] "s"(rfl(trivial))
           : "memory", "vcc", "scc", "m0", LRA_WAIT_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
-            "v116", "v117", "v118", "v119", "v124");
+            "v115", "v116", "v117", "v118", "v119", "v124");
       ncmd += bl1_0 - bl1; mlen -= (int32_t)(quota0 - quota);   // (a command of the run takes one of the command block's count, and from the quota what it takes from the metablock)
       SPLIT_LAP(1);
 #ifdef BROTLI_AMD_PROFILE_SPLIT

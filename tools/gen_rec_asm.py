@@ -55,6 +55,15 @@ class Asm:
             self.ool.append((line.strip(), comment)); comment = None
 
 
+def out_of_line(A, emit):
+    """what `emit` writes -- its straight way, then what lies out of line of IT -- behind the blocks out of line so far (numeric labels are looked for forward)"""
+    main_keep, ool_keep = A.main, A.ool
+    A.main, A.ool = [], []
+    emit()
+    ool_keep.extend(A.main); ool_keep.extend(A.ool)
+    A.main, A.ool = main_keep, ool_keep
+
+
 def plain_test(p, q):
     """s95 < 0 unless: 0 < distance s93 <= min(P, max_backward), copy length s92 <= min(63, distance, quota - 1)   (p: the output position, q: the quota, in front of the copy)"""
     return f"""
@@ -96,15 +105,15 @@ s_add_i32 s93, s93, s97
 {b}:"""
 
 
-def word_test(p, q, fail, src_lo, src_hi):
+def word_test(p, q, fail, src_lo, src_hi, within):
     """The command is not a plain copy.  A word of the static dictionary as it stands (decode.rs:2593-2640 with transform 0: every word of the
     reference's alice29 is one)?  distance s93 beyond min(P, max_backward), 4 <= length s92 <= 24, (distance - max_distance - 1) >> bits[length] == 0,
-    length < quota, the distance block's count s94 there -> its address in {src_lo}:{src_hi}; anything else: {fail}.  (p, q as plain_test; lane n of
+    length < quota, the distance block's count s94 there -> its address in {src_lo}:{src_hi}; a distance within the window: {within} (see overlap_test); anything else: {fail}.  (p, q as plain_test; lane n of
     %[wtab]: kDictOffsetsByLength[n] | kDictSizeBitsByLength[n] << 24; lanes 6 / 7 of the parameters: the dictionary's address)"""
     return f"""
 s_min_u32 s95, {p}, %[maxb]
 s_cmp_le_u32 s93, s95
-s_cbranch_scc1 {fail}f
+s_cbranch_scc1 {within}f
 s_cmp_gt_u32 s93, 0x7ffffffc
 s_cbranch_scc1 {fail}f
 s_sub_u32 s96, s92, 4
@@ -128,6 +137,28 @@ v_readlane_b32 {src_lo}, %[params], 6
 v_readlane_b32 {src_hi}, %[params], 7
 s_add_u32 {src_lo}, {src_lo}, s96
 s_addc_u32 {src_hi}, {src_hi}, 0"""
+
+
+def overlap_test(q, fail):
+    """... or a copy that repeats itself (decode.rs:2641-2680 copies byte by byte: byte i of it is byte i mod distance of its source): 0 < distance s93 < length
+    s92 <= 63, length < quota, the distance block's count s94 there -> v115 = lane mod distance, what the copy's load takes for its lanes' offsets
+    (lane d of %[mtab]: 65536 / d + 1 -- lane * that >> 16 is lane / d for lanes and distances below 64); anything else: {fail}"""
+    return f"""
+s_cmp_eq_u32 s93, 0
+s_cbranch_scc1 {fail}f
+s_cmp_gt_u32 s92, 63
+s_cbranch_scc1 {fail}f
+s_cmp_ge_u32 s92, {q}
+s_cbranch_scc1 {fail}f
+s_cmp_lt_i32 s94, 0
+s_cbranch_scc1 {fail}f
+s_cmp_ge_u32 s93, s92
+s_cbranch_scc1 {fail}f
+v_readlane_b32 s96, %[mtab], s93
+v_mul_u32_u24 v115, %[lane], s96
+v_lshrrev_b32 v115, 16, v115
+v_mul_u32_u24 v115, v115, s93
+v_sub_u32 v115, %[lane], v115"""
 
 
 PUSH = """
@@ -193,7 +224,8 @@ def request_and_copy(A, p_expr_regs):
     s89 lanes -- stored, this command's load issued, the loop closed.  Where wave 2 has not written that record yet (rare) the same store and load
     lie out of line and end the run with bit 0 of ok cleared.  p_expr_regs: (register that holds the output position in front of this command's copy,
     lanes of the store register or None, the register pair that holds the address of the copy's source -- in the output, or in the static dictionary)"""
-    pcopy, merged, src = p_expr_regs
+    pcopy, merged, src = p_expr_regs[:3]
+    off = p_expr_regs[3] if len(p_expr_regs) > 3 else "%[lane]"   # (the lanes' offsets into the copy's source: the lane, or lane mod distance)
     tell, back = L(), L()
     norec, look, have = L(), L(), L()
 
@@ -215,7 +247,7 @@ s_bfm_b64 exec, %[pn], 0
 global_store_byte %[lane], v124, s[96:97]"""
         return t + f"""
 s_bfm_b64 exec, s92, 0
-global_load_ubyte v124, %[lane], {src}
+global_load_ubyte v124, {off}, {src}
 s_mov_b64 exec, -1
 s_mov_b32 %[pn], s92
 s_add_u32 %[P], {pcopy}, s92"""
@@ -365,11 +397,26 @@ s_sub_u32 %[quota], %[quota], s92
 s_bfe_u32 s95, s90, 0x70010
 s_add_u32 s84, s84, s95""", "the copy's source; counts; the reader moves on by the record's bits")
     request_and_copy(A, ("%[P]", None, "s[88:89]"))
+    ov = L()
     A.o(f"{word}:")
-    A.o(word_test("%[P]", "%[quota]", "90", "s88", "s89"))
+    A.o(word_test("%[P]", "%[quota]", "90", "s88", "s89", ov))
     A.o("""
 s_mov_b32 %[bl2], s94
 s_branch 4b""", "a word: the distance's count, nothing pushed (decode.rs:2643-2644)")
+    A.o(f"{ov}:")
+    A.o(overlap_test("%[quota]", "90"))
+    A.o("s_mov_b32 %[bl2], s94")
+    A.o(PUSH)
+    A.o("""
+s_add_u32 s88, %[outlo], %[P]
+s_addc_u32 s89, %[outhi], 0
+s_sub_u32 s88, s88, s93
+s_subb_u32 s89, s89, 0
+s_sub_u32 %[bl1], %[bl1], 1
+s_sub_u32 %[quota], %[quota], s92
+s_bfe_u32 s95, s90, 0x70010
+s_add_u32 s84, s84, s95""", "a copy that repeats itself: the same command, its load by lane mod distance")
+    out_of_line(A, lambda: request_and_copy(A, ("%[P]", None, "s[88:89]", "v115")))
     # the other kinds of distance of a command without literals
     short, zero = L(), L()
     A.o(f"""
@@ -527,11 +574,27 @@ s_sub_u32 %[bl1], %[bl1], 1
 s_lshl_b32 s95, %[ndw], 5
 s_sub_u32 s84, s95, %[cnt]""", "it is a plain command: the copy's source, the counts, the reader's position")
     request_and_copy(A, ("s85", True, "s[86:87]"))
+    ov2 = L()
     A.o(f"{word2}:")
-    A.o(word_test("s85", "s88", "190", "s86", "s87"))
+    A.o(word_test("s85", "s88", "190", "s86", "s87", ov2))
     A.o(f"""
 s_mov_b32 %[bl2], s94
 s_branch {join2}b""")
+    A.o(f"{ov2}:")
+    A.o(overlap_test("s88", "190"))
+    A.o("s_mov_b32 %[bl2], s94")
+    A.o(PUSH)
+    A.o("""
+s_add_u32 s86, %[outlo], s85
+s_addc_u32 s87, %[outhi], 0
+s_sub_u32 s86, s86, s93
+s_subb_u32 s87, s87, 0
+s_sub_u32 %[quota], s88, s92
+s_sub_u32 %[bl0], %[bl0], s91
+s_sub_u32 %[bl1], %[bl1], 1
+s_lshl_b32 s95, %[ndw], 5
+s_sub_u32 s84, s95, %[cnt]""")
+    out_of_line(A, lambda: request_and_copy(A, ("s85", True, "s[86:87]", "v115")))
     A.o(f"""
 {extra_refill}:
 s_cmp_gt_u32 %[ndw], 63
