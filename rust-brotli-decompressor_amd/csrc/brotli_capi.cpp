@@ -216,8 +216,10 @@ uint32_t small_arena(const BrotliAmdBatch* b, uint32_t per_cu) {
 }
 
 // What kind of stream is each of the batch's?  A launch of the shape at hand in which nothing is decoded: every stream's header is read up
-// to the literal context map of its first compressed metablock (BROTLI_AMD_FLAG_PROBE).  kind[i]: bit 0 there is such a metablock,
-// bit 1 its literals do not depend on context, bit 2 it is large enough for a command engine.  (Round 4 guessed from the batch's size and its
+// to the literal context map of its first compressed metablock (BROTLI_AMD_FLAG_PROBE) -- where that says 'an engine's kind', on through its literal codes
+// and its first command code.  kind[i]: bit 0 there is such a metablock, bit 1 its literals do not depend on context, bit 2 it is large enough for a
+// command engine, bit 3 (round 6) its commands are SHORT -- text: the engines' kind by the first three, and yet four such streams a CU on a wave each with
+// the command records (lean_rec_commands) do 2.4 times what an engine block does with them one after the other: they are not sent to engine blocks.  (Round 4 guessed from the batch's size and its
 // mean compressed size: 1024 x 1 MiB of engine-shaped streams went through one-wave blocks -- 129 GB/s where engine blocks do 148 --, and
 // could not be told from 1024 context-modelled texts, which engine blocks take at half speed.  The probe costs a launch of some tens of
 // microseconds and reads the facts.)
@@ -234,7 +236,7 @@ int probe_streams(BrotliAmdBatch* b, uint32_t n, hipStream_t stream, std::vector
   ok = ok && hip_ok(hipMemcpyAsync(b->h_status, b->d_status, sizeof(BrotliAmdStreamStatus) * n, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(status)");
   ok = ok && hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize(probe)");
   if (!ok) return -1;
-  for (uint32_t i = 0; i < n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_PROBE) kind[i] = (uint8_t)(b->h_status[i].engine_commands & 7u);
+  for (uint32_t i = 0; i < n; i++) if (b->h_status[i].result == BROTLI_AMD_RESULT_PROBE) kind[i] = (uint8_t)(b->h_status[i].engine_commands & 15u);
   return 0;
 }
 
@@ -336,7 +338,15 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
         b->last_probe_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         b->probe_kind = kind; b->probe_key = key;
       }
-      for (uint32_t i = 0; i < n; i++) if (kind[i] == 7u) in_engine += b->h_descs[i].in_size;
+      for (uint32_t i = 0; i < n; i++) if (kind[i] == 7u) in_engine += b->h_descs[i].in_size;   // (15: the engines' kind but for its short commands -- text)
+      if (getenv("BROTLI_AMD_DEBUG_PROBE")) {
+        uint32_t h[16] = {}; for (uint32_t i = 0; i < n; i++) h[kind[i] & 15u]++;
+        fprintf(stderr, "probe: %u streams, kinds", n); for (int k = 0; k < 16; k++) if (h[k]) fprintf(stderr, " %d:%u", k, h[k]);
+        fprintf(stderr, "; engine bytes %llu of %llu; results", (unsigned long long)in_engine, (unsigned long long)in_total);
+        uint32_t r[8] = {}; for (uint32_t i = 0; i < n; i++) r[b->h_status[i].result < 8 ? b->h_status[i].result : 7]++;
+        for (int k = 0; k < 8; k++) if (r[k]) fprintf(stderr, " %d:%u", k, r[k]);
+        fprintf(stderr, "\n");
+      }
       if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
     }
   }

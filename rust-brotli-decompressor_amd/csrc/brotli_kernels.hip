@@ -66,6 +66,10 @@ constexpr int E_EXUBERANT_NIBBLE = -1, E_RESERVED = -2, E_EXUBERANT_META_NIBBLE 
               E_PADDING_2 = -15, E_DISTANCE = -16, E_UNREACHABLE = -31;
 constexpr int E_RETRY_ARENA = 100;  // internal: see BROTLI_AMD_FLAG_NO_SPILL
 constexpr int E_PROBE = 101;        // internal: see BROTLI_AMD_FLAG_PROBE
+#ifndef BROTLI_AMD_PROBE_SHORT
+#define BROTLI_AMD_PROBE_SHORT 4
+#endif
+constexpr uint32_t PROBE_SHORT_COMMANDS = BROTLI_AMD_PROBE_SHORT;   // a stream's commands are "short" (the probe's bit 3) where, by its first command code's own probabilities, less than this share -- one in so many -- of its BYTES comes from commands that insert or copy more than 63
 
 // ---- small constant tables (RFC 7932 sections 3.5, 4, 5, 6) ----
 // (decode.rs:801-853's three small tables -- kCodeLengthCodeOrder = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15},
@@ -1780,7 +1784,8 @@ enum { L_BUF_LO, L_BUF_HI, L_CNT, L_NEXT_DW, L_ISSUED, L_END_DW, L_P_LO, L_P_HI,
 static_assert(L_COUNT * 4 <= 192, "LDS_LEAN too small");
 // (parse / copy split and command records, see copier_wave / rec_wave)
 enum { L_SP_HEAD = L_COUNT, L_SP_LIT = L_COUNT + 1, L_SP_ORIGIN = L_COUNT + 2 /* dword the record ring's positions count from */,
-       L_SP_REC = L_COUNT + 3 /* command records (rec_wave) in use */, L_SP_COUNT = L_COUNT + 4 };
+       L_SP_REC = L_COUNT + 3 /* command records (rec_wave) in use */, L_SP_WAITED = L_COUNT + 4 /* why the record loop left: 1 wave 2's records were not there yet, 2 a command with more than 63 literals or a copy of more than 63 bytes, 0 anything else */,
+       L_SP_COUNT = L_COUNT + 5 };
 static_assert(L_SP_COUNT * 4 <= 192, "LDS_LEAN too small");
 enum { LS_BEGIN = 0, LS_AFTER_HEAD = 1, LS_LITERALS_REST = 2, LS_DISTANCE = 3, LS_POST_DISTANCE = 4, LS_COMMAND_DONE = 5,
        LS_LITERALS_AT_LIMIT = 6, LS_NEEDS_INPUT = 7, LS_LITERAL_ROUNDS = 8 };
@@ -2564,6 +2569,8 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     if (pend_n) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pend_store8(out + pend_pos, pend_n, lane); pend_n = 0; }
   };
   bool rec_ok = request();
+  bool waited_out = false;   // (the loop is left because the records are not there: not a verdict on the stream's commands, see process_commands)
+  bool long_cmd = false;     // (... because of a command longer than the run takes: that is one)
   static const bool no_run_asm = false;
   const uint32_t ctx_tree_abs = ctx_tree_v + LDS_FIXED;   // (the run's literals: a context's tree as an address)
 #ifdef BROTLI_AMD_PROFILE_RUN_WAIT
@@ -2616,7 +2623,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
       if (br.next_dw >= win_end) continue;
     }
     for (uint32_t spins = 0; !rec_ok && spins < 8u; spins++) { if (spins) __builtin_amdgcn_s_sleep(4); rec_ok = request(); }  // (wave 2 is rarely behind)
-    if (!rec_ok) break;
+    if (!rec_ok) { waited_out = true; break; }
     const uint32_t rec_lo = rfl(rec_v.x), rec_hi = rfl(rec_v.y);
     if (!(rec_lo & XR_VALID)) break;
     const uint32_t n = rec_lo & 0xFFFFu, nb = (rec_lo >> 16) & 127u;
@@ -2627,6 +2634,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     if (rec_lo & XR_LITERALS) {
       // ---- literals: the tree depends on the two bytes before (decode.rs:2463-2551) ----
       const uint32_t ins = rec_hi;
+      if (ins > 63u) long_cmd = true;   // (more literals than the run takes: what a stream of long literal runs does at every command)
       if (ins > 16u || ins >= quota || ins > bl0) break;
       advance(nb);
       if (!ctx_regs) {
@@ -2738,7 +2746,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
           word = w.total != 0u && w.total < quota && (int32_t)w.total <= mlen;
         }
       }
-      if (!word) { if (committed) stage = LS_POST_DISTANCE; break; }
+      if (!word) { if (n > 63u) long_cmd = true; if (committed) stage = LS_POST_DISTANCE; break; }
     }
     if (!committed) {
       if (!(rec_lo & XR_IMPLICIT)) bl2--;
@@ -2788,6 +2796,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     LEAN_ST(L_D0, d0); LEAN_ST(L_D1, d1); LEAN_ST(L_D2, d2); LEAN_ST(L_D3, d3); LEAN_ST(L_NCMD_LO, ncmd);
     LEAN_ST(L_INSERT, insert_len); LEAN_ST(L_COPY, copy_len); LEAN_ST(L_DCODE, distance_code); LEAN_ST(L_DCTX, distance_context);
     LEAN_ST(L_LITS_LEFT, 0u);
+    LEAN_ST(L_SP_WAITED, waited_out ? 1u : long_cmd ? 2u : 0u);
   }
   lds_sync();
   return rfl(stage);
@@ -3206,7 +3215,7 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   constexpr bool tree_cache = CACHED;
   // (cached tables: a tree that changes keeps its address -- the records' parser is told by a word of the ring's header that the
   // codes it parses with are no longer the ones, and lean_rec_commands starts a new epoch: it compares addresses)
-  auto records_stale = [&]() { if (tree_cache && !CTX_NEVER && rec_base != 0u) { if (lane == 0) lds_st32(rec_base + 4u * (uint32_t)XW_CMD_TREE, 0u); lds_sync(); } };
+  auto records_stale = [&]() { if (tree_cache && rec_base != 0u) { if (lane == 0) lds_st32(rec_base + 4u * (uint32_t)XW_CMD_TREE, 0u); lds_sync(); } };
   static_assert(!CACHED || LDS_ONLY, "the cache is for the loops that read their tables out of LDS");
   auto cached_tree = [&](const uint32_t tree, const uint32_t slot, const uint32_t bytes) -> uint32_t {
     if (!tree_cache) return tree;
@@ -3344,8 +3353,12 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
   // what this wave parses (copier_wave, lean_split_commands).  They stay engaged, idle while the checked stages run, until the
   // metablock is done.
   bool split_on = false, helpers_on = false;
-  if (LDS_ONLY && !CTX_NEVER && hc_ld(HC_NW_ALL) >= 4u && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS && mlen >= (int32_t)SP_MIN_MLEN && (g_engine_mode & 6u) != 6u) {
-    split_on = (g_engine_mode & 2u) == 0u;
+  // (round 6) ... and of a metablock WITHOUT context too, in blocks that have helper waves and no command engine: the records and the hand-written run take
+  // text -- a dozen bytes a command -- at 2.4 times what the one-wave loop does (1024 x lcet10 at -q 5: 10.4 -> 25 GB/s); a stream of long copies and long
+  // literal runs leaves the run at every command, which is noticed after three calls that took next to nothing (rec_off; BROTLI_AMD_ENGINE=norecall: never)
+  const bool rec_plain = CTX_NEVER && (g_engine_mode & 32u) == 0u && !scan_block;
+  if (LDS_ONLY && (!CTX_NEVER || rec_plain) && hc_ld(HC_NW_ALL) >= 4u && hc_ld(HC_KIND) != (uint32_t)HK_NO_ROUNDS && mlen >= (int32_t)SP_MIN_MLEN && (g_engine_mode & 6u) != 6u) {
+    split_on = !CTX_NEVER && (g_engine_mode & 2u) == 0u;
     // the records' ring: what is left of the LDS arena now that the tables of this metablock are built (no large window: a
     // record's distance has at most 24 extra bits); positions count from the dword the reader is in now
     const uint32_t free_at = tree_cache ? TREE_CACHE_BYTES + tree_cache_lit_slots(rfl(args->reserved_)) * TREE_CACHE_LIT_STRIDE : (a.top + 15u) & ~15u;   // (cached tables: behind the cache; `reserved_` is the LDS part's real size)
@@ -3367,7 +3380,22 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
       hc_st(HC_SEQ, hc_ld(HC_SEQ) + 1u);
     }
   }
-  if (LDS_ONLY && !CTX_NEVER && !helpers_on && lane == 0) LEAN_ST(L_SP_REC, 0u);
+  if (LDS_ONLY && !helpers_on && lane == 0) LEAN_ST(L_SP_REC, 0u);
+  uint32_t rec_poor = 0u;   // (a metablock without context) calls of the record loop in a row that took little and ended at a command too long for the run
+  auto rec_off = [&]() {   // ... and the way back to the one-wave loop and its rounds: wave 2 goes back to sleep, as at the metablock's end
+    sp_st(rec_base, XW_STOP, 1u);
+    for (uint32_t spins = 0; sp_ld(rec_base, XW_STOP) != 2u; spins++) {
+      if (spins > SP_SPIN_CAP) { hc_st(HC_KIND, (uint32_t)HK_NO_ROUNDS); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+#ifdef BROTLI_AMD_REC_DEBUG
+    if (blockIdx.x == 0 && lane == 0) printf("rec_off: stop word %u kind %u ncmd %llu mlen %d\n", sp_ld(rec_base, XW_STOP), hc_ld(HC_KIND), (unsigned long long)num_commands, mlen);
+#endif
+    rec_base = 0u; helpers_on = split_on;
+    hc_st(HC_EXT_BASE, 0u);
+    if (lane == 0) LEAN_ST(L_SP_REC, 0u);
+    lds_sync();
+  };
   uint32_t force_checked = 0;  // commands that go through the checked stages before the engine (or the lean loop) is tried again:
                                // the command the engine stopped at, more of them after invocations that got nowhere
 
@@ -3495,6 +3523,8 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         if (!CTX_NEVER) {
           LEAN_ST(L_P1, p1); LEAN_ST(L_P2, p2); LEAN_ST(L_CTX_REGS, ctx_src == CTX_REGS ? 1u : 0u); LEAN_ST(L_TRIVIAL, trivial);
           LEAN_ST(L_CTX_LUT, ctx_lut);
+        } else if (rec_base != 0u) {   // (the record loop's words for a metablock without context: one tree, the context bytes whatever they are)
+          LEAN_ST(L_P1, 0u); LEAN_ST(L_P2, 0u); LEAN_ST(L_CTX_REGS, 1u); LEAN_ST(L_TRIVIAL, 1u); LEAN_ST(L_CTX_LUT, (uint32_t)LDS_CTX_LUT);
         }
       }
       lds_sync();
@@ -3506,8 +3536,21 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
         if (hc_ld(HC_FAILED) != 0u) STOP(E_UNREACHABLE);    // the copier did not answer (never seen)
         engine_commands += LEAN_LD(L_NCMD_LO);
       } else {
-        stage = !CTX_NEVER && rec_base != 0u ? rfl(lean_rec_commands(ctx_tree_v)) : rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
-        if (!CTX_NEVER && rec_base != 0u) engine_commands += LEAN_LD(L_NCMD_LO);
+        stage = rec_base != 0u ? rfl(lean_rec_commands(ctx_tree_v)) : rfl(lean_commands<CTX_NEVER>(lut_vgpr, ctx_tree_v));
+        if (rec_base != 0u) {
+          const uint32_t took_ = LEAN_LD(L_NCMD_LO);
+          engine_commands += took_;
+          // (a metablock without context has another road: what a call of the record loop takes, halved and added up -- a stream of long copies or long
+          // literal runs leaves the run at every command, and every way out costs what forty of its commands do)
+#ifdef BROTLI_AMD_REC_DEBUG
+          if (CTX_NEVER && blockIdx.x == 0 && lane == 0) printf("rec call: took %u waited %u poor %u stage %u ncmd %llu\n", took_, LEAN_LD(L_SP_WAITED), rec_poor, stage, (unsigned long long)num_commands);
+#endif
+          // (a metablock without context has another road.  A stream of long copies or long literal runs leaves the run at every such command, and every way
+          // out costs what forty of the run's commands do: six calls in a row that ended at a LONG command having taken less than sixty-four, and the
+          // one-wave loop and its rounds have the rest of the metablock.  The first commands of a text -- words of the dictionary with their transforms while
+          // the window is empty -- end calls too, but not like that.)
+          if (CTX_NEVER) { if (took_ >= 64u) rec_poor = 0u; else if (LEAN_LD(L_SP_WAITED) == 2u && ++rec_poor >= 6u) rec_off(); }
+        }
       }
       br.buf = (uint64_t)LEAN_LD(L_BUF_LO) | ((uint64_t)LEAN_LD(L_BUF_HI) << 32);
       br.cnt = LEAN_LD(L_CNT); br.next_dw = LEAN_LD(L_NEXT_DW); br.issued_half = LEAN_LD(L_ISSUED);
@@ -3666,6 +3709,7 @@ rounds_again:
         uint32_t part = (uint32_t)i < bl0 ? (uint32_t)i : bl0;
         if (lim < (uint64_t)part) part = (uint32_t)lim;
         if (part >= SPEC_ROUND_MIN) {
+          if (rec_base != 0u) rec_off();   // (a literal run for the helper waves' rounds: wave 2 is one of them -- and a stream of such runs is not the record loop's)
           FLUSH_LITERALS();
           FLUSH_PENDING();
           lds_sync();
@@ -4312,6 +4356,53 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
             if (__ballot(mine != rdlane(mine, 0)) != 0ull) { ctx_never = false; break; }
           }
           s.engine_commands = 1u | (ctx_never ? 2u : 0u) | (rfl((uint32_t)s.mlen) >= ENGINE_ONLY_MIN_MLEN ? 4u : 0u);
+          if (s.engine_commands != 7u) return E_PROBE;
+          // (round 6) ... and are its commands SHORT?  The command engines take a stream of long copies and long literal runs at ten
+          // times what one wave does; text -- a dozen bytes a command -- they take at a tenth of that, and four streams a CU on a wave each
+          // with the command records and the hand-written run (lean_rec_commands) do 2.4 times as much (1024 x lcet10 at -q 5: 10.4 -> 25 GB/s).
+          // What the command codes say -- each of them: of the bytes a code's commands stand for (insert base + copy base, each command by the code's own probability: a
+          // symbol of length L has 2^(8 - L) of the root table's slots, or its share of a second-level table), which part comes from commands that insert or
+          // copy more than 63 bytes -- what the run does not take.  Text: a few per cent; the metric's make-up and the survey's: nine tenths.  Bit 3.
+          {
+            uint32_t ndirect = s.num_direct - 16;
+            uint32_t num_dist_codes = 16 + ndirect + ((s.large_window ? 62u : 24u) << (s.postfix_bits + 1));
+            (void)num_dist_codes;
+            TRY(decode_context_map(s, s.nbt2 << 2, &s.num_dist_trees, &s.dist_ctx_map));
+            TRY(decode_tree_group(s, 256, 256, s.num_lit_trees, &s.lit_trees));
+            TRY(decode_tree_group(s, 704, 704, s.nbt1, &s.cmd_trees));
+            Arena a2 = s.ar; a2.uniformize();
+            bool every_short = true;   // (every command block type's code: the encoder gives a stream's parts codes of their own -- the metric's seed one, its copies another)
+            for (uint32_t ct = 0; ct < rfl(s.nbt1); ct++) {
+            const uint32_t tree = a2.ld32<false>(rfl(s.cmd_trees) + 4u * ct);
+            // (bytes by the code's own probabilities: a slot of the root table weighs 128, a slot of a second-level table of k index bits 128 >> k;
+            // a command's bytes: its insert base + its copy base; LONG: either beyond 63)
+            uint32_t all = 0, lng = 0;
+            auto take = [&](const uint32_t cmd, const uint32_t w) {
+              if (cmd >= 704u) return;
+              const uint32_t cell = cmd >> 6;
+              const uint32_t ins_code = (((0x298500u >> (cell * 2)) & 3u) << 3) | ((cmd >> 3) & 7u), copy_code = (((0x262444u >> (cell * 2)) & 3u) << 3) | (cmd & 7u);
+              const uint32_t ib = kInsBase[ins_code], cb = kCopyBase[copy_code], v = (ib + cb) * w;
+              all += v; if (ib > 63u || cb > 63u) lng += v;
+            };
+            auto entry = [&](const uint32_t off) -> uint32_t { return off < a2.lds_limit ? lds_ld16(LDS_FIXED + off) : (uint32_t)*reinterpret_cast<gu16*>(a2.glb + off); };
+            for (uint32_t k = 0; k < 4u; k++) {
+              const uint32_t e = entry(tree + ((lane_id() * 4u + k) << 1));
+              const uint32_t len = e & 15u;
+              if (len == 0u) continue;
+              if (len <= (uint32_t)ROOT_BITS) take(e >> 4, 128u);
+              else {
+                const uint32_t kb = len - (uint32_t)ROOT_BITS;   // (a pointer: its second-level table has 2^kb slots from entry e >> 4 on)
+                for (uint32_t j2 = 0; j2 < (1u << kb); j2++) take(entry(tree + (((e >> 4) + j2) << 1)) >> 4, 128u >> kb);
+              }
+            }
+            for (uint32_t m = 32u; m != 0u; m >>= 1) { all += __shfl_xor(all, m); lng += __shfl_xor(lng, m); }
+            if (!(all != 0u && lng < all / PROBE_SHORT_COMMANDS)) every_short = false;
+#ifdef BROTLI_AMD_REC_DEBUG
+            if (blockIdx.x < 2u && lane_id() == 0) printf("probe: block %u code %u of %u: all %u long %u tree %u lds_limit %u mlen %d\n", blockIdx.x, ct, s.nbt1, all, lng, tree, a2.lds_limit, s.mlen);
+#endif
+            }
+            if (every_short) s.engine_commands |= 8u;
+          }
           return E_PROBE;
         }
         uint32_t ndirect = s.num_direct - 16;
@@ -4737,8 +4828,9 @@ extern "C" hipError_t BROTLI_AMD_LAUNCH(const BrotliAmdStreamDesc* descs, Brotli
       // "split" turns it on); bit 2: no command records ("norec")
       // bit 3: the path engine as two engines of eight waves that take the stream's regions in turns ("path2"; experiment)
       // bit 4: tables beyond the LDS part are read where they lie instead of the trees in use being cached ("nocache": A/B)
+      // bit 5: NO command records for metablocks without context ("norecall": A/B -- round 6 gave such metablocks the records and the hand-written run in blocks with helper waves)
       // (static storage: the asynchronous copy reads it after this function has returned)
-      static const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : strcmp(eng, "nocache") == 0 ? 18u : 2u;
+      static const uint32_t mode = strcmp(eng, "scan") == 0 ? 3u : strcmp(eng, "split") == 0 ? 0u : strcmp(eng, "norec") == 0 ? 6u : strcmp(eng, "path2") == 0 ? 10u : strcmp(eng, "nocache") == 0 ? 18u : strcmp(eng, "norecall") == 0 ? 34u : 2u;
       hipError_t e2 = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_engine_mode), &mode, sizeof mode, 0, hipMemcpyHostToDevice, stream);
       if (e2 != hipSuccess) return e2;
     }
