@@ -458,7 +458,7 @@ def main():
             legs = []
             if w.encoder_available():
                 legs += [("longbackref_512x4MiB", 3, None), ("longbackrefq9_256x4MiB", 5, None), ("longbackref_1024x1MiB", 5, None), ("longbackref_4096x1MiB", 3, None),
-                         ("recompressed:lcet10.txt.compressedq5x1024", 3, None), ("recompressed:lcet10.txt.compressedq5x256", 3, None),
+                         ("recompressed:lcet10.txt.compressedq5x1024", 3, None), ("recompressed:lcet10.txt.compressedq5x256", 3, None), ("recompressed:mapsdatazrh.compressedq5x1024", 3, None),
                          ("surveymix_256x4MiB", 5, None), ("longbackref_32x4MiB", 5, None), ("longbackrefmix_200", 3, None), ("longbackref_1x64MiB", 3, 1)]
                 if os.environ.get("BROTLI_BENCH_NO_1GIB") is None:
                     legs.append(("longbackref_1x1024MiB", 1, 1))  # BASELINE config 3 as written: ONE stream of 1 GiB
@@ -471,7 +471,7 @@ def main():
                     extra.append({"id": name, "error": str(ex)[:100]})
             out["extra_legend"] = ("id = bench.py --workload name (alice29x1024 = BASELINE config 2; highentropy_256x4MiB = config 4; longbackref_1x1024MiB = config 3 as written, ONE 1 GiB stream, "
                                    "1x64MiB the same at 64 MiB; surveymix = SURVEY 8(a1)'s make-up, a quarter of each stream Zipf seed; 512x4MiB = the metric's streams twice; q9 = the metric's data at -q9; "
-                                   "1024x1MiB = its make-up in 1 MiB streams (four a CU: engine blocks, the device's choice), 4096x1MiB = sixteen a CU (one-wave blocks: streams in flight); recompressed:lcet10 = real text at -q5, 256 / 1024 copies); n streams, D / C bytes out / in, MBps decompressed whole job, "
+                                   "1024x1MiB = its make-up in 1 MiB streams (four a CU: engine blocks, the device's choice), 4096x1MiB = sixteen a CU (one-wave blocks: streams in flight); recompressed:lcet10 = real text at -q5, 256 / 1024 copies -- 1024: four a CU on a wave each with the command records, the device's choice since round 6; recompressed:mapsdatazrh = the reference's map-tile fixture at -q5, 1024 copies: neither text nor long copies, one-wave blocks); n streams, D / C bytes out / in, MBps decompressed whole job, "
                                    "frac = (C+D)/t/8 TB/s, dfrac = D/t/8 TB/s, traffic = HBM bytes a launch from profiles/pmc_r*_<id>.json (null: no PMC pass committed), Mcmd_s = million commands/s, "
                                    "B_cmd bytes a command, eng = share of commands a command engine took, pass2 = streams that needed a second launch, cus = blocks (CUs) that worked on each stream (batches of up to half the CUs' streams: gangs of 8 / 4 / 2; 32x4MiB = 32 of the metric's streams, eight blocks each; mix_200 = one 64 MiB stream among 199 of 1 MiB, a POOL launch: blocks without a stream of their own help the largest stream still being decoded), cpu = [oracle MB/s on all host threads, on 1 thread, threads]")
             out["extra_configs"] = extra

@@ -66,10 +66,13 @@ constexpr int E_EXUBERANT_NIBBLE = -1, E_RESERVED = -2, E_EXUBERANT_META_NIBBLE 
               E_PADDING_2 = -15, E_DISTANCE = -16, E_UNREACHABLE = -31;
 constexpr int E_RETRY_ARENA = 100;  // internal: see BROTLI_AMD_FLAG_NO_SPILL
 constexpr int E_PROBE = 101;        // internal: see BROTLI_AMD_FLAG_PROBE
-#ifndef BROTLI_AMD_PROBE_SHORT
-#define BROTLI_AMD_PROBE_SHORT 4
+#ifndef BROTLI_AMD_PROBE_LONG_PERCENT
+#define BROTLI_AMD_PROBE_LONG_PERCENT 75
 #endif
-constexpr uint32_t PROBE_SHORT_COMMANDS = BROTLI_AMD_PROBE_SHORT;   // a stream's commands are "short" (the probe's bit 3) where, by its first command code's own probabilities, less than this share -- one in so many -- of its BYTES comes from commands that insert or copy more than 63
+// A stream is the command engines' kind by its commands where, by SOME command code's own probabilities, at least this share of the code's BYTES comes from commands
+// that insert or copy more than 63 bytes; otherwise its commands are "short" (the probe's bit 3).  Text: 4 - 11 %; map tiles 33 - 60 %: the engines take them at a
+// quarter of what one-wave blocks do; the metric's make-up and the survey's: one of their codes 97 - 99 %.
+constexpr uint32_t PROBE_LONG_PERCENT = BROTLI_AMD_PROBE_LONG_PERCENT;
 
 // ---- small constant tables (RFC 7932 sections 3.5, 4, 5, 6) ----
 // (decode.rs:801-853's three small tables -- kCodeLengthCodeOrder = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15},
@@ -4396,7 +4399,7 @@ __device__ __forceinline__ int decode_stream(Stream& s, bool have_header, uint64
               }
             }
             for (uint32_t m = 32u; m != 0u; m >>= 1) { all += __shfl_xor(all, m); lng += __shfl_xor(lng, m); }
-            if (!(all != 0u && lng < all / PROBE_SHORT_COMMANDS)) every_short = false;
+            if (all == 0u || (uint64_t)lng * 100u >= (uint64_t)all * PROBE_LONG_PERCENT) every_short = false;
 #ifdef BROTLI_AMD_REC_DEBUG
             if (blockIdx.x < 2u && lane_id() == 0) printf("probe: block %u code %u of %u: all %u long %u tree %u lds_limit %u mlen %d\n", blockIdx.x, ct, s.nbt1, all, lng, tree, a2.lds_limit, s.mlen);
 #endif
