@@ -463,13 +463,14 @@ def main():
                 if os.environ.get("BROTLI_BENCH_NO_1GIB") is None:
                     legs.append(("longbackref_1x1024MiB", 1, 1))  # BASELINE config 3 as written: ONE stream of 1 GiB
                 legs.append(("highentropy_256x4MiB", 5, None))
+            legs.append(("alice29x4096", 3, None))    # (sixteen streams a CU: four-wave blocks that take them off the queue, the device's choice since round 6)
             legs.append(("alice29x1024", 10, None))   # (the BASELINE configurations last: the end of the line is what a truncated copy keeps)
             for name, steps, nu in legs:
                 try:
                     extra.append(time_single_gpu(pkg, torch, dev, name, steps, 0 if name == "longbackref_1x1024MiB" else 1, nu, cpu_budget_s=0.0 if args.no_cpu_baseline else 3.0))
                 except SystemExit as ex:  # a failing leg must not hide the headline
                     extra.append({"id": name, "error": str(ex)[:100]})
-            out["extra_legend"] = ("id = bench.py --workload name (alice29x1024 = BASELINE config 2; highentropy_256x4MiB = config 4; longbackref_1x1024MiB = config 3 as written, ONE 1 GiB stream, "
+            out["extra_legend"] = ("id = bench.py --workload name (alice29x1024 = BASELINE config 2; alice29x4096 = the same fixture sixteen a CU; highentropy_256x4MiB = config 4; longbackref_1x1024MiB = config 3 as written, ONE 1 GiB stream, "
                                    "1x64MiB the same at 64 MiB; surveymix = SURVEY 8(a1)'s make-up, a quarter of each stream Zipf seed; 512x4MiB = the metric's streams twice; q9 = the metric's data at -q9; "
                                    "1024x1MiB = its make-up in 1 MiB streams (four a CU: engine blocks, the device's choice), 4096x1MiB = sixteen a CU (one-wave blocks: streams in flight); recompressed:lcet10 = real text at -q5, 256 / 1024 copies -- 1024: four a CU on a wave each with the command records, the device's choice since round 6; recompressed:mapsdatazrh = the reference's map-tile fixture at -q5, 1024 copies: neither text nor long copies, one-wave blocks); n streams, D / C bytes out / in, MBps decompressed whole job, "
                                    "frac = (C+D)/t/8 TB/s, dfrac = D/t/8 TB/s, traffic = HBM bytes a launch from profiles/pmc_r*_<id>.json (null: no PMC pass committed), Mcmd_s = million commands/s, "

@@ -320,7 +320,13 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
   std::vector<uint8_t> kind;
   for (uint32_t i = 0; i < n; i++) b->h_descs[i].flags &= ~(BROTLI_AMD_FLAG_ENGINE_ONLY | BROTLI_AMD_FLAG_DEFER);
   b->last_probe_ms = 0.0f;
-  if (can16 && !no_wide && b->auto_arena && b->grid > b->cus && n <= queue_max * b->cus) {
+  // (round 6) ... and beyond that many: one-wave blocks, fourteen a CU -- unless the streams are the RECORD LOOP's: context-modelled ones and text (the probe's
+  // kinds 5 and 15), which four-wave blocks, four a CU, taking the streams off the queue one after the other, decode half as fast again as fourteen
+  // one-wave blocks a CU do (4096 x alice29: 13.2 -> 19+ GB/s; 4096 x lcet10 at -q 5: 16.6 -> 24+): the same probe says which
+  const bool few = n <= queue_max * b->cus;
+  static const bool no_record_blocks = getenv("BROTLI_AMD_NO_RECORD_BLOCKS") != nullptr;  // (experiments)
+  bool record_blocks = false;
+  if (b->auto_arena && b->grid > b->cus && (few ? can16 && !no_wide : !no_record_blocks)) {
     // more streams than CUs, few enough for engine blocks to pay where the streams are the engines' kind: the device says which are.
     // Not for batches of small streams (a mean of less than 8 KiB compressed: an engine has nothing to spread out, and the probe -- a
     // launch and a wait on the caller's stream -- would cost such a batch more than its decode), and not twice for the same descriptors.
@@ -347,9 +353,15 @@ int submit(BrotliAmdBatch* b, uint32_t n, hipStream_t stream) {  // h_descs[0..n
         for (int k = 0; k < 8; k++) if (r[k]) fprintf(stderr, " %d:%u", k, r[k]);
         fprintf(stderr, "\n");
       }
-      if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; }
+      if (few) { if (in_engine * 2u >= in_total && in_engine != 0u) { engine_queue = true; b->grid = b->cus; b->cur_per_cu = 0; } }
+      else {
+        uint64_t in_rec = 0;
+        for (uint32_t i = 0; i < n; i++) if (kind[i] == 5u || kind[i] == 15u) in_rec += b->h_descs[i].in_size;
+        record_blocks = in_rec * 2u >= in_total && in_rec != 0u;
+      }
     }
   }
+  if (record_blocks) { b->cur_arena = b->lds_arena; b->cur_per_cu = 0; b->grid = std::min(n, b->grid_max); b->waves = 4u; }
   if (can16 && b->grid <= b->cus) { b->cur_arena = arena16; b->waves = 16; }
   // Fewer streams than half the CUs: GANGS of blocks, a CU each, on one stream -- its owner and one, three or seven helper blocks that take
   // the path engine's regions in turns with it (csrc/brotli_path_engine.h, PE_CFG_REMOTE).  Eight streams' gangs are launched side by side,
