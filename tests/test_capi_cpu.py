@@ -3,6 +3,7 @@ loudly (never silently) when no HIP device is usable."""
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -138,3 +139,12 @@ def test_how_many_blocks_a_stream_gets(lib):
     assert _plan(lib, [big] + [100_000] * 39, pool_env=0) == (4, 160)
     assert _plan(lib, [MB] * 200, pool_env=2) == (0x108, 256)
     assert _plan(lib, [MB] * 100, pool_env=2) == (2, 208)      # (where there are gangs, a forced pool does not replace them)
+
+
+def test_the_hand_written_run_is_what_its_generator_writes(tmp_path):
+    """csrc/brotli_rec_run_asm.h (LEAN_REC_RUN_ASM: the record loop's plain commands) is GENERATED by tools/gen_rec_asm.py: the committed
+    header and the script must not drift apart"""
+    import subprocess
+    out = tmp_path / "run.h"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_rec_asm.py"), "--out=" + str(out)], stdout=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "rust-brotli-decompressor_amd", "csrc", "brotli_rec_run_asm.h")).read()

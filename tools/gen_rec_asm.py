@@ -679,6 +679,9 @@ def main():
         out.append('  "%s%s"%s \\' % (text, sep, c))
     out[-1] = out[-1][:-2]
     path = os.path.join(ROOT, "rust-brotli-decompressor_amd", "csrc", "brotli_rec_run_asm_wait.h" if PROFILE_WAIT else "brotli_rec_run_asm.h")
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):   # (tests: the committed header is what this script writes)
+            path = a[len("--out="):]
     open(path, "w").write("\n".join(out) + "\n")
     print("wrote", path, len(lines), "lines")
 
