@@ -1448,12 +1448,13 @@ __device__ unsigned long long g_split_prof[40];
 // position or marked unusable -- nothing depends on a guess.
 //   record: word 0 = copy length (16 bits) | bits of the command (head, or head + distance) << 16 | flags; word 1 = insert
 //   length (commands with literals), else the distance (explicit) or the distance symbol (ring codes 0..15).
-constexpr uint32_t SPX_POS = 1024u;                   // ring size in stream bits
+constexpr uint32_t SPX_POS = 1024u;                   // ring size in stream bits (at most: see XW_RING_MASK)
+constexpr uint32_t SPX_POS_MIN = 512u;                // ... and at least: a metablock whose tables leave less room than that has no records
 constexpr uint32_t SPX_CTL_BYTES = 256u;
 constexpr uint32_t SPX_BYTES = SPX_CTL_BYTES + SPX_POS * 8u;
 enum { XW_FRONT = 0 /* u64: positions below are written (low), for parameter epoch (high) */, XW_POS = 2 /* the parser's position (lags) */,
        XW_EPOCH = 3, XW_STOP = 4, XW_ORIGIN_DW = 5, XW_LIMIT = 6, XW_CMD_TREE = 7, XW_DT0 = 8, XW_POSTFIX = 12, XW_NUM_DIRECT = 13,
-       XW_DICT_LO = 14, XW_DICT_HI = 15 /* the static dictionary (device address) */, XW_WORDS = 16 };
+       XW_DICT_LO = 14, XW_DICT_HI = 15 /* the static dictionary (device address) */, XW_RING_MASK = 16 /* the ring's positions less one: SPX_POS - 1, or half of that where the arena has no more room (round 6) */, XW_WORDS = 17 };
 enum : uint32_t { XR_VALID = 1u << 23, XR_LITERALS = 1u << 24, XR_IMPLICIT = 1u << 25, XR_DCTX_SHIFT = 26, XR_SHORT = 1u << 28,
        XR_NOT_RUN = 1u << 31 /* not a record the hand-written run takes: not valid, or a copy of more than 63 bytes (its tests are one sign test) */ };
 __device__ __noinline__ void rec_wave();
@@ -2390,7 +2391,7 @@ __device__ __noinline__ void rec_wave() {
   uint32_t lut = 0;  // per-lane image of the insert / copy code tables (as the decoding wave's)
   if (lane < 24) lut = (uint32_t)kInsBase[lane] | ((uint32_t)kInsExtra[lane] << 16);
   else if (lane >= 32 && lane < 56) lut = (uint32_t)kCopyBase[lane - 32] | ((uint32_t)kCopyExtra[lane - 32] << 16);
-  const uint32_t origin_dw = sp_ld(xb, XW_ORIGIN_DW), limit = sp_ld(xb, XW_LIMIT);
+  const uint32_t origin_dw = sp_ld(xb, XW_ORIGIN_DW), limit = sp_ld(xb, XW_LIMIT), ring_mask = sp_ld(xb, XW_RING_MASK);
   uint32_t epoch = 0, F = 0, cmd_tree = 0, dt0 = 0, dt1 = 0, dt2 = 0, dt3 = 0, postfix_bits = 0, num_direct = 0, idle = 0;
   for (;;) {
     if (sp_ld(xb, XW_STOP) != 0u) break;
@@ -2405,7 +2406,7 @@ __device__ __noinline__ void rec_wave() {
     }
     if (epoch == 0u) { __builtin_amdgcn_s_sleep(8); continue; }
     if (F < (pos & ~63u)) F = pos & ~63u;  // the parser went ahead (literals, commands by hand)
-    if (F + 64u > limit || F + 64u > pos + (SPX_POS - 64u)) {  // the end of what may be read, or a lap ahead of the parser
+    if (F + 64u > limit || F + 64u > pos + (ring_mask - 63u)) {  // the end of what may be read, or a lap ahead of the parser
       idle++;  // (a lap is some forty commands: the parser is a long way off; polling costs the parser on this SIMD its issue slots)
       if (idle < 4u) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(64);
       continue;
@@ -2433,7 +2434,7 @@ __device__ __noinline__ void rec_wave() {
     w0 |= (bits & 127u) << 16;
     if (valid) w0 |= XR_VALID;
     if (!valid || h.copy > 63u) w0 |= XR_NOT_RUN;
-    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[ring + ((p & (SPX_POS - 1u)) << 3)]) = ((uint64_t)w1 << 32) | w0;
+    *reinterpret_cast<__attribute__((address_space(3))) uint64_t*>(&g_smem[ring + ((p & ring_mask) << 3)]) = ((uint64_t)w1 << 32) | w0;
     F += 64u;
     lds_release();
     if (lane == 0) *reinterpret_cast<volatile __attribute__((address_space(3))) uint64_t*>(&g_smem[xb + 4u * XW_FRONT]) = ((uint64_t)epoch << 32) | F;
@@ -2467,7 +2468,7 @@ __device__ __noinline__ void rec_wave() {
 #define LRA_WAIT_OPERAND
 #define LRA_WAIT_CLOBBERS
 #endif
-static_assert(XR_VALID == 0x800000u && XR_LITERALS == 0x1000000u && XR_IMPLICIT == (1u << 25) && XR_DCTX_SHIFT == 26 && XR_SHORT == (1u << 28) && XR_NOT_RUN == (1u << 31) && SPX_POS == 1024u, "LEAN_REC_RUN_ASM spells these out");
+static_assert(XR_VALID == 0x800000u && XR_LITERALS == 0x1000000u && XR_IMPLICIT == (1u << 25) && XR_DCTX_SHIFT == 26 && XR_SHORT == (1u << 28) && XR_NOT_RUN == (1u << 31), "LEAN_REC_RUN_ASM spells these out");
 
 // The lean loop of a context-modelled metablock whose command records are there (rec_wave): nothing of a command's head is
 // parsed here, and a command without literals is not parsed at all -- copy length, distance and the bits to skip come out of
@@ -2534,11 +2535,12 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
   uint32_t distance_context = 0;
 
   const uint32_t xb = hc_ld(HC_EXT_BASE), xring = xb + SPX_CTL_BYTES;
-  const uint32_t origin_bits = LEAN_LD(L_SP_ORIGIN) << 5;
+  const uint32_t origin_bits = LEAN_LD(L_SP_ORIGIN) << 5, ring_mask = sp_ld(xb, XW_RING_MASK);
   uint32_t front_c = 0;
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   u32x2 rec_v = {0u, 0u};
   uint32_t my_epoch = sp_ld(xb, XW_EPOCH);
+  bool new_epoch = false;   // (wave 2 starts over at the reader's position: its first records are a thousand clocks away, not there yet)
   {
     // the prefix codes the records are parsed with: new ones (the first time, after a block switch) start a new epoch
     const bool same = my_epoch != 0u && sp_ld(xb, XW_CMD_TREE) == LDS_FIXED + cmd_tree && sp_ld(xb, XW_DT0) == LDS_FIXED + dt0 && sp_ld(xb, XW_DT0 + 1) == LDS_FIXED + dt1 &&
@@ -2551,6 +2553,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
       my_epoch++;
       lds_release();
       sp_st(xb, XW_EPOCH, my_epoch);
+      new_epoch = true;
     }
   }
   // the record at the reader's position, once wave 2 has written it (rel: stream bits from the ring's origin)
@@ -2564,7 +2567,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
       front_c = rfl((uint32_t)(f >> 32)) == my_epoch ? rfl((uint32_t)f) : 0u;
       if (rel >= front_c) return false;
     }
-    rec_v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(&g_smem[xring + ((rel & (SPX_POS - 1u)) << 3)]);
+    rec_v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(&g_smem[xring + ((rel & ring_mask) << 3)]);
     return true;
   };
   // the copy in flight goes to memory (its bytes have arrived)
@@ -2572,6 +2575,9 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
     if (pend_n) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pend_store8(out + pend_pos, pend_n, lane); pend_n = 0; }
   };
   bool rec_ok = request();
+  // (behind a block switch the records are parsed anew: waiting for the first of them here -- a thousand clocks -- instead of leaving, which sends a command through the checked
+  // loop at ten times that: twenty block switches a stream of alice29)
+  if (new_epoch) for (uint32_t spins = 0; !rec_ok && spins < 96u; spins++) { __builtin_amdgcn_s_sleep(4); rec_ok = request(); }
   bool waited_out = false;   // (the loop is left because the records are not there: not a verdict on the stream's commands, see process_commands)
   bool long_cmd = false;     // (... because of a command longer than the run takes: that is one)
   static const bool no_run_asm = false;
@@ -2609,7 +2615,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_rec_commands
             [ok] "+s"(ok), [p1] "+s"(p1s), [p2] "+s"(p2s), [said] "+s"(saids), [front] "+s"(fronts), [rx] "+v"(rx), [ry] "+v"(ry) LRA_WAIT_OPERAND
           : [cur] "v"(br.cur), [lane] "v"(lane), [lut0] "v"(lut0v), [lut1] "v"(lut1v), [ctxtree] "v"(ctx_tree_abs), [dlut] "v"(dlut), [params] "v"(run_params), [wtab] "v"(run_wtab), [mtab] "v"(run_mtab),
             [cb] "s"(br.chunk_base), [outlo] "s"((uint32_t)(uintptr_t)out), [outhi] "s"((uint32_t)((uint64_t)(uintptr_t)out >> 32)),
-            [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [org] "s"(origin_bits),
+            [maxb] "s"(max_backward), [lim] "s"(lim), [xring] "s"(xring), [rmask] "s"(ring_mask), [org] "s"(origin_bits),
             [littree] "s"(rfl(LDS_FIXED + lit_tree)), [trivial] "s"(rfl(trivial))
           : "memory", "vcc", "scc", "m0", LRA_WAIT_CLOBBERS "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99",
             "v115", "v116", "v117", "v118", "v119", "v124");
@@ -2880,7 +2886,7 @@ __device__ __noinline__ __attribute__((aligned(256))) uint32_t lean_split_comman
       if (rel_ < 0x40000000u) { \
         if (rel_ >= front_c) { const uint64_t f_ = *reinterpret_cast<volatile __attribute__((address_space(3))) uint64_t*>(&g_smem[xb + 4u * XW_FRONT]); \
           front_c = rfl((uint32_t)(f_ >> 32)) == my_epoch ? rfl((uint32_t)f_) : 0u; lds_acquire(); SPLIT_COUNT(14, 1); } \
-        if (rel_ < front_c) { rec_v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(&g_smem[xring + ((rel_ & (SPX_POS - 1u)) << 3)]); rec_ok = true; } } } } while (0)
+        if (rel_ < front_c) { rec_v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2*>(&g_smem[xring + ((rel_ & sp_ld(xb, XW_RING_MASK)) << 3)]); rec_ok = true; } } } } while (0)
 
   // one record: lane 0 writes its four words, then the head (LDS operations of a wave execute in order)
 #define SP_POST(W0_, W1_, W2_, W3_) do { \
@@ -3367,14 +3373,19 @@ __device__ __noinline__ int process_commands(HotArgs* args) {
     const uint32_t free_at = tree_cache ? TREE_CACHE_BYTES + tree_cache_lit_slots(rfl(args->reserved_)) * TREE_CACHE_LIT_STRIDE : (a.top + 15u) & ~15u;   // (cached tables: behind the cache; `reserved_` is the LDS part's real size)
     const uint32_t lds_room = tree_cache ? rfl(args->reserved_) : a.lds_limit;
     const uint32_t origin_dw = (br.next_dw - ((br.cnt + 31u) >> 5)) & ~1u;
-    if ((g_engine_mode & 4u) == 0u && lds_room >= free_at + SPX_BYTES && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u) rec_base = LDS_FIXED + free_at;
+    const uint32_t ring_pos = lds_room >= free_at + SPX_BYTES ? SPX_POS : SPX_POS_MIN;   // (round 6: half a ring where the tables leave no room for a whole one -- text at -q 11 in blocks of four waves)
+    if ((g_engine_mode & 4u) == 0u && lds_room >= free_at + SPX_CTL_BYTES + ring_pos * 8u && rfl(args->large_window) == 0u && br.end_dw > origin_dw + 80u) rec_base = LDS_FIXED + free_at;
+#ifdef BROTLI_AMD_REC_DEBUG
+    if (blockIdx.x == 0 && lane == 0) printf("records: room %u free_at %u need %u cache %d -> %s\n", lds_room, free_at, (uint32_t)SPX_BYTES, (int)tree_cache, rec_base != 0u ? "yes" : "no");
+#endif
     if (split_on || rec_base != 0u) {
       helpers_on = true;
       lds_sync();
       hc_st(HC_EXT_BASE, rec_base);
       if (rec_base != 0u && lane < (uint32_t)XW_WORDS)
         lds_st32(rec_base + 4u * lane, lane == (uint32_t)XW_ORIGIN_DW ? origin_dw : lane == (uint32_t)XW_LIMIT ? ((br.end_dw - origin_dw - 8u) << 5) & ~63u :
-                                       lane == (uint32_t)XW_DICT_LO ? (uint32_t)(uintptr_t)dict : lane == (uint32_t)XW_DICT_HI ? (uint32_t)((uint64_t)(uintptr_t)dict >> 32) : 0u);
+                                       lane == (uint32_t)XW_DICT_LO ? (uint32_t)(uintptr_t)dict : lane == (uint32_t)XW_DICT_HI ? (uint32_t)((uint64_t)(uintptr_t)dict >> 32) :
+                                       lane == (uint32_t)XW_RING_MASK ? ring_pos - 1u : 0u);
       if (split_on && lane < (uint32_t)CW_WORDS)
         lds_st32(sp_ctl_base() + 4u * lane, lane == (uint32_t)CW_OUT_LO ? (uint32_t)(uintptr_t)out : lane == (uint32_t)CW_OUT_HI ? (uint32_t)((uint64_t)(uintptr_t)out >> 32) : 0u);
       if (lane == 0) { LEAN_ST(L_SP_HEAD, 0u); LEAN_ST(L_SP_LIT, 0u); LEAN_ST(L_SP_ORIGIN, origin_dw); LEAN_ST(L_SP_REC, rec_base != 0u ? 1u : 0u); }

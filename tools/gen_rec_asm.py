@@ -261,7 +261,7 @@ s_cbranch_scc1 {tell}f
 s_cmp_ge_u32 s95, %[front]
 s_cbranch_scc1 {look}f
 {have}:
-s_and_b32 s95, s95, 0x3ff
+s_and_b32 s95, s95, %[rmask]
 s_lshl_b32 s95, s95, 3
 s_add_u32 s95, s95, %[xring]
 v_mov_b32 %[rx], s95
@@ -356,6 +356,7 @@ s_lshl_b32 s82, %[cb], 5
 s_sub_u32 s82, s82, %[org]""", "POS, LIMM1 (signed: a window that has no room left says so), RB")
     # ---------------- top of the loop ----------------
     A.m("""
+.p2align 6
 1:
 s_waitcnt lgkmcnt(0)
 v_readfirstlane_b32 s90, %[rx]
