@@ -608,6 +608,36 @@ def test_context_modelled_streams_with_and_without_the_helper_waves(pkg, copies)
         assert all(r[5] >= 0.9 * r[4] for i, r in enumerate(rows[mode]) if i % 7 < 4), (mode, rows[mode][:7])
 
 
+def test_text_at_every_quality_in_blocks_of_four_waves(pkg):
+    """The reference's text fixtures encoded again at -q 1, 5, 9 and 11 (window 22; at 11 a metablock's tables leave LDS no room for a
+    whole ring of command records: wave 2 writes half a ring, XW_RING_MASK), a valid copy, a truncated and a damaged one each, more streams
+    than four a CU: blocks of four waves whose wave 2 parses records (rec_wave / lean_rec_commands).  Status words and bytes the oracle's."""
+    ref = _enc()
+    gold = os.path.join(ROOT, "tests", "golden", "testdata")
+    rnd = random.Random(77)
+    uniq, caps = [], []
+    for n in ("lcet10.txt.compressed", "plrabn12.txt.compressed"):
+        _, raw = oracle.decode(open(os.path.join(gold, n), "rb").read(), 1 << 20, 1)
+        for q in (1, 5, 9, 11):
+            c = ref.encode(raw, q, 22)
+            bad = bytearray(c); bad[rnd.randrange(len(c) // 4, len(c))] ^= 1 << rnd.randrange(8)
+            uniq += [c, c[: rnd.randrange(len(c) // 2, len(c))], bytes(bad)]; caps += [len(raw)] * 3
+    want = [oracle.decode(d, cap, 1) for d, cap in zip(uniq, caps)]
+    copies = 48                                                 # 24 x 48 = 1152 streams > 4 x 256 CUs
+    b = pkg.Batch(len(uniq) * copies)
+    res, outs = b.decode_host(uniq * copies, caps * copies, 1)
+    b.close()
+    wrong = []
+    for i, (r, o) in enumerate(zip(res, outs)):
+        info, exp = want[i % len(uniq)]
+        if (r.result, r.error_code, r.decoded_size, o) != (info.result, info.error_code, info.decoded_size, exp) or \
+                (info.result == 1 and (r.consumed, r.num_commands, r.num_metablocks) != (info.consumed, info.num_commands, info.num_metablocks)):
+            wrong.append((i, r.result, r.error_code, r.decoded_size, info.result, info.error_code, info.decoded_size))
+    assert not wrong, (len(wrong), wrong[:8])
+    valid = [r for i, r in enumerate(res) if i % 3 == 0]
+    assert sum(r.engine_commands for r in valid) >= 0.9 * sum(r.num_commands for r in valid)
+
+
 def test_batches_and_one_shot_calls_from_several_threads(pkg):
     """Contexts of different block shapes launched from several threads at once (engine blocks of sixteen waves, small
     batches of one-wave blocks, one-shot calls): setting the kernel's LDS attribute and launching is one critical section
