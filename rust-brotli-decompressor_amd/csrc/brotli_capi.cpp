@@ -661,6 +661,17 @@ extern "C" int BrotliAmdBatchWait(BrotliAmdBatch* b, BrotliAmdResult* results) {
               b->last_gang, st[0], st[1], st[2], st[10], st[11], st[12], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[13], st[14], st[15], st[16], st[18], st[20], st[19], st[17], st[21], st[23], st[22], st[24], st[25], st[26], st[27], st[28], st[29], st[38], st[30], st[31], st[32], st[33], st[34], st[36], st[37], st[35], st[39]);
   }
 #endif
+#ifdef BROTLI_AMD_GANG_TRACE
+  if (b->last_gang > 1u && b->d_gang) {   // (profile build: the first regions of one invocation of the first stream's gang, the shared 100 MHz clock at every hand-over)
+    static unsigned long long tr[64][16];
+    if (hipMemcpy(tr, b->d_gang + 1024 + (40u << 10), sizeof tr, hipMemcpyDeviceToHost) == hipSuccess)
+      for (int k = 0; k < 64 && tr[k][6]; k++) {
+        fprintf(stderr, "GT %d blk %llu m %llu ndep %llu :", k, tr[k][15] >> 32, tr[k][15] & 0xffffull, (tr[k][15] >> 16) & 0xffffull);
+        for (int q = 0; q < 15; q++) fprintf(stderr, " %llu", tr[k][q]);
+        fprintf(stderr, "\n");
+      }
+  }
+#endif
   if (retry_with_larger_arenas(b) != 0) return -1;
   if (b->exact_limit && settle_output_limits(b) != 0) return -1;
   if (results) {

@@ -58,6 +58,7 @@ constexpr uint32_t PE_GROW_BELOW = PE_WCAP / 4u;  // closure states below which 
 constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluation takes; a run that needs more goes on in the lane's next evaluation
 constexpr uint32_t PE_SYNC_ROUNDS = GW + 1;  // rounds between waves the chunk entries get to settle: enough for any code
 constexpr uint32_t PE_CMDS = PE_RBL / 32u;          // commands one region's walk lists at most
+constexpr uint32_t PE_DEP_ROUNDS = 6;             // levels of copies that build on each other which go side by side (execute); deeper ones in order
 constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this long are stored by their command's lane, four bytes a step
 #ifndef BROTLI_AMD_PE_LANE_COPY
 #define BROTLI_AMD_PE_LANE_COPY 16
@@ -127,6 +128,7 @@ constexpr uint32_t PE_RS = PE_NEXT + 4 * PE_CMDS;                   // 64 bytes 
 constexpr uint32_t PE_DLIST = PE_NEXT;                            // u16 per copy that reads the region's own output: its command (the records are dead by then)
 constexpr uint32_t PE_WLIST = PE_NEXT + 4 * PE_CMDS + 1024;        // u16 per command whose copy is a word of the static dictionary that goes out inside the pass (PE_DICT)
 static_assert(PE_WLIST + 2 * PE_CMDS <= PE_NEXT + PE_STATES * 2, "the words' list lies in the records' room");
+static_assert(5u * PE_CMDS <= PE_RANKS * 2u, "the dependent copies' ranges and levels lie in the ranks' room");
 constexpr uint32_t PE_WSTB = PE_WCAP * 2 > PE_CMDS * 16 ? PE_WCAP * 2 : PE_CMDS * 16;  // (bytes of that room: its larger tenant)
 constexpr uint32_t PE_LIST = PE_WST + PE_WSTB;                    // u16 per listed command (+ 1): its state as bit | kind << 15
 constexpr uint32_t PE_ANCH = PE_LIST + (PE_CMDS + 8) * 2;         // u32 per anchor of the walk: list index | state id << 16
@@ -173,7 +175,7 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_DEPCHG = 107 /* the dependent copies' levels: bit r, round r changed one */, PEC_DEPLV0 = 108 /* ... levels of the copies that do not lag */, PEC_DEPLV1 = 109 /* ... and of those that do */, PEC_DEPDEEP = 110 /* ... some are deeper than the rounds go */, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
        PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */, PEC_SCRATCH = 130 /* stores that are not meant land here */, PEC_GBAR = 131 /* the engine's barrier: arrivals so far */,
        // two engines (words of the shared block): what they tell each other
        PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
@@ -233,6 +235,12 @@ __device__ __forceinline__ uint32_t pe_atomic_add_uniform(uint32_t addr, uint32_
   asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %[r], %[a], %[v]\n\ts_mov_b64 exec, %[sv]\n\ts_waitcnt lgkmcnt(0)"
                : [r] "=&v"(r), [sv] "=&s"(sv) : [a] "v"(addr), [v] "v"(v) : "memory");
   return rfl(r);
+}
+__device__ __forceinline__ uint32_t pe_atomic_or(uint32_t addr, uint32_t v) {
+  return __hip_atomic_fetch_or(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t pe_atomic_max(uint32_t addr, uint32_t v) {
+  return __hip_atomic_fetch_max(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ uint32_t pe_atomic_min(uint32_t addr, uint32_t v) {
   return __hip_atomic_fetch_min(reinterpret_cast<pe_lds_u32*>(&g_smem[addr]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -953,6 +961,14 @@ pe_again:
   uint32_t rseq = 0;                                     // regions of this invocation so far (the one at hand included)
   uint32_t kseq = 0; (void)kseq;                         // (two engines: the number of the region this engine is at)
   uint64_t gs_arr = 0; (void)gs_arr;                     // (gang statistics: when the stream arrived at this engine's region)
+#ifdef BROTLI_AMD_GANG_TRACE   // (a gang: a line a region of invocation BROTLI_AMD_GANG_TRACE with wave 0's clock at every hand-over -- which chain binds?)
+  uint64_t gt_ts[15] = {};
+#define GT(k) do { gt_ts[k] = __builtin_amdgcn_s_memrealtime(); } while (0)   // (the 100 MHz clock all CUs share: s_memtime is a CU's own)
+#define GTC(w, v) do { if (lane == 0) pe_atomic_add_uniform(pb + PE_CTL + 4u * (120u + (w)), (v)); } while (0)
+#else
+#define GT(k) do { } while (0)
+#define GTC(w, v) do { } while (0)
+#endif
 #ifdef BROTLI_AMD_PROFILE_REGIONS
   uint64_t rg_ts[10] = {}; uint64_t rg_prev_end = 0; uint64_t rg_rt[4] = {}; uint32_t rg_rn[4] = {};
 #define RG_STAMP(k) do { rg_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1849,6 +1865,7 @@ pe_again:
     }
     PE_PROF(6);
     if (REMOTE && me == 0) GANG_STAT(gc, 24, __builtin_amdgcn_s_memtime() - gs_arr);   // arrival .. walk done
+    if (REMOTE && me == 0) GT(1);
     {
       const uint32_t k0 = bw << 6;
       uint32_t na_k, m_k;
@@ -1895,8 +1912,10 @@ pe_again:
     PE_BAR();
     RG_STAMP(0);   // walk + details done
     if (REMOTE && me == 0) GANG_STAT(gc, 25, __builtin_amdgcn_s_memtime() - gs_arr);   // .. details done
+    if (REMOTE && me == 0) GT(2);
     if (REMOTE) {
       if (me == 0) full_arrival(true);
+      if (me == 0) GT(3);
       PE_BAR();
       if (pe_ctl_ld(pb, PEC_PLAN) == 2u) return;
       P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
@@ -1983,7 +2002,7 @@ pe_pass:
         const uint32_t reach = st.P < (uint64_t)(uint32_t)st.max_backward ? (uint32_t)st.P : (uint32_t)st.max_backward;
         if (__ballot(active && kind == SCK_EXPLICIT && val > reach) != 0ull && lane == 0) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_DCAND]) = 1u;
       }
-      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DICTK, 0xFFFFFFFFu); lds_st32(pb + PE_CTL + 4u * PEC_WNEXT, 0u); }   // (... and the execute's items are handed out from the first)
+      if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DICTK, 0xFFFFFFFFu); lds_st32(pb + PE_CTL + 4u * PEC_WNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPCHG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPLV0, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPLV1, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPDEEP, 0u); }   // (... and the execute's items are handed out from the first)
       PE_BAR();
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
@@ -2215,6 +2234,7 @@ pe_pass:
     }
     PE_PROF(11);
     if (REMOTE && me == 0) GANG_STAT(gc, 26, __builtin_amdgcn_s_memtime() - gs_arr);   // .. resolve done (wave 0 past the publish)
+    if (REMOTE && me == 0) GT(4);
     // (a gang) Two waits for other CUs' output: here for the regions up to the one before the region before -- the literals, and the copies that
     // read nothing younger, start at once --, and behind them for the region before, whose last bytes only the copies marked `dep` in the resolve
     // read (with uniform distances a handful a region: they go with the copies that read this region's own output).  The word is another CU's:
@@ -2244,6 +2264,7 @@ pe_pass:
       else if (kseq != 0u) { waited1 = await_output(kseq, 8u); if (waited1 > 6000u && gang_m >= 8u) pe_ctl_st(pb, PEC_RELAX, 1u); GANG_STAT(gc, 30, 1); }
       lds_sync();
       pe_ctl_st(pbs, PEC_EXECUTED, kseq);
+      GT(5);
     }
     if (PIPE) {
       // the region before's output is in memory before this one's copies read it (its engine says so)
@@ -2369,7 +2390,6 @@ pe_pass:
       // (c) waits for both)
       PE_PROF(8);
       RG_STAMP(2);   // (a) done
-      const uint32_t kp = pe_ctl_ld(pb, PEC_KP);
       PE_COUNT(28, kp);
       if (!PIPE) {   // (wave 0 says where the stream goes on behind the resolve's last barrier, while the others execute: as a rule long since)
         while (pe_ctl_ld(pb, PEC_NXOK) != rseq) __builtin_amdgcn_s_sleep(1);
@@ -2443,73 +2463,132 @@ pe_pass:
 #endif
       PE_PROF(9);
       RG_STAMP(3);   // (b) done (this wave's share)
-      if (REMOTE && me == 0 && kseq != 0u && relaxed) {   // (the region before's output: in front of the dependent copies' first barrier, and of the word that says this region's is there)
-        const uint32_t waited2 = await_output(kseq, 8u);
-        if (waited1 + waited2 < 1500u) pe_ctl_st(pb, PEC_RELAX, 0u);
-      }
-      // (c) copies that read the region's own output.
+      if (REMOTE && me == 0) GT(8);
+      // (a gang whose executes wait twice) The second wait -- for the region before's output -- stands in front of the word that says this region's is
+      // there, and in front of the copies that read that output (`lagging` ones: their source begins in front of the region) and of those that build on them.
+      auto second_wait = [&]() {
+        if (REMOTE && me == 0 && kseq != 0u && relaxed) {
+          const uint32_t waited2 = await_output(kseq, 8u);
+          if (waited1 + waited2 < 1500u) pe_ctl_st(pb, PEC_RELAX, 0u);
+        }
+        if (REMOTE && me == 0) GT(9);
+      };
+      // (c) copies that read the region's own output (`dependent` ones; a gang whose executes wait twice: and the `lagging` ones, whose source begins in
+      // front of the region -- in the region before's output, which may still be on its way).  Through round 5 those that build on another one went one
+      // after the other on one wave, a memory round trip each (a gang's region of the copy part: 19 of 241, 28 K clocks behind the second wait).  Now by
+      // LEVELS: a copy's level is one more than the highest level among the earlier dependent copies whose destination its source touches (destinations
+      // lie in command order: two binary searches give that range [a, b) of the list), 0 where there is none; a level's copies are independent of each
+      // other and go side by side, loads first, then stores.  The levels settle by relaxation over the list (they only grow; after r rounds every copy
+      // of level < r has its own): PE_DEP_ROUNDS rounds at most, what is deeper goes in order behind the rest, as before.  Lagging spreads the same way
+      // (bit 7): what neither lags nor builds on a copy that does is done in front of the second wait.
       const uint32_t ndep = pe_ctl_ld(pb, PEC_ANYDEP);
       PE_COUNT(13, ndep);
-      // The general way: one after the other where they build on each other (a wave's stores are visible to its later loads).
-      auto dependent_copies_in_order = [&]() {
-        // Which of them only read what (a) and (b) wrote -- literals and copies from in front of the region?  Those whose
-        // source does not touch the destination of an earlier dependent copy (destinations lie in command order: a binary
-        // search), and that do not overlap themselves.  They go side by side, one wave each (bit 29 of w0); the rest in order.
+      auto dependent_copies = [&]() {
+        const bool lagging = REMOTE && relaxed && kseq != 0u;
+        const uint32_t DA = pb + PE_POR, DB = DA + 2u * PE_CMDS, DL = DB + 2u * PE_CMDS;   // (the ranks' room: nobody reads a rank behind the details)
         for (uint32_t j = T; j < ndep; j += 64u * GW) {
           const uint32_t k = lds_ld16(pb + PE_DLIST + (j << 1));
           const uint32_t ra = pb + PE_REC + (k << 4);
           const uint32_t cn = lds_ld32(ra + 8u), dist = lds_ld32(ra + 12u);
           const uint32_t dst = lds_ld32(pb + PE_OFF + (k << 2)) + (lds_ld32(ra + 4u) & 0xFFFFu);
-          bool ready = dist >= cn && dist <= dst;  // (a source that begins in front of the region reads only what is complete)
-          if (REMOTE && dist >= cn && dst + cn <= dist) ready = true;   // (a gang: a source that lies in the region before's output, whole: it builds on nothing of this region's)
-          else if (dist >= cn) {
-            const uint32_t s_lo = dist <= dst ? dst - dist : 0u, s_hi = dst + cn - dist;  // the source's part inside the region
-            // the first earlier dependent copy whose destination ends behind s_lo
-            uint32_t lo_ = 0, hi_ = j;
+          // the source's part inside the region (a copy that repeats itself: what lies in front of its destination)
+          const uint32_t s_lo = dist <= dst ? dst - dist : 0u, s_hi = dist >= cn ? (dst + cn > dist ? dst + cn - dist : 0u) : dst;
+          uint32_t a = j, b = j;
+          if (s_hi > s_lo) {
+            uint32_t lo_ = 0, hi_ = j;   // the first earlier dependent copy whose destination ends behind s_lo
             while (lo_ < hi_) {
               const uint32_t mid = (lo_ + hi_) >> 1;
               const uint32_t km = lds_ld16(pb + PE_DLIST + (mid << 1));
               const uint32_t de = lds_ld32(pb + PE_OFF + (km << 2)) + (lds_ld32(pb + PE_REC + (km << 4) + 4u) & 0xFFFFu) + lds_ld32(pb + PE_REC + (km << 4) + 8u);
               if (de > s_lo) hi_ = mid; else lo_ = mid + 1u;
             }
-            ready = true;
-            if (lo_ < j) {
-              const uint32_t km = lds_ld16(pb + PE_DLIST + (lo_ << 1));
+            a = lo_; hi_ = j;            // ... and the first from there on whose destination begins at s_hi or behind it
+            while (lo_ < hi_) {
+              const uint32_t mid = (lo_ + hi_) >> 1;
+              const uint32_t km = lds_ld16(pb + PE_DLIST + (mid << 1));
               const uint32_t ds = lds_ld32(pb + PE_OFF + (km << 2)) + (lds_ld32(pb + PE_REC + (km << 4) + 4u) & 0xFFFFu);
-              ready = ds >= s_hi;
+              if (ds >= s_hi) hi_ = mid; else lo_ = mid + 1u;
             }
+            b = lo_;
           }
-          if (ready) lds_st32(ra, lds_ld32(ra) | (1u << 29));
+          lds_st16(DA + (j << 1), a); lds_st16(DB + (j << 1), b);
+          lds_st8(DL + j, (a < b ? 1u : 0u) | ((lagging && dist > dst) ? 0x80u : 0u));
         }
+        // this wave's copies: lane l has entry me + GW l of the list in its registers
+        const uint32_t myj = me + GW * lane;
+        const bool have = myj < ndep;
+        const uint32_t e_k = have ? lds_ld16(pb + PE_DLIST + (myj << 1)) : 0u;
+        const uint32_t e_ra = pb + PE_REC + (e_k << 4);
+        const uint32_t e_n = lds_ld32(e_ra + 8u), e_d = lds_ld32(e_ra + 12u), e_p = lds_ld32(pb + PE_OFF + (e_k << 2)) + (lds_ld32(e_ra + 4u) & 0xFFFFu);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PE_BAR();
-        RG_STAMP(4);   // dependent copies classified, everybody's (a) and (b) in memory
-        for (uint32_t j = me; j < ndep; j += GW) {
-          const uint32_t k = rfl(lds_ld16(pb + PE_DLIST + (j << 1)));
-          const uint32_t ra = pb + PE_REC + (k << 4);
-          const uint32_t r0 = rfl(lds_ld32(ra));
-          if (((r0 >> 29) & 1u) == 0u) continue;
-          const uint32_t cn = rfl(lds_ld32(ra + 8u)), dist = rfl(lds_ld32(ra + 12u));
-          if (staged) { stage_copy(rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (rfl(lds_ld32(ra + 4u)) & 0xFFFFu), cn, dist); continue; }
-          gu8* const dst = o + rfl(lds_ld32(pb + PE_OFF + (k << 2))) + (rfl(lds_ld32(ra + 4u)) & 0xFFFFu); gu8* const src = dst - dist;
-          if (cn <= 64u) { uint32_t t = 0; if (lane < cn) t = src[lane]; if (lane < cn) dst[lane] = (uint8_t)t; }
-          else {
-              const uint32_t n16 = cn >> 4;
-              for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
-              const uint32_t tail = n16 << 4;
-              if (tail + lane < cn) dst[tail + lane] = src[tail + lane];
+        RG_STAMP(4);   // the dependent copies' ranges, everybody's (a) and (b) in memory
+        if (REMOTE && me == 0) GT(10);
+        for (uint32_t round = 0; round < PE_DEP_ROUNDS; round++) {   // (bit r of PEC_DEPCHG: round r changed a level -- written in round r only, read behind its barrier)
+          bool chg = false;
+          for (uint32_t j = T; j < ndep; j += 64u * GW) {
+            const uint32_t a = lds_ld16(DA + (j << 1)), b = lds_ld16(DB + (j << 1)), cur = lds_ld8(DL + j);
+            uint32_t mx = 0, lg = cur & 0x80u;
+            for (uint32_t i2 = a; i2 < b; i2++) { const uint32_t v = lds_ld8(DL + i2); mx = (v & 0x7Fu) > mx ? (v & 0x7Fu) : mx; lg |= v & 0x80u; }
+            const uint32_t nv = a < b ? ((mx + 1u < 0x7Fu ? mx + 1u : 0x7Fu) | lg) : cur;
+            if (nv != cur) { lds_st8(DL + j, nv); chg = true; }
+          }
+          if (__ballot(chg) != 0ull && lane == 0) pe_atomic_or(pb + PE_CTL + 4u * PEC_DEPCHG, 1u << round);
+          PE_BAR();
+          if (((pe_ctl_ld(pb, PEC_DEPCHG) >> round) & 1u) == 0u) break;
+        }
+        // what this wave's copies are: level | lagging << 7; those of level PE_DEP_ROUNDS and more are the last wave's, in order (bit 29 of w0: not)
+        const uint32_t e_l = have ? lds_ld8(DL + myj) : 0xFFu;
+        const bool shallow = have && (e_l & 0x7Fu) < PE_DEP_ROUNDS;
+        if (shallow) lds_st32(e_ra, lds_ld32(e_ra) | (1u << 29));
+        { const uint64_t sh0 = __ballot(shallow && (e_l & 0x80u) == 0u), sh1 = __ballot(shallow && (e_l & 0x80u) != 0u), deep = __ballot(have && !shallow);
+          uint32_t m0 = 0, m1 = 0;
+          for (uint64_t q = sh0; q; q &= q - 1ull) { const uint32_t v = rdlane(e_l, (uint32_t)__builtin_ctzll(q)) & 0x7Fu; m0 = v + 1u > m0 ? v + 1u : m0; }
+          for (uint64_t q = sh1; q; q &= q - 1ull) { const uint32_t v = rdlane(e_l, (uint32_t)__builtin_ctzll(q)) & 0x7Fu; m1 = v + 1u > m1 ? v + 1u : m1; }
+          if (lane == 0) { if (m0) pe_atomic_max(pb + PE_CTL + 4u * PEC_DEPLV0, m0); if (m1) pe_atomic_max(pb + PE_CTL + 4u * PEC_DEPLV1, m1); if (deep) pe_atomic_max(pb + PE_CTL + 4u * PEC_DEPDEEP, 1u); } }
+        PE_BAR();
+        const uint32_t nlv0 = pe_ctl_ld(pb, PEC_DEPLV0), nlv1 = pe_ctl_ld(pb, PEC_DEPLV1);   // levels (their number) without and with lagging
+        const bool any_deep = pe_ctl_ld(pb, PEC_DEPDEEP) != 0u;
+        auto one_copy = [&](const uint32_t dpos, const uint32_t n, const uint32_t dist) {
+          if (staged) { stage_copy(dpos, n, dist); return; }
+          gu8* const dst = o + dpos; gu8* const src = dst - dist;
+          if (dist < n) {
+            // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
+            if (dist >= 64u) { for (uint32_t q = lane; q < n + lane; q += 64u) if (q < n) dst[q] = src[q]; }  // a step reads what earlier steps wrote
+            else {
+              uint32_t mm = lane % dist; const uint32_t step = 64u % dist;
+              for (uint32_t q = 0; q < n; q += 64u) { if (q + lane < n) dst[q + lane] = src[mm]; mm += step; if (mm >= dist) mm -= dist; }
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PE_BAR();
-        RG_STAMP(5);   // the ready ones done
-        if (me == GW - 1u) {
-#ifdef BROTLI_AMD_PROFILE_SCAN
-          const uint64_t dep_t0 = __builtin_amdgcn_s_memtime(); uint32_t dep_n = 0;
-#endif
-#ifdef BROTLI_AMD_PROFILE_REGIONS
-          const uint64_t rg_io0 = __builtin_amdgcn_s_memtime(); uint32_t rg_ion = 0;
-#endif
+          } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
+          else {
+            const uint32_t n16 = n >> 4;
+            for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
+            const uint32_t tail = n16 << 4;
+            if (tail + lane < n) dst[tail + lane] = src[tail + lane];
+          }
+        };
+        auto level = [&](const uint32_t code) {   // this wave's copies of one level: four loads in flight where they are plain ones of at most 64 bytes
+          uint64_t mm = __ballot(shallow && e_l == code);
+          while (mm) {
+            uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            auto take = [&](uint32_t& t, uint32_t& pn, uint32_t& pp) {
+              if (!mm) return;
+              const uint32_t i2 = (uint32_t)__builtin_ctzll(mm);
+              mm &= mm - 1ull;
+              const uint32_t n = rdlane(e_n, i2), dist = rdlane(e_d, i2), dpos = rdlane(e_p, i2);
+              if (!staged && dist >= n && n <= 64u) { if (lane < n) t = *(o + dpos - dist + lane); pn = n; pp = dpos; }
+              else one_copy(dpos, n, dist);
+            };
+            take(t0, n0, p0); take(t1, n1, p1); take(t2, n2, p2); take(t3, n3, p3);
+            if (lane < n0) o[p0 + lane] = (uint8_t)t0;
+            if (lane < n1) o[p1 + lane] = (uint8_t)t1;
+            if (lane < n2) o[p2 + lane] = (uint8_t)t2;
+            if (lane < n3) o[p3 + lane] = (uint8_t)t3;
+          }
+        };
+        // the copies of level PE_DEP_ROUNDS and more (and, a gang: whatever they build on may lag), in command order
+        auto in_order = [&]() {
+          const uint32_t kp = kp_all;
           for (uint32_t k0 = ks & ~63u; k0 < kp; k0 += 64u) {
             const uint32_t k = k0 + lane;
             const uint32_t ra = pb + PE_REC + ((k < kp ? k : 0u) << 4);
@@ -2518,48 +2597,34 @@ pe_pass:
             while (dm) {
               const uint32_t kk = (uint32_t)__builtin_ctzll(dm);
               dm &= dm - 1ull;
-#ifdef BROTLI_AMD_PROFILE_SCAN
-              dep_n++;
-#endif
-#ifdef BROTLI_AMD_PROFILE_REGIONS
-              rg_ion++;
-#endif
-              const uint32_t n = rdlane(xn, kk), dist = rdlane(xd, kk), dpos = rdlane(xo, kk) + (rdlane(x1, kk) & 0xFFFFu);
-              if (staged) { stage_copy(dpos, n, dist); continue; }
-              gu8* const dst = o + dpos; gu8* const src = dst - dist;
-              if (dist < n) {
-                // the copy overlaps itself (decode.rs:2657-2663, 2690-2720: byte by byte, so a pattern of `dist` bytes repeats)
-                if (dist >= 64u) { for (uint32_t q = lane; q < n + lane; q += 64u) if (q < n) dst[q] = src[q]; }  // a step reads what earlier steps wrote
-                else {
-                  uint32_t mm = lane % dist; const uint32_t step = 64u % dist;
-                  for (uint32_t q = 0; q < n; q += 64u) { if (q + lane < n) dst[q + lane] = src[mm]; mm += step; if (mm >= dist) mm -= dist; }
-                }
-              } else if (n <= 64u) { uint32_t t = 0; if (lane < n) t = src[lane]; if (lane < n) dst[lane] = (uint8_t)t; }
-              else {
-              const uint32_t n16 = n >> 4;
-              for (uint32_t q = lane; q < n16; q += 64u) *reinterpret_cast<gu32x4*>(dst + (uint64_t)q * 16) = *reinterpret_cast<gu32x4*>(src + (uint64_t)q * 16);
-              const uint32_t tail = n16 << 4;
-              if (tail + lane < n) dst[tail + lane] = src[tail + lane];
-            }
+              one_copy(rdlane(xo, kk) + (rdlane(x1, kk) & 0xFFFFu), rdlane(xn, kk), rdlane(xd, kk));
             }
           }
-#ifdef BROTLI_AMD_PROFILE_REGIONS
+        };
+        for (uint32_t lv = 0; lv < nlv0; lv++) {
+          level(lv);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (blockIdx.x == 0 && lane == 0) printf("   in order: %u copies, %llu ticks\n", rg_ion, (unsigned long long)(__builtin_amdgcn_s_memtime() - rg_io0));
-#endif
-#ifdef BROTLI_AMD_PROFILE_SCAN
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (blockIdx.x == 0 && lane == 0) { atomicAdd(&g_path_prof[34], (unsigned long long)(__builtin_amdgcn_s_memtime() - dep_t0)); atomicAdd(&g_path_prof[35], (unsigned long long)dep_n); }
-#endif
+          PE_BAR();
         }
-      
+        RG_STAMP(5);   // what does not wait for the region before is done
+        if (REMOTE && me == 0) GT(11);
+        second_wait();
+        if (nlv1 != 0u || any_deep) PE_BAR();
+        for (uint32_t lv = 0; lv < nlv1; lv++) {
+          level(lv | 0x80u);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          PE_BAR();
+        }
+        if (any_deep && me == GW - 1u) in_order();
       };
-      if (ndep != 0u) dependent_copies_in_order();
+      if (ndep != 0u) dependent_copies(); else second_wait();
       if (staged) {
         // the region's output, out of the stage in one piece: sixteen bytes a thread and step
         PE_BAR();
+        if (REMOTE && me == 0) GT(12);
         const uint32_t tot = pe_ctl_ld(pb, PEC_OUTTOT);
         write_out(sg, o, tot);
+        if (REMOTE && me == 0) GT(13);
       }
       PE_PROF(10);
     }
@@ -2585,6 +2650,14 @@ pe_pass:
       if (PIPE2 && T == 0u) { lds_sync(); pe_ctl_st(pbs, PEC_EXECUTED, kseq + 1u); }
       if (REMOTE && T == 0u) { const uint64_t t0_ = __builtin_amdgcn_s_memtime(); (void)t0_; GANG_STAT(gc, 27, t0_ - gs_arr); gang_release();
  GANG_STAT(gc, 17, __builtin_amdgcn_s_memtime() - t0_); gang_st64(gc, GC_EXEC, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
+#ifdef BROTLI_AMD_GANG_TRACE
+      if (REMOTE && T == 0u && epoch == (uint32_t)(BROTLI_AMD_GANG_TRACE) && kseq < 64u) { GT(6);   // (the last 8 KiB of the arena's image: a block of sixteen waves has 40 KiB of arena)
+        gt_ts[12] = (uint64_t)pe_ctl_ld(pb, 120u) | ((uint64_t)pe_ctl_ld(pb, 121u) << 16) | ((uint64_t)pe_ctl_ld(pb, 122u) << 32) | ((uint64_t)pe_ctl_ld(pb, 123u) << 48);
+        gt_ts[13] = (gt_ts[6] & ~0xFFFFFFFFull) | pe_ctl_ld(pb, 124u);
+        pe_ctl_st(pb, 120u, 0u); pe_ctl_st(pb, 121u, 0u); pe_ctl_st(pb, 122u, 0u); pe_ctl_st(pb, 123u, 0u);
+        for (uint32_t q = 0; q < 15u; q++) gang_st64(gc, GC_ARENA + (40u << 10) + 128u * kseq + 8u * q, gt_ts[q]);
+        gang_st64(gc, GC_ARENA + (40u << 10) + 128u * kseq + 120u, (uint64_t)pe_ctl_ld(pb, PEC_KP) | ((uint64_t)blockIdx.x << 32) | ((uint64_t)pe_ctl_ld(pb, PEC_ANYDEP) << 16)); }
+#endif
     }
   };
 #if !PE_CFG_PIPE && !PE_CFG_REMOTE
@@ -2685,7 +2758,7 @@ pe_pass:
       uint32_t plan;
       for (;;) {
         const bool built = pe_ctl_ld(pb, PEC_GO) != 0u;
-        if (built) { const uint64_t tb_ = __builtin_amdgcn_s_memtime(); (void)tb_; (void)build(); if (me == 0) { GANG_STAT(gc, 4, 1); if (role == 0u) GANG_STAT(gc, 20, __builtin_amdgcn_s_memtime() - tb_); } }
+        if (built) { const uint64_t tb_ = __builtin_amdgcn_s_memtime(); (void)tb_; (void)build(); GT(7); if (me == 0) { GANG_STAT(gc, 4, 1); if (role == 0u) GANG_STAT(gc, 20, __builtin_amdgcn_s_memtime() - tb_); } }
         // -- the stream arrives (or the plan has changed, or the invocation is over) --
         if (me == 0) {
           const uint32_t mygen = pe_ctl_ld(pb, PEC_MYGEN), want = (epoch << 12) | kseq;
@@ -2699,7 +2772,7 @@ pe_pass:
             if (arrived || stopped || replanned) break;
             __builtin_amdgcn_s_sleep(1); PE_SPIN_CHECK(spins);
           }
-          GANG_STAT(gc, role == 0u ? 6 : 7, __builtin_amdgcn_s_memtime() - t0_); gs_arr = __builtin_amdgcn_s_memtime();
+          GANG_STAT(gc, role == 0u ? 6 : 7, __builtin_amdgcn_s_memtime() - t0_); gs_arr = __builtin_amdgcn_s_memtime(); GT(0);
 
           plan = 2u;   // 0: the tables are the ones, 1: once more where the stream is, 2: the invocation is over, 3: once more by the new plan, then wait again
           if (stopped) { }
@@ -2954,3 +3027,5 @@ pe_pass:
 #undef PE_DICT
 #undef PE_SPIN_CHECK
 #undef RG_STAMP
+#undef GT
+#undef GTC
