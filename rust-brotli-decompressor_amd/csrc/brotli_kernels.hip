@@ -1214,7 +1214,7 @@ __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_
 //            behind a release fence, in front of EPOCH; a helper's acquire fence stands behind its look at EPOCH)
 constexpr uint32_t GC_JOINED = 0, GC_EPOCH = 4, GC_READY = 8, GC_PLAN = 16, GC_STOP = 24, GC_EXEC = 32, GC_ARENA_BYTES = 40, GC_ENTRY = 48, GC_MEMBERS = 56 /* u64: invocation << 32 | blocks of its gang */, GC_STATE = 64,
                    GC_PARAMS = 512, GC_BR = 640, GC_ARENA = 1024, GC_ARENA_CAP = 48u << 10, GC_STRIDE = GC_ARENA + GC_ARENA_CAP;
-constexpr uint32_t GC_QUIT = 0xFFFFFFFFu, GC_STATE_WORDS = 27, GC_MAX_REGIONS = 4000;   // (the state's granules: 25 words of PeStream, the resolve's flags, the bytes its region put out)
+constexpr uint32_t GC_QUIT = 0xFFFFFFFFu, GC_STATE_WORDS = 28, GC_MAX_REGIONS = 4000;   // (the state's granules: 25 words of PeStream, the resolve's flags, the bytes its region put out, those of the region before it)
 static_assert(GC_STRIDE == BROTLI_AMD_GANG_CTL_BYTES && GC_STATE + 8u * GC_STATE_WORDS <= GC_PARAMS, "the gang's control block");
 __device__ __forceinline__ gu8* gang_ctl() { return (gu8*)(uintptr_t)((uint64_t)hc_ld(HC_GANG_LO) | ((uint64_t)hc_ld(HC_GANG_HI) << 32)); }
 __device__ __forceinline__ uint32_t gang_ld32(gu8* gc, uint32_t off) { return __hip_atomic_load(reinterpret_cast<__attribute__((address_space(1))) uint32_t*>(gc + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -58,6 +58,10 @@ constexpr uint32_t PE_GROW_BELOW = PE_WCAP / 4u;  // closure states below which 
 constexpr uint32_t PE_HOPCAP = 8;                 // hops through J1 one evaluation takes; a run that needs more goes on in the lane's next evaluation
 constexpr uint32_t PE_SYNC_ROUNDS = GW + 1;  // rounds between waves the chunk entries get to settle: enough for any code
 constexpr uint32_t PE_CMDS = PE_RBL / 32u;          // commands one region's walk lists at most
+#ifndef BROTLI_AMD_PE_DEPTH2_MIN
+#define BROTLI_AMD_PE_DEPTH2_MIN 16
+#endif
+constexpr uint32_t PE_DEPTH2_MIN = BROTLI_AMD_PE_DEPTH2_MIN;   // a gang of this many blocks and more may have three executes under way (see the execute's waits)
 constexpr uint32_t PE_DEP_ROUNDS = 6;             // levels of copies that build on each other which go side by side (execute); deeper ones in order
 constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this long are stored by their command's lane, four bytes a step
 #ifndef BROTLI_AMD_PE_LANE_COPY
@@ -175,7 +179,7 @@ static_assert(PE_J1F % 16 == 0 && PE_PM % 16 == 0 && PE_REC % 16 == 0 && PE_POR 
 enum { PEN_END = 0xFFFFu, PEN_BYHAND = 0xFFFEu, PEN_NONE = 0xFFFDu, PEN_FIRST_SPECIAL = 0xFFF0u };
 // control words of a region (from 64 on; the invocation's parameters are the scan engine's SCC_*)
 enum { PEC_LBDW = 64, PEC_LE = 65, PEC_L = 66, PEC_LP = 67, PEC_RN = 68, PEC_WN = 69, PEC_TMIN = 70, PEC_M = 71, PEC_GO = 72, PEC_KP = 73,
-       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_DEPCHG = 107 /* the dependent copies' levels: bit r, round r changed one */, PEC_DEPLV0 = 108 /* ... levels of the copies that do not lag */, PEC_DEPLV1 = 109 /* ... and of those that do */, PEC_DEPDEEP = 110 /* ... some are deeper than the rounds go */, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
+       PEC_P0_LO = 74, PEC_P0_HI = 75, PEC_ANYDEP = 76, PEC_CHG = 77 /* three words */, PEC_STATE = 160 /* the stream's state between wave 0's uses of it: PeStream */, PEC_CONT = 96, PEC_NEXT_LBDW = 97, PEC_ON = 98, PEC_NA = 99, PEC_NBIG = 101, PEC_TAILN = 102, PEC_TAILNEXT = 103, PEC_READY = 104, PEC_ENT = 105, PEC_MODE = 106, PEC_DEPCHG = 107 /* the dependent copies' levels: bit r, round r changed one */, PEC_DEPLV0 = 108 /* ... levels of the copies that do not lag */, PEC_DEPLV1 = 109 /* ... and of those that do */, PEC_DEPDEEP = 110 /* ... some are deeper than the rounds go */, PEC_PREVOUT = 111 /* (a gang) the bytes of the region before's output */, PEC_DEPTH = 112 /* ... how many regions before this one its resolve took for still under way: PEC_RELAX when the stream arrived */, PEC_TAKE = 107, PEC_BKP = 108 /* + batch: 16 words */, PEC_NEXTRANK = 100, PEC_WSUM = 80 /* + wave: 16 words */, PEC_NAPUB = 125 /* anchors the walk has published */, PEC_WDONE = 126 /* the walk is over */,
        PEC_STAGED = 127 /* the region's output is put together in LDS */, PEC_OUTTOT = 128 /* its size */, PEC_TDN = 129 /* entries of the distance code's table */, PEC_SCRATCH = 130 /* stores that are not meant land here */, PEC_GBAR = 131 /* the engine's barrier: arrivals so far */,
        // two engines (words of the shared block): what they tell each other
        PEC_RESOLVED = 132 /* regions whose resolve is through: the stream's state is the next one's */, PEC_EXECUTED = 133 /* regions whose output is in memory */,
@@ -1674,7 +1678,9 @@ pe_again:
       const PeStream st = pe_st_load(pbs);
       ok_ = (walked && st.b == pe_ctl_ld(pb, PEC_MYENTRY) && st.quota >= SC_MIN_QUOTA && st.bl1 != 0u) ? 1u : 0u;
       pe_ctl_st(pb, PEC_P0_LO, (uint32_t)st.P); pe_ctl_st(pb, PEC_P0_HI, (uint32_t)(st.P >> 32));
-      pe_ctl_st(pb, PEC_LAG, pe_ctl_ld(pb, PEC_RELAX) == 1u ? rdlane((uint32_t)v, 26) : 0u);
+      { const uint32_t rl = pe_ctl_ld(pb, PEC_RELAX), g26 = rdlane((uint32_t)v, 26), g27 = rdlane((uint32_t)v, 27);   // (the sizes of the two regions before this one)
+        pe_ctl_st(pb, PEC_PREVOUT, g26); pe_ctl_st(pb, PEC_DEPTH, rl);
+        pe_ctl_st(pb, PEC_LAG, rl == 2u ? g26 + g27 : rl == 1u ? g26 : 0u); }
     }
     if (ok_ == 0u) {
       if (!arrived) GANG_STAT(gc, 32, 1); else if ((rdlane((uint32_t)v, 25) & 1u) == 0u) GANG_STAT(gc, 33, 1); else { const PeStream st = pe_st_load(pbs); if (st.b != pe_ctl_ld(pb, PEC_MYENTRY)) GANG_STAT(gc, 34, 1); else GANG_STAT(gc, 36, 1); }
@@ -2218,7 +2224,7 @@ pe_pass:
           // invocation's end in a word of its own behind them (whoever waits for a region that will not come looks at it)
           pe_ctl_st(pb, PEC_MYNEXT, sn.b);
           lds_sync();
-          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : lane == 25u ? (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1) | (pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 8u : 0u) : pe_ctl_ld(pb, PEC_OUTTOT);
+          const uint32_t v = lane < 25u ? *reinterpret_cast<lds_vu32*>(&g_smem[pbs + PE_CTL + 4u * (PEC_STATE + (lane < 25u ? lane : 0u))]) : lane == 25u ? (cont ? 1u : 0u) | ((pe_ctl_ld(pbs, PEC_DECLINE) & 3u) << 1) | (pe_ctl_ld(pb, PEC_DSEEN) != 0u ? 8u : 0u) : lane == 27u ? pe_ctl_ld(pb, PEC_PREVOUT) : pe_ctl_ld(pb, PEC_OUTTOT);
           if (lane < GC_STATE_WORDS) gang_st64(gc, GC_STATE + 8u * lane, (uint64_t)v | ((uint64_t)((epoch << 12) | (kseq + 1u)) << 32));
           if (!cont) { gang_drain(); if (lane == 0u) gang_st64(gc, GC_STOP, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
         }
@@ -2260,7 +2266,12 @@ pe_pass:
     const bool relaxed = REMOTE && pe_ctl_ld(pb, PEC_LAG) != 0u;   // (the resolve marked the copies that read the region before's output)
     uint32_t waited1 = 0; (void)waited1;
     if (REMOTE && me == 0) {
-      if (relaxed) { if (kseq >= 2u) waited1 = await_output(kseq - 1u, 9u); }
+      if (relaxed) {
+        // (the resolve marked the copies that read the one or the two regions before: as many executes besides this one may be under way)
+        const uint32_t depth = pe_ctl_ld(pb, PEC_DEPTH);
+        if (kseq >= depth + 1u) waited1 = await_output(kseq - depth, 9u);
+        if (depth == 1u && waited1 > 6000u && gang_m >= PE_DEPTH2_MIN) pe_ctl_st(pb, PEC_RELAX, 2u);
+      }
       else if (kseq != 0u) { waited1 = await_output(kseq, 8u); if (waited1 > 6000u && gang_m >= 8u) pe_ctl_st(pb, PEC_RELAX, 1u); GANG_STAT(gc, 30, 1); }
       lds_sync();
       pe_ctl_st(pbs, PEC_EXECUTED, kseq);
@@ -2469,7 +2480,7 @@ pe_pass:
       auto second_wait = [&]() {
         if (REMOTE && me == 0 && kseq != 0u && relaxed) {
           const uint32_t waited2 = await_output(kseq, 8u);
-          if (waited1 + waited2 < 1500u) pe_ctl_st(pb, PEC_RELAX, 0u);
+          if (waited1 + waited2 < 1500u) pe_ctl_st(pb, PEC_RELAX, pe_ctl_ld(pb, PEC_DEPTH) - 1u);   // (both short: one execute fewer in flight will do)
         }
         if (REMOTE && me == 0) GT(9);
       };
