@@ -1919,13 +1919,6 @@ pe_again:
     RG_STAMP(0);   // walk + details done
     if (REMOTE && me == 0) GANG_STAT(gc, 25, __builtin_amdgcn_s_memtime() - gs_arr);   // .. details done
     if (REMOTE && me == 0) GT(2);
-    if (REMOTE) {
-      if (me == 0) full_arrival(true);
-      if (me == 0) GT(3);
-      PE_BAR();
-      if (pe_ctl_ld(pb, PEC_PLAN) == 2u) return;
-      P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
-    }
     const uint32_t m = pe_ctl_ld(pb, PEC_M);
     PE_PROF(7);
     // ---- resolve: wave w takes batch w (64 commands), all batches side by side.  What one batch needs from the batches in front
@@ -1939,7 +1932,10 @@ pe_again:
 pe_pass:
     uint32_t my_exec = 0;  // commands of this wave's batch that are executed (counted from the batch's first: those below ks are not)
     {
-      const PeStream st = pe_st_load(pbs);
+      // (a gang: the stream's state is the region before's resolve's to send, and what this resolve does in front of its first barrier -- the sums, the ring
+      // against an unknown ring -- does not ask for it: wave 0 waits for it behind that, see full_arrival)
+      PeStream st{};
+      if (!REMOTE) st = pe_st_load(pbs);
       const bool mine = bw < nb;
       const uint32_t k0 = bw << 6;
       const uint32_t K = mine ? (m - k0 < 64u ? m - k0 : 64u) : 0u;
@@ -2009,7 +2005,13 @@ pe_pass:
         if (__ballot(active && kind == SCK_EXPLICIT && val > reach) != 0ull && lane == 0) *reinterpret_cast<lds_vu32*>(&g_smem[pb + PE_CTL + 4u * PEC_DCAND]) = 1u;
       }
       if (T == 0u) { lds_st32(pb + PE_CTL + 4u * PEC_KP, m); lds_st32(pb + PE_CTL + 4u * PEC_BIGNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DICTK, 0xFFFFFFFFu); lds_st32(pb + PE_CTL + 4u * PEC_WNEXT, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPCHG, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPLV0, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPLV1, 0u); lds_st32(pb + PE_CTL + 4u * PEC_DEPDEEP, 0u); }   // (... and the execute's items are handed out from the first)
+      if (REMOTE && me == 0) { full_arrival(true); GT(3); }
       PE_BAR();
+      if (REMOTE) {
+        if (pe_ctl_ld(pb, PEC_PLAN) == 2u) return;
+        P0 = (uint64_t)pe_ctl_ld(pb, PEC_P0_LO) | ((uint64_t)pe_ctl_ld(pb, PEC_P0_HI) << 32);
+        st = pe_st_load(pbs);
+      }
       // what lies in front of this batch
       uint32_t c_lit = 0, c_cmd = 0, c_dst = 0, c_out = 0;
       int32_t d0 = st.d0, d1 = st.d1, d2 = st.d2, d3 = st.d3;
