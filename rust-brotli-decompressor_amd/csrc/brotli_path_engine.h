@@ -2561,6 +2561,10 @@ pe_pass:
           if (lane == 0) { if (m0) pe_atomic_max(pb + PE_CTL + 4u * PEC_DEPLV0, m0); if (m1) pe_atomic_max(pb + PE_CTL + 4u * PEC_DEPLV1, m1); if (deep) pe_atomic_max(pb + PE_CTL + 4u * PEC_DEPDEEP, 1u); } }
         PE_BAR();
         const uint32_t nlv0 = pe_ctl_ld(pb, PEC_DEPLV0), nlv1 = pe_ctl_ld(pb, PEC_DEPLV1);   // levels (their number) without and with lagging
+#ifdef BROTLI_AMD_GANG_TRACE
+        { for (uint32_t q = 0; q < 4u; q++) { const uint32_t c_ = (uint32_t)__popcll(__ballot(shallow && e_l == (0x80u | q))); if (c_ && lane == 0) pe_atomic_add_uniform(pb + PE_CTL + 4u * (120u + q), c_); }
+          if (T == 0u) pe_ctl_st(pb, 124u, nlv0 | (nlv1 << 8) | ((pe_ctl_ld(pb, PEC_DEPDEEP) != 0u ? 1u : 0u) << 16)); }
+#endif
         const bool any_deep = pe_ctl_ld(pb, PEC_DEPDEEP) != 0u;
         auto one_copy = [&](const uint32_t dpos, const uint32_t n, const uint32_t dist) {
           if (staged) { stage_copy(dpos, n, dist); return; }
@@ -2627,7 +2631,9 @@ pe_pass:
           level(lv | 0x80u);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           PE_BAR();
+          if (REMOTE && me == 0 && lv == 0u) GT(12);
         }
+        if (REMOTE && me == 0) GT(14);
         if (any_deep && me == GW - 1u) in_order();
       };
       if (ndep != 0u) dependent_copies(); else second_wait();
@@ -2665,7 +2671,6 @@ pe_pass:
  GANG_STAT(gc, 17, __builtin_amdgcn_s_memtime() - t0_); gang_st64(gc, GC_EXEC, ((uint64_t)epoch << 32) | (uint64_t)(kseq + 1u)); }
 #ifdef BROTLI_AMD_GANG_TRACE
       if (REMOTE && T == 0u && epoch == (uint32_t)(BROTLI_AMD_GANG_TRACE) && kseq < 64u) { GT(6);   // (the last 8 KiB of the arena's image: a block of sixteen waves has 40 KiB of arena)
-        gt_ts[12] = (uint64_t)pe_ctl_ld(pb, 120u) | ((uint64_t)pe_ctl_ld(pb, 121u) << 16) | ((uint64_t)pe_ctl_ld(pb, 122u) << 32) | ((uint64_t)pe_ctl_ld(pb, 123u) << 48);
         gt_ts[13] = (gt_ts[6] & ~0xFFFFFFFFull) | pe_ctl_ld(pb, 124u);
         pe_ctl_st(pb, 120u, 0u); pe_ctl_st(pb, 121u, 0u); pe_ctl_st(pb, 122u, 0u); pe_ctl_st(pb, 123u, 0u);
         for (uint32_t q = 0; q < 15u; q++) gang_st64(gc, GC_ARENA + (40u << 10) + 128u * kseq + 8u * q, gt_ts[q]);
