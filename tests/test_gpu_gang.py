@@ -178,6 +178,70 @@ def test_helpers_that_never_turn_up(pkg):
         assert r.engine_commands >= 0.9 * r.num_commands, (r.engine_commands, r.num_commands)
 
 
+def _chained_copies(seed, size):
+    """data whose copies BUILD ON EACH OTHER: units of 9 .. 40 bytes, each the unit before it with a byte or two changed -- a copy from one unit back
+    and a literal, hundreds in a row (every copy reads what the copy before it wrote: levels far beyond PE_DEP_ROUNDS, the execute's in-order tail) --,
+    stretches of units that repeat units from a few KiB back (copies that read the REGION BEFORE's output: a gang's lagging copies, and what builds on
+    them), and long runs of one short pattern (copies that repeat themselves)"""
+    rnd = random.Random(seed)
+    out = bytearray(rnd.randbytes(256))
+    while len(out) < size:
+        k = rnd.random()
+        if k < 0.6:
+            u = rnd.randrange(9, 41)
+            unit = bytearray(out[-u:])
+            for _ in range(rnd.randrange(20, 400)):
+                unit[rnd.randrange(u)] = rnd.randrange(256)
+                if rnd.random() < 0.3:
+                    unit[rnd.randrange(u)] = rnd.randrange(256)
+                out += unit
+        elif k < 0.9:
+            back = rnd.randrange(2000, 60000)
+            if back < len(out):
+                for _ in range(rnd.randrange(5, 60)):
+                    a = len(out) - back + rnd.randrange(-200, 200)
+                    a = max(0, min(a, len(out) - 64))
+                    out += out[a:a + rnd.randrange(8, 64)]
+                    if rnd.random() < 0.5:
+                        out.append(rnd.randrange(256))
+        else:
+            pat = rnd.randbytes(rnd.randrange(1, 9))
+            out += pat * rnd.randrange(20, 300)
+    return bytes(out[:size])
+
+
+@pytest.mark.parametrize("blocks", ["16", "8", "0"])
+def test_copies_that_build_on_each_other(pkg, blocks):
+    """The execute's levels (csrc/brotli_path_engine.h, `dependent_copies`; the reference copies byte by byte, decode.rs:2641-2720): chains of copies
+    far deeper than the levels go, copies that read the region before's output and copies that build on those, copies that repeat themselves -- one long
+    stream by sixteen blocks, by eight and by one, and a batch of shorter ones, whole and with buffers that end inside a chain."""
+    w = _w()
+    rnd = random.Random(5)
+    datas, caps = [], []
+    raw = _chained_copies(900, 6 << 20)
+    for q in (5, 9):
+        c = w.brotli_compress(raw, q, 22)
+        datas.append(c); caps.append(len(raw))
+    for k in range(4):
+        r = _chained_copies(910 + k, rnd.randrange(300 << 10, 1 << 20))
+        c = w.brotli_compress(r, rnd.choice([4, 5, 6]), rnd.choice([18, 20, 22]))
+        datas += [c, c]; caps += [len(r), rnd.randrange(len(r) // 2, len(r))]
+    old = os.environ.get("BROTLI_AMD_GANG")
+    os.environ["BROTLI_AMD_GANG"] = blocks
+    try:
+        res, outs, gang = _decode(pkg, datas[:1], caps[:1])      # (one long stream: the gang asked for)
+        assert gang == (int(blocks) or 1)
+        _against_oracle(res, outs, datas[:1], caps[:1])
+        assert res[0].engine_commands >= 0.9 * res[0].num_commands
+        res, outs, gang = _decode(pkg, datas, caps)
+        _against_oracle(res, outs, datas, caps)
+    finally:
+        if old is None:
+            os.environ.pop("BROTLI_AMD_GANG", None)
+        else:
+            os.environ["BROTLI_AMD_GANG"] = old
+
+
 def test_batches_of_small_streams_get_no_gangs(pkg):
     """a gang has something to divide from 64 KiB of compressed data on (a dozen regions) and costs a launch ten microseconds: batches whose
     largest stream is smaller are launched with one block a stream, whatever their number; one large stream among them brings the gangs back"""
