@@ -68,7 +68,7 @@ constexpr uint32_t PE_LANE_LITS = 64;             // literal runs up to this lon
 #define BROTLI_AMD_PE_LANE_COPY 16
 #endif
 constexpr uint32_t PE_LANE_COPY = BROTLI_AMD_PE_LANE_COPY;  // copies up to this long from in front of the region are done by their command's lane (16-byte loads, 16 .. 64)
-static_assert(PE_LANE_COPY % 16 == 0 && PE_LANE_COPY >= 16 && PE_LANE_COPY <= 64, "lane copies");
+static_assert(PE_LANE_COPY == 16, "lane copies: a region that is put together in LDS takes its short copies out of ONE sixteen-byte load (32 and 64 were round 3's experiment, before the stage)");
 #ifndef BROTLI_AMD_PE_RUN_MIN
 #define BROTLI_AMD_PE_RUN_MIN 6000
 #endif
